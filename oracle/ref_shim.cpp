@@ -1,0 +1,71 @@
+/*
+ * ref_shim.cpp -- C-ABI veneer over the REAL reference (dblalock/sprintz).
+ * TEST INFRASTRUCTURE ONLY.
+ *
+ * This file contains no codec logic.  It is compiled together with the
+ * reference's own sources *where they lie* under /root/reference/cpp/Compress
+ * (see oracle/Makefile, target _ref) into oracle/_ref/libsprintz_ref.so, which
+ * is used (a) to pin the CPU restatement and mint tests/golden/, and (b) as
+ * the "reference" CPU baseline in bench.py.  Nothing under oracle/_ref/ is
+ * committed; no reference source is copied into this repository.
+ */
+#include <stdint.h>
+#include <stddef.h>
+#include "sprintz.h"   /* -I/root/reference/cpp/Compress : sprintz.h:16-32 */
+
+extern "C" {
+
+int64_t ref_compress(int codec, int elem_bytes, const void* src, uint32_t len, void* dest,
+                     uint16_t ndims, int write_size)
+{
+    const bool ws = write_size != 0;
+    if (elem_bytes == 1) {
+        return codec ? sprintz_compress_xff_8b((const uint8_t*)src, len, (int8_t*)dest, ndims, ws)
+                     : sprintz_compress_delta_8b((const uint8_t*)src, len, (int8_t*)dest, ndims, ws);
+    }
+    return codec ? sprintz_compress_xff_16b((const uint16_t*)src, len, (int16_t*)dest, ndims, ws)
+                 : sprintz_compress_delta_16b((const uint16_t*)src, len, (int16_t*)dest, ndims, ws);
+}
+
+int64_t ref_decompress(int codec, int elem_bytes, const void* src, void* dest)
+{
+    if (elem_bytes == 1) {
+        return codec ? sprintz_decompress_xff_8b((const int8_t*)src, (uint8_t*)dest)
+                     : sprintz_decompress_delta_8b((const int8_t*)src, (uint8_t*)dest);
+    }
+    return codec ? sprintz_decompress_xff_16b((const int16_t*)src, (uint16_t*)dest)
+                 : sprintz_decompress_delta_16b((const int16_t*)src, (uint16_t*)dest);
+}
+
+/* chunk loops so that the CPU baseline is timed without per-call FFI overhead */
+uint64_t ref_compress_chunks(int codec, int elem_bytes, const void* src, uint64_t total_len,
+                             uint32_t chunk_len, uint16_t ndims,
+                             uint8_t* dest, size_t dest_stride, int64_t* ret_elems)
+{
+    const uint8_t* s = (const uint8_t*)src;
+    uint64_t c = 0, total = 0;
+    for (uint64_t off = 0; off < total_len; off += chunk_len, c++) {
+        uint32_t n = (uint32_t)((total_len - off < chunk_len) ? (total_len - off) : chunk_len);
+        int64_t r = ref_compress(codec, elem_bytes, s + off * (uint64_t)elem_bytes, n,
+                                 dest + c * dest_stride, ndims, 1);
+        if (ret_elems) ret_elems[c] = r;
+        if (r > 0) total += (uint64_t)r;
+    }
+    return total;
+}
+
+uint64_t ref_decompress_chunks(int codec, int elem_bytes, const uint8_t* comp,
+                               const uint64_t* offsets, uint64_t nchunks,
+                               uint32_t chunk_len, void* out)
+{
+    uint8_t* o = (uint8_t*)out;
+    uint64_t total = 0;
+    for (uint64_t c = 0; c < nchunks; c++) {
+        int64_t n = ref_decompress(codec, elem_bytes, comp + offsets[c],
+                                   o + c * (uint64_t)chunk_len * (uint64_t)elem_bytes);
+        if (n > 0) total += (uint64_t)n;
+    }
+    return total;
+}
+
+}  // extern "C"

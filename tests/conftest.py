@@ -1,0 +1,44 @@
+import os
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (HERE, ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """Our CPU restatement; built on demand (gcc only, a second or two)."""
+    import subprocess
+    from harness import ORACLE_SO, Oracle
+    if not os.path.exists(ORACLE_SO):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def reference():
+    """The compiled reference, if oracle/_ref was built (needs /root/reference at build time)."""
+    from harness import Reference
+    if not Reference.available():
+        pytest.skip("oracle/_ref/libsprintz_ref.so not built (reference sources absent)")
+    return Reference()
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import json
+    import numpy as np
+    gdir = os.path.join(HERE, "golden")
+    with open(os.path.join(gdir, "golden_v1.json")) as f:
+        manifest = json.load(f)["cases"]
+    arrays = np.load(os.path.join(gdir, "golden_v1.npz"))
+    return manifest, arrays

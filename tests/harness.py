@@ -1,0 +1,203 @@
+"""Shared test plumbing: ctypes bindings for the oracle (our CPU restatement)
+and, when it has been built, the compiled reference (oracle/_ref); plus the
+input families of the reference's own test-suite.
+
+Input families mirror cpp/Compress/test/compress_testing.hpp:
+  "known" squares + simple patterns  (:251-303)
+  zeros                               (:380-386)
+  fuzz: random then successively /2   (:347-370)
+  sparse: random with most values 0   (:409-423)
+and the size list of test_codec (:452-463).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libsprintz_ref.so")
+
+CODECS = {"delta": 0, "xff": 1}
+DTYPES = {1: np.uint8, 2: np.uint16}
+
+# sizes used by the reference's test_codec (compress_testing.hpp:452-463)
+REF_TEST_SIZES = [1, 2, 7, 8, 15, 16, 17, 31, 32, 33, 63, 64, 66, 71, 72, 73, 127, 128,
+                  129, 135, 136, 137, 4096, 4113]
+
+
+def _bind(lib, name, restype, argtypes):
+    f = getattr(lib, name)
+    f.restype = restype
+    f.argtypes = argtypes
+    return f
+
+
+class Oracle:
+    """Our scalar C restatement (oracle/sprintz_oracle.c)."""
+
+    def __init__(self, path=ORACLE_SO):
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} missing: run `make -C oracle` or __graft_entry__.build()")
+        self.lib = C.CDLL(path)
+        self._compress = _bind(self.lib, "oracle_compress_ws", C.c_int64,
+                               [C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint16,
+                                C.c_int, C.POINTER(C.c_size_t)])
+        self._decompress = _bind(self.lib, "oracle_decompress_q", C.c_int64,
+                                 [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int])
+        self._decompress_ex = _bind(self.lib, "oracle_decompress_ex", C.c_int64,
+                                    [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_size_t)])
+        self._bound = _bind(self.lib, "oracle_compress_bound", C.c_size_t,
+                            [C.c_int, C.c_uint32, C.c_uint16])
+        self._compress_chunks = _bind(self.lib, "oracle_compress_chunks", C.c_uint64,
+                                      [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint16,
+                                       C.c_void_p, C.c_size_t, C.c_void_p])
+        self._decompress_chunks = _bind(self.lib, "oracle_decompress_chunks", C.c_uint64,
+                                        [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64,
+                                         C.c_uint32, C.c_void_p])
+
+    def bound(self, esz, n, ndims):
+        return int(self._bound(esz, n, ndims))
+
+    def compress(self, codec, data, ndims, write_size=True):
+        """-> (stream bytes as np.uint8, return value in elements)"""
+        data = np.ascontiguousarray(data)
+        esz = data.dtype.itemsize
+        n = data.size
+        out = np.full(self.bound(esz, n, ndims) + 64, 0xAB, dtype=np.uint8)
+        nb = C.c_size_t(0)
+        ret = self._compress(CODECS[codec], esz, data.ctypes.data, n, out.ctypes.data, ndims,
+                             int(write_size), C.byref(nb))
+        return out[:nb.value].copy(), int(ret)
+
+    def decompress(self, codec, stream, esz, capacity, quirk=0):
+        """-> (decoded elements as np array, return value)"""
+        stream = np.ascontiguousarray(stream, dtype=np.uint8)
+        padded = np.concatenate([stream, np.zeros(64, np.uint8)])
+        out = np.full(capacity + 64, 0xCD, dtype=DTYPES[esz])
+        ret = self._decompress(CODECS[codec], esz, padded.ctypes.data, out.ctypes.data, quirk)
+        return out[:max(int(ret), 0)].copy(), int(ret)
+
+    def stream_nbytes(self, codec, stream, esz, capacity):
+        """byte length implied by the stream's own framing (buffer may be longer)"""
+        stream = np.ascontiguousarray(stream, dtype=np.uint8)
+        out = np.zeros(capacity + 64, dtype=DTYPES[esz])
+        used = C.c_size_t(0)
+        self._decompress_ex(CODECS[codec], esz, stream.ctypes.data, out.ctypes.data, 0, C.byref(used))
+        return int(used.value)
+
+    def compress_chunks(self, codec, data, chunk_len, ndims):
+        """-> (list of per-chunk streams)"""
+        data = np.ascontiguousarray(data)
+        esz = data.dtype.itemsize
+        n = data.size
+        nchunks = (n + chunk_len - 1) // chunk_len
+        stride = self.bound(esz, chunk_len, ndims)
+        dest = np.zeros(nchunks * stride + 64, np.uint8)
+        sizes = np.zeros(nchunks, np.uint32)
+        self._compress_chunks(CODECS[codec], esz, data.ctypes.data, n, chunk_len, ndims,
+                              dest.ctypes.data, stride, sizes.ctypes.data)
+        return [dest[c * stride:c * stride + int(sizes[c])].copy() for c in range(nchunks)]
+
+    def decompress_chunks(self, codec, comp, offsets, esz, chunk_len, total_len):
+        comp = np.ascontiguousarray(comp, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        out = np.zeros(total_len + 64, DTYPES[esz])
+        self._decompress_chunks(CODECS[codec], esz, comp.ctypes.data, offsets.ctypes.data,
+                                len(offsets), chunk_len, out.ctypes.data)
+        return out[:total_len]
+
+
+class Reference:
+    """The compiled reference (oracle/_ref/libsprintz_ref.so); only exists where
+    /root/reference was available at build time (it does travel to the GPU box)."""
+
+    def __init__(self, path=REF_SO):
+        self.lib = C.CDLL(path)
+        self._compress = _bind(self.lib, "ref_compress", C.c_int64,
+                               [C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint16, C.c_int])
+        self._decompress = _bind(self.lib, "ref_decompress", C.c_int64,
+                                 [C.c_int, C.c_int, C.c_void_p, C.c_void_p])
+        self._compress_chunks = _bind(self.lib, "ref_compress_chunks", C.c_uint64,
+                                      [C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint16,
+                                       C.c_void_p, C.c_size_t, C.c_void_p])
+        self._decompress_chunks = _bind(self.lib, "ref_decompress_chunks", C.c_uint64,
+                                        [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64,
+                                         C.c_uint32, C.c_void_p])
+
+    @staticmethod
+    def available():
+        return os.path.exists(REF_SO)
+
+    def compress_raw(self, codec, data, ndims, write_size=True):
+        """-> (whole poison-filled output buffer, return value in elements).
+        Buffer sized as the reference's tests do (compress_testing.hpp:145-147)
+        plus slack for its 8-byte read-modify-write windows."""
+        data = np.ascontiguousarray(data)
+        esz = data.dtype.itemsize
+        n = data.size
+        # the reference reads 8-byte windows past the end of the input rows
+        src = np.concatenate([data.ravel(), np.zeros(64, data.dtype)])
+        cap = (n * 3 // 2 + 64) * esz + 16 * ndims * esz + 256
+        out = np.full(cap, 0xAB, dtype=np.uint8)
+        ret = self._compress(CODECS[codec], esz, src.ctypes.data, n, out.ctypes.data, ndims, int(write_size))
+        return out, int(ret)
+
+    def decompress(self, codec, stream, esz, capacity, ndims_hint=64):
+        stream = np.ascontiguousarray(stream, dtype=np.uint8)
+        padded = np.concatenate([stream, np.zeros(256, np.uint8)])
+        out = np.full(capacity + 64 + 4 * max(ndims_hint, 32), 0xCD, dtype=DTYPES[esz])
+        ret = self._decompress(CODECS[codec], esz, padded.ctypes.data, out.ctypes.data)
+        return out[:max(int(ret), 0)].copy(), int(ret)
+
+
+# ----------------------------------------------------------------- inputs
+
+def gen_known(n, esz):
+    """squares pattern: (i%16)^2 + ((i/16)%16)  (compress_testing.hpp:295-303)"""
+    i = np.arange(n, dtype=np.int64)
+    return (((i % 16) ** 2) + ((i // 16) % 16)).astype(DTYPES[esz])
+
+
+def gen_patterns(n, esz):
+    """the simple patterns of compress_testing.hpp:251-284 (+ a few more)"""
+    dt = DTYPES[esz]
+    i = np.arange(n, dtype=np.int64)
+    top = (1 << (8 * esz)) - 1
+    yield "zeros", np.zeros(n, dt)
+    yield "ones", np.ones(n, dt)
+    yield "max", np.full(n, top, dt)
+    yield "iota", (i % (top + 1)).astype(dt)
+    yield "iota_mod64", (i % 64).astype(dt)
+    yield "alt_0_max", np.where(i % 2 == 0, 0, top).astype(dt)
+    yield "mod3", (i % 3).astype(dt)
+    yield "squares", gen_known(n, esz)
+
+
+def gen_fuzz(rng, n, esz, shift):
+    """random then successive /2 to shrink the range (compress_testing.hpp:347-370)"""
+    top = 1 << (8 * esz)
+    x = rng.integers(0, top, size=n, dtype=np.int64)
+    return (x >> shift).astype(DTYPES[esz])
+
+
+def gen_sparse(rng, n, esz, frac):
+    """mostly zeros (compress_testing.hpp:409-423)"""
+    top = 1 << (8 * esz)
+    x = rng.integers(0, top, size=n, dtype=np.int64)
+    keep = rng.random(n) < frac
+    return np.where(keep, x, 0).astype(DTYPES[esz])
+
+
+def gen_walk(rng, n, ndims, esz, step, flat_every=0):
+    """per-column wrapping random walk, steps uniform in
+    [-step, step]; optionally every `flat_every`-th 64-row span is held at
+    constant slope to trigger RLE."""
+    rows = (n + ndims - 1) // ndims
+    steps = rng.integers(-step, step + 1, size=(rows, ndims), dtype=np.int64)
+    if flat_every:
+        span = (np.arange(rows) // 64) % flat_every == 0
+        steps[span] = 0
+    x = np.cumsum(steps, axis=0) + rng.integers(0, 1 << (8 * esz), size=(1, ndims))
+    x = np.mod(x, 1 << (8 * esz)).astype(DTYPES[esz])
+    return x.ravel()[:n]
