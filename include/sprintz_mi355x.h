@@ -1,0 +1,157 @@
+/*
+ * sprintz_mi355x.h -- C-ABI of libsprintz_mi355x.so: the Sprintz codec hot path
+ * (forecast -> zigzag -> per-block nbits -> bit-pack -> RLE) on AMD MI355X
+ * (gfx950), bit-exact with dblalock/sprintz cpp/Compress.
+ *
+ * Plain C: pointers and sizes only.  Two groups of entry points:
+ *
+ *  (1) Drop-in single-call API.  One symbol per reference function of
+ *      cpp/Compress/sprintz.h:16-32, same argument meaning, same return
+ *      values (ELEMENTS, -1 for ndims == 0, floor'ed for odd 16-bit byte
+ *      lengths -- sprintz_xff_rle.cpp:554), HOST pointers in and out.
+ *      The reference's functions have C++ linkage (default argument
+ *      `write_size=true`); include/sprintz_dropin.hpp re-declares them with
+ *      exactly the reference's C++ signatures on top of these C symbols, so
+ *      a caller such as the lzbench fork (reference README.md:29) relinks
+ *      unchanged.  One call = one chunk = one wavefront's worth of work: it
+ *      is correct, not fast.  See (2).
+ *
+ *  (2) Batched device API.  The unit of GPU parallelism is the CHUNK: an
+ *      independent compress() call on a contiguous slice, exactly what
+ *      lzbench's block-size option does (reference README.md:58 "1KB and
+ *      10KB blocks").  Predictor state resets per chunk, so chunks are
+ *      embarrassingly parallel.  DEVICE pointers, explicit hipStream_t
+ *      (passed as void* so that this header needs no HIP include).
+ *
+ * All functions return 0 / a non-negative count on success and a negative
+ * SPRINTZ_E_* code on failure.  There is NO CPU fallback anywhere in this
+ * library: without a usable HIP device every entry point fails with
+ * SPRINTZ_E_NO_DEVICE.
+ */
+#ifndef SPRINTZ_MI355X_H
+#define SPRINTZ_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPRINTZ_MI355X_ABI_VERSION 1
+
+/* codec ids */
+#define SPRINTZ_CODEC_DELTA 0   /* sprintz_*_delta_*  (sprintz_delta_rle.cpp / sprintz_delta_lowdim.cpp) */
+#define SPRINTZ_CODEC_XFF   1   /* sprintz_*_xff_*    (sprintz_xff_rle.cpp   / sprintz_xff_lowdim.cpp), FIRE */
+
+/* error codes */
+#define SPRINTZ_E_INVALID    (-1)   /* bad argument; also what the reference returns for ndims == 0 (sprintz.cpp:36) */
+#define SPRINTZ_E_NO_DEVICE  (-2)   /* no HIP device / HIP runtime error at init */
+#define SPRINTZ_E_HIP        (-3)   /* a HIP call failed (see sprintz_mi355x_last_error) */
+#define SPRINTZ_E_UNSUPPORTED (-4)  /* ndims above SPRINTZ_MI355X_MAX_NDIMS */
+#define SPRINTZ_E_CORRUPT    (-5)   /* decoder: stream header disagrees with the arguments */
+
+#define SPRINTZ_MI355X_MAX_NDIMS 512
+
+/* Extra readable bytes the decoder may touch after the last stream byte and
+ * the encoder after the last input element (aligned 8-byte windows; the
+ * reference has the same kind of contract). */
+#define SPRINTZ_MI355X_READ_SLACK 16
+
+int         sprintz_mi355x_abi_version(void);
+const char* sprintz_mi355x_last_error(void);     /* thread-local, never NULL */
+
+/* ------------------------------------------------------------------------
+ * (1) Drop-in single-call API (host pointers).  Replaces, one to one:
+ *   sprintz_compress_delta_8b    sprintz.h:18 / sprintz.cpp:57
+ *   sprintz_decompress_delta_8b  sprintz.h:20 / sprintz.cpp:75
+ *   sprintz_compress_xff_8b      sprintz.h:22 / sprintz.cpp:98
+ *   sprintz_decompress_xff_8b    sprintz.h:24 / sprintz.cpp:115
+ *   sprintz_compress_delta_16b   sprintz.h:28 / sprintz.cpp:138
+ *   sprintz_decompress_delta_16b sprintz.h:30 / sprintz.cpp:156
+ *   sprintz_compress_xff_16b     sprintz.h:32 / sprintz.cpp:180
+ *   sprintz_decompress_xff_16b   sprintz.h:34 / sprintz.cpp:197
+ * `dest` capacity: the reference's callers allocate len*3/2+64 elements for
+ * compression and len+64 for decompression (test/compress_testing.hpp:145-147);
+ * this implementation writes at most sprintz_mi355x_compress_bound() bytes /
+ * exactly the decoded elements (it never over-runs like the reference does).
+ * write_size == 0 omits the 8-byte header (sprintz_xff_rle.cpp:119-127).
+ * ---------------------------------------------------------------------- */
+int64_t sprintz_mi355x_compress_delta_8b (const uint8_t*  src, uint32_t len, int8_t*  dest, uint16_t ndims, int write_size);
+int64_t sprintz_mi355x_compress_xff_8b   (const uint8_t*  src, uint32_t len, int8_t*  dest, uint16_t ndims, int write_size);
+int64_t sprintz_mi355x_compress_delta_16b(const uint16_t* src, uint32_t len, int16_t* dest, uint16_t ndims, int write_size);
+int64_t sprintz_mi355x_compress_xff_16b  (const uint16_t* src, uint32_t len, int16_t* dest, uint16_t ndims, int write_size);
+
+int64_t sprintz_mi355x_decompress_delta_8b (const int8_t*  src, uint8_t*  dest);
+int64_t sprintz_mi355x_decompress_xff_8b   (const int8_t*  src, uint8_t*  dest);
+int64_t sprintz_mi355x_decompress_delta_16b(const int16_t* src, uint16_t* dest);
+int64_t sprintz_mi355x_decompress_xff_16b  (const int16_t* src, uint16_t* dest);
+
+/* Headerless decode (the reference's 5-argument kernel form,
+ * sprintz_xff.h:56-58 / sprintz_xff_rle.cpp:1181-1190): needed for streams
+ * written with write_size == 0. */
+int64_t sprintz_mi355x_decompress_noheader(int codec, int elem_bytes, const void* src, void* dest,
+                                           uint16_t ndims, uint32_t ngroups, uint16_t remaining_len);
+
+/* ------------------------------------------------------------------------
+ * (2) Batched device API (device pointers, asynchronous on `hip_stream`).
+ * ---------------------------------------------------------------------- */
+
+/* Worst-case compressed bytes of one chunk (multiple of 16). */
+size_t sprintz_mi355x_compress_bound(int elem_bytes, uint32_t chunk_len, uint16_t ndims);
+
+/* Number of chunks total_len splits into. */
+uint64_t sprintz_mi355x_num_chunks(uint64_t total_len, uint32_t chunk_len);
+
+/* Compress: d_src holds total_len elements, row-major [row][ndims]; chunk c
+ * covers elements [c*chunk_len, min((c+1)*chunk_len, total_len)) and is
+ * compressed exactly as sprintz_compress_<codec>_<w>b(src+c*chunk_len, n,
+ * dest, ndims, true) would.  Chunk c's stream is written at
+ * d_slots + c*slot_stride (slot_stride >= compress_bound, multiple of 16,
+ * d_slots 16-byte aligned); d_sizes[c] receives its exact byte length and
+ * d_rets[c] (optional, may be NULL) the reference's element-count return.
+ * d_src must be readable for SPRINTZ_MI355X_READ_SLACK bytes past its end. */
+int sprintz_mi355x_compress_batch(int codec, int elem_bytes,
+                                  const void* d_src, uint64_t total_len, uint32_t chunk_len, uint16_t ndims,
+                                  void* d_slots, size_t slot_stride,
+                                  uint32_t* d_sizes, int64_t* d_rets, void* hip_stream);
+
+/* Compact slot-strided chunk streams into one dense buffer: exclusive scan of
+ * sizes -> d_offsets[0..nchunks] (d_offsets[nchunks] = total bytes), then a
+ * coalesced copy.  `align` (power of two, 1..16) rounds every chunk start up;
+ * align=1 gives the byte-dense concatenation.  d_dense capacity must be
+ * >= sum(round_up(size, align)) + SPRINTZ_MI355X_READ_SLACK.
+ * d_scan_tmp: scratch of sprintz_mi355x_compact_tmp_bytes(nchunks) bytes. */
+size_t sprintz_mi355x_compact_tmp_bytes(uint64_t nchunks);
+int sprintz_mi355x_compact(const void* d_slots, size_t slot_stride, const uint32_t* d_sizes,
+                           uint64_t nchunks, uint32_t align,
+                           void* d_dense, uint64_t* d_offsets, void* d_scan_tmp, void* hip_stream);
+
+/* Decompress: chunk c's stream starts at d_comp + d_offsets[c] (any byte
+ * alignment) and is decoded exactly as sprintz_decompress_<codec>_<w>b would,
+ * to d_out + c*chunk_len elements.  d_rets[c] (optional) receives the
+ * element count decoded (the reference's return value), or a negative
+ * SPRINTZ_E_* if the stream header's ndims differs from `ndims`.
+ * d_comp must be readable for SPRINTZ_MI355X_READ_SLACK bytes past the last
+ * stream byte. */
+int sprintz_mi355x_decompress_batch(int codec, int elem_bytes,
+                                    const void* d_comp, const uint64_t* d_offsets, uint64_t nchunks,
+                                    uint32_t chunk_len, uint16_t ndims,
+                                    void* d_out, int64_t* d_rets, void* hip_stream);
+
+/* ------------------------------------------------------------------------
+ * Host convenience: chunked codec over host buffers (what lzbench does per
+ * block).  Stages through device memory; PCIe-inclusive by construction.
+ * comp layout: chunk streams concatenated byte-dense; offsets[nchunks+1].
+ * ---------------------------------------------------------------------- */
+int64_t sprintz_mi355x_compress_chunked_host(int codec, int elem_bytes, const void* src, uint64_t total_len,
+                                             uint32_t chunk_len, uint16_t ndims,
+                                             void* comp, size_t comp_capacity, uint64_t* offsets);
+int64_t sprintz_mi355x_decompress_chunked_host(int codec, int elem_bytes, const void* comp,
+                                               const uint64_t* offsets, uint64_t nchunks,
+                                               uint32_t chunk_len, uint16_t ndims, void* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPRINTZ_MI355X_H */

@@ -1,0 +1,20 @@
+"""sprintz_amd -- MI355X-native Sprintz codec hot path.
+
+The product is ``libsprintz_mi355x.so`` (C-ABI: include/sprintz_mi355x.h, HIP
+kernels in sprintz_amd/csrc).  This package is the host-side mirror of the
+reference's interface (cpp/Compress/sprintz.h) on top of it.
+"""
+from . import _lib
+from ._lib import SprintzError, abi_version, last_error
+from .codec import (ChunkedCodec, CompressedBatch, compress_chunked, decompress_chunked, decompress_noheader,
+                    sprintz_compress_delta_8b, sprintz_compress_delta_16b, sprintz_compress_xff_8b,
+                    sprintz_compress_xff_16b, sprintz_decompress_delta_8b, sprintz_decompress_delta_16b,
+                    sprintz_decompress_xff_8b, sprintz_decompress_xff_16b)
+
+__all__ = [
+    "SprintzError", "abi_version", "last_error", "ChunkedCodec", "CompressedBatch",
+    "compress_chunked", "decompress_chunked", "decompress_noheader",
+    "sprintz_compress_delta_8b", "sprintz_compress_delta_16b", "sprintz_compress_xff_8b", "sprintz_compress_xff_16b",
+    "sprintz_decompress_delta_8b", "sprintz_decompress_delta_16b", "sprintz_decompress_xff_8b",
+    "sprintz_decompress_xff_16b",
+]

@@ -1,0 +1,105 @@
+"""ctypes binding of libsprintz_mi355x.so (C-ABI: include/sprintz_mi355x.h).
+
+The library is the product; this module only loads it and declares
+signatures.  There is no Python or CPU fallback: if the shared object is
+missing the import fails loudly, and every entry point returns
+SPRINTZ_E_NO_DEVICE when no HIP device is usable.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsprintz_mi355x.so")
+
+E_INVALID, E_NO_DEVICE, E_HIP, E_UNSUPPORTED, E_CORRUPT = -1, -2, -3, -4, -5
+CODEC_DELTA, CODEC_XFF = 0, 1
+READ_SLACK = 16
+MAX_NDIMS = 512
+
+
+class SprintzError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libsprintz_mi355x error {code}: {msg}")
+        self.code = code
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C sprintz_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # Share torch's HIP runtime when torch is in the process: both libraries
+    # resolve libamdhip64.so.7 by SONAME, so importing torch first makes device
+    # pointers and streams interchangeable.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for pure ctypes users
+        pass
+    return C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+
+lib = _load()
+
+_vp, _i, _u16, _u32, _u64, _i64, _sz = C.c_void_p, C.c_int, C.c_uint16, C.c_uint32, C.c_uint64, C.c_int64, C.c_size_t
+
+
+def _sig(name, restype, *argtypes):
+    f = getattr(lib, name)
+    f.restype = restype
+    f.argtypes = list(argtypes)
+    return f
+
+
+abi_version = _sig("sprintz_mi355x_abi_version", _i)
+_last_error = _sig("sprintz_mi355x_last_error", C.c_char_p)
+
+# (1) drop-in single-call API, host pointers
+compress = {
+    ("delta", 1): _sig("sprintz_mi355x_compress_delta_8b", _i64, _vp, _u32, _vp, _u16, _i),
+    ("xff", 1): _sig("sprintz_mi355x_compress_xff_8b", _i64, _vp, _u32, _vp, _u16, _i),
+    ("delta", 2): _sig("sprintz_mi355x_compress_delta_16b", _i64, _vp, _u32, _vp, _u16, _i),
+    ("xff", 2): _sig("sprintz_mi355x_compress_xff_16b", _i64, _vp, _u32, _vp, _u16, _i),
+}
+decompress = {
+    ("delta", 1): _sig("sprintz_mi355x_decompress_delta_8b", _i64, _vp, _vp),
+    ("xff", 1): _sig("sprintz_mi355x_decompress_xff_8b", _i64, _vp, _vp),
+    ("delta", 2): _sig("sprintz_mi355x_decompress_delta_16b", _i64, _vp, _vp),
+    ("xff", 2): _sig("sprintz_mi355x_decompress_xff_16b", _i64, _vp, _vp),
+}
+decompress_noheader = _sig("sprintz_mi355x_decompress_noheader", _i64, _i, _i, _vp, _vp, _u16, _u32, _u16)
+
+# (2) batched device API
+compress_bound = _sig("sprintz_mi355x_compress_bound", _sz, _i, _u32, _u16)
+num_chunks = _sig("sprintz_mi355x_num_chunks", _u64, _u64, _u32)
+compress_batch = _sig("sprintz_mi355x_compress_batch", _i, _i, _i, _vp, _u64, _u32, _u16, _vp, _sz, _vp, _vp, _vp)
+compact_tmp_bytes = _sig("sprintz_mi355x_compact_tmp_bytes", _sz, _u64)
+compact = _sig("sprintz_mi355x_compact", _i, _vp, _sz, _vp, _u64, _u32, _vp, _vp, _vp, _vp)
+decompress_batch = _sig("sprintz_mi355x_decompress_batch", _i, _i, _i, _vp, _vp, _u64, _u32, _u16, _vp, _vp, _vp)
+
+# host convenience
+compress_chunked_host = _sig("sprintz_mi355x_compress_chunked_host", _i64, _i, _i, _vp, _u64, _u32, _u16, _vp, _sz, _vp)
+decompress_chunked_host = _sig("sprintz_mi355x_decompress_chunked_host", _i64, _i, _i, _vp, _vp, _u64, _u32, _u16, _vp)
+
+EXPORTED_SYMBOLS = [
+    "sprintz_mi355x_abi_version", "sprintz_mi355x_last_error",
+    "sprintz_mi355x_compress_delta_8b", "sprintz_mi355x_compress_xff_8b",
+    "sprintz_mi355x_compress_delta_16b", "sprintz_mi355x_compress_xff_16b",
+    "sprintz_mi355x_decompress_delta_8b", "sprintz_mi355x_decompress_xff_8b",
+    "sprintz_mi355x_decompress_delta_16b", "sprintz_mi355x_decompress_xff_16b",
+    "sprintz_mi355x_decompress_noheader",
+    "sprintz_mi355x_compress_bound", "sprintz_mi355x_num_chunks",
+    "sprintz_mi355x_compress_batch", "sprintz_mi355x_compact_tmp_bytes", "sprintz_mi355x_compact",
+    "sprintz_mi355x_decompress_batch",
+    "sprintz_mi355x_compress_chunked_host", "sprintz_mi355x_decompress_chunked_host",
+]
+
+
+def last_error():
+    return _last_error().decode("utf-8", "replace")
+
+
+def check(rc):
+    """raise on negative return codes of the batched API"""
+    if rc < 0:
+        raise SprintzError(rc, last_error())
+    return rc

@@ -1,0 +1,227 @@
+"""Host-side mirror of the reference interface for the codec path.
+
+Two layers, both thin over the C-ABI (include/sprintz_mi355x.h):
+
+* ``sprintz_compress_delta_8b(src, len, dest, ndims, write_size=True)`` & co:
+  the eight functions of the reference's cpp/Compress/sprintz.h:16-32 with the
+  same names, argument order, units (ELEMENTS) and return values; ``src`` and
+  ``dest`` are caller-owned numpy arrays, as the reference's are caller-owned
+  C buffers.  One call == one chunk on the GPU: correct, not fast.
+
+* ``ChunkedCodec``: the batched device API on torch tensors resident in HBM;
+  this is what bench.py measures.  Chunk == independent compress() call
+  (lzbench block, reference README.md:58).
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+
+_NP = {1: np.uint8, 2: np.uint16}
+_CODEC_ID = {"delta": _lib.CODEC_DELTA, "xff": _lib.CODEC_XFF}
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _compress(codec, esz, src, length, dest, ndims, write_size):
+    src = np.ascontiguousarray(src)
+    if src.dtype.itemsize != esz or src.size < length:
+        raise ValueError("src dtype/size does not match the call")
+    if not dest.flags["C_CONTIGUOUS"] or not dest.flags["WRITEABLE"]:
+        raise ValueError("dest must be a writable contiguous array")
+    need = _lib.compress_bound(esz, length, ndims) if ndims else 8
+    if dest.nbytes < min(need, (length * 3 // 2 + 64) * esz):
+        raise ValueError("dest too small (reference callers allocate len*3/2+64 elements)")
+    return int(_lib.compress[(codec, esz)](_np_ptr(src), length, _np_ptr(dest), ndims, int(bool(write_size))))
+
+
+def _decompress(codec, esz, src, dest):
+    src = np.ascontiguousarray(src)
+    if not dest.flags["C_CONTIGUOUS"] or not dest.flags["WRITEABLE"]:
+        raise ValueError("dest must be a writable contiguous array")
+    return int(_lib.decompress[(codec, esz)](_np_ptr(src), _np_ptr(dest)))
+
+
+# ---- the reference's eight entry points (sprintz.h:16-32)
+def sprintz_compress_delta_8b(src, len, dest, ndims, write_size=True):  # noqa: A002 - reference's name
+    return _compress("delta", 1, src, len, dest, ndims, write_size)
+
+
+def sprintz_decompress_delta_8b(src, dest):
+    return _decompress("delta", 1, src, dest)
+
+
+def sprintz_compress_xff_8b(src, len, dest, ndims, write_size=True):  # noqa: A002
+    return _compress("xff", 1, src, len, dest, ndims, write_size)
+
+
+def sprintz_decompress_xff_8b(src, dest):
+    return _decompress("xff", 1, src, dest)
+
+
+def sprintz_compress_delta_16b(src, len, dest, ndims, write_size=True):  # noqa: A002
+    return _compress("delta", 2, src, len, dest, ndims, write_size)
+
+
+def sprintz_decompress_delta_16b(src, dest):
+    return _decompress("delta", 2, src, dest)
+
+
+def sprintz_compress_xff_16b(src, len, dest, ndims, write_size=True):  # noqa: A002
+    return _compress("xff", 2, src, len, dest, ndims, write_size)
+
+
+def sprintz_decompress_xff_16b(src, dest):
+    return _decompress("xff", 2, src, dest)
+
+
+def decompress_noheader(codec, esz, src, dest, ndims, ngroups, remaining_len):
+    """5-argument kernel form for write_size=False streams (sprintz_xff.h:56-58)."""
+    src = np.ascontiguousarray(src)
+    return int(_lib.decompress_noheader(_CODEC_ID[codec], esz, _np_ptr(src), _np_ptr(dest), ndims, ngroups, remaining_len))
+
+
+# ---- batched device API ------------------------------------------------------
+
+@dataclass
+class CompressedBatch:
+    """Dense container: chunk c's stream is data[offsets[c]:offsets[c]+sizes[c]]
+    (each stream bit-exact with the reference's output for that chunk)."""
+    data: "torch.Tensor"       # uint8, device; readable READ_SLACK bytes past total
+    offsets: "torch.Tensor"    # int64 [nchunks+1], device (offsets[-1] = total bytes incl. alignment padding)
+    sizes: "torch.Tensor"      # int32 [nchunks], device: exact stream bytes
+    nchunks: int
+    total_len: int             # elements before compression
+    chunk_len: int
+    ndims: int
+
+    def total_bytes(self):
+        return int(self.offsets[-1].item())
+
+    def stream_bytes(self):
+        return int(self.sizes.to("cpu", dtype=__import__("torch").int64).sum().item())
+
+
+class ChunkedCodec:
+    """Batched Sprintz codec on one GPU.
+
+    codec: "delta" | "xff"; elem_bytes: 1 | 2; ndims: columns; chunk_len:
+    elements per independent chunk (10 KB of uint16 = 5120).
+    """
+
+    def __init__(self, codec, elem_bytes, ndims, chunk_len, device=None, align=16):
+        import torch
+        if codec not in _CODEC_ID:
+            raise ValueError("codec must be 'delta' or 'xff'")
+        if elem_bytes not in (1, 2):
+            raise ValueError("elem_bytes must be 1 or 2")
+        if not torch.cuda.is_available():
+            raise _lib.SprintzError(_lib.E_NO_DEVICE, "no HIP device visible to torch; there is no CPU fallback")
+        self.torch = torch
+        self.codec, self.esz, self.ndims, self.chunk_len, self.align = codec, elem_bytes, int(ndims), int(chunk_len), align
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.dtype = torch.uint8 if elem_bytes == 1 else torch.uint16
+        self.slot_stride = int(_lib.compress_bound(elem_bytes, self.chunk_len, self.ndims))
+        self._ws = {}
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def workspace(self, nchunks):
+        """slot buffer / sizes / scan scratch, cached per nchunks"""
+        t = self.torch
+        ws = self._ws.get(nchunks)
+        if ws is None:
+            ws = dict(
+                slots=t.empty(nchunks * self.slot_stride, dtype=t.uint8, device=self.device),
+                sizes=t.empty(nchunks, dtype=t.int32, device=self.device),
+                rets=t.empty(nchunks, dtype=t.int64, device=self.device),
+                tmp=t.empty(int(_lib.compact_tmp_bytes(nchunks)), dtype=t.uint8, device=self.device),
+            )
+            self._ws = {nchunks: ws}
+        return ws
+
+    def _padded_view(self, src):
+        """device tensor readable READ_SLACK bytes past its end (copy only if needed)"""
+        t = self.torch
+        flat = src.reshape(-1)
+        buf = t.empty(flat.numel() * self.esz + _lib.READ_SLACK, dtype=t.uint8, device=self.device)
+        buf[:flat.numel() * self.esz] = flat.view(t.uint8)
+        return buf
+
+    def compress_to_slots(self, src_padded_u8, total_len, ws=None):
+        """encode kernel only: src (uint8 view, padded) -> slot-strided streams + sizes"""
+        nchunks = int(_lib.num_chunks(total_len, self.chunk_len))
+        ws = ws or self.workspace(nchunks)
+        _lib.check(_lib.compress_batch(_CODEC_ID[self.codec], self.esz, src_padded_u8.data_ptr(), total_len,
+                                       self.chunk_len, self.ndims, ws["slots"].data_ptr(), self.slot_stride,
+                                       ws["sizes"].data_ptr(), ws["rets"].data_ptr(), self._stream()))
+        return ws
+
+    def compact(self, ws, nchunks, dense=None, offsets=None):
+        t = self.torch
+        if dense is None:
+            dense = t.empty(nchunks * self.slot_stride + _lib.READ_SLACK, dtype=t.uint8, device=self.device)
+        if offsets is None:
+            offsets = t.empty(nchunks + 1, dtype=t.int64, device=self.device)
+        _lib.check(_lib.compact(ws["slots"].data_ptr(), self.slot_stride, ws["sizes"].data_ptr(), nchunks, self.align,
+                                dense.data_ptr(), offsets.data_ptr(), ws["tmp"].data_ptr(), self._stream()))
+        return dense, offsets
+
+    def compress(self, src):
+        """src: device tensor of dtype uint8/uint16, any shape, row-major [.., ndims]."""
+        t = self.torch
+        if src.dtype.itemsize != self.esz or src.dtype.is_floating_point or src.device != self.device:
+            raise ValueError(f"src must be a {self.esz}-byte integer tensor on {self.device}")
+        total_len = src.numel()
+        nchunks = int(_lib.num_chunks(total_len, self.chunk_len))
+        ws = self.compress_to_slots(self._padded_view(src.contiguous()), total_len)
+        dense, offsets = self.compact(ws, nchunks)
+        total = int(offsets[-1].item())
+        data = dense[: total + _lib.READ_SLACK].clone()
+        return CompressedBatch(data, offsets, ws["sizes"].clone(), nchunks, total_len, self.chunk_len, self.ndims)
+
+    def decompress(self, batch, out=None, rets=None):
+        """-> device tensor of total_len elements (chunk c at c*chunk_len)."""
+        t = self.torch
+        if out is None:
+            out = t.empty(batch.nchunks * self.chunk_len, dtype=self.dtype, device=self.device)
+        self.decompress_into(batch.data, batch.offsets, batch.nchunks, out, rets)
+        return out[: batch.total_len]
+
+    def decompress_into(self, data, offsets, nchunks, out, rets=None):
+        """decode kernel only (what the bench times)"""
+        _lib.check(_lib.decompress_batch(_CODEC_ID[self.codec], self.esz, data.data_ptr(), offsets.data_ptr(), nchunks,
+                                         self.chunk_len, self.ndims, out.data_ptr(),
+                                         rets.data_ptr() if rets is not None else None, self._stream()))
+
+
+# ---- host convenience (lzbench-style, PCIe inclusive) ---------------------------
+
+def compress_chunked(codec, data, ndims, chunk_len):
+    """numpy in -> (stream bytes np.uint8, offsets np.uint64[nchunks+1])"""
+    data = np.ascontiguousarray(data)
+    esz = data.dtype.itemsize
+    nchunks = int(_lib.num_chunks(data.size, chunk_len))
+    cap = nchunks * int(_lib.compress_bound(esz, chunk_len, ndims)) + 64
+    comp = np.empty(cap, np.uint8)
+    offsets = np.zeros(nchunks + 1, np.uint64)
+    total = _lib.compress_chunked_host(_CODEC_ID[codec], esz, _np_ptr(data), data.size, chunk_len, ndims,
+                                       _np_ptr(comp), cap, _np_ptr(offsets))
+    _lib.check(total)
+    return comp[:total].copy(), offsets
+
+
+def decompress_chunked(codec, comp, offsets, esz, ndims, chunk_len):
+    comp = np.ascontiguousarray(comp, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    nchunks = len(offsets) - 1
+    out = np.empty(nchunks * chunk_len, _NP[esz])
+    n = _lib.decompress_chunked_host(_CODEC_ID[codec], esz, _np_ptr(comp), _np_ptr(offsets), nchunks, chunk_len, ndims,
+                                     _np_ptr(out))
+    _lib.check(n)
+    return out[:n]

@@ -1,0 +1,544 @@
+// api.hip -- C-ABI of libsprintz_mi355x.so (include/sprintz_mi355x.h): argument
+// checking, lane-mapping selection, kernel launches, the size-scan/compaction
+// kernels and the host-pointer drop-in wrappers.  No codec arithmetic on the
+// host; the only host-side stream logic is the framing walk that sizes the
+// H2D copy of the length-less reference decompress() signature.
+#include "../../include/sprintz_mi355x.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "launch.h"
+
+using namespace sprintz;
+
+namespace {
+
+thread_local std::string g_last_error = "";
+
+int fail(int code, const char* what, hipError_t e = hipSuccess)
+{
+    g_last_error = what;
+    if (e != hipSuccess) {
+        g_last_error += ": ";
+        g_last_error += hipGetErrorString(e);
+    }
+    return code;
+}
+
+#define HIP_TRY(expr)                                              \
+    do {                                                           \
+        hipError_t e_ = (expr);                                    \
+        if (e_ != hipSuccess) return fail(SPRINTZ_E_HIP, #expr, e_); \
+    } while (0)
+
+int ensure_device()
+{
+    static int state = 0;   // 0 unknown, 1 ok, -1 none
+    if (state == 0) {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        state = (e == hipSuccess && n > 0) ? 1 : -1;
+    }
+    if (state < 0) return fail(SPRINTZ_E_NO_DEVICE, "no usable HIP device (libsprintz_mi355x has no CPU fallback)");
+    return 0;
+}
+
+bool is_lowdim(int esz, int D) { return esz == 1 ? D <= 4 : D <= 2; }   // sprintz.cpp:34-50
+
+struct Mapping { int log2DP; int cpl; };
+
+// Choose lanes-per-chunk (DP = 2^k) and columns-per-lane so that DP*CPL >= D
+// with little padding; among mappings within 75% of the best lane utilisation
+// prefer the widest group (better coalescing of the D*esz-byte rows).
+Mapping choose_mapping(int D, bool lowdim)
+{
+    if (lowdim) {
+        int l = 0;
+        while ((1 << l) < D) l++;
+        return {l, 1};
+    }
+    double best = 0;
+    for (int l = 0; l <= 6; l++)
+        for (int c : kCplSet)
+            if ((1 << l) * c >= D) best = std::max(best, (double)D / ((1 << l) * c));
+    Mapping m{6, 8};
+    bool found = false;
+    for (int l = 6; l >= 0 && !found; l--) {
+        for (int c : kCplSet) {
+            if ((1 << l) * c < D) continue;
+            if ((double)D / ((1 << l) * c) >= 0.75 * best) { m = {l, c}; found = true; break; }
+        }
+    }
+    return m;
+}
+
+uint32_t next_pow2(uint32_t x)
+{
+    uint32_t p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+size_t group_bytes_max(int esz, int D)
+{
+    const size_t hb = esz == 1 ? 3 : 4;
+    return (2 * (size_t)D * hb + 7) / 8 + 16 * (size_t)D * esz;
+}
+
+// ---------------------------------------------------------------- compaction kernels
+
+constexpr int kScanBlock = 1024;
+
+__global__ void __launch_bounds__(kScanBlock) scan_local_kernel(const uint32_t* sizes, uint64_t n, uint32_t align,
+                                                                uint64_t* offsets, uint64_t* block_sums)
+{
+    __shared__ uint64_t sh[kScanBlock];
+    const uint64_t i = (uint64_t)blockIdx.x * kScanBlock + threadIdx.x;
+    const uint64_t a = align - 1;
+    uint64_t v = i < n ? (((uint64_t)sizes[i] + a) & ~a) : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < kScanBlock; off <<= 1) {
+        uint64_t t = threadIdx.x >= (unsigned)off ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    if (i < n) offsets[i] = sh[threadIdx.x] - v;
+    if (threadIdx.x == kScanBlock - 1) block_sums[blockIdx.x] = sh[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(kScanBlock) scan_blocks_kernel(uint64_t* block_sums, uint64_t nblocks, uint64_t* total_out)
+{
+    __shared__ uint64_t sh[kScanBlock];
+    __shared__ uint64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint64_t base = 0; base < nblocks; base += kScanBlock) {
+        const uint64_t i = base + threadIdx.x;
+        const uint64_t v = i < nblocks ? block_sums[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < kScanBlock; off <<= 1) {
+            uint64_t t = threadIdx.x >= (unsigned)off ? sh[threadIdx.x - off] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nblocks) block_sums[i] = carry + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == kScanBlock - 1) carry += sh[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+
+__global__ void __launch_bounds__(kScanBlock) scan_add_kernel(uint64_t* offsets, uint64_t n, const uint64_t* block_sums)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * kScanBlock + threadIdx.x;
+    if (i < n) offsets[i] += block_sums[blockIdx.x];
+}
+
+// one wavefront per chunk: slot -> dense
+__global__ void __launch_bounds__(kThreads) compact_copy_kernel(const uint8_t* slots, uint64_t slot_stride, const uint32_t* sizes,
+                                                                const uint64_t* offsets, uint64_t nchunks, uint32_t align,
+                                                                uint8_t* dense)
+{
+    const uint64_t c = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (c >= nchunks) return;
+    const uint8_t* s = slots + c * slot_stride;
+    uint8_t* d = dense + offsets[c];
+    const uint32_t sz = sizes[c];
+    if (align == 16) {
+        const uint32_t nunits = (sz + 15u) >> 4;     // slots are zero padded to 16
+        for (uint32_t u = lane; u < nunits; u += 64) ((uint4*)d)[u] = ((const uint4*)s)[u];
+    } else {
+        for (uint32_t j = lane; j < sz; j += 64) d[j] = s[j];
+    }
+}
+
+// ---------------------------------------------------------------- launch helpers
+
+int check_common(int codec, int esz, uint16_t ndims)
+{
+    if (codec != SPRINTZ_CODEC_DELTA && codec != SPRINTZ_CODEC_XFF) return fail(SPRINTZ_E_INVALID, "codec must be 0 (delta) or 1 (xff)");
+    if (esz != 1 && esz != 2) return fail(SPRINTZ_E_INVALID, "elem_bytes must be 1 or 2");
+    if (ndims == 0) return fail(SPRINTZ_E_INVALID, "ndims == 0 (reference: sprintz.cpp:36 returns -1)");
+    if (ndims > SPRINTZ_MI355X_MAX_NDIMS) return fail(SPRINTZ_E_UNSUPPORTED, "ndims above SPRINTZ_MI355X_MAX_NDIMS");
+    return 0;
+}
+
+int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offsets, uint64_t nchunks,
+                  uint32_t chunk_len, uint16_t ndims, void* d_out, int64_t* d_rets, hipStream_t st,
+                  int noheader, uint32_t nh_ngroups, uint32_t nh_remaining)
+{
+    if (nchunks == 0) return 0;
+    const int D = ndims;
+    const bool lowdim = is_lowdim(esz, D);
+    const Mapping m = choose_mapping(D, lowdim);
+    const int DP = 1 << m.log2DP;
+
+    DecodeArgs a{};
+    a.comp = (const uint8_t*)d_comp;
+    a.offsets = d_offsets;
+    a.nchunks = nchunks;
+    a.chunk_len = chunk_len;
+    a.D = D;
+    a.log2DP = m.log2DP;
+    a.out = d_out;
+    a.rets = d_rets;
+    a.noheader = noheader;
+    a.nh_ngroups = nh_ngroups;
+    a.nh_remaining = nh_remaining;
+
+    // LDS-transposed 16-byte stores need every 8 x D block of the output 16-byte aligned
+    const size_t blk_bytes = (size_t)8 * D * esz;
+    const size_t stride = ((blk_bytes + 15) & ~(size_t)15) + 16;     // +16: spread groups over LDS banks
+    const size_t groups_per_block = kThreads / DP;
+    size_t shmem = 0;
+    a.vec_store = 0;
+    if (blk_bytes % 16 == 0 && ((uintptr_t)d_out % 16) == 0 && ((uint64_t)chunk_len * esz) % 16 == 0 &&
+        stride * groups_per_block <= 64 * 1024) {
+        a.vec_store = 1;
+        a.lds_group_stride = (uint32_t)stride;
+        shmem = stride * groups_per_block;
+    }
+
+    const uint64_t threads = nchunks * (uint64_t)DP;
+    const uint64_t grid = (threads + kThreads - 1) / kThreads;
+    if (grid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
+    hipError_t e = esz == 1 ? launch_decode_w8(codec == SPRINTZ_CODEC_XFF, lowdim, m.cpl, (unsigned)grid, shmem, st, a)
+                            : launch_decode_w16(codec == SPRINTZ_CODEC_XFF, lowdim, m.cpl, (unsigned)grid, shmem, st, a);
+    if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "decode kernel launch", e);
+    return 0;
+}
+
+int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uint32_t chunk_len, uint16_t ndims,
+                  void* d_slots, size_t slot_stride, uint32_t* d_sizes, int64_t* d_rets, hipStream_t st, int write_size)
+{
+    const uint64_t nchunks = sprintz_mi355x_num_chunks(total_len, chunk_len);
+    if (nchunks == 0) return 0;
+    const int D = ndims;
+    const bool lowdim = is_lowdim(esz, D);
+    const Mapping m = choose_mapping(D, lowdim);
+    const int DP = 1 << m.log2DP;
+
+    EncodeArgs a{};
+    a.src = d_src;
+    a.total_len = total_len;
+    a.chunk_len = chunk_len;
+    a.nchunks = nchunks;
+    a.D = D;
+    a.log2DP = m.log2DP;
+    a.slots = (uint8_t*)d_slots;
+    a.slot_stride = slot_stride;
+    a.sizes = d_sizes;
+    a.rets = d_rets;
+    a.write_size = write_size;
+    a.cap = next_pow2((uint32_t)group_bytes_max(esz, D) + 48u);
+    const size_t shmem = (size_t)a.cap * (kThreads / DP);
+    if (shmem > 160 * 1024) return fail(SPRINTZ_E_UNSUPPORTED, "ndims too large for the LDS output ring");
+
+    const uint64_t threads = nchunks * (uint64_t)DP;
+    const uint64_t grid = (threads + kThreads - 1) / kThreads;
+    if (grid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
+    hipError_t e = esz == 1 ? launch_encode_w8(codec == SPRINTZ_CODEC_XFF, lowdim, m.cpl, (unsigned)grid, shmem, st, a)
+                            : launch_encode_w16(codec == SPRINTZ_CODEC_XFF, lowdim, m.cpl, (unsigned)grid, shmem, st, a);
+    if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "encode kernel launch", e);
+    return 0;
+}
+
+// RAII device buffer for the host-pointer wrappers
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+};
+
+// Host framing walk: how many bytes does this stream span and how many
+// elements does it decode to?  Needed because the reference's decompress()
+// signature carries no length (sprintz.h:20) but an H2D copy must be sized.
+// Touches headers and run lengths only -- no sample is decoded here.
+void walk_stream(const uint8_t* s, int esz, int D, uint32_t ngroups, uint32_t remaining, bool lowdim,
+                 uint64_t* nbytes, uint64_t* nelems)
+{
+    const int W = 8 * esz, HB = esz == 1 ? 3 : 4;
+    const uint32_t hdr_bytes = (2u * D * HB + 7u) / 8u;
+    uint64_t pos = 0, blocks = 0;
+    auto field = [&](const uint8_t* h, uint32_t idx) {
+        const uint32_t bit = idx * HB;
+        uint32_t x = h[bit >> 3];
+        if (((bit & 7) + HB) > 8) x |= (uint32_t)h[(bit >> 3) + 1] << 8;
+        return (x >> (bit & 7)) & ((1u << HB) - 1);
+    };
+    for (uint32_t g = 0; g < ngroups; g++) {
+        const uint8_t* h = s + pos;
+        pos += hdr_bytes;
+        for (int slot = 0; slot < 2; slot++) {
+            uint32_t total = 0;
+            for (int d = 0; d < D; d++) {
+                uint32_t f = field(h, slot * D + d);
+                total += (f == (uint32_t)(W - 1)) ? (uint32_t)W : f;
+            }
+            if (total == 0) {
+                uint32_t b0 = s[pos++], len = b0 & 0x7f;
+                if (b0 & 0x80) len |= (uint32_t)s[pos++] << 7;
+                blocks += len;
+            } else {
+                pos += lowdim ? total : 8ull * ((total + 7) / 8);
+                blocks += 1;
+            }
+        }
+    }
+    *nbytes = pos + (uint64_t)remaining * esz;
+    *nelems = blocks * 8ull * D + remaining;
+}
+
+int64_t compress_host(int codec, int esz, const void* src, uint32_t len, void* dest, uint16_t ndims, int write_size)
+{
+    if (ndims == 0) { fail(SPRINTZ_E_INVALID, "ndims == 0"); return -1; }          // sprintz.cpp:36
+    int rc = check_common(codec, esz, ndims);
+    if (rc) return rc;
+    if (len > (1u << 30)) return fail(SPRINTZ_E_UNSUPPORTED, "single call limited to 2^30 elements");
+    if ((rc = ensure_device())) return rc;
+    const size_t bound = sprintz_mi355x_compress_bound(esz, len, ndims);
+    DevBuf d_src, d_slot, d_meta;
+    HIP_TRY(d_src.alloc((size_t)len * esz + SPRINTZ_MI355X_READ_SLACK));
+    HIP_TRY(d_slot.alloc(bound));
+    HIP_TRY(d_meta.alloc(16));
+    HIP_TRY(hipMemcpy(d_src.p, src, (size_t)len * esz, hipMemcpyHostToDevice));
+    uint32_t* d_size = (uint32_t*)d_meta.p;
+    int64_t* d_ret = (int64_t*)((uint8_t*)d_meta.p + 8);
+    rc = encode_launch(codec, esz, d_src.p, len, len ? len : 1, ndims, d_slot.p, bound, d_size, d_ret, nullptr, write_size);
+    if (rc) return rc;
+    if (len == 0) {   // zero elements: header only (reference: :116-124 with len == 0)
+        uint8_t h[8] = {0};
+        h[6] = (uint8_t)(ndims & 0xff); h[7] = (uint8_t)(ndims >> 8);
+        if (write_size) memcpy(dest, h, 8);
+        return write_size ? 8 / esz : 0;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    uint32_t size = 0;
+    int64_t ret = 0;
+    HIP_TRY(hipMemcpy(&size, d_size, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&ret, d_ret, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dest, d_slot.p, size, hipMemcpyDeviceToHost));
+    return ret;
+}
+
+int64_t decompress_host(int codec, int esz, const void* src, void* dest, int noheader, uint16_t nh_ndims,
+                        uint32_t nh_ngroups, uint16_t nh_remaining)
+{
+    const uint8_t* s = (const uint8_t*)src;
+    uint32_t ngroups, remaining;
+    uint16_t ndims;
+    if (!noheader) {
+        uint16_t r16;
+        memcpy(&ngroups, s, 4);
+        memcpy(&r16, s + 4, 2);
+        memcpy(&ndims, s + 6, 2);
+        remaining = r16;
+    } else {
+        ngroups = nh_ngroups; remaining = nh_remaining; ndims = nh_ndims;
+    }
+    if (ndims == 0) { fail(SPRINTZ_E_INVALID, "ndims == 0"); return -1; }          // sprintz.cpp:36
+    int rc = check_common(codec, esz, ndims);
+    if (rc) return rc;
+    if ((rc = ensure_device())) return rc;
+    const uint32_t hlen = noheader ? 0 : 8;
+    uint64_t nbytes = 0, nelems = 0;
+    walk_stream(s + hlen, esz, ndims, ngroups, remaining, is_lowdim(esz, ndims), &nbytes, &nelems);
+    nbytes += hlen;
+    if (nelems == 0) return 0;
+    if (nelems > (1ull << 31)) return fail(SPRINTZ_E_UNSUPPORTED, "single call limited to 2^31 elements");
+    DevBuf d_comp, d_out, d_meta;
+    HIP_TRY(d_comp.alloc(nbytes + SPRINTZ_MI355X_READ_SLACK));
+    HIP_TRY(d_out.alloc(nelems * esz));
+    HIP_TRY(d_meta.alloc(16));
+    HIP_TRY(hipMemcpy(d_comp.p, src, nbytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(d_meta.p, 0, 16));
+    uint64_t* d_off = (uint64_t*)d_meta.p;
+    int64_t* d_ret = (int64_t*)((uint8_t*)d_meta.p + 8);
+    rc = decode_launch(codec, esz, d_comp.p, d_off, 1, (uint32_t)nelems, ndims, d_out.p, d_ret, nullptr,
+                       noheader, ngroups, remaining);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    int64_t ret = 0;
+    HIP_TRY(hipMemcpy(&ret, d_ret, 8, hipMemcpyDeviceToHost));
+    if (ret < 0) return fail((int)ret, "decoder rejected the stream");
+    HIP_TRY(hipMemcpy(dest, d_out.p, (size_t)ret * esz, hipMemcpyDeviceToHost));
+    return ret;
+}
+
+}  // namespace
+
+// =============================================================== exported C-ABI
+extern "C" {
+
+int sprintz_mi355x_abi_version(void) { return SPRINTZ_MI355X_ABI_VERSION; }
+const char* sprintz_mi355x_last_error(void) { return g_last_error.c_str(); }
+
+size_t sprintz_mi355x_compress_bound(int elem_bytes, uint32_t chunk_len, uint16_t ndims)
+{
+    const size_t esz = (size_t)elem_bytes, D = ndims ? ndims : 1;
+    const size_t hb = elem_bytes == 1 ? 3 : 4;
+    const size_t hdr_bytes = (2 * D * hb + 7) / 8;
+    const size_t max_groups = chunk_len / (16 * D) + 1;
+    // header + per group (header + 2 run bytes worst case beyond raw) + raw payload + flush padding
+    const size_t b = 8 + max_groups * (hdr_bytes + 3) + (size_t)chunk_len * esz + 32;
+    return (b + 15) & ~(size_t)15;
+}
+
+uint64_t sprintz_mi355x_num_chunks(uint64_t total_len, uint32_t chunk_len)
+{
+    if (chunk_len == 0) return 0;
+    return (total_len + chunk_len - 1) / chunk_len;
+}
+
+int sprintz_mi355x_compress_batch(int codec, int elem_bytes, const void* d_src, uint64_t total_len, uint32_t chunk_len,
+                                  uint16_t ndims, void* d_slots, size_t slot_stride, uint32_t* d_sizes, int64_t* d_rets,
+                                  void* hip_stream)
+{
+    int rc = check_common(codec, elem_bytes, ndims);
+    if (rc) return rc;
+    if (chunk_len == 0 || chunk_len > (1u << 30)) return fail(SPRINTZ_E_INVALID, "chunk_len must be in 1..2^30");
+    if (!d_src || !d_slots || !d_sizes) return fail(SPRINTZ_E_INVALID, "null device pointer");
+    if (slot_stride % 16 || (uintptr_t)d_slots % 16) return fail(SPRINTZ_E_INVALID, "slots must be 16-byte aligned/strided");
+    if (slot_stride < sprintz_mi355x_compress_bound(elem_bytes, chunk_len, ndims))
+        return fail(SPRINTZ_E_INVALID, "slot_stride below sprintz_mi355x_compress_bound");
+    if ((rc = ensure_device())) return rc;
+    return encode_launch(codec, elem_bytes, d_src, total_len, chunk_len, ndims, d_slots, slot_stride, d_sizes, d_rets,
+                         (hipStream_t)hip_stream, 1);
+}
+
+size_t sprintz_mi355x_compact_tmp_bytes(uint64_t nchunks)
+{
+    return (size_t)((nchunks + kScanBlock - 1) / kScanBlock + 1) * sizeof(uint64_t);
+}
+
+int sprintz_mi355x_compact(const void* d_slots, size_t slot_stride, const uint32_t* d_sizes, uint64_t nchunks, uint32_t align,
+                           void* d_dense, uint64_t* d_offsets, void* d_scan_tmp, void* hip_stream)
+{
+    if (align == 0 || align > 16 || (align & (align - 1))) return fail(SPRINTZ_E_INVALID, "align must be a power of two <= 16");
+    if (!d_slots || !d_sizes || !d_dense || !d_offsets || !d_scan_tmp) return fail(SPRINTZ_E_INVALID, "null device pointer");
+    int rc = ensure_device();
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (nchunks == 0) {
+        HIP_TRY(hipMemsetAsync(d_offsets, 0, 8, st));
+        return 0;
+    }
+    const uint64_t nblocks = (nchunks + kScanBlock - 1) / kScanBlock;
+    uint64_t* tmp = (uint64_t*)d_scan_tmp;
+    hipLaunchKernelGGL(scan_local_kernel, dim3((unsigned)nblocks), dim3(kScanBlock), 0, st, d_sizes, nchunks, align, d_offsets, tmp);
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(kScanBlock), 0, st, tmp, nblocks, d_offsets + nchunks);
+    hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nblocks), dim3(kScanBlock), 0, st, d_offsets, nchunks, tmp);
+    const uint64_t grid = (nchunks * 64 + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL(compact_copy_kernel, dim3((unsigned)grid), dim3(kThreads), 0, st, (const uint8_t*)d_slots,
+                       (uint64_t)slot_stride, d_sizes, d_offsets, nchunks, align, (uint8_t*)d_dense);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int sprintz_mi355x_decompress_batch(int codec, int elem_bytes, const void* d_comp, const uint64_t* d_offsets, uint64_t nchunks,
+                                    uint32_t chunk_len, uint16_t ndims, void* d_out, int64_t* d_rets, void* hip_stream)
+{
+    int rc = check_common(codec, elem_bytes, ndims);
+    if (rc) return rc;
+    if (chunk_len == 0) return fail(SPRINTZ_E_INVALID, "chunk_len == 0");
+    if (!d_comp || !d_offsets || !d_out) return fail(SPRINTZ_E_INVALID, "null device pointer");
+    if ((rc = ensure_device())) return rc;
+    return decode_launch(codec, elem_bytes, d_comp, d_offsets, nchunks, chunk_len, ndims, d_out, d_rets,
+                         (hipStream_t)hip_stream, 0, 0, 0);
+}
+
+// ---- drop-in single-call API (host pointers)
+int64_t sprintz_mi355x_compress_delta_8b(const uint8_t* s, uint32_t n, int8_t* d, uint16_t nd, int ws)    { return compress_host(SPRINTZ_CODEC_DELTA, 1, s, n, d, nd, ws); }
+int64_t sprintz_mi355x_compress_xff_8b(const uint8_t* s, uint32_t n, int8_t* d, uint16_t nd, int ws)      { return compress_host(SPRINTZ_CODEC_XFF, 1, s, n, d, nd, ws); }
+int64_t sprintz_mi355x_compress_delta_16b(const uint16_t* s, uint32_t n, int16_t* d, uint16_t nd, int ws) { return compress_host(SPRINTZ_CODEC_DELTA, 2, s, n, d, nd, ws); }
+int64_t sprintz_mi355x_compress_xff_16b(const uint16_t* s, uint32_t n, int16_t* d, uint16_t nd, int ws)   { return compress_host(SPRINTZ_CODEC_XFF, 2, s, n, d, nd, ws); }
+
+int64_t sprintz_mi355x_decompress_delta_8b(const int8_t* s, uint8_t* d)    { return decompress_host(SPRINTZ_CODEC_DELTA, 1, s, d, 0, 0, 0, 0); }
+int64_t sprintz_mi355x_decompress_xff_8b(const int8_t* s, uint8_t* d)      { return decompress_host(SPRINTZ_CODEC_XFF, 1, s, d, 0, 0, 0, 0); }
+int64_t sprintz_mi355x_decompress_delta_16b(const int16_t* s, uint16_t* d) { return decompress_host(SPRINTZ_CODEC_DELTA, 2, s, d, 0, 0, 0, 0); }
+int64_t sprintz_mi355x_decompress_xff_16b(const int16_t* s, uint16_t* d)   { return decompress_host(SPRINTZ_CODEC_XFF, 2, s, d, 0, 0, 0, 0); }
+
+int64_t sprintz_mi355x_decompress_noheader(int codec, int elem_bytes, const void* src, void* dest, uint16_t ndims,
+                                           uint32_t ngroups, uint16_t remaining_len)
+{
+    return decompress_host(codec, elem_bytes, src, dest, 1, ndims, ngroups, remaining_len);
+}
+
+// ---- host convenience: chunked codec over host buffers
+int64_t sprintz_mi355x_compress_chunked_host(int codec, int elem_bytes, const void* src, uint64_t total_len, uint32_t chunk_len,
+                                             uint16_t ndims, void* comp, size_t comp_capacity, uint64_t* offsets)
+{
+    int rc = check_common(codec, elem_bytes, ndims);
+    if (rc) return rc;
+    if (chunk_len == 0) return fail(SPRINTZ_E_INVALID, "chunk_len == 0");
+    if ((rc = ensure_device())) return rc;
+    const uint64_t nchunks = sprintz_mi355x_num_chunks(total_len, chunk_len);
+    if (nchunks == 0) { offsets[0] = 0; return 0; }
+    const size_t stride = sprintz_mi355x_compress_bound(elem_bytes, chunk_len, ndims);
+    DevBuf d_src, d_slots, d_sizes, d_dense, d_offs, d_tmp;
+    HIP_TRY(d_src.alloc(total_len * elem_bytes + SPRINTZ_MI355X_READ_SLACK));
+    HIP_TRY(d_slots.alloc(stride * nchunks));
+    HIP_TRY(d_sizes.alloc(nchunks * 4));
+    HIP_TRY(d_offs.alloc((nchunks + 1) * 8));
+    HIP_TRY(d_tmp.alloc(sprintz_mi355x_compact_tmp_bytes(nchunks)));
+    HIP_TRY(d_dense.alloc(stride * nchunks + SPRINTZ_MI355X_READ_SLACK));
+    HIP_TRY(hipMemcpy(d_src.p, src, total_len * elem_bytes, hipMemcpyHostToDevice));
+    rc = encode_launch(codec, elem_bytes, d_src.p, total_len, chunk_len, ndims, d_slots.p, stride, (uint32_t*)d_sizes.p,
+                       nullptr, nullptr, 1);
+    if (rc) return rc;
+    rc = sprintz_mi355x_compact(d_slots.p, stride, (const uint32_t*)d_sizes.p, nchunks, 1, d_dense.p, (uint64_t*)d_offs.p,
+                                d_tmp.p, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(offsets, d_offs.p, (nchunks + 1) * 8, hipMemcpyDeviceToHost));
+    const uint64_t total = offsets[nchunks];
+    if (total > comp_capacity) return fail(SPRINTZ_E_INVALID, "comp_capacity too small");
+    HIP_TRY(hipMemcpy(comp, d_dense.p, total, hipMemcpyDeviceToHost));
+    return (int64_t)total;
+}
+
+int64_t sprintz_mi355x_decompress_chunked_host(int codec, int elem_bytes, const void* comp, const uint64_t* offsets,
+                                               uint64_t nchunks, uint32_t chunk_len, uint16_t ndims, void* out)
+{
+    int rc = check_common(codec, elem_bytes, ndims);
+    if (rc) return rc;
+    if (chunk_len == 0) return fail(SPRINTZ_E_INVALID, "chunk_len == 0");
+    if ((rc = ensure_device())) return rc;
+    if (nchunks == 0) return 0;
+    const uint64_t total = offsets[nchunks];
+    DevBuf d_comp, d_offs, d_out, d_rets;
+    HIP_TRY(d_comp.alloc(total + SPRINTZ_MI355X_READ_SLACK));
+    HIP_TRY(d_offs.alloc(nchunks * 8));
+    HIP_TRY(d_out.alloc(nchunks * (uint64_t)chunk_len * elem_bytes));
+    HIP_TRY(d_rets.alloc(nchunks * 8));
+    HIP_TRY(hipMemcpy(d_comp.p, comp, total, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_offs.p, offsets, nchunks * 8, hipMemcpyHostToDevice));
+    rc = decode_launch(codec, elem_bytes, d_comp.p, (const uint64_t*)d_offs.p, nchunks, chunk_len, ndims, d_out.p,
+                       (int64_t*)d_rets.p, nullptr, 0, 0, 0);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<int64_t> rets(nchunks);
+    HIP_TRY(hipMemcpy(rets.data(), d_rets.p, nchunks * 8, hipMemcpyDeviceToHost));
+    int64_t sum = 0;
+    for (uint64_t c = 0; c < nchunks; c++) {
+        if (rets[c] < 0) return fail((int)rets[c], "decoder rejected a chunk stream");
+        sum += rets[c];
+    }
+    // chunks are full except possibly the last: decoded data is contiguous
+    HIP_TRY(hipMemcpy(out, d_out.p, (size_t)sum * elem_bytes, hipMemcpyDeviceToHost));
+    return sum;
+}
+
+}  // extern "C"

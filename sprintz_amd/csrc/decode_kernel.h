@@ -1,0 +1,240 @@
+// decode_kernel.h -- batched Sprintz decoder for gfx950, generic lane mapping.
+//
+// Replaces (bit-exact on every stream the reference encoder emits):
+//   decompress_rowmajor_xff_rle<>           sprintz_xff_rle.cpp:569-1179
+//   decompress_rowmajor_delta_rle<>         sprintz_delta_rle.cpp:418-772
+//   decompress_rowmajor_{delta,xff}_rle_lowdim<>  sprintz_delta_lowdim.cpp:398-794,
+//                                                 sprintz_xff_lowdim.cpp:414-1119
+// The 16-bit FIRE run replay implements the inverse of the reference ENCODER
+// (coefficient << 12); the reference decoder's run path uses << 4
+// (sprintz_xff_rle.cpp:894-901) and does not invert its own encoder there --
+// see DESIGN.md "Reference decoder quirk".
+#pragma once
+
+#include "sprintz_device.h"
+
+namespace sprintz {
+
+struct DecodeArgs {
+    const uint8_t* comp;        // compressed bytes
+    const uint64_t* offsets;    // [nchunks] byte offset of each chunk stream
+    uint64_t nchunks;
+    uint32_t chunk_len;         // elements per decoded chunk slot (output stride)
+    int D;                      // ndims
+    int log2DP;                 // lanes per chunk = 1 << log2DP
+    void* out;                  // decoded elements, chunk c at out + c*chunk_len
+    int64_t* rets;              // optional per-chunk element counts
+    int vec_store;              // 1: LDS-transposed 16-byte stores are legal (alignment checked on host)
+    uint32_t lds_group_stride;  // bytes of LDS per group when vec_store
+    // headerless form (sprintz_xff.h:56-58)
+    int noheader;
+    uint32_t nh_ngroups;
+    uint32_t nh_remaining;
+};
+
+constexpr int64_t kErrCorrupt = -5;
+
+template <int W, bool FIRE, bool LOWDIM, int CPL>
+__global__ void __launch_bounds__(kThreads) decode_kernel(DecodeArgs a)
+{
+    using U = typename Elem<W>::U;
+    constexpr int HB = Elem<W>::HB;
+    constexpr uint32_t MASK = Elem<W>::MASK;
+    constexpr int ESZ = W / 8;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const int DP = 1 << a.log2DP;
+    const int D = a.D;
+    const uint64_t gtid = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+    const uint64_t chunk = gtid >> a.log2DP;
+    const int lane_d = (int)(threadIdx.x & (uint32_t)(DP - 1));
+    if (chunk >= a.nchunks) return;                 // whole groups leave together
+
+    const uint8_t* s = a.comp + a.offsets[chunk];
+    U* const o = (U*)a.out + chunk * (uint64_t)a.chunk_len;
+    uint8_t* const lds = smem + (size_t)(threadIdx.x >> a.log2DP) * a.lds_group_stride;
+
+    // ---- 8-byte stream header (format.h:48-62)
+    uint32_t groups_left, remaining, pos;
+    if (!a.noheader) {
+        const uint32_t w0 = load_u32_any(s), w1 = load_u32_any(s + 4);
+        groups_left = w0;
+        remaining = w1 & 0xffffu;
+        pos = 8;
+        if ((int)(w1 >> 16) != D) {
+            if (lane_d == 0 && a.rets) a.rets[chunk] = kErrCorrupt;
+            return;
+        }
+    } else {
+        groups_left = a.nh_ngroups;
+        remaining = a.nh_remaining;
+        pos = 0;
+    }
+
+    const uint32_t hdr_bytes = (2u * (uint32_t)D * HB + 7u) >> 3;
+    const uint32_t blk_elems = 8u * (uint32_t)D;
+
+    // per-column predictor state (all start at 0: sprintz_xff_rle.cpp:149-152)
+    uint32_t pv[CPL];
+    int pd[CPL], ctr[CPL];
+    uint32_t nb0[CPL], nb1[CPL];     // nbits of the two slots of the current group
+    uint32_t tot0 = 0, tot1 = 0;
+#pragma unroll
+    for (int k = 0; k < CPL; k++) { pv[k] = 0; pd[k] = 0; ctr[k] = 0; nb0[k] = 0; nb1[k] = 0; }
+
+    uint32_t out_elems = 0;
+    int slot = 2;
+    uint32_t run_left = 0;
+    bool corrupt = false;
+
+    for (;;) {
+        uint32_t z[8][CPL];
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int k = 0; k < CPL; k++) z[i][k] = 0;
+
+        bool have = false;
+        if (run_left > 0) {                      // inside a RUN: zero errors (sprintz_xff_rle.cpp:828-958)
+            run_left--;
+            have = true;
+        } else {
+            for (;;) {
+                if (slot == 2) {
+                    if (groups_left == 0) break;
+                    groups_left--;
+                    // group header: 2*D fields of HB bits, LSB-first (sprintz_xff_rle.cpp:713-735)
+                    uint32_t s0 = 0, s1 = 0;
+#pragma unroll
+                    for (int k = 0; k < CPL; k++) {
+                        const int col = lane_d * CPL + k;
+                        uint32_t f0 = 0, f1 = 0;
+                        if (col < D) {
+                            f0 = fetch_bits(s + pos, (uint32_t)col * HB, HB);
+                            f1 = fetch_bits(s + pos, (uint32_t)(D + col) * HB, HB);
+                        }
+                        nb0[k] = f0 == (uint32_t)(W - 1) ? (uint32_t)W : f0;   // :747-749,763-765
+                        nb1[k] = f1 == (uint32_t)(W - 1) ? (uint32_t)W : f1;
+                        s0 += nb0[k];
+                        s1 += nb1[k];
+                    }
+                    // both slot totals in one butterfly
+                    const uint32_t both = group_sum(s0 | (s1 << 16), DP);
+                    tot0 = both & 0xffffu;
+                    tot1 = both >> 16;
+                    pos += hdr_bytes;
+                    slot = 0;
+                }
+                const uint32_t total = slot ? tot1 : tot0;
+                if (total == 0) {                // RUN slot: varint length in blocks (:829-833)
+                    const uint32_t b0 = load_u8(s + pos);
+                    uint32_t len = b0 & 0x7fu;
+                    if (b0 & 0x80u) { len |= load_u8(s + pos + 1) << 7; pos += 2; }
+                    else pos += 1;
+                    slot++;
+                    if (len > 0) { run_left = len - 1; have = true; break; }
+                    // len == 0: padding slot, look at the next one
+                } else {                         // packed block
+                    uint32_t cur[CPL], lane_bits = 0;
+#pragma unroll
+                    for (int k = 0; k < CPL; k++) { cur[k] = slot ? nb1[k] : nb0[k]; lane_bits += cur[k]; }
+                    uint32_t tot_unused;
+                    uint32_t off = group_excl_scan(lane_bits, lane_d, DP, tot_unused);
+                    if constexpr (!LOWDIM) {
+                        // row r: LSB-first bit stream of the D fields, padded to a byte (:961-990)
+                        const uint32_t row_bits = ((total + 7u) >> 3) << 3;
+#pragma unroll
+                        for (int k = 0; k < CPL; k++) {
+#pragma unroll
+                            for (int i = 0; i < 8; i++)
+                                z[i][k] = fetch_bits(s + pos, (uint32_t)i * row_bits + off, cur[k]);
+                            off += cur[k];
+                        }
+                        pos += row_bits;         // 8 rows * row_bytes
+                    } else {
+                        // column-major: nbits[d] bytes per column (sprintz_delta_lowdim.cpp:561-603)
+#pragma unroll
+                        for (int k = 0; k < CPL; k++) {
+#pragma unroll
+                            for (int i = 0; i < 8; i++)
+                                z[i][k] = fetch_bits(s + pos, off * 8u + (uint32_t)i * cur[k], cur[k]);
+                            off += cur[k];
+                        }
+                        pos += total;
+                    }
+                    slot++;
+                    have = true;
+                    break;
+                }
+            }
+        }
+        if (!have) break;
+        if (out_elems + blk_elems > a.chunk_len) { corrupt = true; break; }   // never write outside the chunk slot
+
+        // ---- zigzag^-1 + forecast recurrence, lane-local down each column (:993-1150)
+        uint32_t v[8][CPL];
+#pragma unroll
+        for (int k = 0; k < CPL; k++) {
+            const int coef = FIRE ? fire_coef<W, LOWDIM>(ctr[k]) : 0;
+            int grad = 0;
+            uint32_t pvk = pv[k];
+            int pdk = pd[k];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int err = unzigzag(z[i][k]);
+                const int pred = FIRE ? fire_predict<W, LOWDIM>(pdk, coef) : 0;
+                const int delta = sext<W>(err + pred);
+                if (FIRE && (i & 1)) grad += sign_times(err, pdk);
+                pvk = (pvk + (uint32_t)delta) & MASK;
+                pdk = delta;
+                v[i][k] = pvk;
+            }
+            pv[k] = pvk;
+            pd[k] = pdk;
+            if (FIRE) ctr[k] = wrap_counter<W>(ctr[k] + (sext<W>(grad) >> 2));   // :1120-1128
+        }
+
+        // ---- store the 8 x D block (contiguous 8*D*ESZ bytes of the output)
+        U* const ob = o + out_elems;
+        if (a.vec_store) {
+            U* const l = (U*)lds;
+#pragma unroll
+            for (int k = 0; k < CPL; k++) {
+                const int col = lane_d * CPL + k;
+                if (col < D) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) l[i * D + col] = (U)v[i][k];
+                }
+            }
+            wave_lds_sync();
+            const uint32_t nunits = (blk_elems * ESZ) >> 4;
+            for (uint32_t u = (uint32_t)lane_d; u < nunits; u += (uint32_t)DP)
+                ((uint4*)ob)[u] = ((const uint4*)lds)[u];
+            wave_lds_sync();
+        } else {
+#pragma unroll
+            for (int k = 0; k < CPL; k++) {
+                const int col = lane_d * CPL + k;
+                if (col < D) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) ob[i * D + col] = (U)v[i][k];
+                }
+            }
+        }
+        out_elems += blk_elems;
+    }
+
+    // ---- verbatim tail (:1171)
+    if (!corrupt && out_elems + remaining > a.chunk_len) corrupt = true;
+    if (!corrupt) {
+        const uint8_t* t = s + pos;
+        for (uint32_t j = (uint32_t)lane_d; j < remaining; j += (uint32_t)DP) {
+            uint32_t x = t[(size_t)j * ESZ];
+            if constexpr (ESZ == 2) x |= (uint32_t)t[(size_t)j * 2 + 1] << 8;
+            o[out_elems + j] = (U)x;
+        }
+    }
+    if (lane_d == 0 && a.rets) a.rets[chunk] = corrupt ? kErrCorrupt : (int64_t)out_elems + remaining;
+}
+
+}  // namespace sprintz

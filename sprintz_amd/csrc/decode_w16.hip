@@ -1,0 +1,8 @@
+// decode_w16.hip -- instantiations of the batched decoder for 16-bit elements.
+#include "launch.h"
+namespace sprintz {
+hipError_t launch_decode_w16(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a)
+{
+    SPRINTZ_DISPATCH(decode_kernel, 16)
+}
+}  // namespace sprintz

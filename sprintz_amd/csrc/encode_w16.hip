@@ -1,0 +1,8 @@
+// encode_w16.hip -- instantiations of the batched encoder for 16-bit elements.
+#include "launch.h"
+namespace sprintz {
+hipError_t launch_encode_w16(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a)
+{
+    SPRINTZ_DISPATCH(encode_kernel, 16)
+}
+}  // namespace sprintz

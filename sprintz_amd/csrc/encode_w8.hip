@@ -1,0 +1,8 @@
+// encode_w8.hip -- instantiations of the batched encoder for 8-bit elements.
+#include "launch.h"
+namespace sprintz {
+hipError_t launch_encode_w8(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a)
+{
+    SPRINTZ_DISPATCH(encode_kernel, 8)
+}
+}  // namespace sprintz

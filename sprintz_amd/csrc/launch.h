@@ -1,0 +1,57 @@
+// launch.h -- host-side dispatch onto the template instantiations.  Each
+// (width, direction) pair lives in its own translation unit so that hipcc can
+// build them in parallel.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "decode_kernel.h"
+#include "encode_kernel.h"
+
+namespace sprintz {
+
+// columns-per-lane values that are instantiated (general layout); low-dim uses CPL = 1
+constexpr int kCplSet[] = {1, 2, 3, 4, 5, 6, 8};
+
+hipError_t launch_decode_w8(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a);
+hipError_t launch_decode_w16(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a);
+hipError_t launch_encode_w8(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
+hipError_t launch_encode_w16(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
+
+template <typename K, typename A>
+inline hipError_t launch_one(K kernel, unsigned grid, size_t shmem, hipStream_t st, const A& a)
+{
+    if (shmem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(kThreads), shmem, st, a);
+    return hipGetLastError();
+}
+
+#define SPRINTZ_DISPATCH(KERNEL, W)                                                                   \
+    if (lowdim) {                                                                                     \
+        if (cpl != 1) return hipErrorInvalidValue;                                                    \
+        return fire ? launch_one(KERNEL<W, true, true, 1>, grid, shmem, st, a)                        \
+                    : launch_one(KERNEL<W, false, true, 1>, grid, shmem, st, a);                      \
+    }                                                                                                 \
+    switch (cpl) {                                                                                    \
+        case 1: return fire ? launch_one(KERNEL<W, true, false, 1>, grid, shmem, st, a)               \
+                            : launch_one(KERNEL<W, false, false, 1>, grid, shmem, st, a);             \
+        case 2: return fire ? launch_one(KERNEL<W, true, false, 2>, grid, shmem, st, a)               \
+                            : launch_one(KERNEL<W, false, false, 2>, grid, shmem, st, a);             \
+        case 3: return fire ? launch_one(KERNEL<W, true, false, 3>, grid, shmem, st, a)               \
+                            : launch_one(KERNEL<W, false, false, 3>, grid, shmem, st, a);             \
+        case 4: return fire ? launch_one(KERNEL<W, true, false, 4>, grid, shmem, st, a)               \
+                            : launch_one(KERNEL<W, false, false, 4>, grid, shmem, st, a);             \
+        case 5: return fire ? launch_one(KERNEL<W, true, false, 5>, grid, shmem, st, a)               \
+                            : launch_one(KERNEL<W, false, false, 5>, grid, shmem, st, a);             \
+        case 6: return fire ? launch_one(KERNEL<W, true, false, 6>, grid, shmem, st, a)               \
+                            : launch_one(KERNEL<W, false, false, 6>, grid, shmem, st, a);             \
+        case 8: return fire ? launch_one(KERNEL<W, true, false, 8>, grid, shmem, st, a)               \
+                            : launch_one(KERNEL<W, false, false, 8>, grid, shmem, st, a);             \
+        default: return hipErrorInvalidValue;                                                         \
+    }
+
+}  // namespace sprintz

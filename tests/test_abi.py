@@ -1,0 +1,83 @@
+"""CPU tests of the boundary: the C-ABI library loads, exports every symbol
+include/sprintz_mi355x.h declares, and fails loudly without a GPU (no compute)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    p = os.path.join(ROOT, "sprintz_amd", "libsprintz_mi355x.so")
+    if not os.path.exists(p):
+        import __graft_entry__
+        __graft_entry__.build()
+    return p
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "sprintz_mi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sprintz_mi355x_\w+)\s*\(", text)))
+
+
+def test_header_declares_the_reference_surface():
+    syms = declared_symbols()
+    for codec in ("delta", "xff"):
+        for w in ("8b", "16b"):
+            assert f"sprintz_mi355x_compress_{codec}_{w}" in syms
+            assert f"sprintz_mi355x_decompress_{codec}_{w}" in syms
+    for s in ("sprintz_mi355x_compress_batch", "sprintz_mi355x_decompress_batch", "sprintz_mi355x_compact"):
+        assert s in syms
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+    lib = C.CDLL(lib_path)
+    for s in declared_symbols():
+        assert hasattr(lib, s), f"{s} declared in include/sprintz_mi355x.h but not exported"
+
+
+def test_python_binding_matches_header(lib_path):
+    from sprintz_amd import _lib
+    assert sorted(_lib.EXPORTED_SYMBOLS) == declared_symbols()
+    assert _lib.abi_version() == 1
+
+
+def test_no_cpu_fallback(lib_path):
+    """Without a GPU every entry point must fail loudly, never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import sprintz_amd
+    src = np.arange(4096, dtype=np.uint16)
+    dest = np.zeros(4096 * 3 // 2 + 64, np.int16)
+    rc = sprintz_amd.sprintz_compress_xff_16b(src, src.size, dest, 8)
+    assert rc == sprintz_amd._lib.E_NO_DEVICE
+    assert "no CPU fallback" in sprintz_amd.last_error()
+    assert not dest.any()
+    with pytest.raises(sprintz_amd.SprintzError):
+        sprintz_amd.ChunkedCodec("xff", 2, 8, 5120)
+
+
+def test_ndims_zero_matches_reference(lib_path):
+    """ndims == 0 -> -1 before touching the device (sprintz.cpp:36)"""
+    import sprintz_amd
+    dest = np.zeros(400, np.int8)
+    assert sprintz_amd.sprintz_compress_delta_8b(np.zeros(100, np.uint8), 100, dest, 0) == -1
+
+
+def test_compress_bound_dominates_oracle_sizes(lib_path, oracle):
+    from sprintz_amd import _lib
+    from harness import gen_fuzz
+    rng = np.random.default_rng(0)
+    for esz in (1, 2):
+        for D in (1, 3, 5, 8, 17, 80, 129):
+            for n in (1, 127, 128, 16 * D, 16 * D * 7 + 3, 5120):
+                d = gen_fuzz(rng, n, esz, 0)
+                for codec in ("delta", "xff"):
+                    s, _ = oracle.compress(codec, d, D)
+                    assert s.size + 16 <= _lib.compress_bound(esz, n, D)

@@ -1,0 +1,223 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI, against
+the oracle and the golden vectors.  Bar: bit-exact stream bytes, byte lengths,
+return values and decoded samples.  Nothing here reads /root/reference."""
+import numpy as np
+import pytest
+
+from harness import DTYPES, REF_TEST_SIZES, gen_fuzz, gen_patterns, gen_sparse, gen_walk
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sz():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import sprintz_amd
+    return sprintz_amd
+
+
+def gpu_compress(sz, codec, data, ndims, write_size=True):
+    esz = data.dtype.itemsize
+    fn = getattr(sz, f"sprintz_compress_{codec}_{8 * esz}b")
+    dest = np.full((data.size * 3 // 2 + 64) * esz + 8 * ndims + 256, 0xAB, np.uint8)
+    ret = fn(data, data.size, dest, ndims, write_size)
+    return dest, ret
+
+
+def gpu_decompress(sz, codec, stream, esz, n):
+    fn = getattr(sz, f"sprintz_decompress_{codec}_{8 * esz}b")
+    dest = np.full(n + 64, 0xCD if esz == 1 else 0xCDCD, DTYPES[esz])
+    ret = fn(np.ascontiguousarray(stream), dest)
+    return dest, ret
+
+
+# ------------------------------------------------------------- single-call API
+
+def test_golden_vectors_single_call(sz, golden):
+    """every golden case: GPU encoder output == reference bytes/return value, GPU decoder inverts it"""
+    manifest, arrays = golden
+    for m in manifest:
+        data = arrays[f"in_{m['idx']}"]
+        want = arrays[f"out_{m['idx']}"]
+        dest, ret = gpu_compress(sz, m["codec"], data, m["ndims"])
+        assert ret == m["ret"], (m, sz.last_error())
+        assert np.array_equal(dest[:want.size], want), m
+        assert (dest[want.size + 16:] == 0xAB).all(), "wrote far outside the stream"
+        dec, dret = gpu_decompress(sz, m["codec"], want, m["esz"], data.size)
+        assert dret == data.size, (m, sz.last_error())
+        assert np.array_equal(dec[:data.size], data), m
+        assert (dec[data.size:] == dec[-1]).all(), "decoder wrote past the decoded length"
+
+
+@pytest.mark.parametrize("esz", [1, 2])
+@pytest.mark.parametrize("codec", ["delta", "xff"])
+def test_reference_test_matrix_single_call(sz, oracle, codec, esz):
+    """sizes and input families of the reference's test_codec (compress_testing.hpp:452-486)"""
+    rng = np.random.default_rng(123)
+    for ndims in [1, 2, 3, 4, 5, 7, 8, 9, 16, 17, 33, 64, 65, 80, 129]:
+        for n in REF_TEST_SIZES:
+            cases = [gen_fuzz(rng, n, esz, sh) for sh in (0, 3, 6) if sh < 8 * esz]
+            cases.append(gen_sparse(rng, n, esz, 0.05))
+            cases.append(gen_walk(rng, n, ndims, esz, 8, flat_every=3))
+            if ndims in (1, 8, 129):
+                cases += [d for _, d in gen_patterns(n, esz)]
+            for d in cases:
+                want, wret = oracle.compress(codec, d, ndims)
+                dest, ret = gpu_compress(sz, codec, d, ndims)
+                assert ret == wret, (codec, esz, ndims, n, sz.last_error())
+                assert np.array_equal(dest[:want.size], want), (codec, esz, ndims, n)
+                dec, dret = gpu_decompress(sz, codec, want, esz, n)
+                assert dret == n and np.array_equal(dec[:n], d), (codec, esz, ndims, n)
+
+
+def test_write_size_false_and_headerless_decode(sz, oracle):
+    rng = np.random.default_rng(7)
+    for codec in ("delta", "xff"):
+        for esz in (1, 2):
+            for ndims in (1, 3, 8, 17):
+                n = 16 * ndims * 6 + 5
+                d = gen_walk(rng, n, ndims, esz, 8)
+                want, wret = oracle.compress(codec, d, ndims, write_size=False)
+                dest, ret = gpu_compress(sz, codec, d, ndims, write_size=False)
+                assert ret == wret and np.array_equal(dest[:want.size], want)
+                full, _ = oracle.compress(codec, d, ndims)
+                ngroups = int(np.frombuffer(full[:4].tobytes(), np.uint32)[0])
+                remaining = int(np.frombuffer(full[4:6].tobytes(), np.uint16)[0])
+                out = np.zeros(n + 64, DTYPES[esz])
+                r = sz.decompress_noheader(codec, esz, want, out, ndims, ngroups, remaining)
+                assert r == n and np.array_equal(out[:n], d)
+
+
+def test_long_runs(sz, oracle):
+    """> 127 blocks (2-byte varint) and > 32767 blocks (run cap, sprintz_xff_rle.cpp:71,455)"""
+    for esz, codec, nd in [(1, "delta", 5), (2, "xff", 8), (1, "xff", 2), (2, "delta", 1)]:
+        for nblocks in (130, 32767 + 5):
+            n = nblocks * 8 * nd + 3
+            d = np.zeros(n, DTYPES[esz])
+            d[-2:] = 7
+            want, wret = oracle.compress(codec, d, nd)
+            dest, ret = gpu_compress(sz, codec, d, nd)
+            assert ret == wret and np.array_equal(dest[:want.size], want)
+            dec, dret = gpu_decompress(sz, codec, want, esz, n)
+            assert dret == n and np.array_equal(dec[:n], d)
+
+
+def test_decoder_is_lossless_where_reference_decoder_is_not(sz, golden):
+    manifest, arrays = golden
+    m = [m for m in manifest if not m["ref_roundtrips"]][0]
+    data, stream = arrays[f"in_{m['idx']}"], arrays[f"out_{m['idx']}"]
+    dec, dret = gpu_decompress(sz, "xff", stream, 2, data.size)
+    assert dret == data.size and np.array_equal(dec[:data.size], data)
+
+
+# ------------------------------------------------------------------ batched API
+
+CONFIGS = [
+    # (name, codec, esz, ndims, chunk_len)      BASELINE.json configs, reduced batch
+    ("cfg1", "delta", 1, 1, 1024),
+    ("cfg2", "xff", 2, 8, 5120),
+    ("cfg3_1k", "delta", 1, 80, 1024),          # raw passthrough in the reference (BASELINE.md finding)
+    ("cfg3_10k", "delta", 1, 80, 10240),
+    ("cfg5", "xff", 2, 32, 5120),
+    ("delta16", "delta", 2, 8, 5120),
+    ("xff8", "xff", 1, 8, 4096),
+    ("odd_d", "xff", 2, 5, 5000),               # chunk not a multiple of the block: ragged tails, scalar store path
+    ("lowdim16", "xff", 2, 2, 4096),
+    ("lowdim8", "xff", 1, 3, 3000),
+]
+
+
+@pytest.mark.parametrize("name,codec,esz,ndims,chunk_len", CONFIGS)
+def test_batched_matches_oracle(sz, oracle, name, codec, esz, ndims, chunk_len):
+    import torch
+    rng = np.random.default_rng(abs(hash(name)) % (1 << 31))
+    nchunks = 300
+    total = nchunks * chunk_len - chunk_len // 3          # ragged last chunk
+    parts = [gen_walk(rng, total // 2, ndims, esz, 8, flat_every=4),
+             gen_fuzz(rng, total - total // 2, esz, 3)]
+    data = np.concatenate(parts)
+    cd = sz.ChunkedCodec(codec, esz, ndims, chunk_len, device="cuda:0")
+    batch = cd.compress(torch.from_numpy(data).cuda())
+    want = oracle.compress_chunks(codec, data, chunk_len, ndims)
+    comp, offs, sizes = batch.data.cpu().numpy(), batch.offsets.cpu().numpy(), batch.sizes.cpu().numpy()
+    assert batch.nchunks == len(want) == nchunks
+    for c in range(nchunks):
+        assert sizes[c] == want[c].size, (name, c)
+        assert np.array_equal(comp[offs[c]:offs[c] + sizes[c]], want[c]), (name, c)
+        assert offs[c] % 16 == 0
+    rets = torch.empty(nchunks, dtype=torch.int64, device="cuda:0")
+    out = cd.decompress(batch, rets=rets)
+    assert np.array_equal(out.cpu().numpy(), data), name
+    r = rets.cpu().numpy()
+    assert (r[:-1] == chunk_len).all() and r[-1] == total - (nchunks - 1) * chunk_len
+
+
+def test_batched_decodes_byte_dense_reference_streams(sz, oracle):
+    """streams concatenated with no alignment (odd offsets) decode identically"""
+    import torch
+    rng = np.random.default_rng(11)
+    codec, esz, ndims, chunk_len, nchunks = "xff", 2, 8, 5120, 64
+    data = gen_walk(rng, nchunks * chunk_len, ndims, esz, 30)
+    streams = oracle.compress_chunks(codec, data, chunk_len, ndims)
+    offs = np.zeros(nchunks + 1, np.int64)
+    offs[1:] = np.cumsum([s.size for s in streams])
+    assert any(o % 2 for o in offs)
+    comp = np.concatenate(streams + [np.zeros(16, np.uint8)])
+    cd = sz.ChunkedCodec(codec, esz, ndims, chunk_len, device="cuda:0")
+    out = torch.empty(nchunks * chunk_len, dtype=torch.uint16, device="cuda:0")
+    cd.decompress_into(torch.from_numpy(comp).cuda(), torch.from_numpy(offs).cuda(), nchunks, out)
+    assert np.array_equal(out.cpu().numpy(), data)
+
+
+def test_decoder_rejects_wrong_ndims(sz, oracle):
+    import torch
+    rng = np.random.default_rng(3)
+    data = gen_walk(rng, 4 * 5120, 8, 2, 8)
+    cd8 = sz.ChunkedCodec("xff", 2, 8, 5120, device="cuda:0")
+    batch = cd8.compress(torch.from_numpy(data).cuda())
+    cd16 = sz.ChunkedCodec("xff", 2, 16, 5120, device="cuda:0")
+    rets = torch.zeros(4, dtype=torch.int64, device="cuda:0")
+    out = torch.zeros(4 * 5120, dtype=torch.uint16, device="cuda:0")
+    cd16.decompress_into(batch.data, batch.offsets, 4, out, rets)
+    assert (rets.cpu().numpy() == sz._lib.E_CORRUPT).all()
+    assert not out.view(torch.int16).any().item()
+
+
+def test_host_chunked_convenience(sz, oracle):
+    rng = np.random.default_rng(5)
+    data = gen_walk(rng, 50 * 5120 + 77, 8, 2, 8, flat_every=5)
+    comp, offs = sz.compress_chunked("xff", data, 8, 5120)
+    want = np.concatenate(oracle.compress_chunks("xff", data, 5120, 8))
+    assert np.array_equal(comp, want)
+    dec = sz.decompress_chunked("xff", comp, offs, 2, 8, 5120)
+    assert np.array_equal(dec, data)
+
+
+# ------------------------------------------------ BASELINE.json full sizes (properties)
+
+def test_full_size_cfg2_roundtrip_and_size_checksum(sz, oracle):
+    """131072 chunks x 10 KB (1.34 GB): encode->decode round trip on the
+    GPU, plus stream-size checksum and full byte comparison against the oracle on a
+    strided sample of chunks."""
+    import torch
+    codec, esz, ndims, chunk_len, nchunks = "xff", 2, 8, 5120, 131072
+    g = torch.Generator(device="cuda:0").manual_seed(123)
+    steps = torch.randint(-8, 9, (nchunks, chunk_len // ndims, ndims), device="cuda:0", generator=g, dtype=torch.int32)
+    steps[:, 192:256] = 0                                    # a flat span per chunk: RLE runs
+    x = (torch.cumsum(steps, dim=1) + 20000).to(torch.int16).view(torch.uint16).reshape(-1)
+    del steps
+    cd = sz.ChunkedCodec(codec, esz, ndims, chunk_len, device="cuda:0")
+    batch = cd.compress(x)
+    out = cd.decompress(batch)
+    assert torch.equal(out.view(torch.int16), x.view(torch.int16))
+    sizes = batch.sizes.cpu().numpy()
+    offs = batch.offsets.cpu().numpy()
+    sample = np.arange(0, nchunks, 997)
+    xs = x.view(torch.int16).reshape(nchunks, chunk_len)[torch.from_numpy(sample).cuda()].cpu().numpy().view(np.uint16)
+    comp = batch.data.cpu().numpy()
+    for j, c in enumerate(sample):
+        want, _ = oracle.compress(codec, xs[j], ndims)
+        assert sizes[c] == want.size
+        assert np.array_equal(comp[offs[c]:offs[c] + sizes[c]], want)
+    assert 2.0 < x.numel() * 2 / sizes.sum() < 6.0
