@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""bench.py -- decompress throughput of the Sprintz hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d "cfg2"): uint16 row-major, 8
+variables, FIRE predictor + bit-pack + RLE (sprintz_*_xff_16b), 10 KB chunks
+(5120 elements), 131072 chunks (1.34 GB raw) PER GPU -- weak scaling, rank r
+owns its own chunk range, no data-path collective; one all-gather of
+compressed byte counts builds the global container layout (untimed setup).
+Synthetic data: per-column wrapping random walk, steps uniform in [-8, 8]
+(SURVEY.md 8d generator G1), generated on the device; `--data uniform`
+switches to iid uniform (the paper's worst case, results.tex:142).
+
+One step = one batched decompress of the rank's whole batch, compressed
+streams + offsets table resident in HBM, output written to HBM.
+value = decompressed bytes of all ranks / max-over-ranks wall time (MB/s, 1e6).
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--nchunks", type=int, default=131072, help="chunks per GPU")
+    p.add_argument("--data", default="walk8", choices=["walk8", "walk300", "uniform", "walkflat"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU work per baseline leg")
+    return p.parse_args()
+
+
+def make_data(torch, kind, nchunks, rows, ndims, device, seed):
+    """[nchunks, rows, ndims] uint16 (as int16 bits); every chunk is an independent series"""
+    g = torch.Generator(device=device).manual_seed(seed)
+    if kind == "uniform":
+        x = torch.randint(0, 65536, (nchunks, rows, ndims), device=device, generator=g, dtype=torch.int32)
+    else:
+        step = 300 if kind == "walk300" else 8
+        x = torch.randint(-step, step + 1, (nchunks, rows, ndims), device=device, generator=g, dtype=torch.int32)
+        if kind == "walkflat":
+            x[:, (torch.arange(rows, device=device) // 64) % 4 == 0] = 0
+        start = torch.randint(0, 65536, (nchunks, 1, ndims), device=device, generator=g, dtype=torch.int32)
+        x = torch.cumsum(x, dim=1, dtype=torch.int32) + start
+    x = (x & 0xFFFF)
+    x = torch.where(x >= 32768, x - 65536, x).to(torch.int16)      # same bits as uint16
+    return x.reshape(-1)
+
+
+def cpu_baseline(batch_np, codec_id, esz, chunk_len, ndims, target_s):
+    """Time the CPU path on a bounded sample of the same compressed chunks, on this host's
+    cores.  kind 'reference' = the real dblalock/sprintz AVX2/BMI2 code compiled into
+    oracle/_ref (travels with the repo); falls back to kind 'port' = our scalar C
+    restatement (oracle/liboracle.so) if that is absent."""
+    import ctypes as C
+
+    import numpy as np
+    from tests.harness import ORACLE_SO, REF_SO
+    comp, offsets, nchunks = batch_np
+    if os.path.exists(REF_SO):
+        lib, fn_name, kind = C.CDLL(REF_SO), "ref_decompress_chunks", "reference"
+    elif os.path.exists(ORACLE_SO):
+        lib, fn_name, kind = C.CDLL(ORACLE_SO), "oracle_decompress_chunks", "port"
+    else:
+        return None
+    fn = getattr(lib, fn_name)
+    fn.restype = C.c_uint64
+    fn.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
+    out = np.zeros(nchunks * chunk_len + 4096, np.uint16)
+    chunk_bytes = chunk_len * esz
+
+    def run(lo, hi, reps):
+        for _ in range(reps):
+            fn(codec_id, esz, comp.ctypes.data, offsets[lo:].ctypes.data, hi - lo, chunk_len,
+               out.ctypes.data + lo * chunk_bytes)
+
+    # calibrate one pass on one thread
+    t0 = time.perf_counter(); run(0, nchunks, 1); t1 = time.perf_counter() - t0
+    reps = max(1, int(target_s / max(t1, 1e-6)))
+    best1 = None
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        s = time.perf_counter(); run(0, nchunks, 1); d = time.perf_counter() - s
+        best1 = d if best1 is None else min(best1, d)
+    one_thread = nchunks * chunk_bytes / best1 / 1e6
+    # all cores: ctypes releases the GIL, one contiguous chunk range per thread
+    cores = os.cpu_count() or 1
+    cores = min(cores, nchunks)
+    bounds = [(nchunks * i // cores, nchunks * (i + 1) // cores) for i in range(cores)]
+    reps_mt = max(1, int(reps))
+    bestm = None
+    for _ in range(3):
+        ths = [threading.Thread(target=run, args=(lo, hi, reps_mt)) for lo, hi in bounds]
+        s = time.perf_counter()
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        d = (time.perf_counter() - s) / reps_mt
+        bestm = d if bestm is None else min(bestm, d)
+    all_cores = nchunks * chunk_bytes / bestm / 1e6
+    return {
+        "value": round(all_cores, 1), "unit": "MB/s", "cores": cores, "kind": kind,
+        "value_1thread": round(one_thread, 1),
+        "sample": f"{nchunks} of the benchmark's own compressed chunks ({nchunks * chunk_bytes / 1e6:.0f} MB raw), "
+                  f"best of {reps} passes on 1 thread and best of 3x{reps_mt} passes on {cores} threads "
+                  f"(one chunk range per thread), sprintz_decompress_xff_16b per chunk, data resident in RAM",
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import sprintz_amd
+    from sprintz_amd import _lib
+    from sprintz_amd.dist import gather_layout, max_over_ranks, sum_over_ranks
+
+    codec_name, esz, ndims, chunk_len = "xff", 2, 8, 5120
+    rows = chunk_len // ndims
+    nchunks = args.nchunks
+    chunk_bytes = chunk_len * esz
+
+    # ---------------- setup (untimed): data, GPU compress, global layout
+    x = make_data(torch, args.data, nchunks, rows, ndims, device, seed=123 + rank)
+    codec = sprintz_amd.ChunkedCodec(codec_name, esz, ndims, chunk_len, device=device)
+    src_padded = codec._padded_view(x)
+    ws = codec.workspace(nchunks)
+    # compress timing (secondary metric): encode kernel + compaction
+    dense = torch.empty(nchunks * codec.slot_stride + _lib.READ_SLACK, dtype=torch.uint8, device=device)
+    offsets = torch.empty(nchunks + 1, dtype=torch.int64, device=device)
+    for _ in range(2):
+        codec.compress_to_slots(src_padded, x.numel(), ws)
+        codec.compact(ws, nchunks, dense, offsets)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    creps = 5
+    e0.record()
+    for _ in range(creps):
+        codec.compress_to_slots(src_padded, x.numel(), ws)
+        codec.compact(ws, nchunks, dense, offsets)
+    e1.record()
+    torch.cuda.synchronize()
+    compress_ms = e0.elapsed_time(e1) / creps
+    total_comp = int(offsets[-1].item())
+    stream_bytes = int(ws["sizes"].to(torch.int64).sum().item())
+    comp = dense[: total_comp + _lib.READ_SLACK].clone()
+    del dense
+    layout = gather_layout(total_comp, device)          # the ONLY collective: 8 bytes per rank
+    out = torch.empty(nchunks * chunk_len, dtype=torch.int16, device=device)
+    rets = torch.empty(nchunks, dtype=torch.int64, device=device)
+
+    # correctness of what is about to be timed
+    codec.decompress_into(comp, offsets, nchunks, out, rets)
+    torch.cuda.synchronize()
+    assert torch.equal(out, x), "GPU decode != input"
+    assert bool((rets == chunk_len).all().item())
+
+    # ---------------- timed region
+    for _ in range(args.warmup):
+        codec.decompress_into(comp, offsets, nchunks, out)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record()                                        # torch's current stream == the launch stream
+        codec.decompress_into(comp, offsets, nchunks, out)
+        b.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    wall = max_over_ranks(wall, device)
+    kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / args.steps     # HIP-event average launch duration
+
+    total_raw = sum_over_ranks(nchunks * chunk_bytes, device)
+    total_stream = sum_over_ranks(stream_bytes, device)
+    value = total_raw * args.steps / wall / 1e6
+
+    # ---------------- roofline of the dominant kernel (decode_kernel<16,FIRE,general,CPL=1>)
+    # algorithmic bytes per launch = compressed stream bytes read + 8 B/chunk offsets + raw bytes written
+    algo_bytes = stream_bytes + 8 * nchunks + nchunks * chunk_bytes
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            t = json.load(open(tpath))
+            if t.get("nchunks") == nchunks and t.get("data") == args.data:
+                traffic = t.get("bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    result = {
+        "metric": "decompress MB/s (and ratio) uint16 rowmajor 8-col, 1/2/4/8 MI355X vs CPU ref",
+        "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u16", "data": f"synthetic ({args.data}, seeded, generated on device)",
+        "config": {"workload": "cfg2: uint16 rowmajor, 8 variables, FIRE predictor + bitpack + RLE "
+                               "(sprintz_xff_16b), 10KB chunks",
+                   "chunks_per_gpu": nchunks, "chunk_bytes": chunk_bytes, "raw_bytes_per_gpu": nchunks * chunk_bytes,
+                   "sharding": f"chunks x{world}, no data-path collective"},
+        "ratio": round(total_raw / total_stream, 4),
+        "compress_MBps": round(nchunks * chunk_bytes / (compress_ms * 1e-3) / 1e6, 1),
+        "kernel_ms": round(kernel_ms, 4),
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "algorithmic_bytes_per_launch": algo_bytes},
+        "container_bytes_all_ranks": layout.total_bytes,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        ns = min(nchunks, 8192)
+        offs_np = offsets[: ns + 1].cpu().numpy().astype("uint64")
+        comp_np = comp[: int(offs_np[ns]) + 64].cpu().numpy()
+        cb = cpu_baseline((comp_np, offs_np, ns), 1, esz, chunk_len, ndims, args.cpu_seconds)
+        if cb is not None:
+            result["cpu_baseline"] = cb
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

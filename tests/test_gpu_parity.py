@@ -160,7 +160,7 @@ def test_batched_decodes_byte_dense_reference_streams(sz, oracle):
     import torch
     rng = np.random.default_rng(11)
     codec, esz, ndims, chunk_len, nchunks = "xff", 2, 8, 5120, 64
-    data = gen_walk(rng, nchunks * chunk_len, ndims, esz, 30)
+    data = gen_walk(rng, nchunks * chunk_len, ndims, esz, 30, flat_every=3)   # runs -> 1-byte varints -> odd sizes
     streams = oracle.compress_chunks(codec, data, chunk_len, ndims)
     offs = np.zeros(nchunks + 1, np.int64)
     offs[1:] = np.cumsum([s.size for s in streams])
