@@ -127,9 +127,11 @@ int sprintz_mi355x_compact(const void* d_slots, size_t slot_stride, const uint32
                            uint64_t nchunks, uint32_t align,
                            void* d_dense, uint64_t* d_offsets, void* d_scan_tmp, void* hip_stream);
 
-/* Decompress: chunk c's stream starts at d_comp + d_offsets[c] (any byte
- * alignment) and is decoded exactly as sprintz_decompress_<codec>_<w>b would,
- * to d_out + c*chunk_len elements.  d_rets[c] (optional) receives the
+/* Decompress: chunk c's stream occupies [d_offsets[c], d_offsets[c+1]) of d_comp
+ * (any byte alignment; d_offsets has nchunks+1 entries, the last one being the
+ * end of the last stream -- the layout sprintz_mi355x_compact produces; padding
+ * between streams is allowed) and is decoded exactly as
+ * sprintz_decompress_<codec>_<w>b would, to d_out + c*chunk_len elements.  d_rets[c] (optional) receives the
  * element count decoded (the reference's return value), or a negative
  * SPRINTZ_E_* if the stream header's ndims differs from `ndims`.
  * d_comp must be readable for SPRINTZ_MI355X_READ_SLACK bytes past the last

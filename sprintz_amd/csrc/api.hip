@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -197,6 +198,7 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
     a.noheader = noheader;
     a.nh_ngroups = nh_ngroups;
     a.nh_remaining = nh_remaining;
+    if (const char* d = getenv("SPRINTZ_MI355X_DBG")) a.dbg = atoi(d);
 
     // LDS-transposed 16-byte stores need every 8 x D block of the output 16-byte aligned
     const size_t blk_bytes = (size_t)8 * D * esz;
@@ -211,11 +213,31 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
         shmem = stride * groups_per_block;
     }
 
+    // Fast path (decode_fast.h): general layout, one column per lane, headered stream,
+    // vector stores legal, and the power-of-two group at least half full.
+    int fdp = 4;
+    while (fdp < D) fdp <<= 1;
+    const bool fast = !lowdim && !noheader && D <= 64 && a.vec_store && 2 * D > fdp && !getenv("SPRINTZ_MI355X_NO_FAST");
+    hipError_t e;
+    if (fast) {
+        a.log2DP = 0;
+        while ((1 << a.log2DP) < fdp) a.log2DP++;
+        const size_t fgroups = kThreads / fdp;
+        const size_t fstride = decode_fast_lds_bytes(8 * esz, fdp, D);
+        a.lds_group_stride = (uint32_t)fstride;
+        const uint64_t fthreads = nchunks * (uint64_t)fdp;
+        const uint64_t fgrid = (fthreads + kThreads - 1) / kThreads;
+        if (fgrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
+        e = esz == 1 ? launch_decode_fast_w8(codec == SPRINTZ_CODEC_XFF, fdp, D == fdp, (unsigned)fgrid, fstride * fgroups, st, a)
+                     : launch_decode_fast_w16(codec == SPRINTZ_CODEC_XFF, fdp, D == fdp, (unsigned)fgrid, fstride * fgroups, st, a);
+        if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "decode_fast kernel launch", e);
+        return 0;
+    }
     const uint64_t threads = nchunks * (uint64_t)DP;
     const uint64_t grid = (threads + kThreads - 1) / kThreads;
     if (grid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
-    hipError_t e = esz == 1 ? launch_decode_w8(codec == SPRINTZ_CODEC_XFF, lowdim, m.cpl, (unsigned)grid, shmem, st, a)
-                            : launch_decode_w16(codec == SPRINTZ_CODEC_XFF, lowdim, m.cpl, (unsigned)grid, shmem, st, a);
+    e = esz == 1 ? launch_decode_w8(codec == SPRINTZ_CODEC_XFF, lowdim, m.cpl, (unsigned)grid, shmem, st, a)
+                 : launch_decode_w16(codec == SPRINTZ_CODEC_XFF, lowdim, m.cpl, (unsigned)grid, shmem, st, a);
     if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "decode kernel launch", e);
     return 0;
 }
@@ -361,11 +383,12 @@ int64_t decompress_host(int codec, int esz, const void* src, void* dest, int noh
     DevBuf d_comp, d_out, d_meta;
     HIP_TRY(d_comp.alloc(nbytes + SPRINTZ_MI355X_READ_SLACK));
     HIP_TRY(d_out.alloc(nelems * esz));
-    HIP_TRY(d_meta.alloc(16));
+    HIP_TRY(d_meta.alloc(24));
     HIP_TRY(hipMemcpy(d_comp.p, src, nbytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(d_meta.p, 0, 16));
+    const uint64_t meta[3] = {0, nbytes, 0};               // offsets[0], offsets[1] (= stream end), ret
+    HIP_TRY(hipMemcpy(d_meta.p, meta, 24, hipMemcpyHostToDevice));
     uint64_t* d_off = (uint64_t*)d_meta.p;
-    int64_t* d_ret = (int64_t*)((uint8_t*)d_meta.p + 8);
+    int64_t* d_ret = (int64_t*)((uint8_t*)d_meta.p + 16);
     rc = decode_launch(codec, esz, d_comp.p, d_off, 1, (uint32_t)nelems, ndims, d_out.p, d_ret, nullptr,
                        noheader, ngroups, remaining);
     if (rc) return rc;
@@ -520,11 +543,11 @@ int64_t sprintz_mi355x_decompress_chunked_host(int codec, int elem_bytes, const 
     const uint64_t total = offsets[nchunks];
     DevBuf d_comp, d_offs, d_out, d_rets;
     HIP_TRY(d_comp.alloc(total + SPRINTZ_MI355X_READ_SLACK));
-    HIP_TRY(d_offs.alloc(nchunks * 8));
+    HIP_TRY(d_offs.alloc((nchunks + 1) * 8));
     HIP_TRY(d_out.alloc(nchunks * (uint64_t)chunk_len * elem_bytes));
     HIP_TRY(d_rets.alloc(nchunks * 8));
     HIP_TRY(hipMemcpy(d_comp.p, comp, total, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_offs.p, offsets, nchunks * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_offs.p, offsets, (nchunks + 1) * 8, hipMemcpyHostToDevice));
     rc = decode_launch(codec, elem_bytes, d_comp.p, (const uint64_t*)d_offs.p, nchunks, chunk_len, ndims, d_out.p,
                        (int64_t*)d_rets.p, nullptr, 0, 0, 0);
     if (rc) return rc;

@@ -30,6 +30,7 @@ struct DecodeArgs {
     int noheader;
     uint32_t nh_ngroups;
     uint32_t nh_remaining;
+    int dbg;                    // timing ablations only (SPRINTZ_MI355X_DBG); 0 in production
 };
 
 constexpr int64_t kErrCorrupt = -5;

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include "decode_kernel.h"
+#include "decode_fast.h"
 #include "encode_kernel.h"
 
 namespace sprintz {
@@ -15,6 +16,9 @@ constexpr int kCplSet[] = {1, 2, 3, 4, 5, 6, 8};
 
 hipError_t launch_decode_w8(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a);
 hipError_t launch_decode_w16(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a);
+// fast path: general layout, one column per lane, LDS-transposed stores (see decode_fast.h)
+hipError_t launch_decode_fast_w8(bool fire, int dp, bool exact, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a);
+hipError_t launch_decode_fast_w16(bool fire, int dp, bool exact, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a);
 hipError_t launch_encode_w8(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
 hipError_t launch_encode_w16(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
 
@@ -51,6 +55,23 @@ inline hipError_t launch_one(K kernel, unsigned grid, size_t shmem, hipStream_t 
                             : launch_one(KERNEL<W, false, false, 6>, grid, shmem, st, a);             \
         case 8: return fire ? launch_one(KERNEL<W, true, false, 8>, grid, shmem, st, a)               \
                             : launch_one(KERNEL<W, false, false, 8>, grid, shmem, st, a);             \
+        default: return hipErrorInvalidValue;                                                         \
+    }
+
+#define SPRINTZ_FAST_CASE(KERNEL, W, DPV)                                                            \
+    case DPV:                                                                                         \
+        if (exact) return fire ? launch_one(KERNEL<W, true, DPV, true>, grid, shmem, st, a)           \
+                               : launch_one(KERNEL<W, false, DPV, true>, grid, shmem, st, a);         \
+        return fire ? launch_one(KERNEL<W, true, DPV, false>, grid, shmem, st, a)                     \
+                    : launch_one(KERNEL<W, false, DPV, false>, grid, shmem, st, a);
+
+#define SPRINTZ_DISPATCH_FAST(KERNEL, W)                                                              \
+    switch (dp) {                                                                                     \
+        SPRINTZ_FAST_CASE(KERNEL, W, 4)                                                               \
+        SPRINTZ_FAST_CASE(KERNEL, W, 8)                                                               \
+        SPRINTZ_FAST_CASE(KERNEL, W, 16)                                                              \
+        SPRINTZ_FAST_CASE(KERNEL, W, 32)                                                              \
+        SPRINTZ_FAST_CASE(KERNEL, W, 64)                                                              \
         default: return hipErrorInvalidValue;                                                         \
     }
 
