@@ -10,9 +10,9 @@
 //   * INPUT.  A group (DP lanes = one chunk) reads its compressed stream
 //     strictly sequentially, so it is read AHEAD of the parser: one 16-byte
 //     global load per lane per refill (DP*16 = one "unit") is issued a whole
-//     step before its bytes are parsed and parked in a per-group LDS ring of 4
-//     units (+ an apron that mirrors the ring head, so that a step's reads
-//     never wrap).  Headers, run lengths and bit fields are then LDS reads
+//     group (16 rows) before its bytes are parsed and parked in a per-group LDS
+//     ring of 6 units (+ an apron that mirrors the ring head, so that a group's
+//     reads never wrap).  Headers, run lengths and bit fields are then LDS reads
 //     (aligned ds_read2_b32 + v_alignbyte_b32) -- no global load sits on the
 //     parse critical path.
 //   * FIELDS. rows are byte aligned, so the in-byte shift of a column is the
@@ -34,18 +34,33 @@ typedef uint32_t __attribute__((aligned(1), may_alias)) u32_unaligned;
 typedef uint16_t __attribute__((aligned(1), may_alias)) u16_unaligned;
 struct __attribute__((aligned(1), packed)) u128_unaligned { uint32_t x, y, z, w; };
 
-// 32 bits at ANY byte address of LDS.  gfx950 replays a misaligned ds_read_b32
-// (SQ_LDS_UNALIGNED_STALL: it made the first ring version 1.7x slower than the
-// global-load kernel), so: one aligned ds_read2_b32 + v_alignbyte_b32, which takes
-// the byte phase straight from the low two address bits (verified on hardware,
-// tools/probes/alignbyte.hip).
-__device__ __forceinline__ uint32_t lds_rd32(const uint8_t* p)
+typedef __attribute__((address_space(3))) const uint32_t lds_u32;
+typedef __attribute__((address_space(3))) const uint8_t lds_u8;
+
+// 32 bits at ANY byte address `a` of LDS.  gfx950 replays a misaligned
+// ds_read_b32 (SQ_LDS_UNALIGNED_STALL: it made the first ring version 1.7x
+// slower than the global-load kernel), so: one aligned ds_read2_b32 +
+// v_alignbyte_b32, which takes the byte phase straight from the low two address
+// bits (verified on hardware, tools/probes/alignbyte.hip).
+__device__ __forceinline__ uint32_t lds_rd32(uint32_t a)
 {
-    const uint32_t a = (uint32_t)(uintptr_t)p;
-    const uint32_t* q = (const uint32_t*)(p - (a & 3u));
+    lds_u32* q = (lds_u32*)(uintptr_t)(a & ~3u);
     return __builtin_amdgcn_alignbyte(q[1], q[0], a);
 }
+__device__ __forceinline__ uint32_t lds_rd8(uint32_t a) { return *(lds_u8*)(uintptr_t)a; }
+__device__ __forceinline__ uint32_t lds_addr(const void* p)
+{
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
 
+// 24-bit multiply-add / multiply, pinned to the full-rate opcodes (hipcc turns
+// __mul24 of values it cannot range-prove into quarter-rate v_mul_lo_u32)
+__device__ __forceinline__ int mad24(int a, int b, int c)
+{
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 // sign(x) in {-1, 0, 1} = clamp(x, -1, 1): one v_med3_i32 (hipcc lowers the C++
 // min/max form to two cmp+cndmask pairs)
 __device__ __forceinline__ int sign_of(int x)
@@ -55,6 +70,10 @@ __device__ __forceinline__ int sign_of(int x)
     return s;
 }
 
+// Where the two per-step block stores go before a lane has produced its first
+// block (the stores are unconditional, see the bottom of the group loop).
+static __device__ uint4 g_decode_sink[kThreads];
+
 // EXACT: ndims == DP (a power of two), so every size is a compile-time constant.
 template <int W, bool FIRE, int DP, bool EXACT>
 __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
@@ -63,12 +82,15 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     constexpr int HB = Elem<W>::HB;
     constexpr int ESZ = W / 8;
     constexpr int LOG2DP = DP == 4 ? 2 : DP == 8 ? 3 : DP == 16 ? 4 : DP == 32 ? 5 : 6;
-    constexpr uint32_t UNIT = DP * 16;                     // bytes one refill brings in
-    constexpr uint32_t RB = 4 * UNIT;                      // ring bytes (power of two)
+    constexpr uint32_t UNIT = DP * 16;                     // bytes one refill unit brings in
     constexpr uint32_t HDRMAX = (2 * DP * HB + 7) / 8;
     constexpr uint32_t BLKMAX = 8 * DP * ESZ;              // largest block payload
-    constexpr uint32_t APRON = (HDRMAX + BLKMAX + 8 + 15) & ~15u;   // one step never reads past r0 + APRON
-    static_assert(RB - UNIT >= 2 * (HDRMAX + BLKMAX + 2) + 3, "ring too small for one step of read-ahead");
+    constexpr uint32_t CG = HDRMAX + 2 * BLKMAX + 4;       // most bytes one group can consume
+    constexpr uint32_t NPEND = (CG + UNIT - 1) / UNIT;     // units requested per group step (2 or 3)
+    constexpr uint32_t RB = 6 * UNIT;                      // ring bytes (6 units: 4 workgroups per CU at D = 8)
+    constexpr uint32_t APRON = (CG + 8 + 15) & ~15u;       // a group never reads past its start + APRON
+    static_assert(RB - UNIT >= 2 * CG + 3, "ring too small for one group of read-ahead");
+    static_assert(NPEND <= 3, "pending registers");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     const int D = EXACT ? DP : a.D;
@@ -77,54 +99,55 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     const int lane_d = (int)(threadIdx.x & (uint32_t)(DP - 1));
     if (chunk >= a.nchunks) return;
 
-    // LDS carve: [ring RB | apron APRON | block staging]
-    uint8_t* const ring = smem + (size_t)(threadIdx.x >> LOG2DP) * a.lds_group_stride;
-    uint8_t* const stage = ring + RB + APRON;
+    // LDS carve per group: [ring RB | apron APRON | block staging]
+    uint8_t* const ringp = smem + (size_t)(threadIdx.x >> LOG2DP) * a.lds_group_stride;
+    const uint32_t ring = lds_addr(ringp);                 // LDS byte address of the ring
+    uint8_t* const stage = ringp + RB + APRON;
 
-    // stream geometry: everything below is relative to gbase (16-byte aligned down)
+    // stream geometry: offsets relative to gbase (stream start aligned down to 16)
     const uint64_t off0 = a.offsets[chunk];
     const uint8_t* const gbase = a.comp + (off0 & ~(uint64_t)15);
-    const uint32_t lim = (uint32_t)(a.offsets[chunk + 1] - (off0 & ~(uint64_t)15));   // first byte not ours
-    uint32_t rp = (uint32_t)(off0 & 15);                   // parse cursor
-    uint32_t fill = 0;                                     // bytes requested from HBM so far
+    const uint32_t lane16 = (uint32_t)lane_d * 16u;
+    const uint8_t* gp = gbase + lane16;                    // this lane's next 16 bytes to request
+    int32_t gleft = (int32_t)(a.offsets[chunk + 1] - (off0 & ~(uint64_t)15)) - (int32_t)lane16;   // > 0: still ours
+    uint32_t rp = (uint32_t)(off0 & 15);                   // parse cursor (stream offset)
+    uint32_t rofs = rp;                                    // parse cursor (ring offset, rp mod RB)
+    uint32_t ahead;                                        // bytes requested and not yet parsed
+    uint32_t cofs = lane16;                                // ring offset where this lane parks its next 16 bytes
     U* ob = (U*)a.out + chunk * (uint64_t)a.chunk_len;     // output cursor
     const bool col_ok = lane_d < D;
-    const uint32_t lane16 = (uint32_t)lane_d * 16u;
 
-    uint4 pend0 = make_uint4(0, 0, 0, 0), pend1 = make_uint4(0, 0, 0, 0);
-    uint32_t npend = 0, fill_c = 0;                        // pending units and where they go
+    uint4 pend[3];
+    uint32_t npend = 0;
 
-    auto gload16 = [&](uint32_t rel) -> uint4 {            // 16 bytes of the stream (clamped to its end + slack)
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (rel < lim) {
-            const u128_unaligned t = *(const u128_unaligned*)(gbase + rel);
-            v = make_uint4(t.x, t.y, t.z, t.w);
+    // Request one unit.  The load is UNCONDITIONAL (address clamped to the stream
+    // start when the unit is not wanted or lies past the stream end) so that the
+    // compiler can count the VMEM operations of a step exactly -- see the wait
+    // discussion at the bottom of the group loop.
+    auto request = [&](uint4& v, bool wanted) {
+        const uint8_t* src = (wanted && gleft > 0) ? gp : gbase;
+        const u128_unaligned t = *(const u128_unaligned*)src;
+        v = make_uint4(t.x, t.y, t.z, t.w);
+        if (wanted) {
+            gp += UNIT;
+            gleft -= (int32_t)UNIT;
         }
-        return v;
     };
-    auto commit = [&](const uint4& v, uint32_t at) {       // park one unit in the ring (+ mirror the ring head)
-        const uint32_t ro = (at & (RB - 1)) + lane16;
-        *(uint4*)(ring + ro) = v;
-        if (ro < APRON) *(uint4*)(ring + RB + ro) = v;
-    };
-    // refill point: land what was requested a step ago, request what now fits
-    auto refill = [&]() {
-        if (npend >= 1) commit(pend0, fill_c);
-        if (npend >= 2) commit(pend1, fill_c + UNIT);
-        const uint32_t room = rp + RB - fill;              // bytes of ring not needed by the parser any more
-        const bool c0 = room >= UNIT, c1 = room >= 2 * UNIT;
-        fill_c = fill;
-        if (c0) pend0 = gload16(fill + lane16);
-        if (c1) pend1 = gload16(fill + UNIT + lane16);
-        npend = (uint32_t)c0 + (uint32_t)c1;
-        fill += npend * UNIT;
-        wave_lds_sync();
+    auto commit = [&](const uint4& v) {                    // park 16 bytes in the ring (+ mirror the ring head)
+        *(uint4*)(ringp + cofs) = v;
+        if (cofs < APRON) *(uint4*)(ringp + RB + cofs) = v;
+        cofs += UNIT;
+        if (cofs >= RB) cofs -= RB;
     };
 
     // ---- prologue: fill the ring, read the 8-byte stream header (format.h:48-62)
 #pragma unroll
-    for (uint32_t u = 0; u < RB / UNIT; u++) commit(gload16(u * UNIT + lane16), u * UNIT);
-    fill = RB;
+    for (uint32_t u = 0; u < RB / UNIT; u++) {
+        uint4 v;
+        request(v, true);
+        commit(v);
+    }
+    ahead = RB - rp;
     wave_lds_sync();
     uint32_t groups_left, remaining;
     {
@@ -132,6 +155,8 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         groups_left = w0;
         remaining = w1 & 0xffffu;
         rp += 8;
+        rofs += 8;
+        ahead -= 8;
         if ((int)(w1 >> 16) != D) {
             if (lane_d == 0 && a.rets) a.rets[chunk] = kErrCorrupt;
             return;
@@ -151,19 +176,96 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     uint32_t out_left = a.chunk_len;                       // capacity guard (elements)
     bool corrupt = false;
 
-    // store the staged 8 x D block (contiguous in the output) and advance
-    auto flush_block = [&]() {
+    // ---- per-block workers ------------------------------------------------------
+    // The staged 8 x D block is contiguous in the output.  Packed blocks are read
+    // back from LDS into `held[slot]` and stored at the BOTTOM of the group step by
+    // two unconditional dwordx4 stores (a slot that produced no packed block
+    // re-stores the previous one: same lane, same address, same data).
+    uint4 held[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+    uint4* held_dst[2] = {&g_decode_sink[threadIdx.x], &g_decode_sink[threadIdx.x]};
+    // after the 8 rows sit in `stage`; slot < 0: store right away (run blocks)
+    auto stage_out = [&](int slot) {
         wave_lds_sync();
-        for (uint32_t u = (uint32_t)lane_d; u < (blk_bytes >> 4); u += DP) ((uint4*)ob)[u] = ((const uint4*)stage)[u];
+        if (DP * 16 >= BLKMAX && slot >= 0) {
+            held[slot] = *(const uint4*)(stage + (lane16 < blk_bytes ? lane16 : 0u));
+            held_dst[slot] = (uint4*)((uint8_t*)ob + (lane16 < blk_bytes ? lane16 : 0u));
+        } else {
+            for (uint32_t u = (uint32_t)lane_d; u < (blk_bytes >> 4); u += DP) ((uint4*)ob)[u] = ((const uint4*)stage)[u];
+        }
         wave_lds_sync();
         ob += blk_elems;
+    };
+    auto run_blocks = [&](uint32_t len) {                  // RUN slot: `len` blocks of zero error (:828-958)
+        for (; len > 0; len--) {
+            if (out_left < blk_elems) { corrupt = true; break; }
+            out_left -= blk_elems;
+            const int coef = FIRE ? fire_coef<W, false>(ctr) : 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int delta = FIRE ? __builtin_amdgcn_sbfe(mad24(pd, coef, 0), W, W) : 0;
+                pv += (uint32_t)delta;
+                pd = delta;
+                if (col_ok) *(U*)(stage_col + i * row_stride) = (U)pv;
+            }
+            stage_out(-1);
+        }
+    };
+    auto fetch_rows = [&](uint32_t (&z)[8], uint32_t at, uint32_t off, uint32_t nb, uint32_t row_bytes) {
+        uint32_t p = at + (off >> 3);
+        const uint32_t sh = off & 7u;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            z[i] = __builtin_amdgcn_ubfe(lds_rd32(p), sh, nb);
+            p += row_bytes;
+        }
+    };
+    auto packed_block = [&](const uint32_t (&z)[8], int slot) {   // zigzag^-1 + forecast recurrence (:993-1150)
+        if (out_left < blk_elems) { corrupt = true; return; }
+        out_left -= blk_elems;
+        int grad = 0;
+        const int coef = FIRE ? fire_coef<W, false>(ctr) : 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int err = (int)(z[i] >> 1) ^ __builtin_amdgcn_sbfe((int)z[i], 0, 1);
+            int delta;
+            if constexpr (FIRE) {
+                if (i & 1) grad = mad24(sign_of(err), pd, grad);
+                delta = __builtin_amdgcn_sbfe(mad24(pd, coef, err << W), W, W);
+            } else {
+                delta = err;
+            }
+            pv += (uint32_t)delta;
+            pd = delta;
+            if (col_ok) *(U*)(stage_col + i * row_stride) = (U)pv;
+        }
+        if constexpr (FIRE) ctr = wrap_counter<W>(ctr + __builtin_amdgcn_sbfe(grad, 2, W - 2));   // sext_W(grad) >> 2
+        stage_out(slot);
+    };
+    auto run_length = [&](uint32_t at, uint32_t& nbytes) -> uint32_t {   // varint in blocks (:829-833)
+        const uint32_t b0 = lds_rd8(at);
+        uint32_t len = b0 & 0x7fu;
+        nbytes = 1;
+        if (b0 & 0x80u) { len |= lds_rd8(at + 1) << 7; nbytes = 2; }
+        return len;
     };
 
     while (groups_left > 0 && !corrupt) {
         groups_left--;
-        refill();
+        // ---- request the units that fit now; they are parked at the bottom of this step
+        {
+            const uint32_t room = RB - ahead;              // ring bytes the parser no longer needs
+            npend = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < NPEND; k++) {
+                const bool wanted = room >= (k + 1) * UNIT;
+                request(pend[k], wanted);
+                npend += wanted ? 1u : 0u;
+            }
+            ahead += npend * UNIT;
+        }
+
         // ---- group header: 2*D fields of HB bits (sprintz_xff_rle.cpp:713-735)
-        const uint8_t* r = ring + (rp & (RB - 1));
+        const uint32_t r = ring + rofs;                    // LDS address of the parse cursor
         uint32_t f0 = 0, f1 = 0;
         if (col_ok) {
             f0 = __builtin_amdgcn_ubfe(lds_rd32(r + hbyte0), hsh0, HB);
@@ -174,75 +276,39 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         const uint32_t nb_both = f0 | (f1 << 16);
         uint32_t tot_both;
         const uint32_t excl_both = group_scan<DP>(nb_both, lane_d, tot_both);
-        r += hdr_bytes;
-        rp += hdr_bytes;
+        const uint32_t tot0 = tot_both & 0xffffu, tot1 = tot_both >> 16;
 
-#pragma unroll
-        for (int slot = 0; slot < 2; slot++) {
-            if (slot == 1) {
-                refill();
-                r = ring + (rp & (RB - 1));
-            }
-            const uint32_t total = slot ? (tot_both >> 16) : (tot_both & 0xffffu);
-            if (total == 0) {
-                // ---- RUN slot: `len` blocks of zero error (:828-958); len == 0 is padding
-                const uint32_t b0 = r[0];
-                uint32_t len = b0 & 0x7fu;
-                uint32_t used = 1;
-                if (b0 & 0x80u) { len |= (uint32_t)r[1] << 7; used = 2; }
-                r += used;
-                rp += used;
-                for (; len > 0; len--) {
-                    if (out_left < blk_elems) { corrupt = true; break; }
-                    out_left -= blk_elems;
-                    const int coef = FIRE ? fire_coef<W, false>(ctr) : 0;
-#pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        const int delta = FIRE ? __builtin_amdgcn_sbfe(__mul24(pd, coef), W, W) : 0;
-                        pv += (uint32_t)delta;
-                        pd = delta;
-                        if (col_ok) *(U*)(stage_col + i * row_stride) = (U)pv;
-                    }
-                    flush_block();
-                }
-            } else {
-                // ---- packed block: 8 byte-aligned rows of `total` bits (:961-1150)
-                if (out_left < blk_elems) { corrupt = true; break; }
-                out_left -= blk_elems;
-                const uint32_t nb = slot ? (nb_both >> 16) : (nb_both & 0xffffu);
-                const uint32_t off = slot ? (excl_both >> 16) : (excl_both & 0xffffu);
-                const uint32_t row_bytes = (total + 7u) >> 3;
-                const uint8_t* p = r + (off >> 3);
-                const uint32_t sh = off & 7u;
-                uint32_t z[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    z[i] = __builtin_amdgcn_ubfe(lds_rd32(p), sh, nb);
-                    p += row_bytes;
-                }
-                r += row_bytes * 8u;
-                rp += row_bytes * 8u;
+        // ---- lay out both slots, then fetch both before computing either
+        const uint32_t at0 = r + hdr_bytes;
+        uint32_t len0 = 0, len1 = 0, bytes0, bytes1;
+        const uint32_t rb0 = (tot0 + 7u) >> 3, rb1 = (tot1 + 7u) >> 3;
+        if (tot0 == 0) len0 = run_length(at0, bytes0); else bytes0 = rb0 * 8u;
+        const uint32_t at1 = at0 + bytes0;
+        if (tot1 == 0) len1 = run_length(at1, bytes1); else bytes1 = rb1 * 8u;
+        const uint32_t used = hdr_bytes + bytes0 + bytes1;
+        uint32_t z0[8], z1[8];
+        if (tot0 != 0) fetch_rows(z0, at0, excl_both & 0xffffu, nb_both & 0xffffu, rb0);
+        if (tot1 != 0) fetch_rows(z1, at1, excl_both >> 16, nb_both >> 16, rb1);
 
-                int grad = 0;
-                const int coef = FIRE ? fire_coef<W, false>(ctr) : 0;
+        if (tot0 == 0) run_blocks(len0); else packed_block(z0, 0);
+        if (!corrupt) { if (tot1 == 0) run_blocks(len1); else packed_block(z1, 1); }
+
+        rp += used;
+        rofs += used;
+        if (rofs >= RB) rofs -= RB;
+        ahead -= used;
+
+        // ---- bottom of the step.  VMEM order inside one step is: NPEND stream loads
+        // (top), [rare: run-block stores], two block stores (here).  gfx950 has ONE
+        // in-order counter for loads and stores, so parking the loads must not wait
+        // for the two stores just issued: with every VMEM op of the common path
+        // unconditional, hipcc emits s_waitcnt vmcnt(2) here instead of vmcnt(0).
+        *held_dst[0] = held[0];
+        *held_dst[1] = held[1];
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const int err = (int)(z[i] >> 1) ^ __builtin_amdgcn_sbfe((int)z[i], 0, 1);
-                    int delta;
-                    if constexpr (FIRE) {
-                        if (i & 1) grad = __mul24(sign_of(err), pd) + grad;
-                        delta = __builtin_amdgcn_sbfe(__mul24(pd, coef) + (err << W), W, W);
-                    } else {
-                        delta = err;
-                    }
-                    pv += (uint32_t)delta;
-                    pd = delta;
-                    if (col_ok) *(U*)(stage_col + i * row_stride) = (U)pv;
-                }
-                if constexpr (FIRE) ctr = wrap_counter<W>(ctr + __builtin_amdgcn_sbfe(grad, 2, W - 2));   // sext_W(grad) >> 2
-                flush_block();
-            }
-        }
+        for (uint32_t k = 0; k < NPEND; k++)
+            if (k < npend) commit(pend[k]);
+        wave_lds_sync();
     }
 
     // ---- verbatim tail (:1171), straight from HBM
@@ -262,10 +328,10 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
 // bytes of LDS one group needs in decode_fast_kernel
 constexpr uint32_t decode_fast_lds_bytes(int W, int DP, int D)
 {
-    const uint32_t unit = DP * 16, rb = 4 * unit;
+    const uint32_t unit = DP * 16, rb = 6 * unit;
     const uint32_t hb = W == 8 ? 3 : 4;
     const uint32_t hdrmax = (2 * DP * hb + 7) / 8, blkmax = 8 * DP * (W / 8);
-    const uint32_t apron = (hdrmax + blkmax + 8 + 15) & ~15u;
+    const uint32_t apron = (hdrmax + 2 * blkmax + 4 + 8 + 15) & ~15u;
     const uint32_t stage = ((8u * D * (W / 8) + 15) & ~15u) + 16;   // +16: spread groups over banks
     return rb + apron + stage;
 }
