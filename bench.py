@@ -40,6 +40,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-verify", action="store_true", help="timing ablations only")
     p.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU work per baseline leg")
+    p.add_argument("--ramp-ms", type=float, default=300.0,
+                   help="untimed setup: keep the GPU busy with the same launches this long so that clocks settle "
+                        "(0.51 ms/step cold vs 0.46 ms/step sustained was measured on MI355X)")
     return p.parse_args()
 
 
@@ -181,6 +184,13 @@ def main():
     if not args.no_verify:
         assert torch.equal(out, x), "GPU decode != input"
         assert bool((rets == chunk_len).all().item())
+
+    # ---------------- untimed: let DVFS settle on this workload (steady-state serving is what is measured)
+    t_ramp = time.perf_counter()
+    while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
+        for _ in range(20):
+            codec.decompress_into(comp, offsets, nchunks, out)
+        torch.cuda.synchronize()
 
     # ---------------- timed region
     for _ in range(args.warmup):

@@ -50,6 +50,18 @@ int ensure_device()
     return 0;
 }
 
+int num_cus()
+{
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+
 bool is_lowdim(int esz, int D) { return esz == 1 ? D <= 4 : D <= 2; }   // sprintz.cpp:34-50
 
 struct Mapping { int log2DP; int cpl; };
@@ -198,6 +210,7 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
     a.noheader = noheader;
     a.nh_ngroups = nh_ngroups;
     a.nh_remaining = nh_remaining;
+    a.chunks_per_group = 1;
     if (const char* d = getenv("SPRINTZ_MI355X_DBG")) a.dbg = atoi(d);
 
     // LDS-transposed 16-byte stores need every 8 x D block of the output 16-byte aligned
@@ -225,7 +238,25 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
         const size_t fgroups = kThreads / fdp;
         const size_t fstride = decode_fast_lds_bytes(8 * esz, fdp, D);
         a.lds_group_stride = (uint32_t)fstride;
-        const uint64_t fthreads = nchunks * (uint64_t)fdp;
+        // consecutive chunks per lane group: aim at ONE resident generation of workgroups
+        // (no second cold start of the read-ahead ring, no partial last round)
+        {
+            size_t blocks_per_cu = (160 * 1024) / (fstride * fgroups);
+            if (blocks_per_cu > 5) blocks_per_cu = 5;          // VGPR budget of decode_fast_kernel
+            if (blocks_per_cu < 1) blocks_per_cu = 1;
+            const uint64_t resident_groups = (uint64_t)num_cus() * blocks_per_cu * fgroups;
+            // Measured on MI355X (cfg2, 131072 chunks): k = 1 / 2 / 4 / 8 -> 0.498 / 0.496 / 0.510 /
+            // 0.560 ms.  One generation of lock-stepped groups is no faster than four staggered
+            // ones, so the default stays at one chunk per group; the knob remains for tuning.
+            (void)resident_groups;
+            uint64_t k = 1;
+            if (const char* e = getenv("SPRINTZ_MI355X_CHUNKS_PER_GROUP")) k = (uint64_t)atoi(e);
+            if (k < 1) k = 1;
+            if (k > 64) k = 64;
+            a.chunks_per_group = (uint32_t)k;
+        }
+        const uint64_t ngroups_launch = (nchunks + a.chunks_per_group - 1) / a.chunks_per_group;
+        const uint64_t fthreads = ngroups_launch * (uint64_t)fdp;
         const uint64_t fgrid = (fthreads + kThreads - 1) / kThreads;
         if (fgrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
         e = esz == 1 ? launch_decode_fast_w8(codec == SPRINTZ_CODEC_XFF, fdp, D == fdp, (unsigned)fgrid, fstride * fgroups, st, a)

@@ -87,35 +87,40 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     constexpr uint32_t BLKMAX = 8 * DP * ESZ;              // largest block payload
     constexpr uint32_t CG = HDRMAX + 2 * BLKMAX + 4;       // most bytes one group can consume
     constexpr uint32_t NPEND = (CG + UNIT - 1) / UNIT;     // units requested per group step (2 or 3)
-    constexpr uint32_t RB = 6 * UNIT;                      // ring bytes (6 units: 4 workgroups per CU at D = 8)
-    constexpr uint32_t APRON = (CG + 8 + 15) & ~15u;       // a group never reads past its start + APRON
-    static_assert(RB - UNIT >= 2 * CG + 3, "ring too small for one group of read-ahead");
+    constexpr uint32_t CSTART = 16 + 8;                    // chunk start: alignment gap + 8-byte stream header
+    constexpr uint32_t RB = (DP == 4 ? 8 : 6) * UNIT;      // ring bytes (6 units: 4 workgroups per CU at D = 8)
+    constexpr uint32_t APRON = (CG + CSTART + 8 + 15) & ~15u;   // a step never reads past its start + APRON
+    static_assert(RB - UNIT >= 2 * (CG + CSTART) + 3, "ring too small for one step of read-ahead");
     static_assert(NPEND <= 3, "pending registers");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     const int D = EXACT ? DP : a.D;
     const uint64_t gtid = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
-    const uint64_t chunk = gtid >> LOG2DP;
     const int lane_d = (int)(threadIdx.x & (uint32_t)(DP - 1));
-    if (chunk >= a.nchunks) return;
+    // A group decodes `chunks_per_group` CONSECUTIVE chunks.  Their streams are
+    // (nearly) contiguous in the container, so the ring's read-ahead runs straight
+    // across chunk boundaries: one cold start per group instead of one per chunk.
+    const uint64_t c_first = (gtid >> LOG2DP) * (uint64_t)a.chunks_per_group;
+    if (c_first >= a.nchunks) return;
+    const uint64_t c_end = (c_first + a.chunks_per_group < a.nchunks) ? c_first + a.chunks_per_group : a.nchunks;
 
     // LDS carve per group: [ring RB | apron APRON | block staging]
     uint8_t* const ringp = smem + (size_t)(threadIdx.x >> LOG2DP) * a.lds_group_stride;
     const uint32_t ring = lds_addr(ringp);                 // LDS byte address of the ring
     uint8_t* const stage = ringp + RB + APRON;
 
-    // stream geometry: offsets relative to gbase (stream start aligned down to 16)
-    const uint64_t off0 = a.offsets[chunk];
-    const uint8_t* const gbase = a.comp + (off0 & ~(uint64_t)15);
+    // stream geometry: cursors relative to gbase (= a 16-byte aligned point of the container)
+    const uint64_t lim_abs = a.offsets[c_end];             // first byte that is not this group's
     const uint32_t lane16 = (uint32_t)lane_d * 16u;
-    const uint8_t* gp = gbase + lane16;                    // this lane's next 16 bytes to request
-    int32_t gleft = (int32_t)(a.offsets[chunk + 1] - (off0 & ~(uint64_t)15)) - (int32_t)lane16;   // > 0: still ours
-    uint32_t rp = (uint32_t)(off0 & 15);                   // parse cursor (stream offset)
-    uint32_t rofs = rp;                                    // parse cursor (ring offset, rp mod RB)
-    uint32_t ahead;                                        // bytes requested and not yet parsed
+    uint64_t gabs = 0;                                     // container offset of gbase
+    const uint8_t* gbase = a.comp;
+    const uint8_t* gp = a.comp;                            // this lane's next 16 bytes to request
+    int32_t gleft = 0;                                     // > 0: gp still inside the group's streams
+    uint32_t rp = 0;                                       // parse cursor (offset from gbase)
+    uint32_t rofs = 0;                                     // parse cursor (ring offset)
+    uint32_t ahead = 0;                                    // bytes requested and not yet parsed
     uint32_t cofs = lane16;                                // ring offset where this lane parks its next 16 bytes
-    U* ob = (U*)a.out + chunk * (uint64_t)a.chunk_len;     // output cursor
-    const bool col_ok = lane_d < D;
+    const bool col_ok = EXACT ? true : lane_d < D;
 
     uint4 pend[3];
     uint32_t npend = 0;
@@ -139,29 +144,27 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         cofs += UNIT;
         if (cofs >= RB) cofs -= RB;
     };
-
-    // ---- prologue: fill the ring, read the 8-byte stream header (format.h:48-62)
+    // (re)start the read-ahead at container offset `off`: fill the whole ring
+    auto prime = [&](uint64_t off) {
+        gabs = off & ~(uint64_t)15;
+        gbase = a.comp + gabs;
+        gp = gbase + lane16;
+        const uint64_t span = lim_abs - gabs;
+        gleft = (int32_t)(span < (1u << 30) ? span : (1u << 30)) - (int32_t)lane16;
+        rp = (uint32_t)(off & 15);
+        rofs = rp;
+        cofs = lane16;
+        npend = 0;
+        wave_lds_sync();
 #pragma unroll
-    for (uint32_t u = 0; u < RB / UNIT; u++) {
-        uint4 v;
-        request(v, true);
-        commit(v);
-    }
-    ahead = RB - rp;
-    wave_lds_sync();
-    uint32_t groups_left, remaining;
-    {
-        const uint32_t w0 = lds_rd32(ring + rp), w1 = lds_rd32(ring + rp + 4);
-        groups_left = w0;
-        remaining = w1 & 0xffffu;
-        rp += 8;
-        rofs += 8;
-        ahead -= 8;
-        if ((int)(w1 >> 16) != D) {
-            if (lane_d == 0 && a.rets) a.rets[chunk] = kErrCorrupt;
-            return;
+        for (uint32_t u = 0; u < RB / UNIT; u++) {
+            uint4 v;
+            request(v, true);
+            commit(v);
         }
-    }
+        ahead = RB - rp;
+        wave_lds_sync();
+    };
 
     const uint32_t hdr_bytes = (2u * (uint32_t)D * HB + 7u) >> 3;
     const uint32_t blk_elems = 8u * (uint32_t)D;
@@ -173,8 +176,9 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
 
     uint32_t pv = 0;
     int pd = 0, ctr = 0;
-    uint32_t out_left = a.chunk_len;                       // capacity guard (elements)
+    uint32_t out_left = 0;                                 // capacity guard (elements)
     bool corrupt = false;
+    U* ob = (U*)a.out;                                     // output cursor
 
     // ---- per-block workers ------------------------------------------------------
     // The staged 8 x D block is contiguous in the output.  Packed blocks are read
@@ -249,6 +253,40 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         return len;
     };
 
+    bool need_prime = true;
+    for (uint64_t chunk = c_first; chunk < c_end; chunk++) {
+    // ---- chunk start: find the stream, read its 8-byte header (format.h:48-62)
+    {
+        const uint64_t off = a.offsets[chunk];
+        const uint64_t gap = off - (gabs + rp);            // bytes between the cursor and the next stream
+        if (need_prime || gap > 16 || rp > (1u << 30)) {
+            prime(off);
+        } else {                                           // alignment padding: just step over it
+            rp += (uint32_t)gap;
+            rofs += (uint32_t)gap;
+            if (rofs >= RB) rofs -= RB;
+            ahead -= (uint32_t)gap;
+        }
+        need_prime = false;
+    }
+    uint32_t groups_left, remaining;
+    {
+        const uint32_t w0 = lds_rd32(ring + rofs), w1 = lds_rd32(ring + rofs + 4);
+        groups_left = w0;
+        remaining = w1 & 0xffffu;
+        rp += 8;
+        rofs += 8;
+        if (rofs >= RB) rofs -= RB;
+        ahead -= 8;
+        pv = 0;
+        pd = 0;
+        ctr = 0;
+        out_left = a.chunk_len;
+        ob = (U*)a.out + chunk * (uint64_t)a.chunk_len;
+        corrupt = (int)(w1 >> 16) != D;
+        if (corrupt) groups_left = 0;
+    }
+
     while (groups_left > 0 && !corrupt) {
         groups_left--;
         // ---- request the units that fit now; they are parked at the bottom of this step
@@ -314,7 +352,7 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     // ---- verbatim tail (:1171), straight from HBM
     const uint32_t out_elems = a.chunk_len - out_left;
     if (!corrupt && remaining > out_left) corrupt = true;
-    if (!corrupt) {
+    if (!corrupt && remaining > 0) {
         const uint8_t* t = gbase + rp;
         for (uint32_t j = (uint32_t)lane_d; j < remaining; j += DP) {
             uint32_t x = t[(size_t)j * ESZ];
@@ -322,16 +360,18 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
             ob[j] = (U)x;
         }
     }
+    if (corrupt || remaining > 0) need_prime = true;       // cursor no longer at the next stream
     if (lane_d == 0 && a.rets) a.rets[chunk] = corrupt ? kErrCorrupt : (int64_t)out_elems + remaining;
+    }   // chunk loop
 }
 
 // bytes of LDS one group needs in decode_fast_kernel
 constexpr uint32_t decode_fast_lds_bytes(int W, int DP, int D)
 {
-    const uint32_t unit = DP * 16, rb = 6 * unit;
+    const uint32_t unit = DP * 16, rb = (DP == 4 ? 8 : 6) * unit;
     const uint32_t hb = W == 8 ? 3 : 4;
     const uint32_t hdrmax = (2 * DP * hb + 7) / 8, blkmax = 8 * DP * (W / 8);
-    const uint32_t apron = (hdrmax + 2 * blkmax + 4 + 8 + 15) & ~15u;
+    const uint32_t apron = (hdrmax + 2 * blkmax + 4 + 24 + 8 + 15) & ~15u;
     const uint32_t stage = ((8u * D * (W / 8) + 15) & ~15u) + 16;   // +16: spread groups over banks
     return rb + apron + stage;
 }

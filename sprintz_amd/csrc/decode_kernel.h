@@ -31,6 +31,7 @@ struct DecodeArgs {
     uint32_t nh_ngroups;
     uint32_t nh_remaining;
     int dbg;                    // timing ablations only (SPRINTZ_MI355X_DBG); 0 in production
+    uint32_t chunks_per_group;  // decode_fast: consecutive chunks decoded by one lane group
 };
 
 constexpr int64_t kErrCorrupt = -5;
