@@ -1,0 +1,57 @@
+// sprintz_dropin.hpp -- the reference's public header, re-declared on top of
+// libsprintz_mi355x.so.  A caller written against dblalock/sprintz
+// cpp/Compress/sprintz.h (sprintz.h:16-32; e.g. the author's lzbench fork,
+// reference README.md:29) includes this file instead and links
+// -lsprintz_mi355x: same names, same C++ signatures (default argument
+// included), same units (ELEMENTS) and return values.
+//
+// Host pointers in and out; every call is one chunk on the GPU (see
+// include/sprintz_mi355x.h for the batched device API that is actually fast).
+#ifndef SPRINTZ_DROPIN_HPP
+#define SPRINTZ_DROPIN_HPP
+
+#include <stdint.h>
+
+#include "sprintz_mi355x.h"
+
+// ================================================================ 8b  (sprintz.h:16-23)
+inline int64_t sprintz_compress_delta_8b(const uint8_t* src, uint32_t len, int8_t* dest, uint16_t ndims,
+                                         bool write_size = true)
+{
+    return sprintz_mi355x_compress_delta_8b(src, len, dest, ndims, write_size ? 1 : 0);
+}
+inline int64_t sprintz_decompress_delta_8b(const int8_t* src, uint8_t* dest)
+{
+    return sprintz_mi355x_decompress_delta_8b(src, dest);
+}
+inline int64_t sprintz_compress_xff_8b(const uint8_t* src, uint32_t len, int8_t* dest, uint16_t ndims,
+                                       bool write_size = true)
+{
+    return sprintz_mi355x_compress_xff_8b(src, len, dest, ndims, write_size ? 1 : 0);
+}
+inline int64_t sprintz_decompress_xff_8b(const int8_t* src, uint8_t* dest)
+{
+    return sprintz_mi355x_decompress_xff_8b(src, dest);
+}
+
+// ================================================================ 16b (sprintz.h:25-32)
+inline int64_t sprintz_compress_delta_16b(const uint16_t* src, uint32_t len, int16_t* dest, uint16_t ndims,
+                                          bool write_size = true)
+{
+    return sprintz_mi355x_compress_delta_16b(src, len, dest, ndims, write_size ? 1 : 0);
+}
+inline int64_t sprintz_decompress_delta_16b(const int16_t* src, uint16_t* dest)
+{
+    return sprintz_mi355x_decompress_delta_16b(src, dest);
+}
+inline int64_t sprintz_compress_xff_16b(const uint16_t* src, uint32_t len, int16_t* dest, uint16_t ndims,
+                                        bool write_size = true)
+{
+    return sprintz_mi355x_compress_xff_16b(src, len, dest, ndims, write_size ? 1 : 0);
+}
+inline int64_t sprintz_decompress_xff_16b(const int16_t* src, uint16_t* dest)
+{
+    return sprintz_mi355x_decompress_xff_16b(src, dest);
+}
+
+#endif  // SPRINTZ_DROPIN_HPP
