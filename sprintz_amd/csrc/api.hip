@@ -299,11 +299,31 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     const size_t shmem = (size_t)a.cap * (kThreads / DP);
     if (shmem > 160 * 1024) return fail(SPRINTZ_E_UNSUPPORTED, "ndims too large for the LDS output ring");
 
+    // Fast path (encode_fast.h): general layout, one column per lane, every 8 x D input
+    // block 16-byte aligned, the power-of-two group at least half full.
+    int fdp = 4;
+    while (fdp < D) fdp <<= 1;
+    const size_t blk_bytes = (size_t)8 * D * esz;
+    const bool fast = !lowdim && D <= 64 && 2 * D > fdp && blk_bytes % 16 == 0 && ((uintptr_t)d_src % 16) == 0 &&
+                      ((uint64_t)chunk_len * esz) % 16 == 0 && !getenv("SPRINTZ_MI355X_NO_FAST");
+    hipError_t e;
+    if (fast) {
+        const size_t fgroups = kThreads / fdp;
+        a.lds_group_stride = (uint32_t)(a.cap + ((blk_bytes + 15) & ~(size_t)15) + 16);
+        const size_t fshmem = (size_t)a.lds_group_stride * fgroups;
+        const uint64_t fthreads = nchunks * (uint64_t)fdp;
+        const uint64_t fgrid = (fthreads + kThreads - 1) / kThreads;
+        if (fgrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
+        e = esz == 1 ? launch_encode_fast_w8(codec == SPRINTZ_CODEC_XFF, fdp, D == fdp, (unsigned)fgrid, fshmem, st, a)
+                     : launch_encode_fast_w16(codec == SPRINTZ_CODEC_XFF, fdp, D == fdp, (unsigned)fgrid, fshmem, st, a);
+        if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "encode_fast kernel launch", e);
+        return 0;
+    }
     const uint64_t threads = nchunks * (uint64_t)DP;
     const uint64_t grid = (threads + kThreads - 1) / kThreads;
     if (grid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
-    hipError_t e = esz == 1 ? launch_encode_w8(codec == SPRINTZ_CODEC_XFF, lowdim, m.cpl, (unsigned)grid, shmem, st, a)
-                            : launch_encode_w16(codec == SPRINTZ_CODEC_XFF, lowdim, m.cpl, (unsigned)grid, shmem, st, a);
+    e = esz == 1 ? launch_encode_w8(codec == SPRINTZ_CODEC_XFF, lowdim, m.cpl, (unsigned)grid, shmem, st, a)
+                 : launch_encode_w16(codec == SPRINTZ_CODEC_XFF, lowdim, m.cpl, (unsigned)grid, shmem, st, a);
     if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "encode kernel launch", e);
     return 0;
 }

@@ -1,0 +1,224 @@
+// encode_fast.h -- batched encoder for the general (row-major payload) layout
+// with one column per lane (D <= 64, 16-byte aligned blocks): same stream bytes
+// as encode_kernel.h (sprintz_xff_rle.cpp:61-555, sprintz_delta_rle.cpp:55-404),
+// cheaper per sample:
+//   * INPUT.  An 8 x D block of the raw input is contiguous (8*D*ESZ bytes): the
+//     group loads it as one 16-byte piece per lane, one block AHEAD of the one
+//     being analysed, transposes it through LDS (ds_write_b128 -> 8 x
+//     ds_read_u16/u8) -- instead of 8 scattered 2-byte global loads per lane;
+//   * the per-block nbits scan runs on DPP (group_ops.h);
+//   * FIRE arithmetic pinned to v_mad_i32_i24 / v_med3_i32 (see decode_fast.h);
+//   * OUTPUT as in encode_kernel.h: fields OR-ed into a zeroed per-group LDS ring
+//     with ds_or_b32, flushed to HBM in aligned 16-byte pieces per stream group.
+#pragma once
+
+#include "decode_fast.h"
+#include "encode_kernel.h"
+
+namespace sprintz {
+
+template <int W, bool FIRE, int DP, bool EXACT>
+__global__ void __launch_bounds__(kThreads) encode_fast_kernel(EncodeArgs a)
+{
+    using U = typename Elem<W>::U;
+    constexpr int HB = Elem<W>::HB;
+    constexpr int ESZ = W / 8;
+    constexpr int LOG2DP = DP == 4 ? 2 : DP == 8 ? 3 : DP == 16 ? 4 : DP == 32 ? 5 : 6;
+    constexpr bool TAIL_LE = FIRE;               // "<=" at sprintz_xff_rle.cpp:362, "<" at sprintz_delta_rle.cpp:226
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const int D = EXACT ? DP : a.D;
+    const uint64_t gtid = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+    const uint64_t chunk = gtid >> LOG2DP;
+    const int lane_d = (int)(threadIdx.x & (uint32_t)(DP - 1));
+    if (chunk >= a.nchunks) return;
+
+    const uint64_t first = chunk * (uint64_t)a.chunk_len;
+    const uint32_t n = (uint32_t)((a.total_len - first < a.chunk_len) ? (a.total_len - first) : a.chunk_len);
+    const U* const sc = (const U*)a.src + first;
+    uint8_t* const gdst = a.slots + chunk * a.slot_stride;
+    const bool col_ok = EXACT ? true : lane_d < D;
+
+    // LDS carve per group: [output ring cap | input block staging]
+    const uint32_t cap = a.cap, capm = cap - 1;
+    uint8_t* const ring = smem + (size_t)(threadIdx.x >> LOG2DP) * a.lds_group_stride;
+    uint32_t* const ring32 = (uint32_t*)ring;
+    uint8_t* const stage = ring + cap;
+
+    for (uint32_t u = (uint32_t)lane_d; u < (cap >> 4); u += DP) ((uint4*)ring)[u] = make_uint4(0, 0, 0, 0);
+    wave_lds_sync();
+
+    uint32_t wpos = a.write_size ? 8u : 0u;   // stream write position (bytes)
+    uint32_t flushed = 0;                     // multiple of 16; ring holds [flushed, flushed + cap)
+
+    auto flush_to = [&](uint32_t upto) {      // [flushed, upto) -> HBM, re-zero
+        wave_lds_sync();
+        const uint32_t nunits = (upto - flushed) >> 4;
+        for (uint32_t u = (uint32_t)lane_d; u < nunits; u += DP) {
+            const uint32_t p = flushed + (u << 4);
+            uint4* r = (uint4*)(ring + (p & capm));
+            *(uint4*)(gdst + p) = *r;
+            *r = make_uint4(0, 0, 0, 0);
+        }
+        flushed = upto;
+        wave_lds_sync();
+    };
+    auto or_bits = [&](uint32_t bp, uint32_t v, uint32_t nb) {   // low nb (<= 16) bits of v at stream bit bp
+        if (nb == 0) return;
+        const uint32_t w = (bp >> 5), sh = bp & 31u;
+        const uint32_t wm = (cap >> 2) - 1;
+        atomicOr(&ring32[w & wm], v << sh);
+        if (sh + nb > 32u) atomicOr(&ring32[(w + 1) & wm], v >> (32u - sh));
+    };
+    auto put_run = [&](uint32_t run) {          // sprintz_xff_rle.cpp:377-384
+        if (lane_d == 0) {
+            ring[wpos & capm] = (uint8_t)((run & 0x7fu) | (run > 0x7fu ? 0x80u : 0u));
+            if (run > 0x7fu) ring[(wpos + 1) & capm] = (uint8_t)(run >> 7);
+        }
+        wpos += run > 0x7fu ? 2u : 1u;
+    };
+
+    const uint32_t hdr_bytes = (2u * (uint32_t)D * HB + 7u) >> 3;
+    const uint32_t blk = 8u * (uint32_t)D;
+    const uint32_t blk_bytes = blk * ESZ;
+    const uint32_t lane16 = (uint32_t)lane_d * 16u;
+    const int64_t limit = (int64_t)n - 2 * (int64_t)blk;    // last_full_group_start (:158)
+    int64_t pos_in = 0;
+    uint32_t ngroups = 0, run = 0, hdr_pos = 0;
+    int slot = 0;
+    uint32_t pv = 0;
+    int pd = 0, ctr = 0;
+
+    auto start_group = [&]() {
+        ngroups++;
+        flush_to(wpos & ~15u);
+        hdr_pos = wpos;
+        wpos += hdr_bytes;
+        slot = 0;
+    };
+    // this lane's 16-byte pieces of the 8 x D block starting at element `pos` (0 past the chunk)
+    constexpr int PIECES = (8 * DP * ESZ + DP * 16 - 1) / (DP * 16);   // 1 (W=16) or 1 (W=8): block <= DP*16 bytes
+    auto load_block = [&](int64_t pos) -> uint4 {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (lane16 < blk_bytes && pos + (int64_t)blk <= (int64_t)n) v = *(const uint4*)((const uint8_t*)(sc + pos) + lane16);
+        return v;
+    };
+    static_assert(PIECES == 1, "one 16-byte piece per lane covers a block");
+
+    bool active = n >= 128u && limit >= 0;      // :116 and the loop guard :160
+    uint4 nxt = make_uint4(0, 0, 0, 0);
+    if (active) {
+        start_group();
+        nxt = load_block(0);
+    }
+    uint8_t* const stage_col = stage + lane_d * ESZ;
+    const uint32_t row_stride = (uint32_t)D * ESZ;
+
+    while (active) {
+        // ---- the block at pos_in is in `nxt`; transpose it through LDS, request the next one
+        if (lane16 < blk_bytes) *(uint4*)(stage + lane16) = nxt;
+        wave_lds_sync();
+        nxt = load_block(pos_in + blk);
+        uint32_t x[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = col_ok ? (uint32_t)*(const U*)(stage_col + i * row_stride) : 0u;
+        wave_lds_sync();
+
+        // ---- forecast + zigzag + OR-mask (:197-298)
+        uint32_t z[8];
+        const int coef = FIRE ? fire_coef<W, false>(ctr) : 0;
+        int grad = 0;
+        uint32_t mask = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int delta = sext<W>((int)(x[i] - pv));
+            int err;
+            if constexpr (FIRE) {
+                const int pred = __builtin_amdgcn_sbfe(mad24(pd, coef, 0), W, W);
+                err = sext<W>(delta - pred);
+                if (i & 1) grad = mad24(sign_of(err), pd, grad);
+            } else {
+                err = delta;
+            }
+            const uint32_t zz = zigzag<W>(err);
+            mask |= zz;
+            z[i] = zz;
+            pv = x[i];
+            pd = delta;
+        }
+        if constexpr (FIRE) ctr = wrap_counter<W>(ctr + __builtin_amdgcn_sbfe(grad, 2, W - 2));
+        const uint32_t nb = col_ok ? nbits_of<W, false>(mask) : 0u;
+        uint32_t total;
+        const uint32_t excl = group_scan<DP>(nb, lane_d, total);
+
+        // ---- RLE state machine (:350-456); group-uniform
+        for (;;) {
+            if (total == 0 && run < 0x7fffu) {
+                run++;
+                pos_in += blk;
+                const bool more = TAIL_LE ? (pos_in <= limit) : (pos_in < limit);
+                if (more) break;
+                slot++;
+                put_run(run);
+                wpos += (uint32_t)(2 - slot);
+                run = 0;
+                active = false;
+                break;
+            }
+            if (run > 0) {
+                slot++;
+                put_run(run);
+                run = 0;
+                if (slot == 2) start_group();            // :430-450
+                continue;
+            }
+            if (col_ok) {
+                const uint32_t f = nb == (uint32_t)W ? (uint32_t)(W - 1) : nb;   // :296
+                or_bits(hdr_pos * 8u + (uint32_t)(slot * D + lane_d) * HB, f, HB);
+            }
+            const uint32_t row_bits = ((total + 7u) >> 3) << 3;
+            uint32_t bp = wpos * 8u + excl;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                or_bits(bp, z[i], nb);
+                bp += row_bits;
+            }
+            wpos += row_bits;                            // 8 rows * row_bytes
+            pos_in += blk;
+            slot++;
+            if (slot == 2) {
+                if (pos_in <= limit) start_group();
+                else active = false;
+            }
+            break;
+        }
+    }
+
+    // ---- verbatim tail through the ring (:553)
+    const uint32_t remaining = (uint32_t)((int64_t)n - pos_in);
+    {
+        const uint8_t* tp = (const uint8_t*)(sc + pos_in);
+        uint32_t left = remaining * ESZ;
+        while (left > 0) {
+            flush_to(wpos & ~15u);
+            const uint32_t room = cap - (wpos - flushed);
+            const uint32_t m = left < room ? left : room;
+            for (uint32_t j = (uint32_t)lane_d; j < m; j += DP) ring[(wpos + j) & capm] = tp[j];
+            wpos += m;
+            tp += m;
+            left -= m;
+        }
+    }
+    flush_to((wpos + 15u) & ~15u);
+
+    if (lane_d == 0) {                                   // format.h:36-45; lane 0 also flushed unit 0
+        if (a.write_size) {
+            ((uint32_t*)gdst)[0] = ngroups;
+            ((uint32_t*)gdst)[1] = (remaining & 0xffffu) | ((uint32_t)D << 16);
+        }
+        a.sizes[chunk] = wpos;
+        if (a.rets) a.rets[chunk] = (int64_t)(wpos / ESZ);
+    }
+}
+
+}  // namespace sprintz

@@ -31,6 +31,7 @@ struct EncodeArgs {
     int64_t* rets;              // optional: reference's element-count return value
     int write_size;             // 0: omit the 8-byte header (sprintz_xff_rle.cpp:119-127)
     uint32_t cap;               // ring bytes per group (power of two, >= max group bytes + 32)
+    uint32_t lds_group_stride;  // encode_fast: LDS bytes per group (ring + input staging)
 };
 
 template <int W, bool FIRE, bool LOWDIM, int CPL>

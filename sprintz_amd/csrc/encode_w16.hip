@@ -5,4 +5,8 @@ hipError_t launch_encode_w16(bool fire, bool lowdim, int cpl, unsigned grid, siz
 {
     SPRINTZ_DISPATCH(encode_kernel, 16)
 }
+hipError_t launch_encode_fast_w16(bool fire, int dp, bool exact, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a)
+{
+    SPRINTZ_DISPATCH_FAST(encode_fast_kernel, 16)
+}
 }  // namespace sprintz

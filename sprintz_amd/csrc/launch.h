@@ -8,6 +8,7 @@
 #include "decode_kernel.h"
 #include "decode_fast.h"
 #include "encode_kernel.h"
+#include "encode_fast.h"
 
 namespace sprintz {
 
@@ -19,6 +20,8 @@ hipError_t launch_decode_w16(bool fire, bool lowdim, int cpl, unsigned grid, siz
 // fast path: general layout, one column per lane, LDS-transposed stores (see decode_fast.h)
 hipError_t launch_decode_fast_w8(bool fire, int dp, bool exact, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a);
 hipError_t launch_decode_fast_w16(bool fire, int dp, bool exact, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a);
+hipError_t launch_encode_fast_w8(bool fire, int dp, bool exact, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
+hipError_t launch_encode_fast_w16(bool fire, int dp, bool exact, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
 hipError_t launch_encode_w8(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
 hipError_t launch_encode_w16(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
 

@@ -81,3 +81,29 @@ def test_compress_bound_dominates_oracle_sizes(lib_path, oracle):
                 for codec in ("delta", "xff"):
                     s, _ = oracle.compress(codec, d, D)
                     assert s.size + 16 <= _lib.compress_bound(esz, n, D)
+
+
+def test_dropin_header_compiles_and_links(lib_path, tmp_path):
+    """a caller written against the reference's sprintz.h builds against include/sprintz_dropin.hpp"""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    src = tmp_path / "caller.cpp"
+    src.write_text(
+        '#include "sprintz_dropin.hpp"\n'
+        "#include <vector>\n"
+        "int main() {\n"
+        "  std::vector<uint16_t> x(4096, 7), y(4096 + 64);\n"
+        "  std::vector<int16_t> c(4096 * 3 / 2 + 64);\n"
+        "  int64_t n = sprintz_compress_xff_16b(x.data(), 4096, c.data(), 8);      // default write_size\n"
+        "  int64_t m = sprintz_decompress_xff_16b(c.data(), y.data());\n"
+        "  int64_t a = sprintz_compress_delta_8b((const uint8_t*)x.data(), 100, (int8_t*)c.data(), 3, false);\n"
+        "  return (n < 0 && m < 0 && a < 0) ? 0 : 1;   // without a GPU every call fails loudly\n"
+        "}\n")
+    exe = tmp_path / "caller"
+    libdir = os.path.dirname(lib_path)
+    cmd = ["g++", "-std=c++14", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+           "-L", libdir, "-lsprintz_mi355x", "-L/opt/rocm/lib", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    assert exe.exists()

@@ -172,6 +172,30 @@ def test_batched_decodes_byte_dense_reference_streams(sz, oracle):
     assert np.array_equal(out.cpu().numpy(), data)
 
 
+@pytest.mark.parametrize("k", [2, 3, 7])
+def test_consecutive_chunks_per_group(sz, oracle, monkeypatch, k):
+    """decode_fast with several consecutive chunks per lane group (ring read-ahead running
+    across chunk boundaries): 16-byte aligned container, byte-dense container, ragged tails"""
+    import torch
+    monkeypatch.setenv("SPRINTZ_MI355X_CHUNKS_PER_GROUP", str(k))
+    rng = np.random.default_rng(100 + k)
+    for codec, esz, ndims, chunk_len, nchunks in [("xff", 2, 8, 5120, 101), ("delta", 1, 16, 4096, 37),
+                                                  ("xff", 2, 8, 5000, 50)]:
+        data = np.concatenate([gen_walk(rng, nchunks * chunk_len // 2, ndims, esz, 8, flat_every=3),
+                               gen_fuzz(rng, nchunks * chunk_len - nchunks * chunk_len // 2, esz, 2)])
+        cd = sz.ChunkedCodec(codec, esz, ndims, chunk_len, device="cuda:0")
+        batch = cd.compress(torch.from_numpy(data).cuda())
+        out = cd.decompress(batch)
+        assert np.array_equal(out.cpu().numpy(), data), (codec, k, "aligned")
+        streams = oracle.compress_chunks(codec, data, chunk_len, ndims)
+        offs = np.zeros(nchunks + 1, np.int64)
+        offs[1:] = np.cumsum([s.size for s in streams])
+        comp = np.concatenate(streams + [np.zeros(16, np.uint8)])
+        out2 = torch.empty(nchunks * chunk_len, dtype=cd.dtype, device="cuda:0")
+        cd.decompress_into(torch.from_numpy(comp).cuda(), torch.from_numpy(offs).cuda(), nchunks, out2)
+        assert np.array_equal(out2.cpu().numpy(), data), (codec, k, "dense")
+
+
 def test_decoder_rejects_wrong_ndims(sz, oracle):
     import torch
     rng = np.random.default_rng(3)
