@@ -109,14 +109,23 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     const uint32_t ring = lds_addr(ringp);                 // LDS byte address of the ring
     uint8_t* const stage = ringp + RB + APRON;
 
-    // stream geometry: cursors relative to gbase (= a 16-byte aligned point of the container)
-    const uint64_t lim_abs = a.offsets[c_end];             // first byte that is not this group's
+    // stream geometry.  All stream loads go through ONE wave-uniform buffer
+    // descriptor that spans the container from this wavefront's first stream to its
+    // end: offsets are 32-bit, and a load that runs past the container returns 0
+    // instead of faulting -- the read-ahead needs no bounds test.
+    const uint64_t wave_first = (((uint64_t)blockIdx.x * kThreads + (threadIdx.x & ~63u)) >> LOG2DP) * (uint64_t)a.chunks_per_group;
+    uint64_t wave_base = a.offsets[wave_first < a.nchunks ? wave_first : 0] & ~(uint64_t)15;
+    wave_base = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(wave_base >> 32)) << 32) |
+                (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)wave_base);
+    // rounded up to whole 16-byte pieces (gfx950 zeroes a dwordx4 whose END is out of range);
+    // the <= 15 extra bytes are inside the SPRINTZ_MI355X_READ_SLACK the API asks for
+    const uint64_t wave_span = ((a.offsets[a.nchunks] - wave_base) + 15) & ~(uint64_t)15;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.comp + wave_base), 0, (uint32_t)(wave_span < 0xffffffffull ? wave_span : 0xffffffffull), 0x00020000);
     const uint32_t lane16 = (uint32_t)lane_d * 16u;
-    uint64_t gabs = 0;                                     // container offset of gbase
-    const uint8_t* gbase = a.comp;
-    const uint8_t* gp = a.comp;                            // this lane's next 16 bytes to request
-    int32_t gleft = 0;                                     // > 0: gp still inside the group's streams
-    uint32_t rp = 0;                                       // parse cursor (offset from gbase)
+    uint64_t gabs = 0;                                     // container offset the cursors below are relative to
+    uint32_t gvo = 0;                                      // this lane's next 16 bytes to request (offset from wave_base)
+    uint32_t rp = 0;                                       // parse cursor (offset from gabs)
     uint32_t rofs = 0;                                     // parse cursor (ring offset)
     uint32_t ahead = 0;                                    // bytes requested and not yet parsed
     uint32_t cofs = lane16;                                // ring offset where this lane parks its next 16 bytes
@@ -125,18 +134,13 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     uint4 pend[3];
     uint32_t npend = 0;
 
-    // Request one unit.  The load is UNCONDITIONAL (address clamped to the stream
-    // start when the unit is not wanted or lies past the stream end) so that the
-    // compiler can count the VMEM operations of a step exactly -- see the wait
-    // discussion at the bottom of the group loop.
+    // Request one unit.  The load is UNCONDITIONAL (an unwanted unit re-reads offset
+    // 0) so that the compiler can count the VMEM operations of a step exactly -- see
+    // the wait discussion at the bottom of the group loop.
     auto request = [&](uint4& v, bool wanted) {
-        const uint8_t* src = (wanted && gleft > 0) ? gp : gbase;
-        const u128_unaligned t = *(const u128_unaligned*)src;
-        v = make_uint4(t.x, t.y, t.z, t.w);
-        if (wanted) {
-            gp += UNIT;
-            gleft -= (int32_t)UNIT;
-        }
+        const auto t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, wanted ? gvo : 0u, 0, 0);
+        v = make_uint4(t[0], t[1], t[2], t[3]);
+        gvo += wanted ? UNIT : 0u;
     };
     auto commit = [&](const uint4& v) {                    // park 16 bytes in the ring (+ mirror the ring head)
         *(uint4*)(ringp + cofs) = v;
@@ -147,10 +151,7 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     // (re)start the read-ahead at container offset `off`: fill the whole ring
     auto prime = [&](uint64_t off) {
         gabs = off & ~(uint64_t)15;
-        gbase = a.comp + gabs;
-        gp = gbase + lane16;
-        const uint64_t span = lim_abs - gabs;
-        gleft = (int32_t)(span < (1u << 30) ? span : (1u << 30)) - (int32_t)lane16;
+        gvo = (uint32_t)(gabs - wave_base) + lane16;
         rp = (uint32_t)(off & 15);
         rofs = rp;
         cofs = lane16;
@@ -353,7 +354,7 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     const uint32_t out_elems = a.chunk_len - out_left;
     if (!corrupt && remaining > out_left) corrupt = true;
     if (!corrupt && remaining > 0) {
-        const uint8_t* t = gbase + rp;
+        const uint8_t* t = a.comp + gabs + rp;
         for (uint32_t j = (uint32_t)lane_d; j < remaining; j += DP) {
             uint32_t x = t[(size_t)j * ESZ];
             if constexpr (ESZ == 2) x |= (uint32_t)t[(size_t)j * 2 + 1] << 8;
