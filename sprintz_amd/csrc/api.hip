@@ -230,7 +230,9 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
     // vector stores legal, and the power-of-two group at least half full.
     int fdp = 4;
     while (fdp < D) fdp <<= 1;
-    const bool fast = !lowdim && !noheader && D <= 64 && a.vec_store && 2 * D > fdp && !getenv("SPRINTZ_MI355X_NO_FAST");
+    // (32-bit offsets inside one wavefront's span of the output)
+    const bool fast = !lowdim && !noheader && D <= 64 && a.vec_store && 2 * D > fdp &&
+                      (uint64_t)chunk_len * esz * 64 * 64 < 0xf0000000ull && !getenv("SPRINTZ_MI355X_NO_FAST");
     hipError_t e;
     if (fast) {
         a.log2DP = 0;

@@ -70,10 +70,6 @@ __device__ __forceinline__ int sign_of(int x)
     return s;
 }
 
-// Where the two per-step block stores go before a lane has produced its first
-// block (the stores are unconditional, see the bottom of the group loop).
-static __device__ uint4 g_decode_sink[kThreads];
-
 // EXACT: ndims == DP (a power of two), so every size is a compile-time constant.
 template <int W, bool FIRE, int DP, bool EXACT>
 __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
@@ -122,6 +118,14 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     const uint64_t wave_span = ((a.offsets[a.nchunks] - wave_base) + 15) & ~(uint64_t)15;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.comp + wave_base), 0, (uint32_t)(wave_span < 0xffffffffull ? wave_span : 0xffffffffull), 0x00020000);
+    // output: one descriptor per wave as well, based at its first chunk's slot; a store
+    // whose offset is out of range is dropped by the hardware, which is what the two
+    // unconditional per-step block stores rely on before a lane has produced a block
+    const uint64_t out_base = (wave_first < a.nchunks ? wave_first : 0) * (uint64_t)a.chunk_len * ESZ;
+    const uint64_t out_span = a.nchunks * (uint64_t)a.chunk_len * ESZ - out_base;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((uint8_t*)a.out + out_base), 0, (uint32_t)(out_span < 0xfffffff0ull ? out_span : 0xfffffff0ull), 0x00020000);
+    constexpr uint32_t kDropStore = 0xfffffff0u;          // out of range of every descriptor
     const uint32_t lane16 = (uint32_t)lane_d * 16u;
     uint64_t gabs = 0;                                     // container offset the cursors below are relative to
     uint32_t gvo = 0;                                      // this lane's next 16 bytes to request (offset from wave_base)
@@ -179,26 +183,30 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     int pd = 0, ctr = 0;
     uint32_t out_left = 0;                                 // capacity guard (elements)
     bool corrupt = false;
-    U* ob = (U*)a.out;                                     // output cursor
+    uint32_t ovo = 0;                                      // output cursor (byte offset from this wave's out_base)
 
     // ---- per-block workers ------------------------------------------------------
     // The staged 8 x D block is contiguous in the output.  Packed blocks are read
     // back from LDS into `held[slot]` and stored at the BOTTOM of the group step by
-    // two unconditional dwordx4 stores (a slot that produced no packed block
-    // re-stores the previous one: same lane, same address, same data).
+    // two unconditional dwordx4 buffer stores (a slot that produced no packed block
+    // re-stores the previous one: same lane, same address, same data; before the
+    // first block the offset is out of range and the hardware drops the store).
     uint4 held[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-    uint4* held_dst[2] = {&g_decode_sink[threadIdx.x], &g_decode_sink[threadIdx.x]};
+    uint32_t held_vo[2] = {kDropStore, kDropStore};
     // after the 8 rows sit in `stage`; slot < 0: store right away (run blocks)
     auto stage_out = [&](int slot) {
         wave_lds_sync();
         if (DP * 16 >= BLKMAX && slot >= 0) {
             held[slot] = *(const uint4*)(stage + (lane16 < blk_bytes ? lane16 : 0u));
-            held_dst[slot] = (uint4*)((uint8_t*)ob + (lane16 < blk_bytes ? lane16 : 0u));
+            held_vo[slot] = lane16 < blk_bytes ? ovo + lane16 : kDropStore;
         } else {
-            for (uint32_t u = (uint32_t)lane_d; u < (blk_bytes >> 4); u += DP) ((uint4*)ob)[u] = ((const uint4*)stage)[u];
+            for (uint32_t u = lane16; u < blk_bytes; u += DP * 16) {
+                const uint4 t = *(const uint4*)(stage + u);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t, t), orsrc, ovo + u, 0, 0);
+            }
         }
         wave_lds_sync();
-        ob += blk_elems;
+        ovo += blk_bytes;
     };
     auto run_blocks = [&](uint32_t len) {                  // RUN slot: `len` blocks of zero error (:828-958)
         for (; len > 0; len--) {
@@ -283,7 +291,7 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         pd = 0;
         ctr = 0;
         out_left = a.chunk_len;
-        ob = (U*)a.out + chunk * (uint64_t)a.chunk_len;
+        ovo = (uint32_t)((chunk - wave_first) * (uint64_t)a.chunk_len * ESZ);
         corrupt = (int)(w1 >> 16) != D;
         if (corrupt) groups_left = 0;
     }
@@ -342,8 +350,8 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         // in-order counter for loads and stores, so parking the loads must not wait
         // for the two stores just issued: with every VMEM op of the common path
         // unconditional, hipcc emits s_waitcnt vmcnt(2) here instead of vmcnt(0).
-        *held_dst[0] = held[0];
-        *held_dst[1] = held[1];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t, held[0]), orsrc, held_vo[0], 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t, held[1]), orsrc, held_vo[1], 0, 0);
 #pragma unroll
         for (uint32_t k = 0; k < NPEND; k++)
             if (k < npend) commit(pend[k]);
@@ -358,7 +366,7 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         for (uint32_t j = (uint32_t)lane_d; j < remaining; j += DP) {
             uint32_t x = t[(size_t)j * ESZ];
             if constexpr (ESZ == 2) x |= (uint32_t)t[(size_t)j * 2 + 1] << 8;
-            ob[j] = (U)x;
+            ((U*)((uint8_t*)a.out + out_base + ovo))[j] = (U)x;
         }
     }
     if (corrupt || remaining > 0) need_prime = true;       // cursor no longer at the next stream
