@@ -228,17 +228,21 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
 
     // Fast path (decode_fast.h): general layout, one column per lane, headered stream,
     // vector stores legal, and the power-of-two group at least half full.
-    int fdp = 4;
-    while (fdp < D) fdp <<= 1;
+    int fdp = 4, fcpl = 1;
+    while (fdp < D && fdp < 64) fdp <<= 1;
+    while (fdp * fcpl < D) fcpl <<= 1;                         // 2 / 4 columns per lane for D in 65..256
     // (32-bit offsets inside one wavefront's span of the output)
-    const bool fast = !lowdim && !noheader && D <= 64 && a.vec_store && 2 * D > fdp &&
+    // and chunks not much shorter than the read-ahead ring (it is filled before the first header is parsed)
+    const size_t fring = decode_fast_lds_bytes(8 * esz, fdp, fcpl, D);
+    const bool fast = !lowdim && !noheader && D <= 256 && a.vec_store && 2 * D > fdp * fcpl &&
+                      (uint64_t)chunk_len * esz * 2 >= fring &&
                       (uint64_t)chunk_len * esz * 64 * 64 < 0xf0000000ull && !getenv("SPRINTZ_MI355X_NO_FAST");
     hipError_t e;
     if (fast) {
         a.log2DP = 0;
         while ((1 << a.log2DP) < fdp) a.log2DP++;
         const size_t fgroups = kThreads / fdp;
-        const size_t fstride = decode_fast_lds_bytes(8 * esz, fdp, D);
+        const size_t fstride = decode_fast_lds_bytes(8 * esz, fdp, fcpl, D);
         a.lds_group_stride = (uint32_t)fstride;
         // consecutive chunks per lane group: aim at ONE resident generation of workgroups
         // (no second cold start of the read-ahead ring, no partial last round)
@@ -261,8 +265,8 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
         const uint64_t fthreads = ngroups_launch * (uint64_t)fdp;
         const uint64_t fgrid = (fthreads + kThreads - 1) / kThreads;
         if (fgrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
-        e = esz == 1 ? launch_decode_fast_w8(codec == SPRINTZ_CODEC_XFF, fdp, D == fdp, (unsigned)fgrid, fstride * fgroups, st, a)
-                     : launch_decode_fast_w16(codec == SPRINTZ_CODEC_XFF, fdp, D == fdp, (unsigned)fgrid, fstride * fgroups, st, a);
+        e = esz == 1 ? launch_decode_fast_w8(codec == SPRINTZ_CODEC_XFF, fdp, fcpl, D == fdp * fcpl, (unsigned)fgrid, fstride * fgroups, st, a)
+                     : launch_decode_fast_w16(codec == SPRINTZ_CODEC_XFF, fdp, fcpl, D == fdp * fcpl, (unsigned)fgrid, fstride * fgroups, st, a);
         if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "decode_fast kernel launch", e);
         return 0;
     }

@@ -70,27 +70,33 @@ __device__ __forceinline__ int sign_of(int x)
     return s;
 }
 
-// EXACT: ndims == DP (a power of two), so every size is a compile-time constant.
-template <int W, bool FIRE, int DP, bool EXACT>
+// CPL columns per lane (column = lane_d*CPL + k); EXACT: ndims == DP*CPL, so every
+// size is a compile-time constant.
+template <int W, bool FIRE, int DP, int CPL, bool EXACT>
 __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
 {
     using U = typename Elem<W>::U;
+    typedef __attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t v4u;
     constexpr int HB = Elem<W>::HB;
     constexpr int ESZ = W / 8;
     constexpr int LOG2DP = DP == 4 ? 2 : DP == 8 ? 3 : DP == 16 ? 4 : DP == 32 ? 5 : 6;
-    constexpr uint32_t UNIT = DP * 16;                     // bytes one refill unit brings in
-    constexpr uint32_t HDRMAX = (2 * DP * HB + 7) / 8;
-    constexpr uint32_t BLKMAX = 8 * DP * ESZ;              // largest block payload
+    constexpr int DCAP = DP * CPL;                         // columns a group can hold
+    constexpr uint32_t ROW16 = DP * 16;                    // bytes one wave-instruction moves per group
+    constexpr uint32_t UNIT = ROW16 * CPL;                 // bytes one refill unit brings in (CPL pieces per lane)
+    constexpr uint32_t HDRMAX = (2 * DCAP * HB + 7) / 8;
+    constexpr uint32_t BLKMAX = 8 * DCAP * ESZ;            // largest block payload = largest decoded block
+    constexpr int PIECES = (BLKMAX + ROW16 - 1) / ROW16;   // 16-byte pieces of a decoded block per lane
     constexpr uint32_t CG = HDRMAX + 2 * BLKMAX + 4;       // most bytes one group can consume
     constexpr uint32_t NPEND = (CG + UNIT - 1) / UNIT;     // units requested per group step (2 or 3)
     constexpr uint32_t CSTART = 16 + 8;                    // chunk start: alignment gap + 8-byte stream header
-    constexpr uint32_t RB = (DP == 4 ? 8 : 6) * UNIT;      // ring bytes (6 units: 4 workgroups per CU at D = 8)
+    constexpr uint32_t RBU = (2 * (CG + CSTART) + 3 + UNIT - 1) / UNIT + 1;   // ring units: 6 @16 bit, 4 @8 bit
+    constexpr uint32_t RB = RBU * UNIT;                    // ring bytes
     constexpr uint32_t APRON = (CG + CSTART + 8 + 15) & ~15u;   // a step never reads past its start + APRON
     static_assert(RB - UNIT >= 2 * (CG + CSTART) + 3, "ring too small for one step of read-ahead");
     static_assert(NPEND <= 3, "pending registers");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
-    const int D = EXACT ? DP : a.D;
+    const int D = EXACT ? DCAP : a.D;
     const uint64_t gtid = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
     const int lane_d = (int)(threadIdx.x & (uint32_t)(DP - 1));
     // A group decodes `chunks_per_group` CONSECUTIVE chunks.  Their streams are
@@ -119,7 +125,7 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(a.comp + wave_base), 0, (uint32_t)(wave_span < 0xffffffffull ? wave_span : 0xffffffffull), 0x00020000);
     // output: one descriptor per wave as well, based at its first chunk's slot; a store
-    // whose offset is out of range is dropped by the hardware, which is what the two
+    // whose offset is out of range is dropped by the hardware, which is what the
     // unconditional per-step block stores rely on before a lane has produced a block
     const uint64_t out_base = (wave_first < a.nchunks ? wave_first : 0) * (uint64_t)a.chunk_len * ESZ;
     const uint64_t out_span = a.nchunks * (uint64_t)a.chunk_len * ESZ - out_base;
@@ -133,22 +139,28 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     uint32_t rofs = 0;                                     // parse cursor (ring offset)
     uint32_t ahead = 0;                                    // bytes requested and not yet parsed
     uint32_t cofs = lane16;                                // ring offset where this lane parks its next 16 bytes
-    const bool col_ok = EXACT ? true : lane_d < D;
 
-    uint4 pend[3];
+    uint4 pend[3][CPL];
     uint32_t npend = 0;
 
-    // Request one unit.  The load is UNCONDITIONAL (an unwanted unit re-reads offset
-    // 0) so that the compiler can count the VMEM operations of a step exactly -- see
-    // the wait discussion at the bottom of the group loop.
-    auto request = [&](uint4& v, bool wanted) {
-        const auto t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, wanted ? gvo : 0u, 0, 0);
-        v = make_uint4(t[0], t[1], t[2], t[3]);
+    // Request one unit (CPL 16-byte pieces per lane).  The loads are UNCONDITIONAL (an
+    // unwanted unit re-reads offset 0) so that the compiler can count the VMEM
+    // operations of a step exactly -- see the wait discussion at the bottom of the loop.
+    auto request = [&](uint4 (&v)[CPL], bool wanted) {
+#pragma unroll
+        for (int j = 0; j < CPL; j++) {
+            const auto t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, wanted ? gvo + j * ROW16 : 0u, 0, 0);
+            v[j] = make_uint4(t[0], t[1], t[2], t[3]);
+        }
         gvo += wanted ? UNIT : 0u;
     };
-    auto commit = [&](const uint4& v) {                    // park 16 bytes in the ring (+ mirror the ring head)
-        *(uint4*)(ringp + cofs) = v;
-        if (cofs < APRON) *(uint4*)(ringp + RB + cofs) = v;
+    auto commit = [&](const uint4 (&v)[CPL]) {             // park one unit in the ring (+ mirror the ring head)
+#pragma unroll
+        for (int j = 0; j < CPL; j++) {
+            const uint32_t ro = cofs + j * ROW16;
+            *(uint4*)(ringp + ro) = v[j];
+            if (ro < APRON) *(uint4*)(ringp + RB + ro) = v[j];
+        }
         cofs += UNIT;
         if (cofs >= RB) cofs -= RB;
     };
@@ -163,7 +175,7 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         wave_lds_sync();
 #pragma unroll
         for (uint32_t u = 0; u < RB / UNIT; u++) {
-            uint4 v;
+            uint4 v[CPL];
             request(v, true);
             commit(v);
         }
@@ -174,13 +186,15 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     const uint32_t hdr_bytes = (2u * (uint32_t)D * HB + 7u) >> 3;
     const uint32_t blk_elems = 8u * (uint32_t)D;
     const uint32_t blk_bytes = blk_elems * ESZ;
-    const uint32_t hbit0 = (uint32_t)lane_d * HB, hbit1 = (uint32_t)(D + lane_d) * HB;
-    const uint32_t hbyte0 = hbit0 >> 3, hsh0 = hbit0 & 7u, hbyte1 = hbit1 >> 3, hsh1 = hbit1 & 7u;
-    uint8_t* const stage_col = stage + lane_d * ESZ;
     const uint32_t row_stride = (uint32_t)D * ESZ;
+    const int col0 = lane_d * CPL;                         // first column of this lane
+    uint8_t* const stage_col = stage + col0 * ESZ;
 
-    uint32_t pv = 0;
-    int pd = 0, ctr = 0;
+    uint32_t pv[CPL];
+    int pd[CPL], ctr[CPL];
+    bool col_ok[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; k++) { pv[k] = 0; pd[k] = 0; ctr[k] = 0; col_ok[k] = EXACT ? true : (col0 + k) < D; }
     uint32_t out_left = 0;                                 // capacity guard (elements)
     bool corrupt = false;
     uint32_t ovo = 0;                                      // output cursor (byte offset from this wave's out_base)
@@ -188,21 +202,28 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     // ---- per-block workers ------------------------------------------------------
     // The staged 8 x D block is contiguous in the output.  Packed blocks are read
     // back from LDS into `held[slot]` and stored at the BOTTOM of the group step by
-    // two unconditional dwordx4 buffer stores (a slot that produced no packed block
+    // unconditional dwordx4 buffer stores (a slot that produced no packed block
     // re-stores the previous one: same lane, same address, same data; before the
     // first block the offset is out of range and the hardware drops the store).
-    uint4 held[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-    uint32_t held_vo[2] = {kDropStore, kDropStore};
+    uint4 held[2][PIECES];
+    uint32_t held_vo[2][PIECES];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+        for (int q = 0; q < PIECES; q++) { held[s2][q] = make_uint4(0, 0, 0, 0); held_vo[s2][q] = kDropStore; }
     // after the 8 rows sit in `stage`; slot < 0: store right away (run blocks)
     auto stage_out = [&](int slot) {
         wave_lds_sync();
-        if (DP * 16 >= BLKMAX && slot >= 0) {
-            held[slot] = *(const uint4*)(stage + (lane16 < blk_bytes ? lane16 : 0u));
-            held_vo[slot] = lane16 < blk_bytes ? ovo + lane16 : kDropStore;
-        } else {
-            for (uint32_t u = lane16; u < blk_bytes; u += DP * 16) {
-                const uint4 t = *(const uint4*)(stage + u);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t, t), orsrc, ovo + u, 0, 0);
+#pragma unroll
+        for (int q = 0; q < PIECES; q++) {
+            const uint32_t u = lane16 + q * ROW16;
+            const bool in = u < blk_bytes;
+            const uint4 t = *(const uint4*)(stage + (in ? u : 0u));
+            if (slot >= 0) {
+                held[slot][q] = t;
+                held_vo[slot][q] = in ? ovo + u : kDropStore;
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, t), orsrc, in ? ovo + u : kDropStore, 0, 0);
             }
         }
         wave_lds_sync();
@@ -212,46 +233,55 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         for (; len > 0; len--) {
             if (out_left < blk_elems) { corrupt = true; break; }
             out_left -= blk_elems;
-            const int coef = FIRE ? fire_coef<W, false>(ctr) : 0;
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int delta = FIRE ? __builtin_amdgcn_sbfe(mad24(pd, coef, 0), W, W) : 0;
-                pv += (uint32_t)delta;
-                pd = delta;
-                if (col_ok) *(U*)(stage_col + i * row_stride) = (U)pv;
+            for (int k = 0; k < CPL; k++) {
+                const int coef = FIRE ? fire_coef<W, false>(ctr[k]) : 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int delta = FIRE ? __builtin_amdgcn_sbfe(mad24(pd[k], coef, 0), W, W) : 0;
+                    pv[k] += (uint32_t)delta;
+                    pd[k] = delta;
+                    if (col_ok[k]) *(U*)(stage_col + k * ESZ + i * row_stride) = (U)pv[k];
+                }
             }
             stage_out(-1);
         }
     };
-    auto fetch_rows = [&](uint32_t (&z)[8], uint32_t at, uint32_t off, uint32_t nb, uint32_t row_bytes) {
-        uint32_t p = at + (off >> 3);
-        const uint32_t sh = off & 7u;
+    auto fetch_rows = [&](uint32_t (&z)[CPL][8], uint32_t at, const uint32_t (&off)[CPL], const uint32_t (&nb)[CPL], uint32_t row_bytes) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            z[i] = __builtin_amdgcn_ubfe(lds_rd32(p), sh, nb);
-            p += row_bytes;
+        for (int k = 0; k < CPL; k++) {
+            uint32_t p = at + (off[k] >> 3);
+            const uint32_t sh = off[k] & 7u;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                z[k][i] = __builtin_amdgcn_ubfe(lds_rd32(p), sh, nb[k]);
+                p += row_bytes;
+            }
         }
     };
-    auto packed_block = [&](const uint32_t (&z)[8], int slot) {   // zigzag^-1 + forecast recurrence (:993-1150)
+    auto packed_block = [&](const uint32_t (&z)[CPL][8], int slot) {   // zigzag^-1 + forecast recurrence (:993-1150)
         if (out_left < blk_elems) { corrupt = true; return; }
         out_left -= blk_elems;
-        int grad = 0;
-        const int coef = FIRE ? fire_coef<W, false>(ctr) : 0;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int err = (int)(z[i] >> 1) ^ __builtin_amdgcn_sbfe((int)z[i], 0, 1);
-            int delta;
-            if constexpr (FIRE) {
-                if (i & 1) grad = mad24(sign_of(err), pd, grad);
-                delta = __builtin_amdgcn_sbfe(mad24(pd, coef, err << W), W, W);
-            } else {
-                delta = err;
+        for (int k = 0; k < CPL; k++) {
+            int grad = 0;
+            const int coef = FIRE ? fire_coef<W, false>(ctr[k]) : 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int err = (int)(z[k][i] >> 1) ^ __builtin_amdgcn_sbfe((int)z[k][i], 0, 1);
+                int delta;
+                if constexpr (FIRE) {
+                    if (i & 1) grad = mad24(sign_of(err), pd[k], grad);
+                    delta = __builtin_amdgcn_sbfe(mad24(pd[k], coef, err << W), W, W);
+                } else {
+                    delta = err;
+                }
+                pv[k] += (uint32_t)delta;
+                pd[k] = delta;
+                if (col_ok[k]) *(U*)(stage_col + k * ESZ + i * row_stride) = (U)pv[k];
             }
-            pv += (uint32_t)delta;
-            pd = delta;
-            if (col_ok) *(U*)(stage_col + i * row_stride) = (U)pv;
+            if constexpr (FIRE) ctr[k] = wrap_counter<W>(ctr[k] + __builtin_amdgcn_sbfe(grad, 2, W - 2));   // sext_W(grad) >> 2
         }
-        if constexpr (FIRE) ctr = wrap_counter<W>(ctr + __builtin_amdgcn_sbfe(grad, 2, W - 2));   // sext_W(grad) >> 2
         stage_out(slot);
     };
     auto run_length = [&](uint32_t at, uint32_t& nbytes) -> uint32_t {   // varint in blocks (:829-833)
@@ -287,9 +317,8 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         rofs += 8;
         if (rofs >= RB) rofs -= RB;
         ahead -= 8;
-        pv = 0;
-        pd = 0;
-        ctr = 0;
+#pragma unroll
+        for (int k = 0; k < CPL; k++) { pv[k] = 0; pd[k] = 0; ctr[k] = 0; }
         out_left = a.chunk_len;
         ovo = (uint32_t)((chunk - wave_first) * (uint64_t)a.chunk_len * ESZ);
         corrupt = (int)(w1 >> 16) != D;
@@ -311,19 +340,35 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
             ahead += npend * UNIT;
         }
 
-        // ---- group header: 2*D fields of HB bits (sprintz_xff_rle.cpp:713-735)
+        // ---- group header: 2*D fields of HB bits (sprintz_xff_rle.cpp:713-735); both slots'
+        // nbits ride in one register (slot 0 in bits 0..15, slot 1 in 16..31)
         const uint32_t r = ring + rofs;                    // LDS address of the parse cursor
-        uint32_t f0 = 0, f1 = 0;
-        if (col_ok) {
-            f0 = __builtin_amdgcn_ubfe(lds_rd32(r + hbyte0), hsh0, HB);
-            f1 = __builtin_amdgcn_ubfe(lds_rd32(r + hbyte1), hsh1, HB);
+        uint32_t nb_both[CPL], lane_both = 0;
+#pragma unroll
+        for (int k = 0; k < CPL; k++) {
+            const uint32_t hbit0 = (uint32_t)(col0 + k) * HB, hbit1 = (uint32_t)(D + col0 + k) * HB;
+            uint32_t f0 = 0, f1 = 0;
+            if (col_ok[k]) {
+                f0 = __builtin_amdgcn_ubfe(lds_rd32(r + (hbit0 >> 3)), hbit0 & 7u, HB);
+                f1 = __builtin_amdgcn_ubfe(lds_rd32(r + (hbit1 >> 3)), hbit1 & 7u, HB);
+            }
+            f0 += (f0 == (uint32_t)(W - 1));               // W-1 means W (:747-749)
+            f1 += (f1 == (uint32_t)(W - 1));
+            nb_both[k] = f0 | (f1 << 16);
+            lane_both += nb_both[k];
         }
-        f0 += (f0 == (uint32_t)(W - 1));                   // W-1 means W (:747-749)
-        f1 += (f1 == (uint32_t)(W - 1));
-        const uint32_t nb_both = f0 | (f1 << 16);
         uint32_t tot_both;
-        const uint32_t excl_both = group_scan<DP>(nb_both, lane_d, tot_both);
+        uint32_t excl_both = group_scan<DP>(lane_both, lane_d, tot_both);
         const uint32_t tot0 = tot_both & 0xffffu, tot1 = tot_both >> 16;
+        uint32_t off0[CPL], off1[CPL], nb0[CPL], nb1[CPL];
+#pragma unroll
+        for (int k = 0; k < CPL; k++) {
+            off0[k] = excl_both & 0xffffu;
+            off1[k] = excl_both >> 16;
+            nb0[k] = nb_both[k] & 0xffffu;
+            nb1[k] = nb_both[k] >> 16;
+            excl_both += nb_both[k];
+        }
 
         // ---- lay out both slots, then fetch both before computing either
         const uint32_t at0 = r + hdr_bytes;
@@ -333,9 +378,9 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         const uint32_t at1 = at0 + bytes0;
         if (tot1 == 0) len1 = run_length(at1, bytes1); else bytes1 = rb1 * 8u;
         const uint32_t used = hdr_bytes + bytes0 + bytes1;
-        uint32_t z0[8], z1[8];
-        if (tot0 != 0) fetch_rows(z0, at0, excl_both & 0xffffu, nb_both & 0xffffu, rb0);
-        if (tot1 != 0) fetch_rows(z1, at1, excl_both >> 16, nb_both >> 16, rb1);
+        uint32_t z0[CPL][8], z1[CPL][8];
+        if (tot0 != 0) fetch_rows(z0, at0, off0, nb0, rb0);
+        if (tot1 != 0) fetch_rows(z1, at1, off1, nb1, rb1);
 
         if (tot0 == 0) run_blocks(len0); else packed_block(z0, 0);
         if (!corrupt) { if (tot1 == 0) run_blocks(len1); else packed_block(z1, 1); }
@@ -345,13 +390,16 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         if (rofs >= RB) rofs -= RB;
         ahead -= used;
 
-        // ---- bottom of the step.  VMEM order inside one step is: NPEND stream loads
-        // (top), [rare: run-block stores], two block stores (here).  gfx950 has ONE
-        // in-order counter for loads and stores, so parking the loads must not wait
-        // for the two stores just issued: with every VMEM op of the common path
-        // unconditional, hipcc emits s_waitcnt vmcnt(2) here instead of vmcnt(0).
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t, held[0]), orsrc, held_vo[0], 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t, held[1]), orsrc, held_vo[1], 0, 0);
+        // ---- bottom of the step.  VMEM order inside one step is: the stream loads (top),
+        // [rare: run-block stores], the block stores (here).  gfx950 has ONE in-order
+        // counter for loads and stores, so parking the loads must not wait for the stores
+        // just issued: with every VMEM op of the common path unconditional, hipcc emits
+        // s_waitcnt vmcnt(<number of stores>) here instead of vmcnt(0).
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+            for (int q = 0; q < PIECES; q++)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, held[s2][q]), orsrc, held_vo[s2][q], 0, 0);
 #pragma unroll
         for (uint32_t k = 0; k < NPEND; k++)
             if (k < npend) commit(pend[k]);
@@ -363,11 +411,14 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     if (!corrupt && remaining > out_left) corrupt = true;
     if (!corrupt && remaining > 0) {
         const uint8_t* t = a.comp + gabs + rp;
-        for (uint32_t j = (uint32_t)lane_d; j < remaining; j += DP) {
-            uint32_t x = t[(size_t)j * ESZ];
-            if constexpr (ESZ == 2) x |= (uint32_t)t[(size_t)j * 2 + 1] << 8;
-            ((U*)((uint8_t*)a.out + out_base + ovo))[j] = (U)x;
+        uint8_t* d = (uint8_t*)a.out + out_base + ovo;
+        const uint32_t nbytes = remaining * ESZ;
+        uint32_t done = 0;
+        if ((((uintptr_t)t | (uintptr_t)d) & 7u) == 0) {   // 8 bytes per lane when both sides allow
+            for (uint32_t j = (uint32_t)lane_d; j < (nbytes >> 3); j += DP) ((uint2*)d)[j] = ((const uint2*)t)[j];
+            done = nbytes & ~7u;
         }
+        for (uint32_t j = done + (uint32_t)lane_d; j < nbytes; j += DP) d[j] = t[j];
     }
     if (corrupt || remaining > 0) need_prime = true;       // cursor no longer at the next stream
     if (lane_d == 0 && a.rets) a.rets[chunk] = corrupt ? kErrCorrupt : (int64_t)out_elems + remaining;
@@ -375,12 +426,15 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
 }
 
 // bytes of LDS one group needs in decode_fast_kernel
-constexpr uint32_t decode_fast_lds_bytes(int W, int DP, int D)
+constexpr uint32_t decode_fast_lds_bytes(int W, int DP, int CPL, int D)
 {
-    const uint32_t unit = DP * 16, rb = (DP == 4 ? 8 : 6) * unit;
+    const uint32_t unit = DP * 16 * CPL;
     const uint32_t hb = W == 8 ? 3 : 4;
-    const uint32_t hdrmax = (2 * DP * hb + 7) / 8, blkmax = 8 * DP * (W / 8);
-    const uint32_t apron = (hdrmax + 2 * blkmax + 4 + 24 + 8 + 15) & ~15u;
+    const uint32_t dcap = DP * CPL;
+    const uint32_t hdrmax = (2 * dcap * hb + 7) / 8, blkmax = 8 * dcap * (W / 8);
+    const uint32_t cg = hdrmax + 2 * blkmax + 4;
+    const uint32_t rb = ((2 * (cg + 24) + 3 + unit - 1) / unit + 1) * unit;
+    const uint32_t apron = (cg + 24 + 8 + 15) & ~15u;
     const uint32_t stage = ((8u * D * (W / 8) + 15) & ~15u) + 16;   // +16: spread groups over banks
     return rb + apron + stage;
 }

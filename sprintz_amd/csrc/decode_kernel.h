@@ -230,11 +230,14 @@ __global__ void __launch_bounds__(kThreads) decode_kernel(DecodeArgs a)
     if (!corrupt && out_elems + remaining > a.chunk_len) corrupt = true;
     if (!corrupt) {
         const uint8_t* t = s + pos;
-        for (uint32_t j = (uint32_t)lane_d; j < remaining; j += (uint32_t)DP) {
-            uint32_t x = t[(size_t)j * ESZ];
-            if constexpr (ESZ == 2) x |= (uint32_t)t[(size_t)j * 2 + 1] << 8;
-            o[out_elems + j] = (U)x;
+        uint8_t* d = (uint8_t*)(o + out_elems);
+        const uint32_t nbytes = remaining * ESZ;
+        uint32_t done = 0;
+        if ((((uintptr_t)t | (uintptr_t)d) & 7u) == 0) {   // 8 bytes per lane when both sides allow
+            for (uint32_t j = (uint32_t)lane_d; j < (nbytes >> 3); j += (uint32_t)DP) ((uint2*)d)[j] = ((const uint2*)t)[j];
+            done = nbytes & ~7u;
         }
+        for (uint32_t j = done + (uint32_t)lane_d; j < nbytes; j += (uint32_t)DP) d[j] = t[j];
     }
     if (lane_d == 0 && a.rets) a.rets[chunk] = corrupt ? kErrCorrupt : (int64_t)out_elems + remaining;
 }

@@ -5,8 +5,8 @@ hipError_t launch_decode_w16(bool fire, bool lowdim, int cpl, unsigned grid, siz
 {
     SPRINTZ_DISPATCH(decode_kernel, 16)
 }
-hipError_t launch_decode_fast_w16(bool fire, int dp, bool exact, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a)
+hipError_t launch_decode_fast_w16(bool fire, int dp, int cpl, bool exact, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a)
 {
-    SPRINTZ_DISPATCH_FAST(decode_fast_kernel, 16)
+    SPRINTZ_DISPATCH_DECODE_FAST(decode_fast_kernel, 16)
 }
 }  // namespace sprintz

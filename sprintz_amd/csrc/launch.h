@@ -18,8 +18,8 @@ constexpr int kCplSet[] = {1, 2, 3, 4, 5, 6, 8};
 hipError_t launch_decode_w8(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a);
 hipError_t launch_decode_w16(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a);
 // fast path: general layout, one column per lane, LDS-transposed stores (see decode_fast.h)
-hipError_t launch_decode_fast_w8(bool fire, int dp, bool exact, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a);
-hipError_t launch_decode_fast_w16(bool fire, int dp, bool exact, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a);
+hipError_t launch_decode_fast_w8(bool fire, int dp, int cpl, bool exact, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a);
+hipError_t launch_decode_fast_w16(bool fire, int dp, int cpl, bool exact, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a);
 hipError_t launch_encode_fast_w8(bool fire, int dp, bool exact, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
 hipError_t launch_encode_fast_w16(bool fire, int dp, bool exact, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
 hipError_t launch_encode_w8(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
@@ -61,7 +61,27 @@ inline hipError_t launch_one(K kernel, unsigned grid, size_t shmem, hipStream_t 
         default: return hipErrorInvalidValue;                                                         \
     }
 
-#define SPRINTZ_FAST_CASE(KERNEL, W, DPV)                                                            \
+#define SPRINTZ_FAST_CASE(KERNEL, W, DPV, CPLV)                                                      \
+    if (dp == DPV && cpl == CPLV) {                                                                   \
+        if (exact) return fire ? launch_one(KERNEL<W, true, DPV, CPLV, true>, grid, shmem, st, a)     \
+                               : launch_one(KERNEL<W, false, DPV, CPLV, true>, grid, shmem, st, a);   \
+        return fire ? launch_one(KERNEL<W, true, DPV, CPLV, false>, grid, shmem, st, a)               \
+                    : launch_one(KERNEL<W, false, DPV, CPLV, false>, grid, shmem, st, a);             \
+    }
+
+// decoder fast path: one column per lane for D <= 64, 2 / 4 columns per lane of a
+// 64-lane group for D <= 128 / 256
+#define SPRINTZ_DISPATCH_DECODE_FAST(KERNEL, W)                                                       \
+    SPRINTZ_FAST_CASE(KERNEL, W, 4, 1)                                                                \
+    SPRINTZ_FAST_CASE(KERNEL, W, 8, 1)                                                                \
+    SPRINTZ_FAST_CASE(KERNEL, W, 16, 1)                                                               \
+    SPRINTZ_FAST_CASE(KERNEL, W, 32, 1)                                                               \
+    SPRINTZ_FAST_CASE(KERNEL, W, 64, 1)                                                               \
+    SPRINTZ_FAST_CASE(KERNEL, W, 64, 2)                                                               \
+    SPRINTZ_FAST_CASE(KERNEL, W, 64, 4)                                                               \
+    return hipErrorInvalidValue;
+
+#define SPRINTZ_ENC_FAST_CASE(KERNEL, W, DPV)                                                        \
     case DPV:                                                                                         \
         if (exact) return fire ? launch_one(KERNEL<W, true, DPV, true>, grid, shmem, st, a)           \
                                : launch_one(KERNEL<W, false, DPV, true>, grid, shmem, st, a);         \
@@ -70,11 +90,11 @@ inline hipError_t launch_one(K kernel, unsigned grid, size_t shmem, hipStream_t 
 
 #define SPRINTZ_DISPATCH_FAST(KERNEL, W)                                                              \
     switch (dp) {                                                                                     \
-        SPRINTZ_FAST_CASE(KERNEL, W, 4)                                                               \
-        SPRINTZ_FAST_CASE(KERNEL, W, 8)                                                               \
-        SPRINTZ_FAST_CASE(KERNEL, W, 16)                                                              \
-        SPRINTZ_FAST_CASE(KERNEL, W, 32)                                                              \
-        SPRINTZ_FAST_CASE(KERNEL, W, 64)                                                              \
+        SPRINTZ_ENC_FAST_CASE(KERNEL, W, 4)                                                           \
+        SPRINTZ_ENC_FAST_CASE(KERNEL, W, 8)                                                           \
+        SPRINTZ_ENC_FAST_CASE(KERNEL, W, 16)                                                          \
+        SPRINTZ_ENC_FAST_CASE(KERNEL, W, 32)                                                          \
+        SPRINTZ_ENC_FAST_CASE(KERNEL, W, 64)                                                          \
         default: return hipErrorInvalidValue;                                                         \
     }
 
