@@ -8,8 +8,9 @@
 //     ds_read_u16/u8) -- instead of 8 scattered 2-byte global loads per lane;
 //   * the per-block nbits scan runs on DPP (group_ops.h);
 //   * FIRE arithmetic pinned to v_mad_i32_i24 / v_med3_i32 (see decode_fast.h);
-//   * OUTPUT as in encode_kernel.h: fields OR-ed into a zeroed per-group LDS ring
-//     with ds_or_b32, flushed to HBM in aligned 16-byte pieces per stream group.
+//   * OUTPUT: fields OR-ed with ds_or_b32 into a zeroed, LINEAR per-group LDS window
+//     (plain offsets, one 64-bit shift per field), whole 16-byte pieces flushed to HBM
+//     per stream group.
 #pragma once
 
 #include "decode_fast.h"
@@ -39,43 +40,56 @@ __global__ void __launch_bounds__(kThreads) encode_fast_kernel(EncodeArgs a)
     uint8_t* const gdst = a.slots + chunk * a.slot_stride;
     const bool col_ok = EXACT ? true : lane_d < D;
 
-    // LDS carve per group: [output ring cap | input block staging]
-    const uint32_t cap = a.cap, capm = cap - 1;
-    uint8_t* const ring = smem + (size_t)(threadIdx.x >> LOG2DP) * a.lds_group_stride;
-    uint32_t* const ring32 = (uint32_t*)ring;
-    uint8_t* const stage = ring + cap;
+    // LDS carve per group: [output window cap | input block staging].  The window is a
+    // LINEAR, zero-initialised image of the stream from `gpos` (16-byte aligned) on:
+    // bit fields are OR-ed into it at plain offsets (no ring arithmetic); whenever a
+    // stream group starts, its whole 16-byte pieces go to HBM and the < 16-byte rest
+    // moves to the front.  cap >= 16 + one group + the close-out bytes.
+    const uint32_t cap = a.cap;
+    uint8_t* const win = smem + (size_t)(threadIdx.x >> LOG2DP) * a.lds_group_stride;
+    uint8_t* const stage = win + cap;
+    const uint32_t win_a = lds_addr(win);
 
-    for (uint32_t u = (uint32_t)lane_d; u < (cap >> 4); u += DP) ((uint4*)ring)[u] = make_uint4(0, 0, 0, 0);
+    for (uint32_t u = (uint32_t)lane_d; u < (cap >> 4); u += DP) ((uint4*)win)[u] = make_uint4(0, 0, 0, 0);
     wave_lds_sync();
 
-    uint32_t wpos = a.write_size ? 8u : 0u;   // stream write position (bytes)
-    uint32_t flushed = 0;                     // multiple of 16; ring holds [flushed, flushed + cap)
+    uint32_t wl = a.write_size ? 8u : 0u;     // write position inside the window (bytes)
+    uint32_t gpos = 0;                        // stream offset of the window start (multiple of 16)
 
-    auto flush_to = [&](uint32_t upto) {      // [flushed, upto) -> HBM, re-zero
+    // whole 16-byte pieces below `upto` (window offset, multiple of 16) -> HBM; re-zero; slide
+    auto drain = [&](uint32_t upto) {
         wave_lds_sync();
-        const uint32_t nunits = (upto - flushed) >> 4;
-        for (uint32_t u = (uint32_t)lane_d; u < nunits; u += DP) {
-            const uint32_t p = flushed + (u << 4);
-            uint4* r = (uint4*)(ring + (p & capm));
-            *(uint4*)(gdst + p) = *r;
+        for (uint32_t u = (uint32_t)lane_d * 16u; u < upto; u += DP * 16) {
+            uint4* r = (uint4*)(win + u);
+            *(uint4*)(gdst + gpos + u) = *r;
             *r = make_uint4(0, 0, 0, 0);
         }
-        flushed = upto;
+        wave_lds_sync();
+        if (upto != 0 && lane_d == 0 && upto < cap) {       // move the partial piece to the front
+            const uint4 v = *(uint4*)(win + upto);
+            *(uint4*)(win + upto) = make_uint4(0, 0, 0, 0);
+            *(uint4*)win = v;
+        }
+        gpos += upto;
+        wl -= upto;
         wave_lds_sync();
     };
-    auto or_bits = [&](uint32_t bp, uint32_t v, uint32_t nb) {   // low nb (<= 16) bits of v at stream bit bp
+    // OR the low nb (<= 16) bits of v at window bit position bp: always two dwords (the
+    // second one is an OR with 0 when the field does not straddle)
+    auto or_bits = [&](uint32_t bp, uint32_t v, uint32_t nb) {
         if (nb == 0) return;
-        const uint32_t w = (bp >> 5), sh = bp & 31u;
-        const uint32_t wm = (cap >> 2) - 1;
-        atomicOr(&ring32[w & wm], v << sh);
-        if (sh + nb > 32u) atomicOr(&ring32[(w + 1) & wm], v >> (32u - sh));
+        const uint64_t x = (uint64_t)v << (bp & 31u);
+        __attribute__((address_space(3))) uint32_t* q =
+            (__attribute__((address_space(3))) uint32_t*)(uintptr_t)(win_a + ((bp >> 3) & ~3u));
+        __hip_atomic_fetch_or(q, (uint32_t)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if ((uint32_t)(x >> 32)) __hip_atomic_fetch_or(q + 1, (uint32_t)(x >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     };
     auto put_run = [&](uint32_t run) {          // sprintz_xff_rle.cpp:377-384
         if (lane_d == 0) {
-            ring[wpos & capm] = (uint8_t)((run & 0x7fu) | (run > 0x7fu ? 0x80u : 0u));
-            if (run > 0x7fu) ring[(wpos + 1) & capm] = (uint8_t)(run >> 7);
+            win[wl] = (uint8_t)((run & 0x7fu) | (run > 0x7fu ? 0x80u : 0u));
+            if (run > 0x7fu) win[wl + 1] = (uint8_t)(run >> 7);
         }
-        wpos += run > 0x7fu ? 2u : 1u;
+        wl += run > 0x7fu ? 2u : 1u;
     };
 
     const uint32_t hdr_bytes = (2u * (uint32_t)D * HB + 7u) >> 3;
@@ -91,9 +105,9 @@ __global__ void __launch_bounds__(kThreads) encode_fast_kernel(EncodeArgs a)
 
     auto start_group = [&]() {
         ngroups++;
-        flush_to(wpos & ~15u);
-        hdr_pos = wpos;
-        wpos += hdr_bytes;
+        drain(wl & ~15u);
+        hdr_pos = wl;
+        wl += hdr_bytes;
         slot = 0;
     };
     // this lane's 16-byte pieces of the 8 x D block starting at element `pos` (0 past the chunk)
@@ -160,7 +174,7 @@ __global__ void __launch_bounds__(kThreads) encode_fast_kernel(EncodeArgs a)
                 if (more) break;
                 slot++;
                 put_run(run);
-                wpos += (uint32_t)(2 - slot);
+                wl += (uint32_t)(2 - slot);
                 run = 0;
                 active = false;
                 break;
@@ -177,13 +191,13 @@ __global__ void __launch_bounds__(kThreads) encode_fast_kernel(EncodeArgs a)
                 or_bits(hdr_pos * 8u + (uint32_t)(slot * D + lane_d) * HB, f, HB);
             }
             const uint32_t row_bits = ((total + 7u) >> 3) << 3;
-            uint32_t bp = wpos * 8u + excl;
+            uint32_t bp = wl * 8u + excl;
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 or_bits(bp, z[i], nb);
                 bp += row_bits;
             }
-            wpos += row_bits;                            // 8 rows * row_bytes
+            wl += row_bits;                              // 8 rows * row_bytes
             pos_in += blk;
             slot++;
             if (slot == 2) {
@@ -194,30 +208,31 @@ __global__ void __launch_bounds__(kThreads) encode_fast_kernel(EncodeArgs a)
         }
     }
 
-    // ---- verbatim tail through the ring (:553)
+    // ---- verbatim tail through the window (:553)
     const uint32_t remaining = (uint32_t)((int64_t)n - pos_in);
     {
         const uint8_t* tp = (const uint8_t*)(sc + pos_in);
         uint32_t left = remaining * ESZ;
         while (left > 0) {
-            flush_to(wpos & ~15u);
-            const uint32_t room = cap - (wpos - flushed);
+            drain(wl & ~15u);
+            const uint32_t room = cap - 16u - wl;
             const uint32_t m = left < room ? left : room;
-            for (uint32_t j = (uint32_t)lane_d; j < m; j += DP) ring[(wpos + j) & capm] = tp[j];
-            wpos += m;
+            for (uint32_t j = (uint32_t)lane_d; j < m; j += DP) win[wl + j] = tp[j];
+            wl += m;
             tp += m;
             left -= m;
         }
     }
-    flush_to((wpos + 15u) & ~15u);
+    const uint32_t total_bytes = gpos + wl;
+    drain((wl + 15u) & ~15u);
 
     if (lane_d == 0) {                                   // format.h:36-45; lane 0 also flushed unit 0
         if (a.write_size) {
             ((uint32_t*)gdst)[0] = ngroups;
             ((uint32_t*)gdst)[1] = (remaining & 0xffffu) | ((uint32_t)D << 16);
         }
-        a.sizes[chunk] = wpos;
-        if (a.rets) a.rets[chunk] = (int64_t)(wpos / ESZ);
+        a.sizes[chunk] = total_bytes;
+        if (a.rets) a.rets[chunk] = (int64_t)(total_bytes / ESZ);
     }
 }
 
