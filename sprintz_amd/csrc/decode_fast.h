@@ -295,8 +295,9 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     bool need_prime = true;
     for (uint64_t chunk = c_first; chunk < c_end; chunk++) {
     // ---- chunk start: find the stream, read its 8-byte header (format.h:48-62)
+    const uint64_t off_c = a.offsets[chunk];
     {
-        const uint64_t off = a.offsets[chunk];
+        const uint64_t off = off_c;
         const uint64_t gap = off - (gabs + rp);            // bytes between the cursor and the next stream
         if (need_prime || gap > 16 || rp > (1u << 30)) {
             prime(off);
@@ -322,6 +323,10 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         out_left = a.chunk_len;
         ovo = (uint32_t)((chunk - wave_first) * (uint64_t)a.chunk_len * ESZ);
         corrupt = (int)(w1 >> 16) != D;
+        // a damaged header must not make the loop spin: every group takes at least its
+        // header and two slot bytes out of the stream
+        const uint64_t stream_len = a.offsets[chunk + 1] - off_c;
+        if ((uint64_t)groups_left * (hdr_bytes + 2u) > stream_len || groups_left > a.chunk_len / blk_elems + 2u) corrupt = true;
         if (corrupt) groups_left = 0;
     }
 

@@ -75,6 +75,10 @@ __global__ void __launch_bounds__(kThreads) decode_kernel(DecodeArgs a)
 
     const uint32_t hdr_bytes = (2u * (uint32_t)D * HB + 7u) >> 3;
     const uint32_t blk_elems = 8u * (uint32_t)D;
+    // a damaged header must not make the loop spin: every group of a valid stream holds at
+    // least one non-empty slot, except the one that closes the stream
+    bool corrupt = groups_left > a.chunk_len / blk_elems + 2u;
+    if (corrupt) groups_left = 0;
 
     // per-column predictor state (all start at 0: sprintz_xff_rle.cpp:149-152)
     uint32_t pv[CPL];
@@ -87,7 +91,6 @@ __global__ void __launch_bounds__(kThreads) decode_kernel(DecodeArgs a)
     uint32_t out_elems = 0;
     int slot = 2;
     uint32_t run_left = 0;
-    bool corrupt = false;
 
     for (;;) {
         uint32_t z[8][CPL];

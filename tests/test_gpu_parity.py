@@ -247,3 +247,36 @@ def test_full_size_cfg2_roundtrip_and_size_checksum(sz, oracle):
         assert sizes[c] == want.size
         assert np.array_equal(comp[offs[c]:offs[c] + sizes[c]], want)
     assert 2.0 < x.numel() * 2 / sizes.sum() < 6.0
+
+
+def test_corrupt_streams_do_not_hang_or_overrun(sz, oracle):
+    """bit-flipped / truncated / header-damaged streams: the decoder must terminate, stay inside
+    each chunk's output slot and either decode something or report SPRINTZ_E_CORRUPT"""
+    import torch
+    rng = np.random.default_rng(77)
+    codec, esz, ndims, chunk_len, nchunks = "xff", 2, 8, 5120, 64
+    data = gen_walk(rng, nchunks * chunk_len, ndims, esz, 8, flat_every=4)
+    cd = sz.ChunkedCodec(codec, esz, ndims, chunk_len, device="cuda:0")
+    batch = cd.compress(torch.from_numpy(data).cuda())
+    comp0 = batch.data.cpu().numpy().copy()
+    offs = batch.offsets.cpu().numpy()
+    for trial in range(6):
+        comp = comp0.copy()
+        if trial == 0:                                   # huge group counts
+            for c in range(nchunks):
+                comp[offs[c]:offs[c] + 4] = 0xFF
+        elif trial == 1:                                 # zeroed streams
+            comp[:] = 0
+        elif trial == 2:                                 # all ones
+            comp[:] = 0xFF
+        else:                                            # random bit flips
+            idx = rng.integers(0, comp.size, comp.size // 50)
+            comp[idx] ^= rng.integers(1, 256, idx.size).astype(np.uint8)
+        guard = 4096
+        out = torch.full((nchunks * chunk_len + guard,), 0x5A5A, dtype=torch.int16, device="cuda:0")
+        rets = torch.zeros(nchunks, dtype=torch.int64, device="cuda:0")
+        cd.decompress_into(torch.from_numpy(comp).cuda(), batch.offsets, nchunks, out, rets)
+        torch.cuda.synchronize()
+        r = rets.cpu().numpy()
+        assert ((r == sz._lib.E_CORRUPT) | ((r >= 0) & (r <= chunk_len))).all(), (trial, r[:8])
+        assert (out[nchunks * chunk_len:].cpu().numpy() == 0x5A5A).all(), trial
