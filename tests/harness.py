@@ -56,6 +56,51 @@ class Oracle:
                                         [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64,
                                          C.c_uint32, C.c_void_p])
 
+    # ---- optional Huffman stage (oracle/huf_oracle.c; our own container, see its header)
+    def _huf_bind(self):
+        if not hasattr(self, "_huf_c"):
+            self._huf_c = _bind(self.lib, "huf_oracle_compress", C.c_uint64,
+                                [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p])
+            self._huf_d = _bind(self.lib, "huf_oracle_decompress", C.c_uint64,
+                                [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p])
+            self._huf_len = _bind(self.lib, "huf_oracle_lengths", None, [C.c_void_p, C.c_void_p])
+
+    def huf_lengths(self, counts):
+        self._huf_bind()
+        counts = np.ascontiguousarray(counts, dtype=np.uint32)
+        lens = np.zeros(256, np.uint8)
+        self._huf_len(counts.ctypes.data, lens.ctypes.data)
+        return lens
+
+    def huf_compress(self, dense, offsets, sizes):
+        """-> (huf bytes, huf_offsets[nchunks+1], tables)"""
+        self._huf_bind()
+        dense = np.ascontiguousarray(dense, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
+        n = len(sizes)
+        out = np.zeros(int(sizes.astype(np.int64).sum()) + 16 * n + 64, np.uint8)
+        ho = np.zeros(n + 1, np.uint64)
+        tables = np.zeros(((n + 63) // 64) * 128, np.uint8)
+        total = self._huf_c(dense.ctypes.data, offsets.ctypes.data, sizes.ctypes.data, n, out.ctypes.data,
+                            ho.ctypes.data, tables.ctypes.data)
+        return out[:total].copy(), ho, tables
+
+    def huf_decompress(self, huf, huf_offsets, tables, dense_capacity, align=16):
+        """-> (dense bytes, offsets[nchunks+1], sizes[nchunks])"""
+        self._huf_bind()
+        huf = np.ascontiguousarray(huf, dtype=np.uint8)
+        huf = np.concatenate([huf, np.zeros(16, np.uint8)])
+        huf_offsets = np.ascontiguousarray(huf_offsets, dtype=np.uint64)
+        tables = np.ascontiguousarray(tables, dtype=np.uint8)
+        n = len(huf_offsets) - 1
+        dense = np.zeros(dense_capacity + 64, np.uint8)
+        offs = np.zeros(n + 1, np.uint64)
+        sizes = np.zeros(n, np.uint32)
+        total = self._huf_d(huf.ctypes.data, huf_offsets.ctypes.data, tables.ctypes.data, n, align, dense.ctypes.data,
+                            offs.ctypes.data, sizes.ctypes.data)
+        return dense[:total].copy(), offs, sizes
+
     def bound(self, esz, n, ndims):
         return int(self._bound(esz, n, ndims))
 
