@@ -142,6 +142,32 @@ int sprintz_mi355x_decompress_batch(int codec, int elem_bytes,
                                     void* d_out, int64_t* d_rets, void* hip_stream);
 
 /* ------------------------------------------------------------------------
+ * (3) Optional Huffman stage over the container (bytes as symbols, after
+ * bit-packing -- what the paper does with Huff0, communicate/ubicomp/
+ * method.tex:293-297).  The reference tree contains NO Huffman coder
+ * (SURVEY.md 8c), so this container format is this library's own (specified in
+ * oracle/huf_oracle.c: 64-chunk segments share a code table, 4 byte-aligned
+ * sub-streams per chunk, 11-bit code limit) and its parity is unpinned; the
+ * Sprintz streams it wraps remain bit-exact with the reference.
+ *   d_tables : ceil(nchunks/64) * 128 bytes of code-length tables
+ *   d_huf    : capacity >= sprintz_mi355x_huf_bound(sum of d_sizes, nchunks)
+ *   d_tmp    : sprintz_mi355x_huf_tmp_bytes(nchunks) bytes of scratch
+ * ---------------------------------------------------------------------- */
+size_t sprintz_mi355x_huf_tmp_bytes(uint64_t nchunks);
+size_t sprintz_mi355x_huf_bound(uint64_t total_stream_bytes, uint64_t nchunks);
+/* container (d_dense, d_offsets[nchunks+1], d_sizes[nchunks] = exact stream bytes)
+ * -> Huffman records at d_huf + d_huf_offsets[c] (d_huf_offsets[nchunks] = total) */
+int sprintz_mi355x_huf_compress_batch(const void* d_dense, const uint64_t* d_offsets, const uint32_t* d_sizes,
+                                      uint64_t nchunks, void* d_huf, uint64_t* d_huf_offsets, void* d_tables,
+                                      void* d_tmp, void* hip_stream);
+/* inverse: rebuilds the container with chunk starts rounded up to `align`
+ * (fills d_offsets[nchunks+1] and d_sizes[nchunks]); feed it to
+ * sprintz_mi355x_decompress_batch. */
+int sprintz_mi355x_huf_decompress_batch(const void* d_huf, const uint64_t* d_huf_offsets, const void* d_tables,
+                                        uint64_t nchunks, uint32_t align, void* d_dense, uint64_t* d_offsets,
+                                        uint32_t* d_sizes, void* d_tmp, void* hip_stream);
+
+/* ------------------------------------------------------------------------
  * Host convenience: chunked codec over host buffers (what lzbench does per
  * block).  Stages through device memory; PCIe-inclusive by construction.
  * comp layout: chunk streams concatenated byte-dense; offsets[nchunks+1].

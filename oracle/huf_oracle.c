@@ -210,6 +210,7 @@ uint64_t huf_oracle_compress(const uint8_t* dense, const uint64_t* offsets, cons
             pos += 12 + enc;
         }
     }
+    pos = (pos + 3) & ~(uint64_t)3;              /* the container ends on a 4-byte boundary too */
     out_offsets[nchunks] = pos;
     return pos;
 }
@@ -266,6 +267,7 @@ uint64_t huf_oracle_decompress(const uint8_t* huf, const uint64_t* huf_offsets, 
         }
     }
     free(dtab);
+    pos = (pos + align - 1) & ~(uint64_t)(align - 1);   /* like sprintz_mi355x_compact: the end is aligned too */
     offsets[nchunks] = pos;
     return pos;
 }

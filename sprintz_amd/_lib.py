@@ -76,6 +76,12 @@ compact_tmp_bytes = _sig("sprintz_mi355x_compact_tmp_bytes", _sz, _u64)
 compact = _sig("sprintz_mi355x_compact", _i, _vp, _sz, _vp, _u64, _u32, _vp, _vp, _vp, _vp)
 decompress_batch = _sig("sprintz_mi355x_decompress_batch", _i, _i, _i, _vp, _vp, _u64, _u32, _u16, _vp, _vp, _vp)
 
+# (3) optional Huffman stage
+huf_tmp_bytes = _sig("sprintz_mi355x_huf_tmp_bytes", _sz, _u64)
+huf_bound = _sig("sprintz_mi355x_huf_bound", _sz, _u64, _u64)
+huf_compress_batch = _sig("sprintz_mi355x_huf_compress_batch", _i, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp)
+huf_decompress_batch = _sig("sprintz_mi355x_huf_decompress_batch", _i, _vp, _vp, _vp, _u64, _u32, _vp, _vp, _vp, _vp, _vp)
+
 # host convenience
 compress_chunked_host = _sig("sprintz_mi355x_compress_chunked_host", _i64, _i, _i, _vp, _u64, _u32, _u16, _vp, _sz, _vp)
 decompress_chunked_host = _sig("sprintz_mi355x_decompress_chunked_host", _i64, _i, _i, _vp, _vp, _u64, _u32, _u16, _vp)
@@ -91,6 +97,8 @@ EXPORTED_SYMBOLS = [
     "sprintz_mi355x_compress_batch", "sprintz_mi355x_compact_tmp_bytes", "sprintz_mi355x_compact",
     "sprintz_mi355x_decompress_batch",
     "sprintz_mi355x_compress_chunked_host", "sprintz_mi355x_decompress_chunked_host",
+    "sprintz_mi355x_huf_tmp_bytes", "sprintz_mi355x_huf_bound",
+    "sprintz_mi355x_huf_compress_batch", "sprintz_mi355x_huf_decompress_batch",
 ]
 
 

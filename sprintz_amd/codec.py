@@ -200,6 +200,55 @@ class ChunkedCodec:
                                          rets.data_ptr() if rets is not None else None, self._stream()))
 
 
+# ---- optional Huffman stage (device) ------------------------------------------------
+
+@dataclass
+class HufBatch:
+    """Huffman-coded container (format: oracle/huf_oracle.c; unpinned vs the reference)."""
+    data: "torch.Tensor"       # uint8 records
+    offsets: "torch.Tensor"    # int64 [nchunks+1]
+    tables: "torch.Tensor"     # uint8 [ceil(nchunks/64)*128]
+    nchunks: int
+    total_len: int
+    chunk_len: int
+    ndims: int
+
+    def total_bytes(self):
+        return int(self.offsets[-1].item()) + int(self.tables.numel())
+
+
+def huf_compress(batch):
+    """CompressedBatch -> HufBatch (entropy-codes the chunk streams on the GPU)"""
+    import torch
+    dev = batch.data.device
+    n = batch.nchunks
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    total = batch.stream_bytes()
+    huf = torch.zeros(int(_lib.huf_bound(total, n)), dtype=torch.uint8, device=dev)   # record gaps (< 4 B) read as 0
+    hoffs = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    tables = torch.empty(((n + 63) // 64) * 128, dtype=torch.uint8, device=dev)
+    tmp = torch.empty(int(_lib.huf_tmp_bytes(n)), dtype=torch.uint8, device=dev)
+    _lib.check(_lib.huf_compress_batch(batch.data.data_ptr(), batch.offsets.data_ptr(), batch.sizes.data_ptr(), n,
+                                       huf.data_ptr(), hoffs.data_ptr(), tables.data_ptr(), tmp.data_ptr(), stream))
+    end = int(hoffs[-1].item())
+    return HufBatch(huf[: end + _lib.READ_SLACK].clone(), hoffs, tables, n, batch.total_len, batch.chunk_len, batch.ndims)
+
+
+def huf_decompress(hb, dense_capacity, align=16):
+    """HufBatch -> CompressedBatch (the exact Sprintz container again)"""
+    import torch
+    dev = hb.data.device
+    n = hb.nchunks
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    dense = torch.zeros(dense_capacity + _lib.READ_SLACK + 16 * n, dtype=torch.uint8, device=dev)
+    offs = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    sizes = torch.empty(n, dtype=torch.int32, device=dev)
+    tmp = torch.empty(int(_lib.compact_tmp_bytes(n)) + 64, dtype=torch.uint8, device=dev)
+    _lib.check(_lib.huf_decompress_batch(hb.data.data_ptr(), hb.offsets.data_ptr(), hb.tables.data_ptr(), n, align,
+                                         dense.data_ptr(), offs.data_ptr(), sizes.data_ptr(), tmp.data_ptr(), stream))
+    return CompressedBatch(dense, offs, sizes, n, hb.total_len, hb.chunk_len, hb.ndims)
+
+
 # ---- host convenience (lzbench-style, PCIe inclusive) ---------------------------
 
 def compress_chunked(codec, data, ndims, chunk_len):

@@ -177,6 +177,24 @@ __global__ void __launch_bounds__(kThreads) compact_copy_kernel(const uint8_t* s
     }
 }
 
+}  // namespace
+
+namespace sprintz {
+// exclusive scan of (aligned) u32 sizes into u64 offsets[n+1]; tmp = sprintz_mi355x_compact_tmp_bytes(n)
+hipError_t launch_size_scan(const uint32_t* d_sizes, uint64_t n, uint32_t align, uint64_t* d_offsets, void* d_tmp, hipStream_t st)
+{
+    if (n == 0) return hipMemsetAsync(d_offsets, 0, 8, st);
+    const uint64_t nblocks = (n + kScanBlock - 1) / kScanBlock;
+    uint64_t* tmp = (uint64_t*)d_tmp;
+    hipLaunchKernelGGL(scan_local_kernel, dim3((unsigned)nblocks), dim3(kScanBlock), 0, st, d_sizes, n, align, d_offsets, tmp);
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(kScanBlock), 0, st, tmp, nblocks, d_offsets + n);
+    hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nblocks), dim3(kScanBlock), 0, st, d_offsets, n, tmp);
+    return hipGetLastError();
+}
+}  // namespace sprintz
+
+namespace {
+
 // ---------------------------------------------------------------- launch helpers
 
 int check_common(int codec, int esz, uint16_t ndims)
@@ -515,11 +533,7 @@ int sprintz_mi355x_compact(const void* d_slots, size_t slot_stride, const uint32
         HIP_TRY(hipMemsetAsync(d_offsets, 0, 8, st));
         return 0;
     }
-    const uint64_t nblocks = (nchunks + kScanBlock - 1) / kScanBlock;
-    uint64_t* tmp = (uint64_t*)d_scan_tmp;
-    hipLaunchKernelGGL(scan_local_kernel, dim3((unsigned)nblocks), dim3(kScanBlock), 0, st, d_sizes, nchunks, align, d_offsets, tmp);
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(kScanBlock), 0, st, tmp, nblocks, d_offsets + nchunks);
-    hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nblocks), dim3(kScanBlock), 0, st, d_offsets, nchunks, tmp);
+    HIP_TRY(launch_size_scan(d_sizes, nchunks, align, d_offsets, d_scan_tmp, st));
     const uint64_t grid = (nchunks * 64 + kThreads - 1) / kThreads;
     hipLaunchKernelGGL(compact_copy_kernel, dim3((unsigned)grid), dim3(kThreads), 0, st, (const uint8_t*)d_slots,
                        (uint64_t)slot_stride, d_sizes, d_offsets, nchunks, align, (uint8_t*)d_dense);

@@ -1,0 +1,401 @@
+// huf.hip -- optional Huffman stage over the bit-packed Sprintz streams (bytes as
+// symbols, applied after bit-packing, as the paper does with Huff0:
+// communicate/ubicomp/method.tex:293-297).
+//
+// Parity status: UNPINNED against the reference -- dblalock/sprintz ships no Huffman
+// coder.  The container format is this repository's own and is
+// specified in oracle/huf_oracle.c (segments of 64 chunks share a code table, 4
+// byte-aligned sub-streams per chunk, 11-bit length limit); the kernels here are
+// bit-exact with that CPU oracle.  Everything upstream of this stage (the Sprintz
+// streams) stays bit-exact with the reference.
+#include "../../include/sprintz_mi355x.h"
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "launch.h"
+
+using namespace sprintz;
+
+namespace {
+
+constexpr int LMAX = 11;
+constexpr int SEG = 64;                 // chunks per segment = 256 threads / 4 sub-streams
+
+typedef uint32_t __attribute__((aligned(1), may_alias)) u32_any;
+
+// ---------------------------------------------------------------- K1: histogram + code lengths + codes
+// one wavefront per segment
+__global__ void __launch_bounds__(64) huf_build_kernel(const uint8_t* dense, const uint64_t* offsets, const uint32_t* sizes,
+                                                       uint64_t nchunks, uint32_t* enc_tables, uint8_t* tables)
+{
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t lcnt[256];      // leaves sorted by (count, symbol): count
+    __shared__ uint16_t lsym[256];      //                                   symbol
+    __shared__ uint32_t w[511];
+    __shared__ uint16_t parent[511];
+    __shared__ uint8_t depth[511];
+    __shared__ uint8_t lens[256];
+    __shared__ uint32_t first[LMAX + 2];
+    const int lane = threadIdx.x;
+    const uint64_t seg = blockIdx.x;
+    const uint64_t c0 = seg * SEG, c1 = (c0 + SEG < nchunks) ? c0 + SEG : nchunks;
+
+    for (int s = lane; s < 256; s += 64) { hist[s] = 0; lens[s] = 0; }
+    __syncthreads();
+    for (uint64_t c = c0; c < c1; c++) {
+        const uint8_t* p = dense + offsets[c];
+        const uint32_t n = sizes[c];
+        if (((uintptr_t)p & 3) == 0) {
+            const uint32_t nw = n >> 2;
+            for (uint32_t i = lane; i < nw; i += 64) {
+                const uint32_t x = ((const uint32_t*)p)[i];
+                atomicAdd(&hist[x & 255], 1u);
+                atomicAdd(&hist[(x >> 8) & 255], 1u);
+                atomicAdd(&hist[(x >> 16) & 255], 1u);
+                atomicAdd(&hist[x >> 24], 1u);
+            }
+            for (uint32_t i = (nw << 2) + lane; i < n; i += 64) atomicAdd(&hist[p[i]], 1u);
+        } else {
+            for (uint32_t i = lane; i < n; i += 64) atomicAdd(&hist[p[i]], 1u);
+        }
+    }
+    __syncthreads();
+
+    // rank sort by (count, symbol): 4 symbols per lane
+    for (int s = lane; s < 256; s += 64) {
+        const uint32_t cs = hist[s];
+        int rank = 0;
+        for (int t = 0; t < 256; t++) {
+            const uint32_t ct = hist[t];
+            rank += (ct < cs || (ct == cs && t < s)) ? 1 : 0;
+        }
+        lcnt[rank] = cs;
+        lsym[rank] = (uint16_t)s;
+    }
+    __syncthreads();
+
+    if (lane == 0) {
+        int z = 0;
+        while (z < 256 && lcnt[z] == 0) z++;                 // zero-count symbols sort first
+        const int nz = 256 - z;
+        const uint32_t* lc = lcnt + z;
+        const uint16_t* ls = lsym + z;
+        if (nz == 1) {
+            lens[ls[0]] = 1;
+        } else if (nz >= 2) {
+            // two-queue Huffman (oracle/huf_oracle.c: huf_oracle_lengths)
+            for (int i = 0; i < nz; i++) w[i] = lc[i];
+            int ql = 0, qi = nz, next = nz;
+            for (int m = 0; m < nz - 1; m++) {
+                int pick[2];
+                for (int t = 0; t < 2; t++) {
+                    const bool has_l = ql < nz, has_i = qi < next;
+                    if (has_l && (!has_i || w[ql] <= w[qi])) pick[t] = ql++;
+                    else pick[t] = qi++;
+                }
+                w[next] = w[pick[0]] + w[pick[1]];
+                parent[pick[0]] = (uint16_t)next;
+                parent[pick[1]] = (uint16_t)next;
+                next++;
+            }
+            depth[next - 1] = 0;
+            for (int i = next - 2; i >= 0; i--) {
+                const int d = depth[parent[i]] + 1;
+                depth[i] = (uint8_t)(d > 255 ? 255 : d);
+            }
+            uint32_t kraft = 0;
+            for (int i = 0; i < nz; i++) {
+                const int l = depth[i] > LMAX ? LMAX : depth[i];
+                lens[ls[i]] = (uint8_t)l;
+                kraft += 1u << (LMAX - l);
+            }
+            while (kraft > (1u << LMAX)) {
+                int best = -1;
+                for (int i = 0; i < nz; i++) {
+                    const int l = lens[ls[i]];
+                    if (l >= LMAX) continue;
+                    if (best < 0) { best = i; continue; }
+                    const int lb = lens[ls[best]];
+                    if (l > lb) best = i;
+                    else if (l == lb) {
+                        if (lc[i] < lc[best]) best = i;
+                        else if (lc[i] == lc[best] && ls[i] > ls[best]) best = i;
+                    }
+                }
+                const int l = lens[ls[best]];
+                kraft -= 1u << (LMAX - l - 1);
+                lens[ls[best]] = (uint8_t)(l + 1);
+            }
+            for (;;) {
+                int best = -1;
+                for (int i = nz - 1; i >= 0; i--) {
+                    const int l = lens[ls[i]];
+                    if (l <= 1) continue;
+                    if (kraft + (1u << (LMAX - l)) > (1u << LMAX)) continue;
+                    if (best < 0) { best = i; continue; }
+                    if (lc[i] > lc[best]) best = i;
+                    else if (lc[i] == lc[best] && ls[i] < ls[best]) best = i;
+                }
+                if (best < 0) break;
+                const int l = lens[ls[best]];
+                kraft += 1u << (LMAX - l);
+                lens[ls[best]] = (uint8_t)(l - 1);
+            }
+        }
+        // first canonical code of every length
+        uint32_t count[LMAX + 2];
+        for (int l = 0; l <= LMAX + 1; l++) count[l] = 0;
+        for (int s = 0; s < 256; s++) count[lens[s]]++;
+        count[0] = 0;
+        uint32_t code = 0;
+        first[0] = 0;
+        for (int l = 1; l <= LMAX; l++) { code = (code + count[l - 1]) << 1; first[l] = code; }
+    }
+    __syncthreads();
+
+    for (int s = lane; s < 256; s += 64) {
+        const int l = lens[s];
+        uint32_t e = 0;
+        if (l) {
+            int before = 0;
+            for (int t = 0; t < s; t++) before += lens[t] == l;
+            const uint32_t c = first[l] + (uint32_t)before;
+            e = (__brev(c) >> (32 - l)) | ((uint32_t)l << 16);
+        }
+        enc_tables[seg * 256 + s] = e;
+    }
+    for (int i = lane; i < 128; i += 64) tables[seg * 128 + i] = (uint8_t)(lens[2 * i] | (lens[2 * i + 1] << 4));
+}
+
+// sub-stream j of an n-symbol chunk: [a, b)
+__device__ __forceinline__ void sub_range(uint32_t n, int j, uint32_t& a, uint32_t& b)
+{
+    const uint32_t q = (n + 3u) >> 2;
+    a = (uint32_t)j * q < n ? (uint32_t)j * q : n;
+    b = (a + q < n) ? a + q : n;
+}
+
+// ---------------------------------------------------------------- K2: encoded sizes
+// one workgroup per segment: thread = (chunk, sub-stream)
+__global__ void __launch_bounds__(256) huf_size_kernel(const uint8_t* dense, const uint64_t* offsets, const uint32_t* sizes,
+                                                       uint64_t nchunks, const uint32_t* enc_tables, uint32_t* rec_sizes, uint64_t* meta)
+{
+    __shared__ uint32_t enc[256];
+    const uint64_t seg = blockIdx.x;
+    enc[threadIdx.x] = enc_tables[seg * 256 + threadIdx.x];
+    __syncthreads();
+    const uint64_t c = seg * SEG + (threadIdx.x >> 2);
+    const int j = threadIdx.x & 3;
+    uint32_t n = 0, sz = 0;
+    if (c < nchunks) {
+        n = sizes[c];
+        const uint8_t* s = dense + offsets[c];
+        uint32_t a, b;
+        sub_range(n, j, a, b);
+        uint32_t bits = 0;
+        for (uint32_t i = a; i < b; i++) bits += enc[s[i]] >> 16;
+        sz = (bits + 7u) >> 3;
+    }
+    // the four sizes of a chunk sit in one quad
+    const int q0 = (int)(threadIdx.x & 63u & ~3u);
+    const uint32_t s0 = __shfl(sz, q0 + 0), s1 = __shfl(sz, q0 + 1), s2 = __shfl(sz, q0 + 2), s3 = __shfl(sz, q0 + 3);
+    if (c < nchunks && j == 0) {
+        const uint64_t encb = (uint64_t)s0 + s1 + s2 + s3;
+        const bool stored = (12 + encb >= 4 + (uint64_t)n) || s0 > 0xffffu || s1 > 0xffffu || s2 > 0xffffu;
+        rec_sizes[c] = stored ? 4u + n : 12u + (uint32_t)encb;
+        meta[c] = (uint64_t)(s0 & 0xffffu) | ((uint64_t)(s1 & 0xffffu) << 16) | ((uint64_t)(s2 & 0xffffu) << 32) | ((uint64_t)stored << 48);
+    }
+}
+
+// ---------------------------------------------------------------- K3: encode
+__global__ void __launch_bounds__(256) huf_encode_kernel(const uint8_t* dense, const uint64_t* offsets, const uint32_t* sizes,
+                                                         uint64_t nchunks, const uint32_t* enc_tables, const uint64_t* meta,
+                                                         uint8_t* huf, const uint64_t* huf_offsets)
+{
+    __shared__ uint32_t enc[256];
+    const uint64_t seg = blockIdx.x;
+    enc[threadIdx.x] = enc_tables[seg * 256 + threadIdx.x];
+    __syncthreads();
+    const uint64_t c = seg * SEG + (threadIdx.x >> 2);
+    const int j = threadIdx.x & 3;
+    if (c >= nchunks) return;
+    const uint32_t n = sizes[c];
+    const uint8_t* s = dense + offsets[c];
+    uint8_t* o = huf + huf_offsets[c];
+    const uint64_t m = meta[c];
+    const bool stored = (m >> 48) & 1;
+    if (j == 0) {
+        *(uint32_t*)o = n | (stored ? 0x80000000u : 0u);                    // records are 4-byte aligned
+        if (!stored) { ((uint32_t*)o)[1] = (uint32_t)m; ((uint32_t*)o)[2] = (uint32_t)(m >> 32) & 0xffffu; }
+    }
+    if (stored) {
+        for (uint32_t i = j; i < n; i += 4) o[4 + i] = s[i];
+        return;
+    }
+    const uint32_t sz0 = (uint32_t)m & 0xffffu, sz1 = (uint32_t)(m >> 16) & 0xffffu, sz2 = (uint32_t)(m >> 32) & 0xffffu;
+    uint8_t* p = o + 12 + (j > 0 ? sz0 : 0u) + (j > 1 ? sz1 : 0u) + (j > 2 ? sz2 : 0u);
+    uint32_t a, b;
+    sub_range(n, j, a, b);
+    uint64_t acc = 0;
+    uint32_t nbits = 0;
+    for (uint32_t i = a; i < b; i++) {
+        const uint32_t e = enc[s[i]];
+        acc |= (uint64_t)(e & 0xffffu) << nbits;
+        nbits += e >> 16;
+        if (nbits >= 32) {
+            *(u32_any*)p = (uint32_t)acc;
+            p += 4;
+            acc >>= 32;
+            nbits -= 32;
+        }
+    }
+    while (nbits > 0) {                                                     // 1..4 tail bytes (zero padded)
+        *p++ = (uint8_t)acc;
+        acc >>= 8;
+        nbits = nbits > 8 ? nbits - 8 : 0;
+    }
+}
+
+// ---------------------------------------------------------------- K4: raw sizes from the record headers
+__global__ void __launch_bounds__(256) huf_rawsize_kernel(const uint8_t* huf, const uint64_t* huf_offsets, uint64_t nchunks, uint32_t* sizes)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c < nchunks) sizes[c] = *(const uint32_t*)(huf + huf_offsets[c]) & 0x7fffffffu;
+}
+
+// ---------------------------------------------------------------- K5: decode
+__global__ void __launch_bounds__(256) huf_decode_kernel(const uint8_t* huf, const uint64_t* huf_offsets, const uint8_t* tables,
+                                                         uint64_t nchunks, uint8_t* dense, const uint64_t* offsets)
+{
+    __shared__ uint8_t lens[256];
+    __shared__ uint32_t count[LMAX + 2];
+    __shared__ uint32_t first[LMAX + 2];
+    __shared__ uint16_t dtab[1 << LMAX];                                    // sym | len << 8
+    const uint64_t seg = blockIdx.x;
+    const int t = threadIdx.x;
+    {
+        const uint8_t nib = tables[seg * 128 + (t >> 1)];
+        lens[t] = (t & 1) ? (nib >> 4) : (nib & 15);
+    }
+    if (t < LMAX + 2) count[t] = 0;
+    for (int k = t; k < (1 << LMAX); k += 256) dtab[k] = 0;
+    __syncthreads();
+    const int l = lens[t];
+    if (l) atomicAdd(&count[l], 1u);
+    __syncthreads();
+    if (t == 0) {
+        uint32_t code = 0;
+        first[0] = 0;
+        uint32_t prev = 0;
+        for (int k = 1; k <= LMAX; k++) { code = (code + prev) << 1; first[k] = code; prev = count[k]; }
+    }
+    __syncthreads();
+    if (l) {
+        int before = 0;
+        for (int u = 0; u < t; u++) before += lens[u] == l;
+        const uint32_t cde = first[l] + (uint32_t)before;
+        const uint32_t rev = __brev(cde) >> (32 - l);
+        for (uint32_t k = rev; k < (1u << LMAX); k += 1u << l) dtab[k] = (uint16_t)(t | (l << 8));
+    }
+    __syncthreads();
+
+    const uint64_t c = seg * SEG + (t >> 2);
+    const int j = t & 3;
+    if (c >= nchunks) return;
+    const uint8_t* r = huf + huf_offsets[c];
+    const uint32_t hdr = *(const uint32_t*)r;
+    const uint32_t n = hdr & 0x7fffffffu;
+    uint8_t* o = dense + offsets[c];
+    if (hdr >> 31) {
+        for (uint32_t i = j; i < n; i += 4) o[i] = r[4 + i];
+        return;
+    }
+    const uint32_t h0 = ((const uint32_t*)r)[1], h1 = ((const uint32_t*)r)[2];
+    const uint32_t sz0 = h0 & 0xffffu, sz1 = h0 >> 16, sz2 = h1 & 0xffffu;
+    const uint8_t* p = r + 12 + (j > 0 ? sz0 : 0u) + (j > 1 ? sz1 : 0u) + (j > 2 ? sz2 : 0u);
+    uint32_t a, b;
+    sub_range(n, j, a, b);
+    uint64_t acc = 0;
+    uint32_t avail = 0;
+    uint32_t i = a;
+    uint32_t pack = 0, npack = 0;
+    for (; i < b; i++) {
+        if (avail < (uint32_t)LMAX) {                                       // <= 10 bits left: top up 32 (reads <= 4 bytes past the sub-stream)
+            acc |= (uint64_t)(*(const u32_any*)p) << avail;
+            p += 4;
+            avail += 32;
+        }
+        const uint32_t e = dtab[(uint32_t)acc & ((1u << LMAX) - 1)];
+        const uint32_t len = e >> 8;
+        acc >>= len;
+        avail -= len;
+        pack |= (e & 255u) << (8 * npack);
+        if (++npack == 4) {
+            *(u32_any*)(o + i - 3) = pack;
+            pack = 0;
+            npack = 0;
+        }
+    }
+    for (uint32_t k = 0; k < npack; k++) o[b - npack + k] = (uint8_t)(pack >> (8 * k));
+}
+
+thread_local std::string g_huf_error;
+
+}  // namespace
+
+extern "C" {
+
+size_t sprintz_mi355x_huf_tmp_bytes(uint64_t nchunks)
+{
+    const uint64_t nseg = (nchunks + SEG - 1) / SEG;
+    // enc tables | meta (u64 per chunk) | record sizes (u32 per chunk) | scan scratch
+    return (size_t)(nseg * 1024 + nchunks * 8 + ((nchunks * 4 + 15) & ~(uint64_t)15) + sprintz_mi355x_compact_tmp_bytes(nchunks) + 64);
+}
+
+size_t sprintz_mi355x_huf_bound(uint64_t total_stream_bytes, uint64_t nchunks)
+{
+    return (size_t)(total_stream_bytes + 8 * nchunks + SPRINTZ_MI355X_READ_SLACK);
+}
+
+int sprintz_mi355x_huf_compress_batch(const void* d_dense, const uint64_t* d_offsets, const uint32_t* d_sizes, uint64_t nchunks,
+                                      void* d_huf, uint64_t* d_huf_offsets, void* d_tables, void* d_tmp, void* hip_stream)
+{
+    if (!d_dense || !d_offsets || !d_sizes || !d_huf || !d_huf_offsets || !d_tables || !d_tmp) return SPRINTZ_E_INVALID;
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (nchunks == 0) return hipMemsetAsync(d_huf_offsets, 0, 8, st) == hipSuccess ? 0 : SPRINTZ_E_HIP;
+    const uint64_t nseg = (nchunks + SEG - 1) / SEG;
+    uint8_t* tmp = (uint8_t*)d_tmp;
+    uint32_t* enc_tables = (uint32_t*)tmp;
+    uint64_t* meta = (uint64_t*)(tmp + nseg * 1024);
+    uint32_t* rec_sizes = (uint32_t*)(tmp + nseg * 1024 + nchunks * 8);
+    void* scan_tmp = tmp + nseg * 1024 + nchunks * 8 + ((nchunks * 4 + 15) & ~(uint64_t)15);
+    hipLaunchKernelGGL(huf_build_kernel, dim3((unsigned)nseg), dim3(64), 0, st, (const uint8_t*)d_dense, d_offsets, d_sizes, nchunks,
+                       enc_tables, (uint8_t*)d_tables);
+    hipLaunchKernelGGL(huf_size_kernel, dim3((unsigned)nseg), dim3(256), 0, st, (const uint8_t*)d_dense, d_offsets, d_sizes, nchunks,
+                       (const uint32_t*)enc_tables, rec_sizes, meta);
+    if (launch_size_scan(rec_sizes, nchunks, 4, d_huf_offsets, scan_tmp, st) != hipSuccess) return SPRINTZ_E_HIP;
+    hipLaunchKernelGGL(huf_encode_kernel, dim3((unsigned)nseg), dim3(256), 0, st, (const uint8_t*)d_dense, d_offsets, d_sizes, nchunks,
+                       (const uint32_t*)enc_tables, (const uint64_t*)meta, (uint8_t*)d_huf, (const uint64_t*)d_huf_offsets);
+    return hipGetLastError() == hipSuccess ? 0 : SPRINTZ_E_HIP;
+}
+
+int sprintz_mi355x_huf_decompress_batch(const void* d_huf, const uint64_t* d_huf_offsets, const void* d_tables, uint64_t nchunks,
+                                        uint32_t align, void* d_dense, uint64_t* d_offsets, uint32_t* d_sizes, void* d_tmp,
+                                        void* hip_stream)
+{
+    if (!d_huf || !d_huf_offsets || !d_tables || !d_dense || !d_offsets || !d_sizes || !d_tmp) return SPRINTZ_E_INVALID;
+    if (align == 0 || align > 16 || (align & (align - 1))) return SPRINTZ_E_INVALID;
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (nchunks == 0) return hipMemsetAsync(d_offsets, 0, 8, st) == hipSuccess ? 0 : SPRINTZ_E_HIP;
+    const uint64_t nseg = (nchunks + SEG - 1) / SEG;
+    hipLaunchKernelGGL(huf_rawsize_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, st, (const uint8_t*)d_huf, d_huf_offsets,
+                       nchunks, d_sizes);
+    if (launch_size_scan(d_sizes, nchunks, align, d_offsets, d_tmp, st) != hipSuccess) return SPRINTZ_E_HIP;
+    hipLaunchKernelGGL(huf_decode_kernel, dim3((unsigned)nseg), dim3(256), 0, st, (const uint8_t*)d_huf, d_huf_offsets,
+                       (const uint8_t*)d_tables, nchunks, (uint8_t*)d_dense, (const uint64_t*)d_offsets);
+    return hipGetLastError() == hipSuccess ? 0 : SPRINTZ_E_HIP;
+}
+
+}  // extern "C"

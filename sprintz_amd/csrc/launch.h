@@ -25,6 +25,8 @@ hipError_t launch_encode_fast_w16(bool fire, int dp, bool exact, unsigned grid, 
 hipError_t launch_encode_w8(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
 hipError_t launch_encode_w16(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
 
+hipError_t launch_size_scan(const uint32_t* d_sizes, uint64_t n, uint32_t align, uint64_t* d_offsets, void* d_tmp, hipStream_t st);
+
 template <typename K, typename A>
 inline hipError_t launch_one(K kernel, unsigned grid, size_t shmem, hipStream_t st, const A& a)
 {

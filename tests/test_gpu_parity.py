@@ -280,3 +280,41 @@ def test_corrupt_streams_do_not_hang_or_overrun(sz, oracle):
         r = rets.cpu().numpy()
         assert ((r == sz._lib.E_CORRUPT) | ((r >= 0) & (r <= chunk_len))).all(), (trial, r[:8])
         assert (out[nchunks * chunk_len:].cpu().numpy() == 0x5A5A).all(), trial
+
+
+# ------------------------------------------------ optional Huffman stage (format: oracle/huf_oracle.c)
+
+@pytest.mark.parametrize("step", [2, 8, 300])
+def test_huffman_stage_matches_oracle_and_roundtrips(sz, oracle, step):
+    """GPU Huffman records, tables and offsets are bit-exact with the CPU oracle of our container
+    format; GPU decode rebuilds the exact Sprintz container; the data survives the whole chain."""
+    import torch
+    rng = np.random.default_rng(40 + step)
+    codec, esz, ndims, chunk_len, nchunks = "xff", 2, 8, 5120, 150          # 3 segments, last one short
+    data = np.concatenate([gen_walk(rng, 100 * chunk_len, ndims, esz, step, flat_every=5),
+                           gen_fuzz(rng, 50 * chunk_len, esz, 0)])            # incompressible chunks -> stored records
+    cd = sz.ChunkedCodec(codec, esz, ndims, chunk_len, device="cuda:0")
+    batch = cd.compress(torch.from_numpy(data).cuda())
+    hb = sz.huf_compress(batch)
+    dense = batch.data.cpu().numpy()
+    offs = batch.offsets.cpu().numpy().astype(np.uint64)
+    sizes = batch.sizes.cpu().numpy().astype(np.uint32)
+    want, want_offs, want_tables = oracle.huf_compress(dense, offs, sizes)
+    got_offs = hb.offsets.cpu().numpy().astype(np.uint64)
+    assert np.array_equal(got_offs, want_offs)
+    assert np.array_equal(hb.tables.cpu().numpy(), want_tables)
+    got = hb.data.cpu().numpy()
+    assert np.array_equal(got[:want.size], want)                            # records, headers, zeroed gaps
+    # cross-decode: the oracle understands the GPU's records
+    od, oo, osz = oracle.huf_decompress(got[:want.size], got_offs, hb.tables.cpu().numpy(), int(offs[-1]))
+    assert np.array_equal(osz, sizes) and np.array_equal(oo, offs)
+    back = sz.huf_decompress(hb, int(offs[-1]))
+    assert np.array_equal(back.offsets.cpu().numpy(), batch.offsets.cpu().numpy())
+    assert np.array_equal(back.sizes.cpu().numpy(), batch.sizes.cpu().numpy())
+    bd = back.data.cpu().numpy()
+    for c in range(nchunks):
+        assert np.array_equal(bd[int(offs[c]):int(offs[c]) + int(sizes[c])], dense[int(offs[c]):int(offs[c]) + int(sizes[c])]), c
+    out = cd.decompress(back)
+    assert np.array_equal(out.cpu().numpy(), data)
+    if step <= 8:                                                            # a third of the chunks is incompressible noise
+        assert hb.total_bytes() < 0.99 * batch.stream_bytes()

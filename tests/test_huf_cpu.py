@@ -23,6 +23,7 @@ def _container(oracle, data, chunk_len, ndims, codec="xff"):
         pos = (pos + 15) & ~15
         offs[i] = pos
         pos += s.size
+    pos = (pos + 15) & ~15
     offs[-1] = pos
     dense = np.zeros(pos + 16, np.uint8)
     for i, s in enumerate(streams):
