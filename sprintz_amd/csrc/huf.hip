@@ -210,6 +210,39 @@ __global__ void __launch_bounds__(256) huf_size_kernel(const uint8_t* dense, con
 }
 
 // ---------------------------------------------------------------- K3: encode
+// One lane per sub-stream.  HBM traffic is kept in whole 16-byte pieces per lane (a
+// lane-per-byte-stream kernel otherwise touches every 128-byte line 32+ times, far
+// apart in time, with 64K such lines open per XCD): the source bytes are read as
+// aligned 16-byte pieces one piece ahead, the coded dwords collect in a 16-byte
+// register window that is stored when full; only the first and last piece of a
+// sub-stream (shared with its neighbours) are written byte-wise.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 __attribute__((aligned(4), may_alias)) u32x4_a4;
+typedef u32x4 __attribute__((aligned(1), may_alias)) u32x4_a1;
+
+__device__ __forceinline__ uint32_t pick_dword(const u32x4& v, uint32_t k)
+{
+    return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
+}
+
+__device__ __forceinline__ void put_dword(u32x4& v, uint32_t k, uint32_t d)
+{
+    v.x = k == 0 ? d : v.x;
+    v.y = k == 1 ? d : v.y;
+    v.z = k == 2 ? d : v.z;
+    v.w = k == 3 ? d : v.w;
+}
+
+// bytes [lo, hi) of the 16-byte window v -> dst[lo..hi)
+__device__ __forceinline__ void store_window_bytes(uint8_t* dst, const u32x4& v, uint32_t lo, uint32_t hi)
+{
+#pragma unroll
+    for (uint32_t k = 0; k < 16; k++) {
+        const uint32_t d = k < 4 ? v.x : k < 8 ? v.y : k < 12 ? v.z : v.w;
+        if (k >= lo && k < hi) dst[k] = (uint8_t)(d >> (8 * (k & 3)));
+    }
+}
+
 __global__ void __launch_bounds__(256) huf_encode_kernel(const uint8_t* dense, const uint64_t* offsets, const uint32_t* sizes,
                                                          uint64_t nchunks, const uint32_t* enc_tables, const uint64_t* meta,
                                                          uint8_t* huf, const uint64_t* huf_offsets)
@@ -222,8 +255,10 @@ __global__ void __launch_bounds__(256) huf_encode_kernel(const uint8_t* dense, c
     const int j = threadIdx.x & 3;
     if (c >= nchunks) return;
     const uint32_t n = sizes[c];
-    const uint8_t* s = dense + offsets[c];
-    uint8_t* o = huf + huf_offsets[c];
+    const uint64_t soff = offsets[c];
+    const uint8_t* s = dense + soff;
+    const uint64_t roff = huf_offsets[c];
+    uint8_t* o = huf + roff;
     const uint64_t m = meta[c];
     const bool stored = (m >> 48) & 1;
     if (j == 0) {
@@ -231,31 +266,80 @@ __global__ void __launch_bounds__(256) huf_encode_kernel(const uint8_t* dense, c
         if (!stored) { ((uint32_t*)o)[1] = (uint32_t)m; ((uint32_t*)o)[2] = (uint32_t)(m >> 32) & 0xffffu; }
     }
     if (stored) {
-        for (uint32_t i = j; i < n; i += 4) o[4 + i] = s[i];
+        const uint32_t nw = n >> 2;
+        for (uint32_t i = j; i < nw; i += 4) ((uint32_t*)(o + 4))[i] = ((const u32_any*)s)[i];
+        for (uint32_t i = (nw << 2) + j; i < n; i += 4) o[4 + i] = s[i];
         return;
     }
     const uint32_t sz0 = (uint32_t)m & 0xffffu, sz1 = (uint32_t)(m >> 16) & 0xffffu, sz2 = (uint32_t)(m >> 32) & 0xffffu;
-    uint8_t* p = o + 12 + (j > 0 ? sz0 : 0u) + (j > 1 ? sz1 : 0u) + (j > 2 ? sz2 : 0u);
+    const uint64_t poff = roff + 12 + (j > 0 ? sz0 : 0u) + (j > 1 ? sz1 : 0u) + (j > 2 ? sz2 : 0u);   // container offset of the sub-stream
     uint32_t a, b;
     sub_range(n, j, a, b);
+
+    // output window = container bytes [wbase, wbase+16), wbase a multiple of 16
+    uint64_t wbase = poff & ~(uint64_t)15;
+    uint32_t wk = (uint32_t)(poff & 15) >> 2;                               // dword of the window the accumulator drains into
+    uint32_t wfirst = (uint32_t)(poff & 15);                                // first window: bytes below this belong to the neighbour
+    u32x4 win = {0, 0, 0, 0};
     uint64_t acc = 0;
-    uint32_t nbits = 0;
-    for (uint32_t i = a; i < b; i++) {
-        const uint32_t e = enc[s[i]];
+    uint32_t nbits = (uint32_t)(poff & 3) * 8;                              // the accumulator starts inside a dword
+    auto flush = [&]() {                                                    // low 32 bits of acc -> window
+        put_dword(win, wk, (uint32_t)acc);
+        acc >>= 32;
+        nbits -= 32;
+        if (++wk == 4) {
+            if (wfirst) store_window_bytes(huf + wbase, win, wfirst, 16);
+            else *(u32x4_a4*)(huf + wbase) = win;
+            wfirst = 0;
+            wbase += 16;
+            wk = 0;
+        }
+    };
+    auto put = [&](uint32_t sym) {
+        const uint32_t e = enc[sym];
         acc |= (uint64_t)(e & 0xffffu) << nbits;
         nbits += e >> 16;
-        if (nbits >= 32) {
-            *(u32_any*)p = (uint32_t)acc;
-            p += 4;
-            acc >>= 32;
-            nbits -= 32;
+    };
+
+    uint32_t i = a;
+    {                                                                       // byte-wise up to a 16-byte boundary of the source
+        uint32_t pro = (16u - (uint32_t)((soff + a) & 15)) & 15u;
+        if (pro > b - a) pro = b - a;
+        for (uint32_t k = 0; k < pro; k++) {
+            put(s[i++]);
+            if (nbits >= 32) flush();
         }
     }
-    while (nbits > 0) {                                                     // 1..4 tail bytes (zero padded)
-        *p++ = (uint8_t)acc;
-        acc >>= 8;
-        nbits = nbits > 8 ? nbits - 8 : 0;
+    if (i + 16 <= b) {
+        u32x4 nxt = *(const u32x4_a1*)(s + i);
+        while (i + 16 <= b) {
+            const u32x4 cur = nxt;
+            i += 16;
+            if (i + 16 <= b) nxt = *(const u32x4_a1*)(s + i);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t d = q == 0 ? cur.x : q == 1 ? cur.y : q == 2 ? cur.z : cur.w;
+                put(d & 255u);
+                put((d >> 8) & 255u);
+                if (nbits >= 32) flush();
+                put((d >> 16) & 255u);
+                put(d >> 24);
+                if (nbits >= 32) flush();
+            }
+        }
     }
+    for (; i < b; i++) {
+        put(s[i]);
+        if (nbits >= 32) flush();
+    }
+    // close: the rest of the accumulator (zero padded to a byte), then the partial window
+    const uint32_t endb = wk * 4 + ((nbits + 7u) >> 3);                     // bytes of the window in use (<= 16 + 3)
+    if (nbits > 0) {
+        put_dword(win, wk, (uint32_t)acc);                                  // wk < 4 here
+    }
+    const uint32_t lo = wfirst;
+    const uint32_t hi = endb < 16u ? endb : 16u;
+    if (hi > lo) store_window_bytes(huf + wbase, win, lo, hi);
 }
 
 // ---------------------------------------------------------------- K4: raw sizes from the record headers
@@ -304,41 +388,97 @@ __global__ void __launch_bounds__(256) huf_decode_kernel(const uint8_t* huf, con
     const uint64_t c = seg * SEG + (t >> 2);
     const int j = t & 3;
     if (c >= nchunks) return;
-    const uint8_t* r = huf + huf_offsets[c];
+    const uint64_t roff = huf_offsets[c];
+    const uint8_t* r = huf + roff;
     const uint32_t hdr = *(const uint32_t*)r;
     const uint32_t n = hdr & 0x7fffffffu;
-    uint8_t* o = dense + offsets[c];
+    const uint64_t ooff = offsets[c];
+    uint8_t* o = dense + ooff;
     if (hdr >> 31) {
-        for (uint32_t i = j; i < n; i += 4) o[i] = r[4 + i];
+        const uint32_t nw = n >> 2;
+        for (uint32_t i = j; i < nw; i += 4) ((u32_any*)o)[i] = ((const uint32_t*)(r + 4))[i];
+        for (uint32_t i = (nw << 2) + j; i < n; i += 4) o[i] = r[4 + i];
         return;
     }
     const uint32_t h0 = ((const uint32_t*)r)[1], h1 = ((const uint32_t*)r)[2];
     const uint32_t sz0 = h0 & 0xffffu, sz1 = h0 >> 16, sz2 = h1 & 0xffffu;
-    const uint8_t* p = r + 12 + (j > 0 ? sz0 : 0u) + (j > 1 ? sz1 : 0u) + (j > 2 ? sz2 : 0u);
+    const uint64_t poff = roff + 12 + (j > 0 ? sz0 : 0u) + (j > 1 ? sz1 : 0u) + (j > 2 ? sz2 : 0u);
     uint32_t a, b;
     sub_range(n, j, a, b);
-    uint64_t acc = 0;
+
+    // The coded bytes arrive as aligned 16-byte pieces of the container, two pieces ahead
+    // of the one being consumed (see the note at huf_encode_kernel).  Pieces past the last
+    // one that holds container bytes are clamped to it: what they would deliver is never
+    // part of a valid symbol.
+    const uint64_t total = huf_offsets[nchunks];
+    const uint64_t last_piece = (total - 1) >> 4;
+    uint64_t piece = poff >> 4;
+    auto load_piece = [&](uint64_t k) -> u32x4 {
+        k = k < last_piece ? k : last_piece;
+        return *(const u32x4_a4*)(huf + (k << 4));
+    };
+    u32x4 cur = load_piece(piece), n1 = load_piece(piece + 1), n2 = load_piece(piece + 2);
+    piece += 3;
+    uint32_t pk = (uint32_t)(poff & 15) >> 2;
+    uint32_t lo = 0, hi = 0;                                                // bit buffer: avail valid bits, LSB first
     uint32_t avail = 0;
-    uint32_t i = a;
-    uint32_t pack = 0, npack = 0;
-    for (; i < b; i++) {
-        if (avail < (uint32_t)LMAX) {                                       // <= 10 bits left: top up 32 (reads <= 4 bytes past the sub-stream)
-            acc |= (uint64_t)(*(const u32_any*)p) << avail;
-            p += 4;
-            avail += 32;
+    auto top_up = [&]() {                                                   // avail < 22 here
+        const uint32_t d = pick_dword(cur, pk);
+        if (++pk == 4) {
+            cur = n1;
+            n1 = n2;
+            n2 = load_piece(piece++);
+            pk = 0;
         }
-        const uint32_t e = dtab[(uint32_t)acc & ((1u << LMAX) - 1)];
+        const uint64_t x = (uint64_t)d << avail;
+        lo |= (uint32_t)x;
+        hi |= (uint32_t)(x >> 32);
+        avail += 32;
+    };
+    auto sym = [&]() -> uint32_t {
+        const uint32_t e = dtab[lo & ((1u << LMAX) - 1)];
         const uint32_t len = e >> 8;
-        acc >>= len;
+        lo = __builtin_amdgcn_alignbit(hi, lo, len);
+        hi >>= len;
         avail -= len;
-        pack |= (e & 255u) << (8 * npack);
-        if (++npack == 4) {
-            *(u32_any*)(o + i - 3) = pack;
-            pack = 0;
-            npack = 0;
+        return e & 255u;
+    };
+    top_up();
+    {
+        const uint32_t drop = (uint32_t)(poff & 3) * 8;                     // the sub-stream starts inside its first dword
+        lo = __builtin_amdgcn_alignbit(hi, lo, drop);
+        hi >>= drop;
+        avail -= drop;
+    }
+
+    uint32_t i = a;
+    {                                                                       // byte-wise up to a 16-byte boundary of the output
+        uint32_t pro = (16u - (uint32_t)((ooff + a) & 15)) & 15u;
+        if (pro > b - a) pro = b - a;
+        for (uint32_t k = 0; k < pro; k++) {
+            if (avail < 22) top_up();
+            o[i++] = (uint8_t)sym();
         }
     }
-    for (uint32_t k = 0; k < npack; k++) o[b - npack + k] = (uint8_t)(pack >> (8 * k));
+    while (i + 16 <= b) {
+        u32x4 w;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (avail < 22) top_up();
+            uint32_t d = sym();
+            d |= sym() << 8;
+            if (avail < 22) top_up();
+            d |= sym() << 16;
+            d |= sym() << 24;
+            if (q == 0) w.x = d; else if (q == 1) w.y = d; else if (q == 2) w.z = d; else w.w = d;
+        }
+        *(u32x4_a1*)(o + i) = w;
+        i += 16;
+    }
+    for (; i < b; i++) {
+        if (avail < 22) top_up();
+        o[i] = (uint8_t)sym();
+    }
 }
 
 thread_local std::string g_huf_error;

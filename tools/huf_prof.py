@@ -7,7 +7,7 @@ dev = torch.device("cuda:0")
 g = torch.Generator(device=dev); g.manual_seed(123)
 steps = torch.randint(-8, 9, (n * 640, 8), generator=g, device=dev, dtype=torch.int32)
 x = (torch.cumsum(steps.view(n, 640, 8), dim=1) & 0xffff).to(torch.uint16).reshape(-1)
-codec = ChunkedCodec("xff", 16, 8, 5120)
+codec = ChunkedCodec("xff", 2, 8, 5120)
 cb = codec.compress(x)
 for _ in range(3):
     hb = huf_compress(cb)
