@@ -26,129 +26,173 @@ constexpr int SEG = 64;                 // chunks per segment = 256 threads / 4 
 
 typedef uint32_t __attribute__((aligned(1), may_alias)) u32_any;
 
-// ---------------------------------------------------------------- K1: histogram + code lengths + codes
-// one wavefront per segment
-__global__ void __launch_bounds__(64) huf_build_kernel(const uint8_t* dense, const uint64_t* offsets, const uint32_t* sizes,
-                                                       uint64_t nchunks, uint32_t* enc_tables, uint8_t* tables)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 __attribute__((aligned(4), may_alias)) u32x4_a4;
+typedef u32x4 __attribute__((aligned(1), may_alias)) u32x4_a1;
+
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v)
 {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t o = __shfl_xor((unsigned long long)v, d);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------- K1: histogram + code lengths + codes
+// One workgroup per segment.  The histogram and the sort run on all 256 threads, the
+// two-queue merge (inherently serial, 255 steps) on thread 0, the length-limit repair --
+// up to a few hundred "find the best symbol, move it one level" rounds -- as a wave-wide
+// arg-max per round instead of a 256-entry scan per round.
+__global__ void __launch_bounds__(256) huf_build_kernel(const uint8_t* dense, const uint64_t* offsets, const uint32_t* sizes,
+                                                        uint64_t nchunks, uint32_t* enc_tables, uint8_t* tables)
+{
+    __shared__ uint32_t hist4[4][256];
     __shared__ uint32_t hist[256];
     __shared__ uint32_t lcnt[256];      // leaves sorted by (count, symbol): count
     __shared__ uint16_t lsym[256];      //                                   symbol
     __shared__ uint32_t w[511];
     __shared__ uint16_t parent[511];
-    __shared__ uint8_t depth[511];
     __shared__ uint8_t lens[256];
     __shared__ uint32_t first[LMAX + 2];
-    const int lane = threadIdx.x;
+    __shared__ uint32_t s_kraft;
+    __shared__ int s_z;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
     const uint64_t seg = blockIdx.x;
     const uint64_t c0 = seg * SEG, c1 = (c0 + SEG < nchunks) ? c0 + SEG : nchunks;
 
-    for (int s = lane; s < 256; s += 64) { hist[s] = 0; lens[s] = 0; }
+    for (int k = 0; k < 4; k++) hist4[k][t] = 0;
+    lens[t] = 0;
+    if (t == 0) s_kraft = 0;
     __syncthreads();
+    uint32_t* const hw = hist4[t >> 6];
     for (uint64_t c = c0; c < c1; c++) {
         const uint8_t* p = dense + offsets[c];
         const uint32_t n = sizes[c];
-        if (((uintptr_t)p & 3) == 0) {
-            const uint32_t nw = n >> 2;
-            for (uint32_t i = lane; i < nw; i += 64) {
-                const uint32_t x = ((const uint32_t*)p)[i];
-                atomicAdd(&hist[x & 255], 1u);
-                atomicAdd(&hist[(x >> 8) & 255], 1u);
-                atomicAdd(&hist[(x >> 16) & 255], 1u);
-                atomicAdd(&hist[x >> 24], 1u);
+        const uint32_t np = n >> 4;
+        for (uint32_t i = t; i < np; i += 256) {
+            const u32x4 x = *(const u32x4_a1*)(p + (size_t)i * 16);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t d = k == 0 ? x.x : k == 1 ? x.y : k == 2 ? x.z : x.w;
+                atomicAdd(&hw[d & 255], 1u);
+                atomicAdd(&hw[(d >> 8) & 255], 1u);
+                atomicAdd(&hw[(d >> 16) & 255], 1u);
+                atomicAdd(&hw[d >> 24], 1u);
             }
-            for (uint32_t i = (nw << 2) + lane; i < n; i += 64) atomicAdd(&hist[p[i]], 1u);
-        } else {
-            for (uint32_t i = lane; i < n; i += 64) atomicAdd(&hist[p[i]], 1u);
         }
+        for (uint32_t i = (np << 4) + t; i < n; i += 256) atomicAdd(&hw[p[i]], 1u);
     }
     __syncthreads();
+    hist[t] = hist4[0][t] + hist4[1][t] + hist4[2][t] + hist4[3][t];
+    __syncthreads();
 
-    // rank sort by (count, symbol): 4 symbols per lane
-    for (int s = lane; s < 256; s += 64) {
-        const uint32_t cs = hist[s];
+    {   // rank sort by (count, symbol)
+        const uint32_t cs = hist[t];
         int rank = 0;
-        for (int t = 0; t < 256; t++) {
-            const uint32_t ct = hist[t];
-            rank += (ct < cs || (ct == cs && t < s)) ? 1 : 0;
+        for (int u = 0; u < 256; u++) {
+            const uint32_t ct = hist[u];
+            rank += (ct < cs || (ct == cs && u < t)) ? 1 : 0;
         }
         lcnt[rank] = cs;
-        lsym[rank] = (uint16_t)s;
+        lsym[rank] = (uint16_t)t;
     }
     __syncthreads();
 
-    if (lane == 0) {
+    if (t == 0) {
         int z = 0;
         while (z < 256 && lcnt[z] == 0) z++;                 // zero-count symbols sort first
+        s_z = z;
         const int nz = 256 - z;
         const uint32_t* lc = lcnt + z;
-        const uint16_t* ls = lsym + z;
-        if (nz == 1) {
-            lens[ls[0]] = 1;
-        } else if (nz >= 2) {
+        if (nz >= 2) {
             // two-queue Huffman (oracle/huf_oracle.c: huf_oracle_lengths)
             for (int i = 0; i < nz; i++) w[i] = lc[i];
             int ql = 0, qi = nz, next = nz;
             for (int m = 0; m < nz - 1; m++) {
                 int pick[2];
-                for (int t = 0; t < 2; t++) {
+                for (int k = 0; k < 2; k++) {
                     const bool has_l = ql < nz, has_i = qi < next;
-                    if (has_l && (!has_i || w[ql] <= w[qi])) pick[t] = ql++;
-                    else pick[t] = qi++;
+                    if (has_l && (!has_i || w[ql] <= w[qi])) pick[k] = ql++;
+                    else pick[k] = qi++;
                 }
                 w[next] = w[pick[0]] + w[pick[1]];
                 parent[pick[0]] = (uint16_t)next;
                 parent[pick[1]] = (uint16_t)next;
                 next++;
             }
-            depth[next - 1] = 0;
-            for (int i = next - 2; i >= 0; i--) {
-                const int d = depth[parent[i]] + 1;
-                depth[i] = (uint8_t)(d > 255 ? 255 : d);
-            }
-            uint32_t kraft = 0;
-            for (int i = 0; i < nz; i++) {
-                const int l = depth[i] > LMAX ? LMAX : depth[i];
-                lens[ls[i]] = (uint8_t)l;
-                kraft += 1u << (LMAX - l);
-            }
-            while (kraft > (1u << LMAX)) {
-                int best = -1;
-                for (int i = 0; i < nz; i++) {
-                    const int l = lens[ls[i]];
-                    if (l >= LMAX) continue;
-                    if (best < 0) { best = i; continue; }
-                    const int lb = lens[ls[best]];
-                    if (l > lb) best = i;
-                    else if (l == lb) {
-                        if (lc[i] < lc[best]) best = i;
-                        else if (lc[i] == lc[best] && ls[i] > ls[best]) best = i;
-                    }
-                }
-                const int l = lens[ls[best]];
-                kraft -= 1u << (LMAX - l - 1);
-                lens[ls[best]] = (uint8_t)(l + 1);
-            }
-            for (;;) {
-                int best = -1;
-                for (int i = nz - 1; i >= 0; i--) {
-                    const int l = lens[ls[i]];
-                    if (l <= 1) continue;
-                    if (kraft + (1u << (LMAX - l)) > (1u << LMAX)) continue;
-                    if (best < 0) { best = i; continue; }
-                    if (lc[i] > lc[best]) best = i;
-                    else if (lc[i] == lc[best] && ls[i] < ls[best]) best = i;
-                }
-                if (best < 0) break;
-                const int l = lens[ls[best]];
-                kraft += 1u << (LMAX - l);
-                lens[ls[best]] = (uint8_t)(l - 1);
-            }
         }
-        // first canonical code of every length
+    }
+    __syncthreads();
+    const int z = s_z;
+    const int nz = 256 - z;
+    if (nz == 1) {
+        if (t == 0) lens[lsym[z]] = 1;
+    } else if (nz >= 2) {
+        // leaf t of the sorted order: depth = steps to the root, clamped to LMAX
+        int myl = 0;
+        if (t < nz) {
+            const int root = 2 * nz - 2;
+            int node = t, d = 0;
+            while (node != root) { node = parent[node]; d++; }
+            myl = d > LMAX ? LMAX : d;
+            atomicAdd(&s_kraft, 1u << (LMAX - myl));
+            lens[lsym[z + t]] = (uint8_t)myl;
+        }
+        __syncthreads();
+        if (t < 64 && s_kraft != (1u << LMAX)) {             // wave 0 repairs; 4 leaves per lane
+            uint32_t kraft = s_kraft;
+            uint32_t cn[4], sy[4], ln[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int i = lane + 64 * e;
+                const bool ok = i < nz;
+                cn[e] = ok ? lcnt[z + i] : 0u;
+                sy[e] = ok ? lsym[z + i] : 0u;
+                ln[e] = ok ? lens[sy[e]] : 0u;
+            }
+            // too many codes for LMAX bits: lengthen the deepest symbol below LMAX (ties:
+            // smallest count, then largest symbol) until the code fits
+            while (kraft > (1u << LMAX)) {
+                uint64_t key[4], best = 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    key[e] = (ln[e] != 0 && ln[e] < (uint32_t)LMAX)
+                                 ? ((uint64_t)ln[e] << 48) | ((uint64_t)(0xffffffffu - cn[e]) << 16) | sy[e] : 0;
+                    best = key[e] > best ? key[e] : best;
+                }
+                best = wave_max_u64(best);
+#pragma unroll
+                for (int e = 0; e < 4; e++) ln[e] += (key[e] == best) ? 1u : 0u;
+                kraft -= 1u << (LMAX - (uint32_t)(best >> 48) - 1);
+            }
+            // room left: shorten the most frequent symbol that still fits (ties: smallest symbol)
+            for (;;) {
+                uint64_t key[4], best = 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    key[e] = (ln[e] > 1 && kraft + (1u << (LMAX - ln[e])) <= (1u << LMAX))
+                                 ? ((uint64_t)cn[e] << 16) | ((uint64_t)(255u - sy[e]) << 4) | ln[e] : 0;
+                    best = key[e] > best ? key[e] : best;
+                }
+                best = wave_max_u64(best);
+                if (best == 0) break;
+#pragma unroll
+                for (int e = 0; e < 4; e++) ln[e] -= (key[e] == best) ? 1u : 0u;
+                kraft += 1u << (LMAX - (uint32_t)(best & 15));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (lane + 64 * e < nz) lens[sy[e]] = (uint8_t)ln[e];
+        }
+    }
+    __syncthreads();
+    if (t == 0) {   // first canonical code of every length
         uint32_t count[LMAX + 2];
         for (int l = 0; l <= LMAX + 1; l++) count[l] = 0;
-        for (int s = 0; s < 256; s++) count[lens[s]]++;
+        for (int u = 0; u < 256; u++) count[lens[u]]++;
         count[0] = 0;
         uint32_t code = 0;
         first[0] = 0;
@@ -156,18 +200,18 @@ __global__ void __launch_bounds__(64) huf_build_kernel(const uint8_t* dense, con
     }
     __syncthreads();
 
-    for (int s = lane; s < 256; s += 64) {
-        const int l = lens[s];
+    {
+        const int l = lens[t];
         uint32_t e = 0;
         if (l) {
             int before = 0;
-            for (int t = 0; t < s; t++) before += lens[t] == l;
+            for (int u = 0; u < t; u++) before += lens[u] == l;
             const uint32_t c = first[l] + (uint32_t)before;
             e = (__brev(c) >> (32 - l)) | ((uint32_t)l << 16);
         }
-        enc_tables[seg * 256 + s] = e;
+        enc_tables[seg * 256 + t] = e;
     }
-    for (int i = lane; i < 128; i += 64) tables[seg * 128 + i] = (uint8_t)(lens[2 * i] | (lens[2 * i + 1] << 4));
+    if (t < 128) tables[seg * 128 + t] = (uint8_t)(lens[2 * t] | (lens[2 * t + 1] << 4));
 }
 
 // sub-stream j of an n-symbol chunk: [a, b)
@@ -179,25 +223,51 @@ __device__ __forceinline__ void sub_range(uint32_t n, int j, uint32_t& a, uint32
 }
 
 // ---------------------------------------------------------------- K2: encoded sizes
-// one workgroup per segment: thread = (chunk, sub-stream)
+// one workgroup per segment.  The chunks are read cooperatively (a 16-byte piece per
+// thread, consecutive threads on consecutive pieces) and the code lengths summed into one
+// LDS counter per (chunk, sub-stream).
 __global__ void __launch_bounds__(256) huf_size_kernel(const uint8_t* dense, const uint64_t* offsets, const uint32_t* sizes,
                                                        uint64_t nchunks, const uint32_t* enc_tables, uint32_t* rec_sizes, uint64_t* meta)
 {
     __shared__ uint32_t enc[256];
+    __shared__ uint32_t cnt[SEG * 4];
     const uint64_t seg = blockIdx.x;
-    enc[threadIdx.x] = enc_tables[seg * 256 + threadIdx.x];
+    const uint32_t t = threadIdx.x;
+    enc[t] = enc_tables[seg * 256 + t] >> 16;                               // code lengths only
+    cnt[t] = 0;
     __syncthreads();
-    const uint64_t c = seg * SEG + (threadIdx.x >> 2);
-    const int j = threadIdx.x & 3;
+    const uint64_t c0 = seg * SEG, c1 = (c0 + SEG < nchunks) ? c0 + SEG : nchunks;
+    for (uint64_t cc = c0; cc < c1; cc++) {
+        const uint32_t n = sizes[cc];
+        const uint8_t* s = dense + offsets[cc];
+        const uint32_t q = (n + 3u) >> 2;
+        uint32_t* const my = cnt + (cc - c0) * 4;
+        auto stream_of = [&](uint32_t pos) { return (uint32_t)(pos >= q) + (uint32_t)(pos >= 2 * q) + (uint32_t)(pos >= 3 * q); };
+        const uint32_t np = (n + 15u) >> 4;
+        for (uint32_t i = t; i < np; i += 256) {
+            const uint32_t pos0 = i * 16;
+            if (pos0 + 16 <= n && stream_of(pos0) == stream_of(pos0 + 15)) {
+                const u32x4 x = *(const u32x4_a1*)(s + pos0);
+                uint32_t bits = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t d = k == 0 ? x.x : k == 1 ? x.y : k == 2 ? x.z : x.w;
+                    bits += enc[d & 255] + enc[(d >> 8) & 255] + enc[(d >> 16) & 255] + enc[d >> 24];
+                }
+                atomicAdd(&my[stream_of(pos0)], bits);
+            } else {
+                const uint32_t end = pos0 + 16 < n ? pos0 + 16 : n;
+                for (uint32_t pos = pos0; pos < end; pos++) atomicAdd(&my[stream_of(pos)], enc[s[pos]]);
+            }
+        }
+    }
+    __syncthreads();
+    const uint64_t c = seg * SEG + (t >> 2);
+    const int j = t & 3;
     uint32_t n = 0, sz = 0;
     if (c < nchunks) {
         n = sizes[c];
-        const uint8_t* s = dense + offsets[c];
-        uint32_t a, b;
-        sub_range(n, j, a, b);
-        uint32_t bits = 0;
-        for (uint32_t i = a; i < b; i++) bits += enc[s[i]] >> 16;
-        sz = (bits + 7u) >> 3;
+        sz = (cnt[t] + 7u) >> 3;
     }
     // the four sizes of a chunk sit in one quad
     const int q0 = (int)(threadIdx.x & 63u & ~3u);
@@ -217,10 +287,6 @@ __global__ void __launch_bounds__(256) huf_size_kernel(const uint8_t* dense, con
 // aligned 16-byte pieces one piece ahead, the coded dwords collect in a 16-byte
 // register window that is stored when full; only the first and last piece of a
 // sub-stream (shared with its neighbours) are written byte-wise.
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef u32x4 __attribute__((aligned(4), may_alias)) u32x4_a4;
-typedef u32x4 __attribute__((aligned(1), may_alias)) u32x4_a1;
-
 __device__ __forceinline__ uint32_t pick_dword(const u32x4& v, uint32_t k)
 {
     return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
@@ -611,7 +677,7 @@ int sprintz_mi355x_huf_compress_batch(const void* d_dense, const uint64_t* d_off
     uint64_t* meta = (uint64_t*)(tmp + nseg * 1024);
     uint32_t* rec_sizes = (uint32_t*)(tmp + nseg * 1024 + nchunks * 8);
     void* scan_tmp = tmp + nseg * 1024 + nchunks * 8 + ((nchunks * 4 + 15) & ~(uint64_t)15);
-    hipLaunchKernelGGL(huf_build_kernel, dim3((unsigned)nseg), dim3(64), 0, st, (const uint8_t*)d_dense, d_offsets, d_sizes, nchunks,
+    hipLaunchKernelGGL(huf_build_kernel, dim3((unsigned)nseg), dim3(256), 0, st, (const uint8_t*)d_dense, d_offsets, d_sizes, nchunks,
                        enc_tables, (uint8_t*)d_tables);
     hipLaunchKernelGGL(huf_size_kernel, dim3((unsigned)nseg), dim3(256), 0, st, (const uint8_t*)d_dense, d_offsets, d_sizes, nchunks,
                        (const uint32_t*)enc_tables, rec_sizes, meta);
