@@ -258,6 +258,26 @@ def main():
     huf_bytes = sum_over_ranks(hb.total_bytes(), device)
     del h_buf, d_buf
 
+    # ---------------- query on compressed data: per-column sum fused into the decode
+    q_part = torch.empty((nchunks, ndims), dtype=torch.int64, device=device)
+    q_res = torch.empty(ndims, dtype=torch.int64, device=device)
+
+    def query_reduce_only():
+        _lib.check(_lib.query_batch(_lib.CODEC_XFF, esz, comp.data_ptr(), offsets.data_ptr(), nchunks, chunk_len, ndims,
+                                    _lib.QUERY_SUM, 0, 0, None, q_part.data_ptr(), None, st))
+        _lib.check(_lib.query_reduce(_lib.QUERY_SUM, q_part.data_ptr(), nchunks, ndims, q_res.data_ptr(), st))
+
+    def query_materialize():
+        _lib.check(_lib.query_batch(_lib.CODEC_XFF, esz, comp.data_ptr(), offsets.data_ptr(), nchunks, chunk_len, ndims,
+                                    _lib.QUERY_SUM, 1, 0, out.data_ptr(), q_part.data_ptr(), None, st))
+        _lib.check(_lib.query_reduce(_lib.QUERY_SUM, q_part.data_ptr(), nchunks, ndims, q_res.data_ptr(), st))
+
+    query_ms = timed(query_reduce_only)
+    if not args.no_verify:
+        want = x.view(torch.int16).to(torch.int64).bitwise_and(0xffff).view(-1, ndims).sum(dim=0)
+        assert torch.equal(q_res, want), "query(sum) != column sums of the input"
+    query_mat_ms = timed(query_materialize)
+
     total_raw = sum_over_ranks(nchunks * chunk_bytes, device)
     total_stream = sum_over_ranks(stream_bytes, device)
     value = total_raw * args.steps / wall / 1e6
@@ -290,6 +310,9 @@ def main():
         "huffman_stage": {"ratio": round(total_raw / huf_bytes, 4), "encode_ms": round(huf_enc_ms, 3),
                           "decode_ms": round(huf_dec_ms, 3),
                           "chain_decompress_MBps": round(nchunks * chunk_bytes / ((huf_dec_ms + wall / args.steps * 1e3) * 1e-3) / 1e6, 1), "parity": "unpinned (no Huffman coder in the reference tree)"},
+        "query_on_compressed": {"op": "sum", "reduce_only_ms": round(query_ms, 3),
+                                "reduce_only_MBps": round(nchunks * chunk_bytes / (query_ms * 1e-3) / 1e6, 1),
+                                "materialize_ms": round(query_mat_ms, 3)},
         "kernel_ms": round(kernel_ms, 4),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

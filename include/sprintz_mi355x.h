@@ -168,6 +168,53 @@ int sprintz_mi355x_huf_decompress_batch(const void* d_huf, const uint64_t* d_huf
                                         uint32_t* d_sizes, void* d_tmp, void* hip_stream);
 
 /* ------------------------------------------------------------------------
+ * Query on compressed data.  Replaces
+ *   query_rowmajor_delta_rle_{8b,16b}(src, dest, const QueryParams&)  cpp/Compress/sprintz_delta.h:95-98
+ *   query_rowmajor_xff_rle_{8b,16b}(src, dest, const QueryParams&)    cpp/Compress/sprintz_xff.h:90-93
+ *   QueryParams{op, materialize}, QueryTypes::{NOOP,REDUCE_MAX,REDUCE_SUM}  cpp/Compress/query.hpp:23-29
+ * The reduction is fused into the decode kernel: with materialize == 0 nothing
+ * but the per-column results leaves the chip.
+ *
+ * Semantics.  The reference computes its reductions into a local object and
+ * throws them away (sprintz_xff_rle_query.cpp:69-104: DUMMY_READ_QUERY_RESULT),
+ * and its functors are unfinished (query.hpp:222 writes every stripe's maximum
+ * to state[0]; query.hpp:84-87,120-123 shift the wrong way and drop columns
+ * 8..15 of every 32), so there is no reference RESULT to be bit-exact with.
+ * Defined here: for column c (element index mod ndims), over ALL decompressed
+ * elements of the chunk including its verbatim tail --
+ *   op 1 (REDUCE_MAX): the unsigned maximum;  op 2 (REDUCE_SUM): the sum of the
+ *   unsigned values, in 64 bits.
+ * The materialised output is bit-exact with decompress (which is what the
+ * reference's own query tests assert, test/test_query.cpp:59-120,180-200).
+ *
+ *   op          : SPRINTZ_QUERY_NOOP / _MAX / _SUM
+ *   materialize : 0 = do not write the decompressed data (d_out may be NULL)
+ *   flags       : SPRINTZ_QUERY_GENERAL_LAYOUT = the stream uses the general
+ *                 row-major layout whatever ndims is, as the reference's
+ *                 *_rowmajor_*_rle_* functions do (sprintz.h's dispatch uses the
+ *                 low-dim layout for ndims <= 4 @8b / <= 2 @16b; that is the default)
+ *   d_partials  : [nchunks][ndims] uint64, per-chunk per-column results
+ *   d_rets      : optional, as in decompress_batch
+ * sprintz_mi355x_query_reduce folds the partials over the chunks:
+ *   d_result[ndims] = max / sum over chunks.
+ * ---------------------------------------------------------------------- */
+#define SPRINTZ_QUERY_NOOP 0
+#define SPRINTZ_QUERY_MAX 1
+#define SPRINTZ_QUERY_SUM 2
+#define SPRINTZ_QUERY_GENERAL_LAYOUT 1u
+int sprintz_mi355x_query_batch(int codec, int elem_bytes, const void* d_comp, const uint64_t* d_offsets, uint64_t nchunks,
+                               uint32_t chunk_len, uint16_t ndims, int op, int materialize, uint32_t flags, void* d_out,
+                               uint64_t* d_partials, int64_t* d_rets, void* hip_stream);
+int sprintz_mi355x_query_reduce(int op, const uint64_t* d_partials, uint64_t nchunks, uint16_t ndims, uint64_t* d_result,
+                                void* hip_stream);
+/* single-call forms over host buffers; result: ndims uint64 (may be NULL);
+ * return value as decompress (elements), < 0 on error */
+int64_t sprintz_mi355x_query_delta_8b(const int8_t* src, uint8_t* dest, int op, int materialize, uint32_t flags, uint64_t* result);
+int64_t sprintz_mi355x_query_delta_16b(const int16_t* src, uint16_t* dest, int op, int materialize, uint32_t flags, uint64_t* result);
+int64_t sprintz_mi355x_query_xff_8b(const int8_t* src, uint8_t* dest, int op, int materialize, uint32_t flags, uint64_t* result);
+int64_t sprintz_mi355x_query_xff_16b(const int16_t* src, uint16_t* dest, int op, int materialize, uint32_t flags, uint64_t* result);
+
+/* ------------------------------------------------------------------------
  * Host convenience: chunked codec over host buffers (what lzbench does per
  * block).  Stages through device memory; PCIe-inclusive by construction.
  * comp layout: chunk streams concatenated byte-dense; offsets[nchunks+1].

@@ -12,6 +12,8 @@
 #include <stdint.h>
 #include <stddef.h>
 #include "sprintz.h"   /* -I/root/reference/cpp/Compress : sprintz.h:16-32 */
+#include "sprintz_delta.h"   /* compress_rowmajor_delta_rle_*: :49-51,68-70; query_rowmajor_delta_rle_*: :95-98 */
+#include "sprintz_xff.h"     /* compress_rowmajor_xff_rle_*: :45-55; query_rowmajor_xff_rle_*: :90-93 */
 
 extern "C" {
 
@@ -66,6 +68,42 @@ uint64_t ref_decompress_chunks(int codec, int elem_bytes, const uint8_t* comp,
         if (n > 0) total += (uint64_t)n;
     }
     return total;
+}
+
+/* the general row-major layout for every ndims (what the reference's query tests feed
+ * query_rowmajor_*: test/test_query.cpp:59-120) */
+int64_t ref_compress_rowmajor(int codec, int elem_bytes, const void* src, uint32_t len, void* dest, uint16_t ndims)
+{
+    if (elem_bytes == 1) {
+        return codec ? compress_rowmajor_xff_rle_8b((const uint8_t*)src, len, (int8_t*)dest, ndims, true)
+                     : compress_rowmajor_delta_rle_8b((const uint8_t*)src, len, (int8_t*)dest, ndims, true);
+    }
+    return codec ? compress_rowmajor_xff_rle_16b((const uint16_t*)src, len, (int16_t*)dest, ndims, true)
+                 : compress_rowmajor_delta_rle_16b((const uint16_t*)src, len, (int16_t*)dest, ndims, true);
+}
+
+int64_t ref_decompress_rowmajor(int codec, int elem_bytes, const void* src, void* dest)
+{
+    if (elem_bytes == 1) {
+        return codec ? decompress_rowmajor_xff_rle_8b((const int8_t*)src, (uint8_t*)dest)
+                     : decompress_rowmajor_delta_rle_8b((const int8_t*)src, (uint8_t*)dest);
+    }
+    return codec ? decompress_rowmajor_xff_rle_16b((const int16_t*)src, (uint16_t*)dest)
+                 : decompress_rowmajor_delta_rle_16b((const int16_t*)src, (uint16_t*)dest);
+}
+
+/* query with materialize (the only observable output of the reference's query path) */
+int64_t ref_query(int codec, int elem_bytes, const void* src, void* dest, int op, int materialize)
+{
+    QueryParams qp;
+    qp.op = (QueryTypes::Operation)op;
+    qp.materialize = materialize != 0;
+    if (elem_bytes == 1) {
+        return codec ? query_rowmajor_xff_rle_8b((const int8_t*)src, (uint8_t*)dest, qp)
+                     : query_rowmajor_delta_rle_8b((const int8_t*)src, (uint8_t*)dest, qp);
+    }
+    return codec ? query_rowmajor_xff_rle_16b((const int16_t*)src, (uint16_t*)dest, qp)
+                 : query_rowmajor_delta_rle_16b((const int16_t*)src, (uint16_t*)dest, qp);
 }
 
 }  // extern "C"

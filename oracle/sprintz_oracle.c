@@ -118,8 +118,50 @@ int64_t oracle_decompress_ex(int codec, int elem_bytes, const void* src, void* d
                              size_t* consumed_bytes)
 {
     const int fire = codec != 0;
-    if (elem_bytes == 1) return decompress_w8((const uint8_t*)src, (uint8_t*)dest, fire, quirk, consumed_bytes);
-    return decompress_w16((const uint8_t*)src, (uint16_t*)dest, fire, quirk, consumed_bytes);
+    if (elem_bytes == 1) return decompress_w8((const uint8_t*)src, (uint8_t*)dest, fire, quirk, 0, consumed_bytes);
+    return decompress_w16((const uint8_t*)src, (uint16_t*)dest, fire, quirk, 0, consumed_bytes);
+}
+
+/* ---- the reference's *_rowmajor_*_rle_* family: general row-major layout for EVERY ndims
+ * (compress_rowmajor_delta_rle_8b sprintz_delta.h:49, ..._xff_rle_16b sprintz_xff.h:53); these are
+ * what its query tests pair with query_rowmajor_* (test/test_query.cpp:59-120). */
+int64_t oracle_compress_rowmajor(int codec, int elem_bytes, const void* src, uint32_t len, void* dest,
+                                 uint16_t ndims, size_t* nbytes_out)
+{
+    if (ndims == 0) return -1;
+    const int fire = codec != 0;
+    if (elem_bytes == 1) return compress_w8((const uint8_t*)src, len, (uint8_t*)dest, ndims, fire, 0, 1, nbytes_out);
+    return compress_w16((const uint16_t*)src, len, (uint8_t*)dest, ndims, fire, 0, 1, nbytes_out);
+}
+
+int64_t oracle_decompress_rowmajor_ex(int codec, int elem_bytes, const void* src, void* dest, int quirk,
+                                      size_t* consumed_bytes)
+{
+    const int fire = codec != 0;
+    if (elem_bytes == 1) return decompress_w8((const uint8_t*)src, (uint8_t*)dest, fire, quirk, 1, consumed_bytes);
+    return decompress_w16((const uint8_t*)src, (uint16_t*)dest, fire, quirk, 1, consumed_bytes);
+}
+
+/* ---- query on compressed data (query.hpp:23-29).  The reference throws its reduction
+ * away (sprintz_xff_rle_query.cpp:69-104) and its functors are unfinished (query.hpp:222,
+ * :84-87), so the RESULT is defined here, by restating what the operation means: op over the
+ * decompressed data, per column (element index mod ndims), tail included, unsigned, 64-bit.
+ * op 1 = max, 2 = sum.  `dest` receives the decompressed data (the materialised output). */
+int64_t oracle_query(int codec, int elem_bytes, const void* src, void* dest, int general, int op, uint64_t* result)
+{
+    uint16_t D;
+    memcpy(&D, (const uint8_t*)src + 6, 2);
+    const int64_t n = general ? oracle_decompress_rowmajor_ex(codec, elem_bytes, src, dest, 0, NULL)
+                              : oracle_decompress_ex(codec, elem_bytes, src, dest, 0, NULL);
+    if (n < 0 || D == 0) return n;
+    for (unsigned d = 0; d < D; d++) result[d] = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const uint64_t x = elem_bytes == 1 ? ((const uint8_t*)dest)[i] : ((const uint16_t*)dest)[i];
+        uint64_t* r = &result[i % D];
+        if (op == 1) { if (x > *r) *r = x; }
+        else if (op == 2) *r += x;
+    }
+    return n;
 }
 
 int64_t oracle_decompress_q(int codec, int elem_bytes, const void* src, void* dest, int quirk)

@@ -64,6 +64,12 @@ int64_t oracle_decompress_ex(int codec, int elem_bytes, const void* src, void* d
                              size_t* consumed_bytes);
 
 /* Worst-case compressed size in bytes for `len` elements of `ndims` columns. */
+/* the reference's *_rowmajor_*_rle_* family (general layout whatever ndims is) and the
+ * semantic definition of query-on-compressed; see sprintz_oracle.c */
+int64_t oracle_compress_rowmajor(int codec, int elem_bytes, const void* src, uint32_t len, void* dest, uint16_t ndims, size_t* nbytes_out);
+int64_t oracle_decompress_rowmajor_ex(int codec, int elem_bytes, const void* src, void* dest, int ref_rle16_quirk, size_t* consumed_bytes);
+int64_t oracle_query(int codec, int elem_bytes, const void* src, void* dest, int general, int op, uint64_t* result);
+
 size_t oracle_compress_bound(int elem_bytes, uint32_t len, uint16_t ndims);
 
 /* Chunked helpers (what lzbench does with its block-size option, README.md:58):

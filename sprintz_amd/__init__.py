@@ -7,14 +7,17 @@ reference's interface (cpp/Compress/sprintz.h) on top of it.
 from . import _lib
 from ._lib import SprintzError, abi_version, last_error
 from .codec import (ChunkedCodec, CompressedBatch, HufBatch, compress_chunked, decompress_chunked, decompress_noheader,
-                    huf_compress, huf_decompress,
+                    huf_compress, huf_decompress, QueryParams, QueryTypes,
+                    query_rowmajor_delta_rle_8b, query_rowmajor_delta_rle_16b, query_rowmajor_xff_rle_8b,
+                    query_rowmajor_xff_rle_16b,
                     sprintz_compress_delta_8b, sprintz_compress_delta_16b, sprintz_compress_xff_8b,
                     sprintz_compress_xff_16b, sprintz_decompress_delta_8b, sprintz_decompress_delta_16b,
                     sprintz_decompress_xff_8b, sprintz_decompress_xff_16b)
 
 __all__ = [
     "SprintzError", "abi_version", "last_error", "ChunkedCodec", "CompressedBatch", "HufBatch", "huf_compress", "huf_decompress",
-    "compress_chunked", "decompress_chunked", "decompress_noheader",
+    "compress_chunked", "decompress_chunked", "decompress_noheader", "QueryParams", "QueryTypes",
+    "query_rowmajor_delta_rle_8b", "query_rowmajor_delta_rle_16b", "query_rowmajor_xff_rle_8b", "query_rowmajor_xff_rle_16b",
     "sprintz_compress_delta_8b", "sprintz_compress_delta_16b", "sprintz_compress_xff_8b", "sprintz_compress_xff_16b",
     "sprintz_decompress_delta_8b", "sprintz_decompress_delta_16b", "sprintz_decompress_xff_8b",
     "sprintz_decompress_xff_16b",

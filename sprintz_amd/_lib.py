@@ -82,6 +82,18 @@ huf_bound = _sig("sprintz_mi355x_huf_bound", _sz, _u64, _u64)
 huf_compress_batch = _sig("sprintz_mi355x_huf_compress_batch", _i, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp)
 huf_decompress_batch = _sig("sprintz_mi355x_huf_decompress_batch", _i, _vp, _vp, _vp, _u64, _u32, _vp, _vp, _vp, _vp, _vp)
 
+# (4) query on compressed data (query.hpp:23-29; sprintz_delta.h:95-98; sprintz_xff.h:90-93)
+QUERY_NOOP, QUERY_MAX, QUERY_SUM = 0, 1, 2
+QUERY_GENERAL_LAYOUT = 1
+query_batch = _sig("sprintz_mi355x_query_batch", _i, _i, _i, _vp, _vp, _u64, _u32, _u16, _i, _i, _u32, _vp, _vp, _vp, _vp)
+query_reduce = _sig("sprintz_mi355x_query_reduce", _i, _i, _vp, _u64, _u16, _vp, _vp)
+query = {
+    ("delta", 1): _sig("sprintz_mi355x_query_delta_8b", _i64, _vp, _vp, _i, _i, _u32, _vp),
+    ("xff", 1): _sig("sprintz_mi355x_query_xff_8b", _i64, _vp, _vp, _i, _i, _u32, _vp),
+    ("delta", 2): _sig("sprintz_mi355x_query_delta_16b", _i64, _vp, _vp, _i, _i, _u32, _vp),
+    ("xff", 2): _sig("sprintz_mi355x_query_xff_16b", _i64, _vp, _vp, _i, _i, _u32, _vp),
+}
+
 # host convenience
 compress_chunked_host = _sig("sprintz_mi355x_compress_chunked_host", _i64, _i, _i, _vp, _u64, _u32, _u16, _vp, _sz, _vp)
 decompress_chunked_host = _sig("sprintz_mi355x_decompress_chunked_host", _i64, _i, _i, _vp, _vp, _u64, _u32, _u16, _vp)
@@ -99,6 +111,9 @@ EXPORTED_SYMBOLS = [
     "sprintz_mi355x_compress_chunked_host", "sprintz_mi355x_decompress_chunked_host",
     "sprintz_mi355x_huf_tmp_bytes", "sprintz_mi355x_huf_bound",
     "sprintz_mi355x_huf_compress_batch", "sprintz_mi355x_huf_decompress_batch",
+    "sprintz_mi355x_query_batch", "sprintz_mi355x_query_reduce",
+    "sprintz_mi355x_query_delta_8b", "sprintz_mi355x_query_xff_8b",
+    "sprintz_mi355x_query_delta_16b", "sprintz_mi355x_query_xff_16b",
 ]
 
 

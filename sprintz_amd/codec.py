@@ -200,6 +200,67 @@ class ChunkedCodec:
                                          rets.data_ptr() if rets is not None else None, self._stream()))
 
 
+    def query(self, batch, op, materialize=False, out=None, reduce=True):
+        """Query on the compressed container (query.hpp:23-29): per-column max / sum fused into
+        the decode; returns (result, out).  result: uint64 tensor [ndims] (reduce=True) or the
+        per-chunk partials [nchunks, ndims]; out: the decompressed elements if materialize."""
+        torch = self.torch
+        n = batch.nchunks
+        opid = {None: _lib.QUERY_NOOP, "noop": _lib.QUERY_NOOP, "max": _lib.QUERY_MAX, "sum": _lib.QUERY_SUM}[op]
+        if materialize and out is None:
+            out = torch.empty(n * self.chunk_len, dtype=self.dtype, device=self.device)
+        partials = torch.empty((n, self.ndims), dtype=torch.int64, device=self.device) if opid else None
+        _lib.check(_lib.query_batch(_CODEC_ID[self.codec], self.esz, batch.data.data_ptr(), batch.offsets.data_ptr(), n,
+                                    self.chunk_len, self.ndims, opid, int(bool(materialize)), 0,
+                                    out.data_ptr() if materialize else None,
+                                    partials.data_ptr() if opid else None, None, self._stream()))
+        res = partials
+        if opid and reduce:
+            res = torch.empty(self.ndims, dtype=torch.int64, device=self.device)
+            _lib.check(_lib.query_reduce(opid, partials.data_ptr(), n, self.ndims, res.data_ptr(), self._stream()))
+        return res, (out[: batch.total_len] if materialize else None)
+
+
+# ---- query on compressed data, single call (the reference's names) -----------------------
+
+class QueryTypes:                       # query.hpp:23-25
+    NOOP, REDUCE_MAX, REDUCE_SUM = 0, 1, 2
+
+
+@dataclass
+class QueryParams:                      # query.hpp:27-30
+    op: int = QueryTypes.NOOP
+    materialize: bool = False
+
+
+def _query(codec, esz, src, dest, qp, general):
+    src = np.ascontiguousarray(src)
+    ndims = int(src.view(np.uint8)[6]) | (int(src.view(np.uint8)[7]) << 8)
+    result = np.zeros(max(ndims, 1), np.uint64)
+    flags = _lib.QUERY_GENERAL_LAYOUT if general else 0
+    ret = int(_lib.query[(codec, esz)](_np_ptr(src), _np_ptr(dest) if dest is not None else None, int(qp.op),
+                                       int(bool(qp.materialize)), flags, _np_ptr(result)))
+    return ret, result[:ndims]
+
+
+def query_rowmajor_delta_rle_8b(src, dest, qp, general_layout=True):
+    """sprintz_delta.h:95; returns (elements, per-column result).  general_layout=True is what the
+    reference's *_rowmajor_*_rle_* streams use; pass False for streams made by sprintz_compress_*."""
+    return _query("delta", 1, src, dest, qp, general_layout)
+
+
+def query_rowmajor_delta_rle_16b(src, dest, qp, general_layout=True):
+    return _query("delta", 2, src, dest, qp, general_layout)
+
+
+def query_rowmajor_xff_rle_8b(src, dest, qp, general_layout=True):
+    return _query("xff", 1, src, dest, qp, general_layout)
+
+
+def query_rowmajor_xff_rle_16b(src, dest, qp, general_layout=True):
+    return _query("xff", 2, src, dest, qp, general_layout)
+
+
 # ---- optional Huffman stage (device) ------------------------------------------------
 
 @dataclass

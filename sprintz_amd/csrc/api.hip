@@ -206,13 +206,21 @@ int check_common(int codec, int esz, uint16_t ndims)
     return 0;
 }
 
+// query-on-compressed options of one decode launch (decode_kernel.h: Q template parameter)
+struct QuerySpec {
+    int q = kQueryOff;          // kQueryOff / kQueryMaterialize / kQueryReduceOnly
+    int qop = 0;                // 1 max, 2 sum
+    uint64_t* qres = nullptr;   // [nchunks][ndims]
+    int general = 0;            // 1: general row-major layout for every ndims (the reference's *_rowmajor_*_rle_* family)
+};
+
 int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offsets, uint64_t nchunks,
                   uint32_t chunk_len, uint16_t ndims, void* d_out, int64_t* d_rets, hipStream_t st,
-                  int noheader, uint32_t nh_ngroups, uint32_t nh_remaining)
+                  int noheader, uint32_t nh_ngroups, uint32_t nh_remaining, const QuerySpec& qs = QuerySpec{})
 {
     if (nchunks == 0) return 0;
     const int D = ndims;
-    const bool lowdim = is_lowdim(esz, D);
+    const bool lowdim = qs.general ? false : is_lowdim(esz, D);
     const Mapping m = choose_mapping(D, lowdim);
     const int DP = 1 << m.log2DP;
 
@@ -229,6 +237,8 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
     a.nh_ngroups = nh_ngroups;
     a.nh_remaining = nh_remaining;
     a.chunks_per_group = 1;
+    a.qop = qs.qop;
+    a.qres = qs.qres;
     if (const char* d = getenv("SPRINTZ_MI355X_DBG")) a.dbg = atoi(d);
 
     // LDS-transposed 16-byte stores need every 8 x D block of the output 16-byte aligned
@@ -237,7 +247,7 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
     const size_t groups_per_block = kThreads / DP;
     size_t shmem = 0;
     a.vec_store = 0;
-    if (blk_bytes % 16 == 0 && ((uintptr_t)d_out % 16) == 0 && ((uint64_t)chunk_len * esz) % 16 == 0 &&
+    if (blk_bytes % 16 == 0 && (qs.q == kQueryReduceOnly || ((uintptr_t)d_out % 16) == 0) && ((uint64_t)chunk_len * esz) % 16 == 0 &&
         stride * groups_per_block <= 64 * 1024) {
         a.vec_store = 1;
         a.lds_group_stride = (uint32_t)stride;
@@ -283,16 +293,16 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
         const uint64_t fthreads = ngroups_launch * (uint64_t)fdp;
         const uint64_t fgrid = (fthreads + kThreads - 1) / kThreads;
         if (fgrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
-        e = esz == 1 ? launch_decode_fast_w8(codec == SPRINTZ_CODEC_XFF, fdp, fcpl, D == fdp * fcpl, (unsigned)fgrid, fstride * fgroups, st, a)
-                     : launch_decode_fast_w16(codec == SPRINTZ_CODEC_XFF, fdp, fcpl, D == fdp * fcpl, (unsigned)fgrid, fstride * fgroups, st, a);
+        e = esz == 1 ? launch_decode_fast_w8(codec == SPRINTZ_CODEC_XFF, fdp, fcpl, D == fdp * fcpl, qs.q, (unsigned)fgrid, fstride * fgroups, st, a)
+                     : launch_decode_fast_w16(codec == SPRINTZ_CODEC_XFF, fdp, fcpl, D == fdp * fcpl, qs.q, (unsigned)fgrid, fstride * fgroups, st, a);
         if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "decode_fast kernel launch", e);
         return 0;
     }
     const uint64_t threads = nchunks * (uint64_t)DP;
     const uint64_t grid = (threads + kThreads - 1) / kThreads;
     if (grid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
-    e = esz == 1 ? launch_decode_w8(codec == SPRINTZ_CODEC_XFF, lowdim, m.cpl, (unsigned)grid, shmem, st, a)
-                 : launch_decode_w16(codec == SPRINTZ_CODEC_XFF, lowdim, m.cpl, (unsigned)grid, shmem, st, a);
+    e = esz == 1 ? launch_decode_w8(codec == SPRINTZ_CODEC_XFF, lowdim, m.cpl, qs.q, (unsigned)grid, shmem, st, a)
+                 : launch_decode_w16(codec == SPRINTZ_CODEC_XFF, lowdim, m.cpl, qs.q, (unsigned)grid, shmem, st, a);
     if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "decode kernel launch", e);
     return 0;
 }
@@ -475,6 +485,73 @@ int64_t decompress_host(int codec, int esz, const void* src, void* dest, int noh
     return ret;
 }
 
+// per-column reduction of the per-chunk partials: thread (r, col) walks chunks r, r+R, ...
+// (a row of partials is contiguous, so consecutive threads read consecutive words)
+__global__ void __launch_bounds__(256) query_reduce_kernel(const uint64_t* partials, uint64_t nchunks, uint32_t D, uint32_t R,
+                                                           int op, unsigned long long* result)
+{
+    const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (tid >= (uint64_t)D * R) return;
+    const uint32_t col = (uint32_t)(tid % D);
+    const uint64_t r = tid / D;
+    unsigned long long acc = 0;
+    for (uint64_t c = r; c < nchunks; c += R) {
+        const unsigned long long x = partials[c * D + col];
+        acc = op == 1 ? (x > acc ? x : acc) : acc + x;
+    }
+    if (op == 1) atomicMax(&result[col], acc);
+    else atomicAdd(&result[col], acc);
+}
+
+// single-call query (mirrors query_rowmajor_{delta,xff}_rle_{8b,16b}: sprintz_delta.h:95-98,
+// sprintz_xff.h:90-93): host stream in, optional materialised data and per-column result out
+int64_t query_host(int codec, int esz, const void* src, void* dest, int op, int materialize, uint64_t* result, int general)
+{
+    if (op < 0 || op > 2) return fail(SPRINTZ_E_INVALID, "op must be 0 (none), 1 (max) or 2 (sum)");
+    if (materialize && !dest) return fail(SPRINTZ_E_INVALID, "materialize without a destination");
+    const uint8_t* s = (const uint8_t*)src;
+    uint32_t ngroups;
+    uint16_t r16, ndims;
+    memcpy(&ngroups, s, 4);
+    memcpy(&r16, s + 4, 2);
+    memcpy(&ndims, s + 6, 2);
+    const uint32_t remaining = r16;
+    if (ndims == 0) { fail(SPRINTZ_E_INVALID, "ndims == 0"); return -1; }
+    int rc = check_common(codec, esz, ndims);
+    if (rc) return rc;
+    if ((rc = ensure_device())) return rc;
+    uint64_t nbytes = 0, nelems = 0;
+    walk_stream(s + 8, esz, ndims, ngroups, remaining, general ? false : is_lowdim(esz, ndims), &nbytes, &nelems);
+    nbytes += 8;
+    if (result) memset(result, 0, (size_t)ndims * 8);
+    if (nelems == 0) return 0;
+    if (nelems > (1ull << 31)) return fail(SPRINTZ_E_UNSUPPORTED, "single call limited to 2^31 elements");
+    DevBuf d_comp, d_out, d_meta, d_res;
+    HIP_TRY(d_comp.alloc(nbytes + SPRINTZ_MI355X_READ_SLACK));
+    if (materialize) HIP_TRY(d_out.alloc(nelems * esz));
+    HIP_TRY(d_meta.alloc(24));
+    HIP_TRY(d_res.alloc((size_t)ndims * 8));
+    HIP_TRY(hipMemset(d_res.p, 0, (size_t)ndims * 8));
+    HIP_TRY(hipMemcpy(d_comp.p, src, nbytes, hipMemcpyHostToDevice));
+    const uint64_t meta[3] = {0, nbytes, 0};
+    HIP_TRY(hipMemcpy(d_meta.p, meta, 24, hipMemcpyHostToDevice));
+    QuerySpec qs;
+    qs.q = materialize ? (op ? kQueryMaterialize : kQueryOff) : kQueryReduceOnly;
+    qs.qop = op;
+    qs.qres = (uint64_t*)d_res.p;
+    qs.general = general;
+    int64_t* d_ret = (int64_t*)((uint8_t*)d_meta.p + 16);
+    rc = decode_launch(codec, esz, d_comp.p, (uint64_t*)d_meta.p, 1, (uint32_t)nelems, ndims, d_out.p, d_ret, nullptr, 0, 0, 0, qs);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    int64_t ret = 0;
+    HIP_TRY(hipMemcpy(&ret, d_ret, 8, hipMemcpyDeviceToHost));
+    if (ret < 0) return fail((int)ret, "decoder rejected the stream");
+    if (materialize) HIP_TRY(hipMemcpy(dest, d_out.p, (size_t)ret * esz, hipMemcpyDeviceToHost));
+    if (result && op) HIP_TRY(hipMemcpy(result, d_res.p, (size_t)ndims * 8, hipMemcpyDeviceToHost));
+    return ret;
+}
+
 }  // namespace
 
 // =============================================================== exported C-ABI
@@ -633,6 +710,64 @@ int64_t sprintz_mi355x_decompress_chunked_host(int codec, int elem_bytes, const 
     // chunks are full except possibly the last: decoded data is contiguous
     HIP_TRY(hipMemcpy(out, d_out.p, (size_t)sum * elem_bytes, hipMemcpyDeviceToHost));
     return sum;
+}
+
+// ---------------------------------------------------------------- query-on-compressed
+int sprintz_mi355x_query_batch(int codec, int elem_bytes, const void* d_comp, const uint64_t* d_offsets, uint64_t nchunks,
+                               uint32_t chunk_len, uint16_t ndims, int op, int materialize, uint32_t flags, void* d_out,
+                               uint64_t* d_partials, int64_t* d_rets, void* hip_stream)
+{
+    int rc = check_common(codec, elem_bytes, ndims);
+    if (rc) return rc;
+    if (op < 0 || op > 2) return fail(SPRINTZ_E_INVALID, "op must be 0 (none), 1 (max) or 2 (sum)");
+    if (flags & ~(uint32_t)SPRINTZ_QUERY_GENERAL_LAYOUT) return fail(SPRINTZ_E_INVALID, "unknown flag");
+    if (chunk_len == 0 || chunk_len > (1u << 30)) return fail(SPRINTZ_E_INVALID, "chunk_len must be in 1..2^30");
+    if (!d_comp || !d_offsets) return fail(SPRINTZ_E_INVALID, "null device pointer");
+    if (materialize && !d_out) return fail(SPRINTZ_E_INVALID, "materialize without a destination");
+    if (op && !d_partials) return fail(SPRINTZ_E_INVALID, "op without a result buffer");
+    if ((rc = ensure_device())) return rc;
+    QuerySpec qs;
+    qs.q = materialize ? (op ? kQueryMaterialize : kQueryOff) : kQueryReduceOnly;
+    qs.qop = op;
+    qs.qres = op ? d_partials : nullptr;
+    qs.general = (flags & SPRINTZ_QUERY_GENERAL_LAYOUT) ? 1 : 0;
+    return decode_launch(codec, elem_bytes, d_comp, d_offsets, nchunks, chunk_len, ndims, d_out, d_rets, (hipStream_t)hip_stream,
+                         0, 0, 0, qs);
+}
+
+int sprintz_mi355x_query_reduce(int op, const uint64_t* d_partials, uint64_t nchunks, uint16_t ndims, uint64_t* d_result,
+                                void* hip_stream)
+{
+    if (op != 1 && op != 2) return fail(SPRINTZ_E_INVALID, "op must be 1 (max) or 2 (sum)");
+    if (!d_partials || !d_result || ndims == 0) return fail(SPRINTZ_E_INVALID, "null device pointer");
+    int rc = ensure_device();
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIP_TRY(hipMemsetAsync(d_result, 0, (size_t)ndims * 8, st));
+    if (nchunks == 0) return 0;
+    uint64_t R = (65536 + ndims - 1) / ndims;
+    if (R > nchunks) R = nchunks;
+    const uint64_t threads = R * ndims;
+    hipLaunchKernelGGL(query_reduce_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, d_partials, nchunks,
+                       (uint32_t)ndims, (uint32_t)R, op, (unsigned long long*)d_result);
+    return hipGetLastError() == hipSuccess ? 0 : fail(SPRINTZ_E_HIP, "query_reduce launch");
+}
+
+int64_t sprintz_mi355x_query_delta_8b(const int8_t* src, uint8_t* dest, int op, int materialize, uint32_t flags, uint64_t* result)
+{
+    return query_host(SPRINTZ_CODEC_DELTA, 1, src, dest, op, materialize, result, (flags & SPRINTZ_QUERY_GENERAL_LAYOUT) != 0);
+}
+int64_t sprintz_mi355x_query_delta_16b(const int16_t* src, uint16_t* dest, int op, int materialize, uint32_t flags, uint64_t* result)
+{
+    return query_host(SPRINTZ_CODEC_DELTA, 2, src, dest, op, materialize, result, (flags & SPRINTZ_QUERY_GENERAL_LAYOUT) != 0);
+}
+int64_t sprintz_mi355x_query_xff_8b(const int8_t* src, uint8_t* dest, int op, int materialize, uint32_t flags, uint64_t* result)
+{
+    return query_host(SPRINTZ_CODEC_XFF, 1, src, dest, op, materialize, result, (flags & SPRINTZ_QUERY_GENERAL_LAYOUT) != 0);
+}
+int64_t sprintz_mi355x_query_xff_16b(const int16_t* src, uint16_t* dest, int op, int materialize, uint32_t flags, uint64_t* result)
+{
+    return query_host(SPRINTZ_CODEC_XFF, 2, src, dest, op, materialize, result, (flags & SPRINTZ_QUERY_GENERAL_LAYOUT) != 0);
 }
 
 }  // extern "C"

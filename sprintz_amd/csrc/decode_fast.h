@@ -72,7 +72,7 @@ __device__ __forceinline__ int sign_of(int x)
 
 // CPL columns per lane (column = lane_d*CPL + k); EXACT: ndims == DP*CPL, so every
 // size is a compile-time constant.
-template <int W, bool FIRE, int DP, int CPL, bool EXACT>
+template <int W, bool FIRE, int DP, int CPL, bool EXACT, int Q = 0>
 __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
 {
     using U = typename Elem<W>::U;
@@ -197,6 +197,31 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     for (int k = 0; k < CPL; k++) { pv[k] = 0; pd[k] = 0; ctr[k] = 0; col_ok[k] = EXACT ? true : (col0 + k) < D; }
     uint32_t out_left = 0;                                 // capacity guard (elements)
     bool corrupt = false;
+    // query-on-compressed (Q != 0): per-column max and sum of the chunk, kept next to the
+    // predictor state; with Q == kQueryReduceOnly the block never leaves the registers
+    uint32_t qmax[CPL];
+    uint64_t qsum[CPL];
+    uint32_t qbs[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; k++) { qmax[k] = 0; qsum[k] = 0; qbs[k] = 0; }
+    auto q_row = [&](int k) {                              // pv[k] carries garbage above bit W: SDWA selects the element
+        if constexpr (Q != 0) {
+            if constexpr (W == 16) {
+                asm("v_max_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+                    : "=v"(qmax[k]) : "v"(qmax[k]), "v"(pv[k]));
+                asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+                    : "=v"(qbs[k]) : "v"(qbs[k]), "v"(pv[k]));
+            } else {
+                asm("v_max_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0"
+                    : "=v"(qmax[k]) : "v"(qmax[k]), "v"(pv[k]));
+                asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0"
+                    : "=v"(qbs[k]) : "v"(qbs[k]), "v"(pv[k]));
+            }
+        }
+    };
+    auto q_block = [&](int k) {
+        if constexpr (Q != 0) { qsum[k] += qbs[k]; qbs[k] = 0; }
+    };
     uint32_t ovo = 0;                                      // output cursor (byte offset from this wave's out_base)
 
     // ---- per-block workers ------------------------------------------------------
@@ -213,6 +238,7 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         for (int q = 0; q < PIECES; q++) { held[s2][q] = make_uint4(0, 0, 0, 0); held_vo[s2][q] = kDropStore; }
     // after the 8 rows sit in `stage`; slot < 0: store right away (run blocks)
     auto stage_out = [&](int slot) {
+        if constexpr (Q == kQueryReduceOnly) return;
         wave_lds_sync();
 #pragma unroll
         for (int q = 0; q < PIECES; q++) {
@@ -241,8 +267,11 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
                     const int delta = FIRE ? __builtin_amdgcn_sbfe(mad24(pd[k], coef, 0), W, W) : 0;
                     pv[k] += (uint32_t)delta;
                     pd[k] = delta;
-                    if (col_ok[k]) *(U*)(stage_col + k * ESZ + i * row_stride) = (U)pv[k];
+                    q_row(k);
+                    if constexpr (Q != kQueryReduceOnly)
+                        if (col_ok[k]) *(U*)(stage_col + k * ESZ + i * row_stride) = (U)pv[k];
                 }
+                q_block(k);
             }
             stage_out(-1);
         }
@@ -296,8 +325,11 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
                 }
                 pv[k] += (uint32_t)delta;
                 pd[k] = delta;
-                if (col_ok[k]) *(U*)(stage_col + k * ESZ + i * row_stride) = (U)pv[k];
+                q_row(k);
+                if constexpr (Q != kQueryReduceOnly)
+                    if (col_ok[k]) *(U*)(stage_col + k * ESZ + i * row_stride) = (U)pv[k];
             }
+            q_block(k);
             if constexpr (FIRE) ctr[k] = wrap_counter<W>(ctr[k] + __builtin_amdgcn_sbfe(grad, 2, W - 2));   // sext_W(grad) >> 2
         }
         stage_out(slot);
@@ -337,7 +369,7 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         if (rofs >= RB) rofs -= RB;
         ahead -= 8;
 #pragma unroll
-        for (int k = 0; k < CPL; k++) { pv[k] = 0; pd[k] = 0; ctr[k] = 0; }
+        for (int k = 0; k < CPL; k++) { pv[k] = 0; pd[k] = 0; ctr[k] = 0; qmax[k] = 0; qsum[k] = 0; }
         out_left = a.chunk_len;
         ovo = (uint32_t)((chunk - wave_first) * (uint64_t)a.chunk_len * ESZ);
         corrupt = (int)(w1 >> 16) != D;
@@ -418,11 +450,13 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         // counter for loads and stores, so parking the loads must not wait for the stores
         // just issued: with every VMEM op of the common path unconditional, hipcc emits
         // s_waitcnt vmcnt(<number of stores>) here instead of vmcnt(0).
+        if constexpr (Q != kQueryReduceOnly) {
 #pragma unroll
-        for (int s2 = 0; s2 < 2; s2++)
+            for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
-            for (int q = 0; q < PIECES; q++)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, held[s2][q]), orsrc, held_vo[s2][q], 0, 0);
+                for (int q = 0; q < PIECES; q++)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, held[s2][q]), orsrc, held_vo[s2][q], 0, 0);
+        }
 #pragma unroll
         for (uint32_t k = 0; k < NPEND; k++)
             if (k < npend) commit(pend[k]);
@@ -432,7 +466,23 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     // ---- verbatim tail (:1171), straight from HBM
     const uint32_t out_elems = a.chunk_len - out_left;
     if (!corrupt && remaining > out_left) corrupt = true;
-    if (!corrupt && remaining > 0) {
+    if constexpr (Q != 0) {
+        // the verbatim tail continues the row-major order: element e sits in column e % D
+        if (!corrupt) {
+            const uint8_t* t = a.comp + gabs + rp;
+#pragma unroll
+            for (int k = 0; k < CPL; k++) {
+                if (!col_ok[k]) continue;
+                for (uint32_t e = (uint32_t)(col0 + k); e < remaining; e += (uint32_t)D) {
+                    const uint32_t x = ESZ == 1 ? (uint32_t)t[e] : (uint32_t)*(const u16_unaligned*)(t + 2 * e);
+                    qmax[k] = x > qmax[k] ? x : qmax[k];
+                    qsum[k] += x;
+                }
+                if (a.qres) a.qres[chunk * (uint64_t)D + (uint64_t)(col0 + k)] = a.qop == 1 ? (uint64_t)qmax[k] : qsum[k];
+            }
+        }
+    }
+    if (!corrupt && remaining > 0 && Q != kQueryReduceOnly) {
         const uint8_t* t = a.comp + gabs + rp;
         uint8_t* d = (uint8_t*)a.out + out_base + ovo;
         const uint32_t nbytes = remaining * ESZ;

@@ -32,11 +32,19 @@ struct DecodeArgs {
     uint32_t nh_remaining;
     int dbg;                    // timing ablations only (SPRINTZ_MI355X_DBG); 0 in production
     uint32_t chunks_per_group;  // decode_fast: consecutive chunks decoded by one lane group
+    // query-on-compressed (sprintz_delta.h:95-98, sprintz_xff.h:90-93, query.hpp:23-29): kernels
+    // instantiated with Q != 0 reduce every column of every chunk while decoding
+    int qop;                    // 1: max, 2: sum (what lands in qres)
+    uint64_t* qres;             // [nchunks][D] per-chunk, per-column partial results
 };
+
+// Q (template): 0 = plain decode; 1 = decode + reduce; 2 = reduce only (nothing is written
+// to `out` -- QueryParams::materialize == false)
+constexpr int kQueryOff = 0, kQueryMaterialize = 1, kQueryReduceOnly = 2;
 
 constexpr int64_t kErrCorrupt = -5;
 
-template <int W, bool FIRE, bool LOWDIM, int CPL>
+template <int W, bool FIRE, bool LOWDIM, int CPL, int Q = 0>
 __global__ void __launch_bounds__(kThreads) decode_kernel(DecodeArgs a)
 {
     using U = typename Elem<W>::U;
@@ -91,6 +99,10 @@ __global__ void __launch_bounds__(kThreads) decode_kernel(DecodeArgs a)
     uint32_t out_elems = 0;
     int slot = 2;
     uint32_t run_left = 0;
+    uint32_t qmax[CPL];
+    uint64_t qsum[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; k++) { qmax[k] = 0; qsum[k] = 0; }
 
     for (;;) {
         uint32_t z[8][CPL];
@@ -197,11 +209,22 @@ __global__ void __launch_bounds__(kThreads) decode_kernel(DecodeArgs a)
             pv[k] = pvk;
             pd[k] = pdk;
             if (FIRE) ctr[k] = wrap_counter<W>(ctr[k] + (sext<W>(grad) >> 2));   // :1120-1128
+            if constexpr (Q != 0) {              // the query functor sees every decoded row (sprintz_xff_rle_query.hpp:346-596)
+                uint32_t bs = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    qmax[k] = v[i][k] > qmax[k] ? v[i][k] : qmax[k];
+                    bs += v[i][k];
+                }
+                qsum[k] += bs;
+            }
         }
 
         // ---- store the 8 x D block (contiguous 8*D*ESZ bytes of the output)
         U* const ob = o + out_elems;
-        if (a.vec_store) {
+        if constexpr (Q == kQueryReduceOnly) {
+            (void)ob;
+        } else if (a.vec_store) {
             U* const l = (U*)lds;
 #pragma unroll
             for (int k = 0; k < CPL; k++) {
@@ -231,7 +254,25 @@ __global__ void __launch_bounds__(kThreads) decode_kernel(DecodeArgs a)
 
     // ---- verbatim tail (:1171)
     if (!corrupt && out_elems + remaining > a.chunk_len) corrupt = true;
-    if (!corrupt) {
+    if constexpr (Q != 0) {
+        // the verbatim tail continues the row-major order: element e sits in column e % D
+        // (out_elems is a multiple of 8*D)
+        if (!corrupt) {
+            const uint8_t* t = s + pos;
+#pragma unroll
+            for (int k = 0; k < CPL; k++) {
+                const int col = lane_d * CPL + k;
+                if (col >= D) continue;
+                for (uint32_t e = (uint32_t)col; e < remaining; e += (uint32_t)D) {
+                    const uint32_t x = ESZ == 1 ? load_u8(t + e) : (load_u8(t + 2 * e) | (load_u8(t + 2 * e + 1) << 8));
+                    qmax[k] = x > qmax[k] ? x : qmax[k];
+                    qsum[k] += x;
+                }
+                if (a.qres) a.qres[chunk * (uint64_t)D + (uint64_t)col] = a.qop == 1 ? (uint64_t)qmax[k] : qsum[k];
+            }
+        }
+    }
+    if (!corrupt && Q != kQueryReduceOnly) {
         const uint8_t* t = s + pos;
         uint8_t* d = (uint8_t*)(o + out_elems);
         const uint32_t nbytes = remaining * ESZ;

@@ -1,11 +1,11 @@
 // decode_w8.hip -- instantiations of the batched decoder for 8-bit elements.
 #include "launch.h"
 namespace sprintz {
-hipError_t launch_decode_w8(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a)
+hipError_t launch_decode_w8(bool fire, bool lowdim, int cpl, int q, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a)
 {
     SPRINTZ_DISPATCH(decode_kernel, 8)
 }
-hipError_t launch_decode_fast_w8(bool fire, int dp, int cpl, bool exact, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a)
+hipError_t launch_decode_fast_w8(bool fire, int dp, int cpl, bool exact, int q, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a)
 {
     SPRINTZ_DISPATCH_DECODE_FAST(decode_fast_kernel, 8)
 }

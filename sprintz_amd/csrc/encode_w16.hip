@@ -3,7 +3,7 @@
 namespace sprintz {
 hipError_t launch_encode_w16(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a)
 {
-    SPRINTZ_DISPATCH(encode_kernel, 16)
+    SPRINTZ_DISPATCH_ENC(encode_kernel, 16)
 }
 hipError_t launch_encode_fast_w16(bool fire, int dp, bool exact, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a)
 {

@@ -15,11 +15,11 @@ namespace sprintz {
 // columns-per-lane values that are instantiated (general layout); low-dim uses CPL = 1
 constexpr int kCplSet[] = {1, 2, 3, 4, 5, 6, 8};
 
-hipError_t launch_decode_w8(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a);
-hipError_t launch_decode_w16(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a);
+hipError_t launch_decode_w8(bool fire, bool lowdim, int cpl, int q, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a);
+hipError_t launch_decode_w16(bool fire, bool lowdim, int cpl, int q, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a);
 // fast path: general layout, one column per lane, LDS-transposed stores (see decode_fast.h)
-hipError_t launch_decode_fast_w8(bool fire, int dp, int cpl, bool exact, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a);
-hipError_t launch_decode_fast_w16(bool fire, int dp, int cpl, bool exact, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a);
+hipError_t launch_decode_fast_w8(bool fire, int dp, int cpl, bool exact, int q, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a);
+hipError_t launch_decode_fast_w16(bool fire, int dp, int cpl, bool exact, int q, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a);
 hipError_t launch_encode_fast_w8(bool fire, int dp, bool exact, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
 hipError_t launch_encode_fast_w16(bool fire, int dp, bool exact, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
 hipError_t launch_encode_w8(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
@@ -39,7 +39,7 @@ inline hipError_t launch_one(K kernel, unsigned grid, size_t shmem, hipStream_t 
     return hipGetLastError();
 }
 
-#define SPRINTZ_DISPATCH(KERNEL, W)                                                                   \
+#define SPRINTZ_DISPATCH_ENC(KERNEL, W)                                                               \
     if (lowdim) {                                                                                     \
         if (cpl != 1) return hipErrorInvalidValue;                                                    \
         return fire ? launch_one(KERNEL<W, true, true, 1>, grid, shmem, st, a)                        \
@@ -63,25 +63,60 @@ inline hipError_t launch_one(K kernel, unsigned grid, size_t shmem, hipStream_t 
         default: return hipErrorInvalidValue;                                                         \
     }
 
-#define SPRINTZ_FAST_CASE(KERNEL, W, DPV, CPLV)                                                      \
+#define SPRINTZ_DISPATCH_Q(KERNEL, W, Q)                                                              \
+    if (lowdim) {                                                                                     \
+        if (cpl != 1) return hipErrorInvalidValue;                                                    \
+        return fire ? launch_one(KERNEL<W, true, true, 1, Q>, grid, shmem, st, a)                     \
+                    : launch_one(KERNEL<W, false, true, 1, Q>, grid, shmem, st, a);                   \
+    }                                                                                                 \
+    switch (cpl) {                                                                                    \
+        case 1: return fire ? launch_one(KERNEL<W, true, false, 1, Q>, grid, shmem, st, a)            \
+                            : launch_one(KERNEL<W, false, false, 1, Q>, grid, shmem, st, a);          \
+        case 2: return fire ? launch_one(KERNEL<W, true, false, 2, Q>, grid, shmem, st, a)            \
+                            : launch_one(KERNEL<W, false, false, 2, Q>, grid, shmem, st, a);          \
+        case 3: return fire ? launch_one(KERNEL<W, true, false, 3, Q>, grid, shmem, st, a)            \
+                            : launch_one(KERNEL<W, false, false, 3, Q>, grid, shmem, st, a);          \
+        case 4: return fire ? launch_one(KERNEL<W, true, false, 4, Q>, grid, shmem, st, a)            \
+                            : launch_one(KERNEL<W, false, false, 4, Q>, grid, shmem, st, a);          \
+        case 5: return fire ? launch_one(KERNEL<W, true, false, 5, Q>, grid, shmem, st, a)            \
+                            : launch_one(KERNEL<W, false, false, 5, Q>, grid, shmem, st, a);          \
+        case 6: return fire ? launch_one(KERNEL<W, true, false, 6, Q>, grid, shmem, st, a)            \
+                            : launch_one(KERNEL<W, false, false, 6, Q>, grid, shmem, st, a);          \
+        case 8: return fire ? launch_one(KERNEL<W, true, false, 8, Q>, grid, shmem, st, a)            \
+                            : launch_one(KERNEL<W, false, false, 8, Q>, grid, shmem, st, a);          \
+        default: return hipErrorInvalidValue;                                                         \
+    }
+
+// q: kQueryOff / kQueryMaterialize / kQueryReduceOnly (decode_kernel.h)
+#define SPRINTZ_DISPATCH(KERNEL, W)                                                                   \
+    if (q == kQueryOff) { SPRINTZ_DISPATCH_Q(KERNEL, W, kQueryOff) }                                  \
+    if (q == kQueryMaterialize) { SPRINTZ_DISPATCH_Q(KERNEL, W, kQueryMaterialize) }                  \
+    SPRINTZ_DISPATCH_Q(KERNEL, W, kQueryReduceOnly)
+
+#define SPRINTZ_FAST_CASE(KERNEL, W, DPV, CPLV, Q)                                                   \
     if (dp == DPV && cpl == CPLV) {                                                                   \
-        if (exact) return fire ? launch_one(KERNEL<W, true, DPV, CPLV, true>, grid, shmem, st, a)     \
-                               : launch_one(KERNEL<W, false, DPV, CPLV, true>, grid, shmem, st, a);   \
-        return fire ? launch_one(KERNEL<W, true, DPV, CPLV, false>, grid, shmem, st, a)               \
-                    : launch_one(KERNEL<W, false, DPV, CPLV, false>, grid, shmem, st, a);             \
+        if (exact) return fire ? launch_one(KERNEL<W, true, DPV, CPLV, true, Q>, grid, shmem, st, a)  \
+                               : launch_one(KERNEL<W, false, DPV, CPLV, true, Q>, grid, shmem, st, a); \
+        return fire ? launch_one(KERNEL<W, true, DPV, CPLV, false, Q>, grid, shmem, st, a)            \
+                    : launch_one(KERNEL<W, false, DPV, CPLV, false, Q>, grid, shmem, st, a);          \
     }
 
 // decoder fast path: one column per lane for D <= 64, 2 / 4 columns per lane of a
 // 64-lane group for D <= 128 / 256
-#define SPRINTZ_DISPATCH_DECODE_FAST(KERNEL, W)                                                       \
-    SPRINTZ_FAST_CASE(KERNEL, W, 4, 1)                                                                \
-    SPRINTZ_FAST_CASE(KERNEL, W, 8, 1)                                                                \
-    SPRINTZ_FAST_CASE(KERNEL, W, 16, 1)                                                               \
-    SPRINTZ_FAST_CASE(KERNEL, W, 32, 1)                                                               \
-    SPRINTZ_FAST_CASE(KERNEL, W, 64, 1)                                                               \
-    SPRINTZ_FAST_CASE(KERNEL, W, 64, 2)                                                               \
-    SPRINTZ_FAST_CASE(KERNEL, W, 64, 4)                                                               \
+#define SPRINTZ_DISPATCH_DECODE_FAST_Q(KERNEL, W, Q)                                                  \
+    SPRINTZ_FAST_CASE(KERNEL, W, 4, 1, Q)                                                             \
+    SPRINTZ_FAST_CASE(KERNEL, W, 8, 1, Q)                                                             \
+    SPRINTZ_FAST_CASE(KERNEL, W, 16, 1, Q)                                                            \
+    SPRINTZ_FAST_CASE(KERNEL, W, 32, 1, Q)                                                            \
+    SPRINTZ_FAST_CASE(KERNEL, W, 64, 1, Q)                                                            \
+    SPRINTZ_FAST_CASE(KERNEL, W, 64, 2, Q)                                                            \
+    SPRINTZ_FAST_CASE(KERNEL, W, 64, 4, Q)                                                            \
     return hipErrorInvalidValue;
+
+#define SPRINTZ_DISPATCH_DECODE_FAST(KERNEL, W)                                                       \
+    if (q == kQueryOff) { SPRINTZ_DISPATCH_DECODE_FAST_Q(KERNEL, W, kQueryOff) }                      \
+    if (q == kQueryMaterialize) { SPRINTZ_DISPATCH_DECODE_FAST_Q(KERNEL, W, kQueryMaterialize) }      \
+    SPRINTZ_DISPATCH_DECODE_FAST_Q(KERNEL, W, kQueryReduceOnly)
 
 #define SPRINTZ_ENC_FAST_CASE(KERNEL, W, DPV)                                                        \
     case DPV:                                                                                         \

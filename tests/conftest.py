@@ -19,8 +19,8 @@ def oracle():
     """Our CPU restatement; built on demand (gcc only, a second or two)."""
     import subprocess
     from harness import ORACLE_SO, Oracle
-    if not os.path.exists(ORACLE_SO):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    # always through make: a no-op when liboracle.so is current, a rebuild when the sources moved on
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
     return Oracle()
 
 
@@ -31,6 +31,18 @@ def reference():
     if not Reference.available():
         pytest.skip("oracle/_ref/libsprintz_ref.so not built (reference sources absent)")
     return Reference()
+
+
+@pytest.fixture(scope="session")
+def golden_rowmajor():
+    """streams of the reference's *_rowmajor_*_rle_* family (oracle/gen_golden_rowmajor.py)"""
+    import json
+    import numpy as np
+    gdir = os.path.join(HERE, "golden")
+    with open(os.path.join(gdir, "golden_rowmajor_v1.json")) as f:
+        manifest = json.load(f)["cases"]
+    arrays = np.load(os.path.join(gdir, "golden_rowmajor_v1.npz"))
+    return manifest, arrays
 
 
 @pytest.fixture(scope="session")

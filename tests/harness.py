@@ -131,6 +131,29 @@ class Oracle:
         self._decompress_ex(CODECS[codec], esz, stream.ctypes.data, out.ctypes.data, 0, C.byref(used))
         return int(used.value)
 
+    # ---- the *_rowmajor_*_rle_* family (general layout for every ndims) and the query semantics
+    def compress_rowmajor(self, codec, data, ndims):
+        f = _bind(self.lib, "oracle_compress_rowmajor", C.c_int64,
+                  [C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint16, C.POINTER(C.c_size_t)])
+        data = np.ascontiguousarray(data)
+        esz = data.dtype.itemsize
+        out = np.full(self.bound(esz, data.size, ndims) + 64, 0xAB, dtype=np.uint8)
+        nb = C.c_size_t(0)
+        ret = f(CODECS[codec], esz, data.ctypes.data, data.size, out.ctypes.data, ndims, C.byref(nb))
+        return out[:nb.value].copy(), int(ret)
+
+    def query(self, codec, stream, esz, capacity, op, general=False):
+        """-> (decompressed data, per-column result uint64[ndims]); op: 1 max, 2 sum"""
+        f = _bind(self.lib, "oracle_query", C.c_int64,
+                  [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p])
+        stream = np.ascontiguousarray(stream, dtype=np.uint8)
+        padded = np.concatenate([stream, np.zeros(64, np.uint8)])
+        ndims = int(stream[6]) | (int(stream[7]) << 8)
+        out = np.zeros(capacity + 64, dtype=DTYPES[esz])
+        res = np.zeros(max(ndims, 1), np.uint64)
+        ret = f(CODECS[codec], esz, padded.ctypes.data, out.ctypes.data, int(general), op, res.ctypes.data)
+        return out[:max(int(ret), 0)].copy(), res[:ndims]
+
     def compress_chunks(self, codec, data, chunk_len, ndims):
         """-> (list of per-chunk streams)"""
         data = np.ascontiguousarray(data)
@@ -173,6 +196,32 @@ class Reference:
     @staticmethod
     def available():
         return os.path.exists(REF_SO)
+
+    def has_query(self):
+        return hasattr(self.lib, "ref_query")
+
+    def compress_rowmajor_raw(self, codec, data, ndims):
+        """compress_rowmajor_{delta,xff}_rle_{8b,16b} (sprintz_delta.h:49, sprintz_xff.h:45-55):
+        -> (whole poison-filled output buffer, return value in elements)"""
+        f = _bind(self.lib, "ref_compress_rowmajor", C.c_int64,
+                  [C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint16])
+        data = np.ascontiguousarray(data)
+        esz = data.dtype.itemsize
+        n = data.size
+        src = np.concatenate([data.ravel(), np.zeros(64, data.dtype)])
+        cap = (n * 3 // 2 + 64) * esz + 16 * ndims * esz + 256
+        out = np.full(cap, 0xAB, dtype=np.uint8)
+        ret = f(CODECS[codec], esz, src.ctypes.data, n, out.ctypes.data, ndims)
+        return out, int(ret)
+
+    def query(self, codec, stream, esz, capacity, op, materialize, ndims_hint=64):
+        """query_rowmajor_*(src, dest, QueryParams{op, materialize}): -> (dest[:ret], ret)"""
+        f = _bind(self.lib, "ref_query", C.c_int64, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int])
+        stream = np.ascontiguousarray(stream, dtype=np.uint8)
+        padded = np.concatenate([stream, np.zeros(256, np.uint8)])
+        out = np.full(capacity + 64 + 4 * max(ndims_hint, 32), 0xCD, dtype=DTYPES[esz])
+        ret = f(CODECS[codec], esz, padded.ctypes.data, out.ctypes.data, op, int(materialize))
+        return out[:max(int(ret), 0)].copy(), int(ret)
 
     def compress_raw(self, codec, data, ndims, write_size=True):
         """-> (whole poison-filled output buffer, return value in elements).

@@ -1,0 +1,141 @@
+"""GPU tests (-m gpu) of query-on-compressed: reductions fused into the decode kernels,
+through the C-ABI, against the oracle's definition (tests/test_query_cpu.py pins that) and the
+streams minted from the compiled reference.  Nothing here reads /root/reference."""
+import zlib
+
+import numpy as np
+import pytest
+
+from harness import DTYPES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sz():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import sprintz_amd
+    return sprintz_amd
+
+
+def _col_reduce(x, D, op):
+    res = np.zeros(D, np.uint64)
+    for c in range(D):
+        col = x[c::D].astype(np.uint64)
+        if col.size:
+            res[c] = col.max() if op == 1 else col.sum()
+    return res
+
+
+def test_query_rowmajor_family_on_reference_streams(sz, golden_rowmajor):
+    """query_rowmajor_{delta,xff}_rle_{8b,16b}(src, dest, QueryParams) on the reference's own streams
+    (general layout for every ndims, incl. 1..4): materialised data == input (also for xff 16b,
+    where the reference's query is not lossless), results == the column reductions."""
+    manifest, arrays = golden_rowmajor
+    for m in manifest:
+        x, stream = arrays[m["name"] + "_in"], arrays[m["name"] + "_stream"]
+        esz, D, n = m["esz"], m["ndims"], m["n"]
+        fn = getattr(sz, f"query_rowmajor_{m['codec']}_rle_{8 * esz}b")
+        src = np.concatenate([stream, np.zeros(32, np.uint8)])
+        for op in (sz.QueryTypes.REDUCE_MAX, sz.QueryTypes.REDUCE_SUM):
+            dest = np.full(n + 64, 0xCD, DTYPES[esz])
+            ret, res = fn(src, dest, sz.QueryParams(op=op, materialize=True))
+            assert ret == n, m
+            assert np.array_equal(dest[:n], x), m
+            assert np.all(dest[n:] == 0xCD), m     # nothing past the end
+            assert np.array_equal(res, _col_reduce(x, D, op)), (m, op)
+        # reduce only: nothing is written
+        dest = np.full(n + 64, 0xCD, DTYPES[esz])
+        ret, res = fn(src, dest, sz.QueryParams(op=sz.QueryTypes.REDUCE_SUM, materialize=False))
+        assert ret == n and np.all(dest == 0xCD), m
+        assert np.array_equal(res, _col_reduce(x, D, 2)), m
+        # NOOP + materialize == decompress (test/test_query.cpp:59-120)
+        if m["n"] in (1000, 4113):
+            ret, _ = fn(src, dest, sz.QueryParams(op=sz.QueryTypes.NOOP, materialize=True))
+            assert ret == n and np.array_equal(dest[:n], x), m
+
+
+def test_query_sprintz_h_layout_streams(sz, oracle):
+    """general_layout=False: streams of the sprintz.h entry points (low-dim layout for small ndims)"""
+    rng = np.random.default_rng(11)
+    for esz in (1, 2):
+        for codec in ("delta", "xff"):
+            for D in (1, 2, 3, 4, 6, 33):
+                for n in (100, 16 * D + 3, 3000):
+                    x = (np.cumsum(rng.integers(-3, 4, n)) % (1 << (8 * esz))).astype(DTYPES[esz])
+                    x[n // 2: n // 2 + n // 5] = 9
+                    stream, _ = oracle.compress(codec, x, D)
+                    fn = getattr(sz, f"query_rowmajor_{codec}_rle_{8 * esz}b")
+                    for op in (1, 2):
+                        dest = np.zeros(n + 64, DTYPES[esz])
+                        ret, res = fn(np.concatenate([stream, np.zeros(32, np.uint8)]), dest,
+                                      sz.QueryParams(op=op, materialize=True), general_layout=False)
+                        assert ret == n and np.array_equal(dest[:n], x), (esz, codec, D, n)
+                        _, want = oracle.query(codec, stream, esz, n, op, general=False)
+                        assert np.array_equal(res, want), (esz, codec, D, n, op)
+
+
+QCONFIGS = [
+    # name, codec, esz, ndims, chunk_len
+    ("cfg2 u16 D=8 xff (fast kernel)", "xff", 2, 8, 5120),
+    ("u16 D=8 delta", "delta", 2, 8, 5120),
+    ("cfg3 u8 D=80 delta 10KB (2 columns per lane)", "delta", 1, 80, 10240),
+    ("u8 D=8 xff", "xff", 1, 8, 4096),
+    ("cfg1 u8 D=1 low-dim", "delta", 1, 1, 1024),
+    ("u16 D=2 low-dim xff", "xff", 2, 2, 2048),
+    ("u16 D=3 generic", "xff", 2, 3, 1001),
+    ("u16 D=32", "xff", 2, 32, 5120),
+    ("u8 D=200 (4 columns per lane)", "xff", 1, 200, 16000),
+    ("u16 D=300 generic", "delta", 2, 300, 9600 + 77),
+]
+
+
+@pytest.mark.parametrize("name,codec,esz,ndims,chunk_len", QCONFIGS)
+def test_query_batch(sz, name, codec, esz, ndims, chunk_len):
+    import torch
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    nchunks = 37
+    n = nchunks * chunk_len - chunk_len // 3                     # ragged last chunk
+    top = 1 << (8 * esz)
+    x = (np.cumsum(rng.integers(-9, 10, n)) % top).astype(DTYPES[esz])
+    x[n // 4: n // 4 + 3 * chunk_len // 2] = 5                   # long runs across a chunk boundary
+    x[n - chunk_len // 2:] = rng.integers(0, top, chunk_len // 2)   # incompressible end
+    codecobj = sz.ChunkedCodec(codec, esz, ndims, chunk_len)
+    xt = torch.from_numpy(x.view(np.int8 if esz == 1 else np.int16)).cuda().view(codecobj.dtype)
+    batch = codecobj.compress(xt)
+    want_part = {op: np.zeros((nchunks, ndims), np.uint64) for op in (1, 2)}
+    for c in range(nchunks):
+        xc = x[c * chunk_len:(c + 1) * chunk_len]
+        for op in (1, 2):
+            want_part[op][c] = _col_reduce(xc, ndims, op)
+    for opname, op in (("max", 1), ("sum", 2)):
+        for materialize in (False, True):
+            part, out = codecobj.query(batch, opname, materialize=materialize, reduce=False)
+            got = part.cpu().numpy().view(np.uint64)
+            assert np.array_equal(got, want_part[op]), (name, opname, materialize)
+            if materialize:
+                assert torch.equal(out, xt), (name, opname)
+            res, _ = codecobj.query(batch, opname, materialize=False, reduce=True)
+            want = want_part[op].max(axis=0) if op == 1 else want_part[op].sum(axis=0)
+            assert np.array_equal(res.cpu().numpy().view(np.uint64), want), (name, opname)
+    # NOOP without materialise: parses the streams, writes nothing, still reports errors/lengths
+    res, out = codecobj.query(batch, None, materialize=False)
+    assert res is None and out is None
+
+
+def test_query_full_size_cfg2(sz):
+    """131 072 cfg2 chunks: the reductions of the reduce-only kernel equal torch's over the input"""
+    import torch
+    n = 131072
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    steps = torch.randint(-8, 9, (n, 640, 8), generator=g, device="cuda", dtype=torch.int32)
+    x = (torch.cumsum(steps, dim=1) & 0xffff).to(torch.uint16).reshape(-1)
+    codec = sz.ChunkedCodec("xff", 2, 8, 5120)
+    batch = codec.compress(x)
+    cols = x.view(torch.int16).to(torch.int64).bitwise_and(0xffff).view(-1, 8)
+    res, _ = codec.query(batch, "max")
+    assert torch.equal(res, cols.max(dim=0).values)
+    res, _ = codec.query(batch, "sum")
+    assert torch.equal(res, cols.sum(dim=0))
