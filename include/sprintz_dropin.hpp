@@ -54,4 +54,34 @@ inline int64_t sprintz_decompress_xff_16b(const int16_t* src, uint16_t* dest)
     return sprintz_mi355x_decompress_xff_16b(src, dest);
 }
 
+// ================================================================ query on compressed data
+// query.hpp:23-29 (QueryTypes, QueryParams); sprintz_delta.h:95-98, sprintz_xff.h:90-93.  Same names
+// and signatures; the overloads with `result` (ndims uint64) return what the reference computes
+// and discards (see include/sprintz_mi355x.h for the definition).  These functions take
+// streams in the general row-major layout whatever ndims is, like the reference's.
+namespace QueryTypes {
+enum Operation { NOOP = 0, REDUCE_MAX, REDUCE_SUM };
+}
+typedef struct QueryParams {
+    QueryTypes::Operation op;
+    bool materialize;
+} QueryParams;
+
+inline int64_t query_rowmajor_delta_rle_8b(const int8_t* src, uint8_t* dest, const QueryParams& qp, uint64_t* result = nullptr)
+{
+    return sprintz_mi355x_query_delta_8b(src, dest, (int)qp.op, qp.materialize ? 1 : 0, SPRINTZ_QUERY_GENERAL_LAYOUT, result);
+}
+inline int64_t query_rowmajor_delta_rle_16b(const int16_t* src, uint16_t* dest, const QueryParams& qp, uint64_t* result = nullptr)
+{
+    return sprintz_mi355x_query_delta_16b(src, dest, (int)qp.op, qp.materialize ? 1 : 0, SPRINTZ_QUERY_GENERAL_LAYOUT, result);
+}
+inline int64_t query_rowmajor_xff_rle_8b(const int8_t* src, uint8_t* dest, const QueryParams& qp, uint64_t* result = nullptr)
+{
+    return sprintz_mi355x_query_xff_8b(src, dest, (int)qp.op, qp.materialize ? 1 : 0, SPRINTZ_QUERY_GENERAL_LAYOUT, result);
+}
+inline int64_t query_rowmajor_xff_rle_16b(const int16_t* src, uint16_t* dest, const QueryParams& qp, uint64_t* result = nullptr)
+{
+    return sprintz_mi355x_query_xff_16b(src, dest, (int)qp.op, qp.materialize ? 1 : 0, SPRINTZ_QUERY_GENERAL_LAYOUT, result);
+}
+
 #endif  // SPRINTZ_DROPIN_HPP

@@ -99,7 +99,11 @@ def test_dropin_header_compiles_and_links(lib_path, tmp_path):
         "  int64_t n = sprintz_compress_xff_16b(x.data(), 4096, c.data(), 8);      // default write_size\n"
         "  int64_t m = sprintz_decompress_xff_16b(c.data(), y.data());\n"
         "  int64_t a = sprintz_compress_delta_8b((const uint8_t*)x.data(), 100, (int8_t*)c.data(), 3, false);\n"
-        "  return (n < 0 && m < 0 && a < 0) ? 0 : 1;   // without a GPU every call fails loudly\n"
+        "  QueryParams qp; qp.op = QueryTypes::REDUCE_MAX; qp.materialize = false;   // query.hpp:23-29\n"
+        "  uint64_t res[8];\n"
+        "  int64_t q = query_rowmajor_xff_rle_16b(c.data(), y.data(), qp);           // sprintz_xff.h:92\n"
+        "  int64_t r = query_rowmajor_delta_rle_8b((const int8_t*)c.data(), (uint8_t*)y.data(), qp, res);\n"
+        "  return (n < 0 && m < 0 && a < 0 && q < 0 && r < 0) ? 0 : 1;   // without a GPU every call fails loudly\n"
         "}\n")
     exe = tmp_path / "caller"
     libdir = os.path.dirname(lib_path)
