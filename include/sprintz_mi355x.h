@@ -168,6 +168,27 @@ int sprintz_mi355x_huf_decompress_batch(const void* d_huf, const uint64_t* d_huf
                                         uint32_t* d_sizes, void* d_tmp, void* hip_stream);
 
 /* ------------------------------------------------------------------------
+ * Column-major matrices (BASELINE.json config 5: "uint16 colmajor, 32
+ * variables").  The matrix X[nrows][ndims] lives in HBM column by column:
+ * element (r, d) at base[d * col_stride + r].  Chunk c holds rows
+ * [c*rows_per_chunk, min((c+1)*rows_per_chunk, nrows)) and its stream is
+ * byte-for-byte what the reference's compress() produces for the row-major
+ * flattening of those rows (len = rows * ndims) -- the transposition happens
+ * in the kernels' addressing (a lane owns a column, so its 8 samples of a
+ * block are one contiguous 16-byte piece), not in memory.
+ *   compress:   col_stride >= nrows
+ *   decompress: col_stride >= nchunks * rows_per_chunk (ragged last chunk:
+ *               rows past nrows are not written by a valid stream)
+ * Containers are interchangeable with the row-major entry points.
+ * ---------------------------------------------------------------------- */
+int sprintz_mi355x_compress_batch_colmajor(int codec, int elem_bytes, const void* d_src, uint64_t nrows, uint64_t col_stride,
+                                           uint32_t rows_per_chunk, uint16_t ndims, void* d_slots, size_t slot_stride,
+                                           uint32_t* d_sizes, int64_t* d_rets, void* hip_stream);
+int sprintz_mi355x_decompress_batch_colmajor(int codec, int elem_bytes, const void* d_comp, const uint64_t* d_offsets,
+                                             uint64_t nchunks, uint32_t rows_per_chunk, uint16_t ndims, uint64_t col_stride,
+                                             void* d_out, int64_t* d_rets, void* hip_stream);
+
+/* ------------------------------------------------------------------------
  * Query on compressed data.  Replaces
  *   query_rowmajor_delta_rle_{8b,16b}(src, dest, const QueryParams&)  cpp/Compress/sprintz_delta.h:95-98
  *   query_rowmajor_xff_rle_{8b,16b}(src, dest, const QueryParams&)    cpp/Compress/sprintz_xff.h:90-93

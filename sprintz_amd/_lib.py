@@ -94,6 +94,10 @@ query = {
     ("xff", 2): _sig("sprintz_mi355x_query_xff_16b", _i64, _vp, _vp, _i, _i, _u32, _vp),
 }
 
+# (5) column-major matrices (BASELINE config 5)
+compress_batch_colmajor = _sig("sprintz_mi355x_compress_batch_colmajor", _i, _i, _i, _vp, _u64, _u64, _u32, _u16, _vp, _sz, _vp, _vp, _vp)
+decompress_batch_colmajor = _sig("sprintz_mi355x_decompress_batch_colmajor", _i, _i, _i, _vp, _vp, _u64, _u32, _u16, _u64, _vp, _vp, _vp)
+
 # host convenience
 compress_chunked_host = _sig("sprintz_mi355x_compress_chunked_host", _i64, _i, _i, _vp, _u64, _u32, _u16, _vp, _sz, _vp)
 decompress_chunked_host = _sig("sprintz_mi355x_decompress_chunked_host", _i64, _i, _i, _vp, _vp, _u64, _u32, _u16, _vp)
@@ -114,6 +118,7 @@ EXPORTED_SYMBOLS = [
     "sprintz_mi355x_query_batch", "sprintz_mi355x_query_reduce",
     "sprintz_mi355x_query_delta_8b", "sprintz_mi355x_query_xff_8b",
     "sprintz_mi355x_query_delta_16b", "sprintz_mi355x_query_xff_16b",
+    "sprintz_mi355x_compress_batch_colmajor", "sprintz_mi355x_decompress_batch_colmajor",
 ]
 
 

@@ -200,6 +200,40 @@ class ChunkedCodec:
                                          rets.data_ptr() if rets is not None else None, self._stream()))
 
 
+    # ---- column-major matrices (BASELINE config 5): cols is a [ndims, col_stride] tensor, variable d in row d
+    def compress_colmajor(self, cols, nrows=None):
+        """cols[d, r] = sample r of variable d.  Chunk = chunk_len/ndims rows of all variables; the
+        streams are what the reference produces for the row-major flattening of those rows."""
+        t = self.torch
+        if cols.dim() != 2 or cols.shape[0] != self.ndims or cols.dtype.itemsize != self.esz or not cols.is_contiguous():
+            raise ValueError("cols must be a contiguous [ndims, col_stride] tensor of the codec's element type")
+        if self.chunk_len % self.ndims:
+            raise ValueError("chunk_len must be a multiple of ndims for column-major data")
+        col_stride = int(cols.shape[1])
+        nrows = col_stride if nrows is None else int(nrows)
+        rows_per_chunk = self.chunk_len // self.ndims
+        nchunks = (nrows + rows_per_chunk - 1) // rows_per_chunk
+        ws = self.workspace(nchunks)
+        _lib.check(_lib.compress_batch_colmajor(_CODEC_ID[self.codec], self.esz, cols.data_ptr(), nrows, col_stride, rows_per_chunk,
+                                                self.ndims, ws["slots"].data_ptr(), self.slot_stride, ws["sizes"].data_ptr(),
+                                                ws["rets"].data_ptr(), self._stream()))
+        dense, offsets = self.compact(ws, nchunks)
+        total = int(offsets[-1].item())
+        return CompressedBatch(dense[: total + _lib.READ_SLACK].clone(), offsets, ws["sizes"].clone(), nchunks,
+                               nrows * self.ndims, self.chunk_len, self.ndims)
+
+    def decompress_colmajor(self, batch, out=None):
+        """-> [ndims, nrows] tensor (out, if given: [ndims, col_stride >= nchunks*rows_per_chunk])"""
+        t = self.torch
+        rows_per_chunk = self.chunk_len // self.ndims
+        nrows = batch.total_len // self.ndims
+        if out is None:
+            out = t.empty((self.ndims, batch.nchunks * rows_per_chunk), dtype=self.dtype, device=self.device)
+        _lib.check(_lib.decompress_batch_colmajor(_CODEC_ID[self.codec], self.esz, batch.data.data_ptr(), batch.offsets.data_ptr(),
+                                                  batch.nchunks, rows_per_chunk, self.ndims, int(out.shape[1]), out.data_ptr(),
+                                                  None, self._stream()))
+        return out[:, :nrows]
+
     def query(self, batch, op, materialize=False, out=None, reduce=True):
         """Query on the compressed container (query.hpp:23-29): per-column max / sum fused into
         the decode; returns (result, out).  result: uint64 tensor [ndims] (reduce=True) or the

@@ -212,6 +212,7 @@ struct QuerySpec {
     int qop = 0;                // 1 max, 2 sum
     uint64_t* qres = nullptr;   // [nchunks][ndims]
     int general = 0;            // 1: general row-major layout for every ndims (the reference's *_rowmajor_*_rle_* family)
+    uint64_t col_stride = 0;    // != 0: column-major destination (DecodeArgs::col_stride)
 };
 
 int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offsets, uint64_t nchunks,
@@ -239,6 +240,8 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
     a.chunks_per_group = 1;
     a.qop = qs.qop;
     a.qres = qs.qres;
+    a.col_stride = qs.col_stride;
+    const uint64_t cs = qs.col_stride;
     if (const char* d = getenv("SPRINTZ_MI355X_DBG")) a.dbg = atoi(d);
 
     // LDS-transposed 16-byte stores need every 8 x D block of the output 16-byte aligned
@@ -247,7 +250,7 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
     const size_t groups_per_block = kThreads / DP;
     size_t shmem = 0;
     a.vec_store = 0;
-    if (blk_bytes % 16 == 0 && (qs.q == kQueryReduceOnly || ((uintptr_t)d_out % 16) == 0) && ((uint64_t)chunk_len * esz) % 16 == 0 &&
+    if (!cs && blk_bytes % 16 == 0 && (qs.q == kQueryReduceOnly || ((uintptr_t)d_out % 16) == 0) && ((uint64_t)chunk_len * esz) % 16 == 0 &&
         stride * groups_per_block <= 64 * 1024) {
         a.vec_store = 1;
         a.lds_group_stride = (uint32_t)stride;
@@ -262,9 +265,12 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
     // (32-bit offsets inside one wavefront's span of the output)
     // and chunks not much shorter than the read-ahead ring (it is filled before the first header is parsed)
     const size_t fring = decode_fast_lds_bytes(8 * esz, fdp, fcpl, D);
-    const bool fast = !lowdim && !noheader && D <= 256 && a.vec_store && 2 * D > fdp * fcpl &&
-                      (uint64_t)chunk_len * esz * 2 >= fring &&
-                      (uint64_t)chunk_len * esz * 64 * 64 < 0xf0000000ull && !getenv("SPRINTZ_MI355X_NO_FAST");
+    const bool fast_common = !lowdim && !noheader && D <= 256 && 2 * D > fdp * fcpl && (uint64_t)chunk_len * esz * 2 >= fring &&
+                             !getenv("SPRINTZ_MI355X_NO_FAST");
+    // column-major: a lane's 8 samples per block are one aligned 16-byte (8-byte) piece of its column
+    const bool fast = cs ? fast_common && qs.q == kQueryOff && cs % 8 == 0 && (chunk_len / (uint32_t)D) % 8 == 0 &&
+                               ((uintptr_t)d_out % 16) == 0 && (uint64_t)D * cs * esz < 0xf0000000ull
+                         : fast_common && a.vec_store && (uint64_t)chunk_len * esz * 64 * 64 < 0xf0000000ull;
     hipError_t e;
     if (fast) {
         a.log2DP = 0;
@@ -308,7 +314,8 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
 }
 
 int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uint32_t chunk_len, uint16_t ndims,
-                  void* d_slots, size_t slot_stride, uint32_t* d_sizes, int64_t* d_rets, hipStream_t st, int write_size)
+                  void* d_slots, size_t slot_stride, uint32_t* d_sizes, int64_t* d_rets, hipStream_t st, int write_size,
+                  uint64_t col_stride = 0)
 {
     const uint64_t nchunks = sprintz_mi355x_num_chunks(total_len, chunk_len);
     if (nchunks == 0) return 0;
@@ -329,6 +336,7 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     a.sizes = d_sizes;
     a.rets = d_rets;
     a.write_size = write_size;
+    a.col_stride = col_stride;
     a.cap = next_pow2((uint32_t)group_bytes_max(esz, D) + 48u);
     const size_t shmem = (size_t)a.cap * (kThreads / DP);
     if (shmem > 160 * 1024) return fail(SPRINTZ_E_UNSUPPORTED, "ndims too large for the LDS output ring");
@@ -338,8 +346,9 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     int fdp = 4;
     while (fdp < D) fdp <<= 1;
     const size_t blk_bytes = (size_t)8 * D * esz;
-    const bool fast = !lowdim && D <= 64 && 2 * D > fdp && blk_bytes % 16 == 0 && ((uintptr_t)d_src % 16) == 0 &&
-                      ((uint64_t)chunk_len * esz) % 16 == 0 && !getenv("SPRINTZ_MI355X_NO_FAST");
+    const bool fast_common = !lowdim && D <= 64 && 2 * D > fdp && ((uintptr_t)d_src % 16) == 0 && !getenv("SPRINTZ_MI355X_NO_FAST");
+    const bool fast = col_stride ? fast_common && col_stride % 8 == 0 && (chunk_len / (uint32_t)D) % 8 == 0
+                                 : fast_common && blk_bytes % 16 == 0 && ((uint64_t)chunk_len * esz) % 16 == 0;
     hipError_t e;
     if (fast) {
         const size_t fgroups = kThreads / fdp;
@@ -768,6 +777,43 @@ int64_t sprintz_mi355x_query_xff_8b(const int8_t* src, uint8_t* dest, int op, in
 int64_t sprintz_mi355x_query_xff_16b(const int16_t* src, uint16_t* dest, int op, int materialize, uint32_t flags, uint64_t* result)
 {
     return query_host(SPRINTZ_CODEC_XFF, 2, src, dest, op, materialize, result, (flags & SPRINTZ_QUERY_GENERAL_LAYOUT) != 0);
+}
+
+// ---------------------------------------------------------------- column-major matrices (BASELINE config 5)
+int sprintz_mi355x_compress_batch_colmajor(int codec, int elem_bytes, const void* d_src, uint64_t nrows, uint64_t col_stride,
+                                           uint32_t rows_per_chunk, uint16_t ndims, void* d_slots, size_t slot_stride,
+                                           uint32_t* d_sizes, int64_t* d_rets, void* hip_stream)
+{
+    int rc = check_common(codec, elem_bytes, ndims);
+    if (rc) return rc;
+    if (rows_per_chunk == 0 || (uint64_t)rows_per_chunk * ndims > (1u << 30))
+        return fail(SPRINTZ_E_INVALID, "rows_per_chunk * ndims must be in 1..2^30");
+    if (col_stride < nrows) return fail(SPRINTZ_E_INVALID, "col_stride < nrows");
+    if (!d_src || !d_slots || !d_sizes) return fail(SPRINTZ_E_INVALID, "null device pointer");
+    if (slot_stride % 16 || (uintptr_t)d_slots % 16) return fail(SPRINTZ_E_INVALID, "slots must be 16-byte aligned/strided");
+    const uint32_t chunk_len = rows_per_chunk * (uint32_t)ndims;
+    if (slot_stride < sprintz_mi355x_compress_bound(elem_bytes, chunk_len, ndims))
+        return fail(SPRINTZ_E_INVALID, "slot_stride below sprintz_mi355x_compress_bound");
+    if ((rc = ensure_device())) return rc;
+    return encode_launch(codec, elem_bytes, d_src, nrows * (uint64_t)ndims, chunk_len, ndims, d_slots, slot_stride, d_sizes, d_rets,
+                         (hipStream_t)hip_stream, 1, col_stride);
+}
+
+int sprintz_mi355x_decompress_batch_colmajor(int codec, int elem_bytes, const void* d_comp, const uint64_t* d_offsets,
+                                             uint64_t nchunks, uint32_t rows_per_chunk, uint16_t ndims, uint64_t col_stride,
+                                             void* d_out, int64_t* d_rets, void* hip_stream)
+{
+    int rc = check_common(codec, elem_bytes, ndims);
+    if (rc) return rc;
+    if (rows_per_chunk == 0 || (uint64_t)rows_per_chunk * ndims > (1u << 30))
+        return fail(SPRINTZ_E_INVALID, "rows_per_chunk * ndims must be in 1..2^30");
+    if (col_stride < nchunks * (uint64_t)rows_per_chunk) return fail(SPRINTZ_E_INVALID, "col_stride < nchunks * rows_per_chunk");
+    if (!d_comp || !d_offsets || !d_out) return fail(SPRINTZ_E_INVALID, "null device pointer");
+    if ((rc = ensure_device())) return rc;
+    QuerySpec qs;
+    qs.col_stride = col_stride;
+    return decode_launch(codec, elem_bytes, d_comp, d_offsets, nchunks, rows_per_chunk * (uint32_t)ndims, ndims, d_out, d_rets,
+                         (hipStream_t)hip_stream, 0, 0, 0, qs);
 }
 
 }  // extern "C"

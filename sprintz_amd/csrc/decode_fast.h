@@ -72,7 +72,10 @@ __device__ __forceinline__ int sign_of(int x)
 
 // CPL columns per lane (column = lane_d*CPL + k); EXACT: ndims == DP*CPL, so every
 // size is a compile-time constant.
-template <int W, bool FIRE, int DP, int CPL, bool EXACT, int Q = 0>
+// CM: column-major destination (DecodeArgs::col_stride): the 8 samples a lane produces per block
+// are contiguous in ITS column -- packed in registers and stored as one 16-byte (8-byte at
+// W == 8) piece per column, no LDS transpose.
+template <int W, bool FIRE, int DP, int CPL, bool EXACT, int Q = 0, bool CM = false>
 __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
 {
     using U = typename Elem<W>::U;
@@ -127,8 +130,13 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     // output: one descriptor per wave as well, based at its first chunk's slot; a store
     // whose offset is out of range is dropped by the hardware, which is what the
     // unconditional per-step block stores rely on before a lane has produced a block
-    const uint64_t out_base = (wave_first < a.nchunks ? wave_first : 0) * (uint64_t)a.chunk_len * ESZ;
-    const uint64_t out_span = a.nchunks * (uint64_t)a.chunk_len * ESZ - out_base;
+    // (column-major: the descriptor starts at this wave's first ROW of column 0 and runs to the
+    //  end of the last column; offsets are column*col_stride + row, in bytes)
+    const uint32_t rows_per_chunk = CM ? a.chunk_len / (uint32_t)(EXACT ? DCAP : a.D) : 0u;
+    const uint64_t out_base = CM ? (wave_first < a.nchunks ? wave_first : 0) * (uint64_t)rows_per_chunk * ESZ
+                                 : (wave_first < a.nchunks ? wave_first : 0) * (uint64_t)a.chunk_len * ESZ;
+    const uint64_t out_span = CM ? (uint64_t)(EXACT ? DCAP : a.D) * a.col_stride * ESZ - out_base
+                                 : a.nchunks * (uint64_t)a.chunk_len * ESZ - out_base;
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((uint8_t*)a.out + out_base), 0, (uint32_t)(out_span < 0xfffffff0ull ? out_span : 0xfffffff0ull), 0x00020000);
     constexpr uint32_t kDropStore = 0xfffffff0u;          // out of range of every descriptor
@@ -237,8 +245,50 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
 #pragma unroll
         for (int q = 0; q < PIECES; q++) { held[s2][q] = make_uint4(0, 0, 0, 0); held_vo[s2][q] = kDropStore; }
     // after the 8 rows sit in `stage`; slot < 0: store right away (run blocks)
+    // column-major: the packed 8 samples of each of this lane's columns
+    uint32_t pk[CPL][4];
+    uint4 cheld[2][CPL];
+    uint32_t cheld_vo[2][CPL];
+    uint32_t cbase[CPL];                                   // byte offset of this lane's columns in the descriptor
+#pragma unroll
+    for (int k = 0; k < CPL; k++) {
+        cbase[k] = CM ? (uint32_t)((uint64_t)(col0 + k) * a.col_stride * ESZ) : 0u;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) { cheld[s2][k] = make_uint4(0, 0, 0, 0); cheld_vo[s2][k] = kDropStore; }
+    }
+    auto pack_row = [&](int k, int i) {                    // pv[k] is row i of the block
+        if constexpr (CM) {
+            if constexpr (W == 16) {
+                if ((i & 1) == 0) pk[k][i >> 1] = pv[k] & 0xffffu;
+                else pk[k][i >> 1] |= pv[k] << 16;
+            } else {
+                if ((i & 3) == 0) pk[k][i >> 2] = pv[k] & 0xffu;
+                else pk[k][i >> 2] |= (pv[k] & 0xffu) << (8 * (i & 3));
+            }
+        }
+    };
+    auto store_col = [&](const uint4& t, uint32_t vo) {
+        if constexpr (W == 16) {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, t), orsrc, vo, 0, 0);
+        } else {
+            typedef __attribute__((__vector_size__(2 * sizeof(uint32_t)))) uint32_t v2u;
+            v2u h = {t.x, t.y};
+            __builtin_amdgcn_raw_buffer_store_b64(h, orsrc, vo, 0, 0);
+        }
+    };
     auto stage_out = [&](int slot) {
         if constexpr (Q == kQueryReduceOnly) return;
+        if constexpr (CM) {                                // ovo counts ROW bytes here
+#pragma unroll
+            for (int k = 0; k < CPL; k++) {
+                const uint4 t = W == 16 ? make_uint4(pk[k][0], pk[k][1], pk[k][2], pk[k][3]) : make_uint4(pk[k][0], pk[k][1], 0, 0);
+                const uint32_t vo = col_ok[k] ? cbase[k] + ovo : kDropStore;
+                if (slot >= 0) { cheld[slot][k] = t; cheld_vo[slot][k] = vo; }
+                else store_col(t, vo);
+            }
+            ovo += 8u * ESZ;
+            return;
+        }
         wave_lds_sync();
 #pragma unroll
         for (int q = 0; q < PIECES; q++) {
@@ -268,7 +318,8 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
                     pv[k] += (uint32_t)delta;
                     pd[k] = delta;
                     q_row(k);
-                    if constexpr (Q != kQueryReduceOnly)
+                    pack_row(k, i);
+                    if constexpr (Q != kQueryReduceOnly && !CM)
                         if (col_ok[k]) *(U*)(stage_col + k * ESZ + i * row_stride) = (U)pv[k];
                 }
                 q_block(k);
@@ -326,7 +377,8 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
                 pv[k] += (uint32_t)delta;
                 pd[k] = delta;
                 q_row(k);
-                if constexpr (Q != kQueryReduceOnly)
+                pack_row(k, i);
+                if constexpr (Q != kQueryReduceOnly && !CM)
                     if (col_ok[k]) *(U*)(stage_col + k * ESZ + i * row_stride) = (U)pv[k];
             }
             q_block(k);
@@ -371,7 +423,8 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
 #pragma unroll
         for (int k = 0; k < CPL; k++) { pv[k] = 0; pd[k] = 0; ctr[k] = 0; qmax[k] = 0; qsum[k] = 0; }
         out_left = a.chunk_len;
-        ovo = (uint32_t)((chunk - wave_first) * (uint64_t)a.chunk_len * ESZ);
+        ovo = CM ? (uint32_t)((chunk - wave_first) * (uint64_t)rows_per_chunk * ESZ)
+                 : (uint32_t)((chunk - wave_first) * (uint64_t)a.chunk_len * ESZ);
         corrupt = (int)(w1 >> 16) != D;
         // a damaged header must not make the loop spin: every group takes at least its
         // header and two slot bytes out of the stream
@@ -450,7 +503,12 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         // counter for loads and stores, so parking the loads must not wait for the stores
         // just issued: with every VMEM op of the common path unconditional, hipcc emits
         // s_waitcnt vmcnt(<number of stores>) here instead of vmcnt(0).
-        if constexpr (Q != kQueryReduceOnly) {
+        if constexpr (Q != kQueryReduceOnly && CM) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++)
+#pragma unroll
+                for (int k = 0; k < CPL; k++) store_col(cheld[s2][k], cheld_vo[s2][k]);
+        } else if constexpr (Q != kQueryReduceOnly) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
@@ -482,7 +540,14 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
             }
         }
     }
-    if (!corrupt && remaining > 0 && Q != kQueryReduceOnly) {
+    if (!corrupt && remaining > 0 && Q != kQueryReduceOnly && CM) {
+        const uint8_t* t = a.comp + gabs + rp;
+        U* const c0 = (U*)((uint8_t*)a.out + out_base + ovo);          // column 0 at the tail's first row
+        for (uint32_t e = (uint32_t)lane_d; e < remaining; e += DP) {
+            const uint32_t x = ESZ == 1 ? (uint32_t)t[e] : (uint32_t)*(const u16_unaligned*)(t + 2 * e);
+            c0[(uint64_t)(e % (uint32_t)D) * a.col_stride + e / (uint32_t)D] = (U)x;
+        }
+    } else if (!corrupt && remaining > 0 && Q != kQueryReduceOnly) {
         const uint8_t* t = a.comp + gabs + rp;
         uint8_t* d = (uint8_t*)a.out + out_base + ovo;
         const uint32_t nbytes = remaining * ESZ;

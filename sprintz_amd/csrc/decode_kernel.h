@@ -34,6 +34,9 @@ struct DecodeArgs {
     uint32_t chunks_per_group;  // decode_fast: consecutive chunks decoded by one lane group
     // query-on-compressed (sprintz_delta.h:95-98, sprintz_xff.h:90-93, query.hpp:23-29): kernels
     // instantiated with Q != 0 reduce every column of every chunk while decoding
+    // column-major destination (BASELINE config 5): element (row r, column d) at out[d*col_stride + r];
+    // chunk c holds rows [c*chunk_len/D, ...).  0 = row-major.
+    uint64_t col_stride;
     int qop;                    // 1: max, 2: sum (what lands in qres)
     uint64_t* qres;             // [nchunks][D] per-chunk, per-column partial results
 };
@@ -62,6 +65,8 @@ __global__ void __launch_bounds__(kThreads) decode_kernel(DecodeArgs a)
 
     const uint8_t* s = a.comp + a.offsets[chunk];
     U* const o = (U*)a.out + chunk * (uint64_t)a.chunk_len;
+    const uint64_t cs = a.col_stride;
+    U* const cm0 = (U*)a.out + (cs ? chunk * (uint64_t)(a.chunk_len / (uint32_t)a.D) : 0);   // column 0 at this chunk's first row
     uint8_t* const lds = smem + (size_t)(threadIdx.x >> a.log2DP) * a.lds_group_stride;
 
     // ---- 8-byte stream header (format.h:48-62)
@@ -224,6 +229,17 @@ __global__ void __launch_bounds__(kThreads) decode_kernel(DecodeArgs a)
         U* const ob = o + out_elems;
         if constexpr (Q == kQueryReduceOnly) {
             (void)ob;
+        } else if (cs) {
+            const uint32_t r0 = out_elems / (uint32_t)D;
+#pragma unroll
+            for (int k = 0; k < CPL; k++) {
+                const int col = lane_d * CPL + k;
+                if (col < D) {
+                    U* const cp = cm0 + (uint64_t)col * cs + r0;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) cp[i] = (U)v[i][k];
+                }
+            }
         } else if (a.vec_store) {
             U* const l = (U*)lds;
 #pragma unroll
@@ -272,7 +288,14 @@ __global__ void __launch_bounds__(kThreads) decode_kernel(DecodeArgs a)
             }
         }
     }
-    if (!corrupt && Q != kQueryReduceOnly) {
+    if (!corrupt && Q != kQueryReduceOnly && cs) {
+        const uint8_t* t = s + pos;
+        const uint32_t r0 = out_elems / (uint32_t)D;
+        for (uint32_t e = (uint32_t)lane_d; e < remaining; e += (uint32_t)DP) {
+            const uint32_t x = ESZ == 1 ? load_u8(t + e) : (load_u8(t + 2 * e) | (load_u8(t + 2 * e + 1) << 8));
+            cm0[(uint64_t)(e % (uint32_t)D) * cs + r0 + e / (uint32_t)D] = (U)x;
+        }
+    } else if (!corrupt && Q != kQueryReduceOnly) {
         const uint8_t* t = s + pos;
         uint8_t* d = (uint8_t*)(o + out_elems);
         const uint32_t nbytes = remaining * ESZ;

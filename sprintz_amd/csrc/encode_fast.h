@@ -18,7 +18,9 @@
 
 namespace sprintz {
 
-template <int W, bool FIRE, int DP, bool EXACT>
+// CM: column-major source (EncodeArgs::col_stride): a lane's 8 samples of a block are
+// contiguous in ITS column -- one 16-byte (8-byte at W == 8) load per lane, no LDS transpose.
+template <int W, bool FIRE, int DP, bool EXACT, bool CM = false>
 __global__ void __launch_bounds__(kThreads) encode_fast_kernel(EncodeArgs a)
 {
     using U = typename Elem<W>::U;
@@ -112,9 +114,18 @@ __global__ void __launch_bounds__(kThreads) encode_fast_kernel(EncodeArgs a)
     };
     // this lane's 16-byte pieces of the 8 x D block starting at element `pos` (0 past the chunk)
     constexpr int PIECES = (8 * DP * ESZ + DP * 16 - 1) / (DP * 16);   // 1 (W=16) or 1 (W=8): block <= DP*16 bytes
+    const U* const cmcol = CM ? (const U*)a.src + first / (uint64_t)D + (uint64_t)lane_d * a.col_stride : nullptr;
     auto load_block = [&](int64_t pos) -> uint4 {
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (lane16 < blk_bytes && pos + (int64_t)blk <= (int64_t)n) v = *(const uint4*)((const uint8_t*)(sc + pos) + lane16);
+        if constexpr (CM) {
+            if (col_ok && pos + (int64_t)blk <= (int64_t)n) {
+                const U* p = cmcol + (uint32_t)pos / (uint32_t)D;          // 8 consecutive rows of this lane's column
+                if constexpr (W == 16) v = *(const uint4*)p;
+                else { const uint2 t = *(const uint2*)p; v.x = t.x; v.y = t.y; }
+            }
+        } else {
+            if (lane16 < blk_bytes && pos + (int64_t)blk <= (int64_t)n) v = *(const uint4*)((const uint8_t*)(sc + pos) + lane16);
+        }
         return v;
     };
     static_assert(PIECES == 1, "one 16-byte piece per lane covers a block");
@@ -130,13 +141,28 @@ __global__ void __launch_bounds__(kThreads) encode_fast_kernel(EncodeArgs a)
 
     while (active) {
         // ---- the block at pos_in is in `nxt`; transpose it through LDS, request the next one
-        if (lane16 < blk_bytes) *(uint4*)(stage + lane16) = nxt;
-        wave_lds_sync();
-        nxt = load_block(pos_in + blk);
         uint32_t x[8];
+        if constexpr (CM) {
+            const uint4 cur = nxt;
+            nxt = load_block(pos_in + blk);
 #pragma unroll
-        for (int i = 0; i < 8; i++) x[i] = col_ok ? (uint32_t)*(const U*)(stage_col + i * row_stride) : 0u;
-        wave_lds_sync();
+            for (int i = 0; i < 8; i++) {
+                if constexpr (W == 16) {
+                    const uint32_t d = (i >> 1) == 0 ? cur.x : (i >> 1) == 1 ? cur.y : (i >> 1) == 2 ? cur.z : cur.w;
+                    x[i] = (i & 1) ? d >> 16 : d & 0xffffu;
+                } else {
+                    const uint32_t d = (i >> 2) == 0 ? cur.x : cur.y;
+                    x[i] = (d >> (8 * (i & 3))) & 0xffu;
+                }
+            }
+        } else {
+            if (lane16 < blk_bytes) *(uint4*)(stage + lane16) = nxt;
+            wave_lds_sync();
+            nxt = load_block(pos_in + blk);
+#pragma unroll
+            for (int i = 0; i < 8; i++) x[i] = col_ok ? (uint32_t)*(const U*)(stage_col + i * row_stride) : 0u;
+            wave_lds_sync();
+        }
 
         // ---- forecast + zigzag + OR-mask (:197-298)
         uint32_t z[8];
@@ -217,7 +243,17 @@ __global__ void __launch_bounds__(kThreads) encode_fast_kernel(EncodeArgs a)
             drain(wl & ~15u);
             const uint32_t room = cap - 16u - wl;
             const uint32_t m = left < room ? left : room;
-            for (uint32_t j = (uint32_t)lane_d; j < m; j += DP) win[wl + j] = tp[j];
+            if constexpr (CM) {
+                const uint32_t done = remaining * ESZ - left;
+                const U* const c0 = (const U*)a.src + first / (uint64_t)D;
+                for (uint32_t j = (uint32_t)lane_d; j < m; j += DP) {
+                    const uint32_t tb = done + j, e = (uint32_t)pos_in + tb / ESZ;
+                    const uint32_t xv = (uint32_t)c0[(uint64_t)(e % (uint32_t)D) * a.col_stride + e / (uint32_t)D];
+                    win[wl + j] = (uint8_t)(xv >> (8u * (tb % ESZ)));
+                }
+            } else {
+                for (uint32_t j = (uint32_t)lane_d; j < m; j += DP) win[wl + j] = tp[j];
+            }
             wl += m;
             tp += m;
             left -= m;

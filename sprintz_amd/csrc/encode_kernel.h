@@ -32,6 +32,10 @@ struct EncodeArgs {
     int write_size;             // 0: omit the 8-byte header (sprintz_xff_rle.cpp:119-127)
     uint32_t cap;               // ring bytes per group (power of two, >= max group bytes + 32)
     uint32_t lds_group_stride;  // encode_fast: LDS bytes per group (ring + input staging)
+    // column-major source (BASELINE config 5): element (row r, column d) at src[d*col_stride + r];
+    // chunk c covers rows [c*chunk_len/D, ...) and is coded as the reference codes the row-major
+    // flattening of that row range.  0 = row-major.
+    uint64_t col_stride;
 };
 
 template <int W, bool FIRE, bool LOWDIM, int CPL>
@@ -54,6 +58,12 @@ __global__ void __launch_bounds__(kThreads) encode_kernel(EncodeArgs a)
     const uint32_t n = (uint32_t)((a.total_len - first < a.chunk_len) ? (a.total_len - first) : a.chunk_len);
     const U* const sc = (const U*)a.src + first;
     uint8_t* const gdst = a.slots + chunk * a.slot_stride;
+    const uint64_t cs = a.col_stride;
+    const U* const cm0 = (const U*)a.src + (cs ? first / (uint64_t)D : 0);     // column 0 at this chunk's first row
+    // element e of the chunk in row-major order
+    auto elem = [&](uint32_t e) -> uint32_t {
+        return cs ? (uint32_t)cm0[(uint64_t)(e % (uint32_t)D) * cs + e / (uint32_t)D] : (uint32_t)sc[e];
+    };
 
     const uint32_t cap = a.cap, capm = cap - 1;
     uint8_t* const ring = smem + (size_t)(threadIdx.x >> a.log2DP) * cap;
@@ -125,8 +135,14 @@ __global__ void __launch_bounds__(kThreads) encode_kernel(EncodeArgs a)
         for (int k = 0; k < CPL; k++) {
             const int col = lane_d * CPL + k;
             uint32_t x[8];
+            if (cs) {
+                const U* const cp = cm0 + (uint64_t)col * cs + (uint32_t)pos_in / (uint32_t)D;
 #pragma unroll
-            for (int i = 0; i < 8; i++) x[i] = (col < D) ? (uint32_t)sc[pos_in + (int64_t)i * D + col] : 0u;
+                for (int i = 0; i < 8; i++) x[i] = (col < D) ? (uint32_t)cp[i] : 0u;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; i++) x[i] = (col < D) ? (uint32_t)sc[pos_in + (int64_t)i * D + col] : 0u;
+            }
             const int coef = FIRE ? fire_coef<W, LOWDIM>(ctr[k]) : 0;
             int grad = 0;
             uint32_t mask = 0, pvk = pv[k];
@@ -212,7 +228,15 @@ __global__ void __launch_bounds__(kThreads) encode_kernel(EncodeArgs a)
             flush_to(wpos & ~15u);
             const uint32_t room = cap - (wpos - flushed);
             const uint32_t m = left < room ? left : room;
-            for (uint32_t j = (uint32_t)lane_d; j < m; j += (uint32_t)DP) ring[(wpos + j) & capm] = tp[j];
+            if (cs) {
+                const uint32_t done = remaining * ESZ - left;          // tail bytes already copied
+                for (uint32_t j = (uint32_t)lane_d; j < m; j += (uint32_t)DP) {
+                    const uint32_t tb = done + j;
+                    ring[(wpos + j) & capm] = (uint8_t)(elem((uint32_t)pos_in + tb / ESZ) >> (8u * (tb % ESZ)));
+                }
+            } else {
+                for (uint32_t j = (uint32_t)lane_d; j < m; j += (uint32_t)DP) ring[(wpos + j) & capm] = tp[j];
+            }
             wpos += m;
             tp += m;
             left -= m;

@@ -93,46 +93,55 @@ inline hipError_t launch_one(K kernel, unsigned grid, size_t shmem, hipStream_t 
     if (q == kQueryMaterialize) { SPRINTZ_DISPATCH_Q(KERNEL, W, kQueryMaterialize) }                  \
     SPRINTZ_DISPATCH_Q(KERNEL, W, kQueryReduceOnly)
 
-#define SPRINTZ_FAST_CASE(KERNEL, W, DPV, CPLV, Q)                                                   \
+#define SPRINTZ_FAST_CASE(KERNEL, W, DPV, CPLV, Q, CMV)                                              \
     if (dp == DPV && cpl == CPLV) {                                                                   \
-        if (exact) return fire ? launch_one(KERNEL<W, true, DPV, CPLV, true, Q>, grid, shmem, st, a)  \
-                               : launch_one(KERNEL<W, false, DPV, CPLV, true, Q>, grid, shmem, st, a); \
-        return fire ? launch_one(KERNEL<W, true, DPV, CPLV, false, Q>, grid, shmem, st, a)            \
-                    : launch_one(KERNEL<W, false, DPV, CPLV, false, Q>, grid, shmem, st, a);          \
+        if (exact) return fire ? launch_one(KERNEL<W, true, DPV, CPLV, true, Q, CMV>, grid, shmem, st, a)  \
+                               : launch_one(KERNEL<W, false, DPV, CPLV, true, Q, CMV>, grid, shmem, st, a); \
+        return fire ? launch_one(KERNEL<W, true, DPV, CPLV, false, Q, CMV>, grid, shmem, st, a)       \
+                    : launch_one(KERNEL<W, false, DPV, CPLV, false, Q, CMV>, grid, shmem, st, a);     \
     }
 
 // decoder fast path: one column per lane for D <= 64, 2 / 4 columns per lane of a
 // 64-lane group for D <= 128 / 256
-#define SPRINTZ_DISPATCH_DECODE_FAST_Q(KERNEL, W, Q)                                                  \
-    SPRINTZ_FAST_CASE(KERNEL, W, 4, 1, Q)                                                             \
-    SPRINTZ_FAST_CASE(KERNEL, W, 8, 1, Q)                                                             \
-    SPRINTZ_FAST_CASE(KERNEL, W, 16, 1, Q)                                                            \
-    SPRINTZ_FAST_CASE(KERNEL, W, 32, 1, Q)                                                            \
-    SPRINTZ_FAST_CASE(KERNEL, W, 64, 1, Q)                                                            \
-    SPRINTZ_FAST_CASE(KERNEL, W, 64, 2, Q)                                                            \
-    SPRINTZ_FAST_CASE(KERNEL, W, 64, 4, Q)                                                            \
+#define SPRINTZ_DISPATCH_DECODE_FAST_Q(KERNEL, W, Q, CMV)                                             \
+    SPRINTZ_FAST_CASE(KERNEL, W, 4, 1, Q, CMV)                                                        \
+    SPRINTZ_FAST_CASE(KERNEL, W, 8, 1, Q, CMV)                                                        \
+    SPRINTZ_FAST_CASE(KERNEL, W, 16, 1, Q, CMV)                                                       \
+    SPRINTZ_FAST_CASE(KERNEL, W, 32, 1, Q, CMV)                                                       \
+    SPRINTZ_FAST_CASE(KERNEL, W, 64, 1, Q, CMV)                                                       \
+    SPRINTZ_FAST_CASE(KERNEL, W, 64, 2, Q, CMV)                                                       \
+    SPRINTZ_FAST_CASE(KERNEL, W, 64, 4, Q, CMV)                                                       \
     return hipErrorInvalidValue;
 
+// the column-major destination exists for the plain decode only (a reduce-only query writes
+// no output, so its layout does not matter)
 #define SPRINTZ_DISPATCH_DECODE_FAST(KERNEL, W)                                                       \
-    if (q == kQueryOff) { SPRINTZ_DISPATCH_DECODE_FAST_Q(KERNEL, W, kQueryOff) }                      \
-    if (q == kQueryMaterialize) { SPRINTZ_DISPATCH_DECODE_FAST_Q(KERNEL, W, kQueryMaterialize) }      \
-    SPRINTZ_DISPATCH_DECODE_FAST_Q(KERNEL, W, kQueryReduceOnly)
+    if (q == kQueryOff && a.col_stride) { SPRINTZ_DISPATCH_DECODE_FAST_Q(KERNEL, W, kQueryOff, true) } \
+    if (a.col_stride && q == kQueryMaterialize) return hipErrorInvalidValue;                          \
+    if (q == kQueryOff) { SPRINTZ_DISPATCH_DECODE_FAST_Q(KERNEL, W, kQueryOff, false) }               \
+    if (q == kQueryMaterialize) { SPRINTZ_DISPATCH_DECODE_FAST_Q(KERNEL, W, kQueryMaterialize, false) } \
+    SPRINTZ_DISPATCH_DECODE_FAST_Q(KERNEL, W, kQueryReduceOnly, false)
 
-#define SPRINTZ_ENC_FAST_CASE(KERNEL, W, DPV)                                                        \
+#define SPRINTZ_ENC_FAST_CASE(KERNEL, W, DPV, CMV)                                                   \
     case DPV:                                                                                         \
-        if (exact) return fire ? launch_one(KERNEL<W, true, DPV, true>, grid, shmem, st, a)           \
-                               : launch_one(KERNEL<W, false, DPV, true>, grid, shmem, st, a);         \
-        return fire ? launch_one(KERNEL<W, true, DPV, false>, grid, shmem, st, a)                     \
-                    : launch_one(KERNEL<W, false, DPV, false>, grid, shmem, st, a);
+        if (exact) return fire ? launch_one(KERNEL<W, true, DPV, true, CMV>, grid, shmem, st, a)      \
+                               : launch_one(KERNEL<W, false, DPV, true, CMV>, grid, shmem, st, a);    \
+        return fire ? launch_one(KERNEL<W, true, DPV, false, CMV>, grid, shmem, st, a)                \
+                    : launch_one(KERNEL<W, false, DPV, false, CMV>, grid, shmem, st, a);
 
-#define SPRINTZ_DISPATCH_FAST(KERNEL, W)                                                              \
+#define SPRINTZ_DISPATCH_FAST_CM(KERNEL, W, CMV)                                                      \
     switch (dp) {                                                                                     \
-        SPRINTZ_ENC_FAST_CASE(KERNEL, W, 4)                                                           \
-        SPRINTZ_ENC_FAST_CASE(KERNEL, W, 8)                                                           \
-        SPRINTZ_ENC_FAST_CASE(KERNEL, W, 16)                                                          \
-        SPRINTZ_ENC_FAST_CASE(KERNEL, W, 32)                                                          \
-        SPRINTZ_ENC_FAST_CASE(KERNEL, W, 64)                                                          \
+        SPRINTZ_ENC_FAST_CASE(KERNEL, W, 4, CMV)                                                      \
+        SPRINTZ_ENC_FAST_CASE(KERNEL, W, 8, CMV)                                                      \
+        SPRINTZ_ENC_FAST_CASE(KERNEL, W, 16, CMV)                                                     \
+        SPRINTZ_ENC_FAST_CASE(KERNEL, W, 32, CMV)                                                     \
+        SPRINTZ_ENC_FAST_CASE(KERNEL, W, 64, CMV)                                                     \
         default: return hipErrorInvalidValue;                                                         \
     }
+
+// a.col_stride != 0 selects the column-major source variant
+#define SPRINTZ_DISPATCH_FAST(KERNEL, W)                                                              \
+    if (a.col_stride) { SPRINTZ_DISPATCH_FAST_CM(KERNEL, W, true) }                                   \
+    SPRINTZ_DISPATCH_FAST_CM(KERNEL, W, false)
 
 }  // namespace sprintz

@@ -91,6 +91,36 @@ def main():
         cd._ws = {}
         torch.cuda.empty_cache()
 
+    # BASELINE config 5 as stated: column-major matrix, 32 variables, 160-row (10 KB) chunks
+    for name, nrows in (("cfg5  u16 D=32 xff COLUMN-MAJOR 1M rows (64 MiB)", 1 << 20), ("cfg5  same, 8M rows (512 MiB)", 1 << 23)):
+        D, rpc, esz = 32, 160, 2
+        g = torch.Generator(device=dev).manual_seed(5)
+        cols = (torch.cumsum(torch.randint(-8, 9, (D, nrows), generator=g, device=dev, dtype=torch.int32), dim=1) & 0xffff).to(torch.uint16)
+        cd = sprintz_amd.ChunkedCodec("xff", esz, D, rpc * D, device=dev)
+        batch = cd.compress_colmajor(cols)
+        nchunks = batch.nchunks
+        out = torch.empty((D, nchunks * rpc), dtype=torch.uint16, device=dev)
+        assert torch.equal(cd.decompress_colmajor(batch, out=out), cols)
+        ws = cd.workspace(nchunks)
+        dense = torch.empty(nchunks * cd.slot_stride + 16, dtype=torch.uint8, device=dev)
+        offs = torch.empty(nchunks + 1, dtype=torch.int64, device=dev)
+        st = cd._stream()
+
+        def enc():
+            _lib.check(_lib.compress_batch_colmajor(_lib.CODEC_XFF, esz, cols.data_ptr(), nrows, nrows, rpc, D, ws["slots"].data_ptr(),
+                                                    cd.slot_stride, ws["sizes"].data_ptr(), ws["rets"].data_ptr(), st))
+            cd.compact(ws, nchunks, dense, offs)
+
+        def dec():
+            _lib.check(_lib.decompress_batch_colmajor(_lib.CODEC_XFF, esz, batch.data.data_ptr(), batch.offsets.data_ptr(), nchunks,
+                                                      rpc, D, int(out.shape[1]), out.data_ptr(), None, st))
+        tc, td = timeit(enc, a.reps), timeit(dec, a.reps)
+        raw = nrows * D * esz
+        print(f"| {name} | {raw / batch.stream_bytes():.3f} | {raw / tc / 1e6:.0f} | {raw / td / 1e6:.0f} | {td:.3f} |", flush=True)
+        del cols, batch, out, dense, offs
+        cd._ws = {}
+        torch.cuda.empty_cache()
+
 
 if __name__ == "__main__":
     main()
