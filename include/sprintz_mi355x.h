@@ -162,10 +162,15 @@ int sprintz_mi355x_huf_compress_batch(const void* d_dense, const uint64_t* d_off
                                       void* d_tmp, void* hip_stream);
 /* inverse: rebuilds the container with chunk starts rounded up to `align`
  * (fills d_offsets[nchunks+1] and d_sizes[nchunks]); feed it to
- * sprintz_mi355x_decompress_batch. */
+ * sprintz_mi355x_decompress_batch.  d_dense holds dense_capacity bytes; a
+ * record that is damaged (does not fit its slot of the container, or whose
+ * output would not fit d_dense) decodes to nothing and gets
+ * d_rets[c] = SPRINTZ_E_CORRUPT (d_rets optional; otherwise the chunk's byte
+ * count) -- damaged input never makes the kernels read or write out of bounds. */
 int sprintz_mi355x_huf_decompress_batch(const void* d_huf, const uint64_t* d_huf_offsets, const void* d_tables,
-                                        uint64_t nchunks, uint32_t align, void* d_dense, uint64_t* d_offsets,
-                                        uint32_t* d_sizes, void* d_tmp, void* hip_stream);
+                                        uint64_t nchunks, uint32_t align, void* d_dense, uint64_t dense_capacity,
+                                        uint64_t* d_offsets, uint32_t* d_sizes, int64_t* d_rets, void* d_tmp,
+                                        void* hip_stream);
 
 /* ------------------------------------------------------------------------
  * Column-major matrices (BASELINE.json config 5: "uint16 colmajor, 32

@@ -329,18 +329,21 @@ def huf_compress(batch):
     return HufBatch(huf[: end + _lib.READ_SLACK].clone(), hoffs, tables, n, batch.total_len, batch.chunk_len, batch.ndims)
 
 
-def huf_decompress(hb, dense_capacity, align=16):
-    """HufBatch -> CompressedBatch (the exact Sprintz container again)"""
+def huf_decompress(hb, dense_capacity, align=16, rets=None):
+    """HufBatch -> CompressedBatch (the exact Sprintz container again).  rets: optional int64
+    tensor [nchunks] receiving each chunk's byte count, or E_CORRUPT for a damaged record."""
     import torch
     dev = hb.data.device
     n = hb.nchunks
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    dense = torch.zeros(dense_capacity + _lib.READ_SLACK + 16 * n, dtype=torch.uint8, device=dev)
+    cap = dense_capacity + 16 * n
+    dense = torch.zeros(cap + _lib.READ_SLACK, dtype=torch.uint8, device=dev)
     offs = torch.empty(n + 1, dtype=torch.int64, device=dev)
     sizes = torch.empty(n, dtype=torch.int32, device=dev)
     tmp = torch.empty(int(_lib.compact_tmp_bytes(n)) + 64, dtype=torch.uint8, device=dev)
     _lib.check(_lib.huf_decompress_batch(hb.data.data_ptr(), hb.offsets.data_ptr(), hb.tables.data_ptr(), n, align,
-                                         dense.data_ptr(), offs.data_ptr(), sizes.data_ptr(), tmp.data_ptr(), stream))
+                                         dense.data_ptr(), cap, offs.data_ptr(), sizes.data_ptr(),
+                                         rets.data_ptr() if rets is not None else None, tmp.data_ptr(), stream))
     return CompressedBatch(dense, offs, sizes, n, hb.total_len, hb.chunk_len, hb.ndims)
 
 

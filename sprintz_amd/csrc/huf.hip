@@ -410,15 +410,42 @@ __global__ void __launch_bounds__(256) huf_encode_kernel(const uint8_t* dense, c
 }
 
 // ---------------------------------------------------------------- K4: raw sizes from the record headers
+// A record is only believed if it lies inside the container and its own header fits in it:
+// nothing below reads or writes outside the buffers on damaged input.
+__device__ __forceinline__ bool record_ok(const uint8_t* huf, const uint64_t* huf_offsets, uint64_t nchunks, uint64_t c, uint32_t& n)
+{
+    const uint64_t total = huf_offsets[nchunks];
+    const uint64_t roff = huf_offsets[c], rend = huf_offsets[c + 1];
+    n = 0;
+    if ((roff & 3) || rend > total || roff + 4 > rend) return false;
+    const uint32_t hdr = *(const uint32_t*)(huf + roff);
+    const uint32_t nn = hdr & 0x7fffffffu;
+    const uint64_t len = rend - roff;
+    if (hdr >> 31) {
+        if (4 + (uint64_t)nn > len) return false;
+    } else {
+        if (len < 12) return false;
+        const uint32_t h0 = ((const uint32_t*)(huf + roff))[1], h1 = ((const uint32_t*)(huf + roff))[2];
+        if (12 + (uint64_t)(h0 & 0xffffu) + (h0 >> 16) + (h1 & 0xffffu) > len) return false;
+        if ((uint64_t)nn > 8 * len) return false;              // every symbol costs at least one bit
+    }
+    n = nn;
+    return true;
+}
+
 __global__ void __launch_bounds__(256) huf_rawsize_kernel(const uint8_t* huf, const uint64_t* huf_offsets, uint64_t nchunks, uint32_t* sizes)
 {
     const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (c < nchunks) sizes[c] = *(const uint32_t*)(huf + huf_offsets[c]) & 0x7fffffffu;
+    if (c >= nchunks) return;
+    uint32_t n;
+    record_ok(huf, huf_offsets, nchunks, c, n);                 // a rejected record decodes to an empty stream
+    sizes[c] = n;
 }
 
 // ---------------------------------------------------------------- K5: decode
 __global__ void __launch_bounds__(256) huf_decode_kernel(const uint8_t* huf, const uint64_t* huf_offsets, const uint8_t* tables,
-                                                         uint64_t nchunks, uint8_t* dense, const uint64_t* offsets)
+                                                         uint64_t nchunks, uint8_t* dense, const uint64_t* offsets,
+                                                         uint64_t dense_capacity, int64_t* rets)
 {
     // 32 KB ring + 4 KB table: four workgroups per CU.  The ring holds, per lane, the next
     // 128 coded bytes of its sub-stream as 32 dwords at ring[d][lane] -- dword d of every
@@ -462,9 +489,12 @@ __global__ void __launch_bounds__(256) huf_decode_kernel(const uint8_t* huf, con
     if (c >= nchunks) return;
     const uint64_t roff = huf_offsets[c];
     const uint8_t* r = huf + roff;
-    const uint32_t hdr = *(const uint32_t*)r;
-    const uint32_t n = hdr & 0x7fffffffu;
+    uint32_t n;
     const uint64_t ooff = offsets[c];
+    const bool ok = record_ok(huf, huf_offsets, nchunks, c, n) && ooff + n <= dense_capacity;
+    if (j == 0 && rets) rets[c] = ok ? (int64_t)n : (int64_t)SPRINTZ_E_CORRUPT;
+    if (!ok) return;
+    const uint32_t hdr = *(const uint32_t*)r;
     uint8_t* o = dense + ooff;
     if (hdr >> 31) {
         const uint32_t nw = n >> 2;
@@ -508,11 +538,7 @@ __global__ void __launch_bounds__(256) huf_decode_kernel(const uint8_t* huf, con
         for (int m = 0; m < 4; m++) {
             uint64_t q = q0 + m;
             q = q < last16 ? q : last16;
-#ifdef HUF_EXP_NOLOAD
-            const uint8_t* src = idle; (void)wanted;
-#else
             const uint8_t* src = wanted ? huf + (q << 4) : idle;
-#endif
             pc.v[m] = *(const u32x4_a4*)src;
         }
         return pc;
@@ -565,7 +591,6 @@ __global__ void __launch_bounds__(256) huf_decode_kernel(const uint8_t* huf, con
     };
 
     uint32_t i = a;
-    uint32_t xacc = 0;
     auto sixteen = [&]() -> u32x4 {
         refill();
         u32x4 r;
@@ -583,11 +608,7 @@ __global__ void __launch_bounds__(256) huf_decode_kernel(const uint8_t* huf, con
         if (pro) refill();
         for (uint32_t k = 0; k < pro; k++) {
             uint32_t w = window();
-#ifdef HUF_EXP_NOBYTES
-            xacc ^= sym(w); i++;
-#else
             o[i++] = (uint8_t)sym(w);
-#endif
         }
     }
     while (((ooff + i) & 63) != 0 && i + 16 <= b) {
@@ -608,11 +629,7 @@ __global__ void __launch_bounds__(256) huf_decode_kernel(const uint8_t* huf, con
             auto part = [&](int m) {
                 uint64_t qq = q0 + m;
                 qq = qq < last16 ? qq : last16;
-#ifdef HUF_EXP_NOLOAD
-                pend.v[m] = *(const u32x4_a4*)idle;
-#else
                 pend.v[m] = *(const u32x4_a4*)(have_pend ? huf + (qq << 4) : idle);
-#endif
             };
             part(0);
             v[q].x = four();
@@ -623,12 +640,8 @@ __global__ void __launch_bounds__(256) huf_decode_kernel(const uint8_t* huf, con
             part(3);
             v[q].w = four();
         }
-#ifdef HUF_EXP_NOSTORE
-        for (int q = 0; q < 4; q++) xacc ^= v[q].x ^ v[q].y ^ v[q].z ^ v[q].w;
-#else
 #pragma unroll
         for (int q = 0; q < 4; q++) *(u32x4_a1*)(o + i + 16 * q) = v[q];
-#endif
         i += 64;
     }
     while (i + 16 <= b) {
@@ -638,13 +651,8 @@ __global__ void __launch_bounds__(256) huf_decode_kernel(const uint8_t* huf, con
     if (i < b) refill();
     for (; i < b; i++) {
         uint32_t w = window();
-#ifdef HUF_EXP_NOBYTES
-        xacc ^= sym(w);
-#else
         o[i] = (uint8_t)sym(w);
-#endif
     }
-    if (xacc == 0x12345678u) o[0] = 1;                                     // keeps the experiment builds honest
 }
 
 thread_local std::string g_huf_error;
@@ -688,8 +696,8 @@ int sprintz_mi355x_huf_compress_batch(const void* d_dense, const uint64_t* d_off
 }
 
 int sprintz_mi355x_huf_decompress_batch(const void* d_huf, const uint64_t* d_huf_offsets, const void* d_tables, uint64_t nchunks,
-                                        uint32_t align, void* d_dense, uint64_t* d_offsets, uint32_t* d_sizes, void* d_tmp,
-                                        void* hip_stream)
+                                        uint32_t align, void* d_dense, uint64_t dense_capacity, uint64_t* d_offsets,
+                                        uint32_t* d_sizes, int64_t* d_rets, void* d_tmp, void* hip_stream)
 {
     if (!d_huf || !d_huf_offsets || !d_tables || !d_dense || !d_offsets || !d_sizes || !d_tmp) return SPRINTZ_E_INVALID;
     if (align == 0 || align > 16 || (align & (align - 1))) return SPRINTZ_E_INVALID;
@@ -699,9 +707,8 @@ int sprintz_mi355x_huf_decompress_batch(const void* d_huf, const uint64_t* d_huf
     hipLaunchKernelGGL(huf_rawsize_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, st, (const uint8_t*)d_huf, d_huf_offsets,
                        nchunks, d_sizes);
     if (launch_size_scan(d_sizes, nchunks, align, d_offsets, d_tmp, st) != hipSuccess) return SPRINTZ_E_HIP;
-    static const unsigned dbg_lds = getenv("SPRINTZ_MI355X_HUF_LDS") ? (unsigned)atoi(getenv("SPRINTZ_MI355X_HUF_LDS")) : 0u;
-    hipLaunchKernelGGL(huf_decode_kernel, dim3((unsigned)nseg), dim3(256), dbg_lds, st, (const uint8_t*)d_huf, d_huf_offsets,
-                       (const uint8_t*)d_tables, nchunks, (uint8_t*)d_dense, (const uint64_t*)d_offsets);
+    hipLaunchKernelGGL(huf_decode_kernel, dim3((unsigned)nseg), dim3(256), 0, st, (const uint8_t*)d_huf, d_huf_offsets,
+                       (const uint8_t*)d_tables, nchunks, (uint8_t*)d_dense, (const uint64_t*)d_offsets, dense_capacity, d_rets);
     return hipGetLastError() == hipSuccess ? 0 : SPRINTZ_E_HIP;
 }
 

@@ -318,3 +318,82 @@ def test_huffman_stage_matches_oracle_and_roundtrips(sz, oracle, step):
     assert np.array_equal(out.cpu().numpy(), data)
     if step <= 8:                                                            # a third of the chunks is incompressible noise
         assert hb.total_bytes() < 0.99 * batch.stream_bytes()
+
+
+def test_huffman_odd_batches(sz, oracle):
+    """chunk counts around the 64-chunk segment size, tiny and empty streams, byte-dense containers"""
+    import torch
+    rng = np.random.default_rng(77)
+    for codec, esz, ndims, chunk_len, nchunks in (("delta", 1, 3, 40, 1), ("xff", 2, 8, 5120, 63), ("xff", 2, 8, 5120, 65),
+                                                  ("delta", 1, 80, 1024, 129), ("xff", 1, 8, 16 * 8 + 5, 200)):
+        data = gen_walk(rng, nchunks * chunk_len - chunk_len // 2, ndims, esz, 3, flat_every=3)
+        cd = sz.ChunkedCodec(codec, esz, ndims, chunk_len, device="cuda:0")
+        batch = cd.compress(torch.from_numpy(data).cuda())
+        hb = sz.huf_compress(batch)
+        dense, offs = batch.data.cpu().numpy(), batch.offsets.cpu().numpy().astype(np.uint64)
+        sizes = batch.sizes.cpu().numpy().astype(np.uint32)
+        want, want_offs, want_tables = oracle.huf_compress(dense, offs, sizes)
+        assert np.array_equal(hb.offsets.cpu().numpy().astype(np.uint64), want_offs), (codec, nchunks)
+        assert np.array_equal(hb.tables.cpu().numpy(), want_tables), (codec, nchunks)
+        assert np.array_equal(hb.data.cpu().numpy()[:want.size], want), (codec, nchunks)
+        rets = torch.empty(nchunks, dtype=torch.int64, device="cuda:0")
+        back = sz.huf_decompress(hb, int(offs[-1]), rets=rets)
+        assert np.array_equal(rets.cpu().numpy(), sizes.astype(np.int64))
+        assert np.array_equal(cd.decompress(back).cpu().numpy(), data), (codec, nchunks)
+
+
+def test_huffman_decoder_survives_damaged_containers(sz):
+    """bit flips in records, headers, offsets and tables: no fault, no hang, no write outside the
+    destination; chunks of untouched segments still decode exactly"""
+    import torch
+    rng = np.random.default_rng(99)
+    codec, esz, ndims, chunk_len, nchunks = "xff", 2, 8, 5120, 256           # 4 segments
+    data = gen_walk(rng, nchunks * chunk_len, ndims, esz, 6, flat_every=4)
+    cd = sz.ChunkedCodec(codec, esz, ndims, chunk_len, device="cuda:0")
+    batch = cd.compress(torch.from_numpy(data).cuda())
+    hb = sz.huf_compress(batch)
+    dense = batch.data.cpu().numpy()
+    offs = batch.offsets.cpu().numpy()
+    sizes = batch.sizes.cpu().numpy()
+    cap = int(offs[-1])
+    h_data, h_offs, h_tabs = hb.data.cpu().numpy().copy(), hb.offsets.cpu().numpy().copy(), hb.tables.cpu().numpy().copy()
+
+    def run(d, o, t, check_segments):
+        bad = sz.HufBatch(torch.from_numpy(d).cuda(), torch.from_numpy(o).cuda(), torch.from_numpy(t).cuda(), nchunks,
+                          hb.total_len, hb.chunk_len, hb.ndims)
+        rets = torch.empty(nchunks, dtype=torch.int64, device="cuda:0")
+        back = sz.huf_decompress(bad, cap, rets=rets)
+        torch.cuda.synchronize()
+        guard = back.data[cap + 16 * nchunks:].cpu().numpy()
+        assert (guard == 0).all()                                           # READ_SLACK past the capacity untouched
+        bd, bo = back.data.cpu().numpy(), back.offsets.cpu().numpy()
+        for c in check_segments:
+            assert bo[c] == offs[c]
+            assert np.array_equal(bd[int(offs[c]):int(offs[c]) + int(sizes[c])], dense[int(offs[c]):int(offs[c]) + int(sizes[c])]), c
+        return rets.cpu().numpy()
+
+    # (a) payload bit flips in segment 1 (chunks 64..127): sizes are unchanged, so every other segment is exact
+    d = h_data.copy()
+    lo, hi = int(h_offs[64]), int(h_offs[128])
+    for pos in rng.integers(lo, hi, 200):
+        if (pos - lo) % 4096 >= 12:                                         # leave most headers alone here
+            d[pos] ^= 1 << int(rng.integers(0, 8))
+    run(d, h_offs, h_tabs, list(range(0, 64)) + list(range(128, 256)))
+    # (b) header damage: absurd symbol counts, sub-stream sizes, stored flags
+    d = h_data.copy()
+    for c in (3, 70, 200):
+        o = int(h_offs[c])
+        d[o:o + 4] = np.frombuffer(np.uint32(0x7fffffff).tobytes(), np.uint8)
+    o = int(h_offs[10]); d[o + 4:o + 10] = 0xff
+    o = int(h_offs[11]); d[o + 3] ^= 0x80
+    r = run(d, h_offs, h_tabs, [])
+    assert r[3] == sz._lib.E_CORRUPT and r[70] == sz._lib.E_CORRUPT and r[200] == sz._lib.E_CORRUPT and r[10] == sz._lib.E_CORRUPT
+    # (c) offsets damage: not monotonic, misaligned, past the end
+    o = h_offs.copy(); o[5] = o[9]; o[100] += 2; o[150] = o[-1] + 4096
+    run(h_data, o, h_tabs, [])
+    # (d) table damage: lengths that are no prefix code at all
+    t = h_tabs.copy(); t[128:256] = 0xff; t[0:64] = 0
+    run(h_data, h_offs, t, list(range(128, 256)))
+    # and the device is still healthy
+    r = run(h_data, h_offs, h_tabs, range(nchunks))
+    assert np.array_equal(r, sizes.astype(np.int64))

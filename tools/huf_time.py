@@ -18,7 +18,8 @@ sizes = torch.empty(n, dtype=torch.int32, device=dev)
 tmp = torch.empty(int(_lib.compact_tmp_bytes(n)) + 64, dtype=torch.uint8, device=dev)
 def dec():
     _lib.check(_lib.huf_decompress_batch(hb.data.data_ptr(), hb.offsets.data_ptr(), hb.tables.data_ptr(), n, 16,
-                                         dense.data_ptr(), offs.data_ptr(), sizes.data_ptr(), tmp.data_ptr(), stream))
+                                         dense.data_ptr(), dense.numel() - 16, offs.data_ptr(), sizes.data_ptr(), None,
+                                         tmp.data_ptr(), stream))
 for _ in range(5): dec()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
