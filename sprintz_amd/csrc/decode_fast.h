@@ -70,6 +70,23 @@ __device__ __forceinline__ int sign_of(int x)
     return s;
 }
 
+// 16-bit FIRE step without the shift: D = (i16)hi16(a) * (i16)b + c.  With X = prev_delta*coef + E
+// the new delta IS the high half of X, so the recurrence feeds X straight back in
+// (verified against the C model and timed at full rate on hardware: tools/probes/mad_i16.hip).
+__device__ __forceinline__ int mad_i16_hi(int a, int b, int c)
+{
+    int d;
+    asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// a + hi16(x): the running value only matters modulo 2^16, so the unsigned high half will do
+__device__ __forceinline__ uint32_t add_hi16(uint32_t a, int x)
+{
+    uint32_t d;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(d) : "v"(a), "v"(x));
+    return d;
+}
+
 // CPL columns per lane (column = lane_d*CPL + k); EXACT: ndims == DP*CPL, so every
 // size is a compile-time constant.
 // CM: column-major destination (DecodeArgs::col_stride): the 8 samples a lane produces per block
@@ -314,9 +331,14 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
                 const int coef = FIRE ? fire_coef<W, false>(ctr[k]) : 0;
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
-                    const int delta = FIRE ? __builtin_amdgcn_sbfe(mad24(pd[k], coef, 0), W, W) : 0;
-                    pv[k] += (uint32_t)delta;
-                    pd[k] = delta;
+                    if constexpr (W == 16 && FIRE) {        // pd[k] holds X (delta in its high half), see packed_block
+                        pd[k] = mad_i16_hi(pd[k], coef, 0);
+                        pv[k] = add_hi16(pv[k], pd[k]);
+                    } else {
+                        const int delta = FIRE ? __builtin_amdgcn_sbfe(mad24(pd[k], coef, 0), W, W) : 0;
+                        pv[k] += (uint32_t)delta;
+                        pd[k] = delta;
+                    }
                     q_row(k);
                     pack_row(k, i);
                     if constexpr (Q != kQueryReduceOnly && !CM)
@@ -367,15 +389,24 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
             const int coef = FIRE ? fire_coef<W, false>(ctr[k]) : 0;
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                int delta;
-                if constexpr (FIRE) {
-                    if (i & 1) grad = mad24(sign_of(e[k][i]), pd[k], grad);   // sign(E) == sign(err)
-                    delta = __builtin_amdgcn_sbfe(mad24(pd[k], coef, e[k][i]), W, W);
+                if constexpr (W == 16 && FIRE) {
+                    // X = prev_delta*coef + E; delta = hi16(X): pd[k] carries X, never the shifted delta
+                    if (i & 1) grad = mad_i16_hi(pd[k], sign_of(e[k][i]), grad);   // sign(E) == sign(err)
+                    pd[k] = mad_i16_hi(pd[k], coef, e[k][i]);
+                    pv[k] = add_hi16(pv[k], pd[k]);
+                } else if constexpr (W == 16) {
+                    pv[k] = add_hi16(pv[k], e[k][i]);                               // delta = E >> 16
                 } else {
-                    delta = e[k][i] >> W;
+                    int delta;
+                    if constexpr (FIRE) {
+                        if (i & 1) grad = mad24(sign_of(e[k][i]), pd[k], grad);
+                        delta = __builtin_amdgcn_sbfe(mad24(pd[k], coef, e[k][i]), W, W);
+                    } else {
+                        delta = e[k][i] >> W;
+                    }
+                    pv[k] += (uint32_t)delta;
+                    pd[k] = delta;
                 }
-                pv[k] += (uint32_t)delta;
-                pd[k] = delta;
                 q_row(k);
                 pack_row(k, i);
                 if constexpr (Q != kQueryReduceOnly && !CM)
