@@ -242,7 +242,6 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
     a.qres = qs.qres;
     a.col_stride = qs.col_stride;
     const uint64_t cs = qs.col_stride;
-    if (const char* d = getenv("SPRINTZ_MI355X_DBG")) a.dbg = atoi(d);
 
     // LDS-transposed 16-byte stores need every 8 x D block of the output 16-byte aligned
     const size_t blk_bytes = (size_t)8 * D * esz;

@@ -30,7 +30,6 @@ struct DecodeArgs {
     int noheader;
     uint32_t nh_ngroups;
     uint32_t nh_remaining;
-    int dbg;                    // timing ablations only (SPRINTZ_MI355X_DBG); 0 in production
     uint32_t chunks_per_group;  // decode_fast: consecutive chunks decoded by one lane group
     // query-on-compressed (sprintz_delta.h:95-98, sprintz_xff.h:90-93, query.hpp:23-29): kernels
     // instantiated with Q != 0 reduce every column of every chunk while decoding
