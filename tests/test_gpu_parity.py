@@ -397,3 +397,22 @@ def test_huffman_decoder_survives_damaged_containers(sz):
     # and the device is still healthy
     r = run(h_data, h_offs, h_tabs, range(nchunks))
     assert np.array_equal(r, sizes.astype(np.int64))
+
+
+@pytest.mark.parametrize("name,codec,esz,ndims,chunk_len", [c for c in CONFIGS if c[0] in ("cfg2", "cfg3_10k", "cfg5", "xff8")])
+def test_generic_kernels_agree_with_the_fast_ones(sz, monkeypatch, name, codec, esz, ndims, chunk_len):
+    """SPRINTZ_MI355X_NO_FAST routes the same calls to decode_kernel.h / encode_kernel.h: same bytes, same samples"""
+    import torch
+    rng = np.random.default_rng(zlib.crc32(name.encode()) + 1)
+    data = np.concatenate([gen_walk(rng, 40 * chunk_len, ndims, esz, 5, flat_every=3), gen_fuzz(rng, 9 * chunk_len + 17 * ndims, esz, 2)])
+    cd = sz.ChunkedCodec(codec, esz, ndims, chunk_len, device="cuda:0")
+    x = torch.from_numpy(data).cuda()
+    fast = cd.compress(x)
+    monkeypatch.setenv("SPRINTZ_MI355X_NO_FAST", "1")
+    slow = cd.compress(x)
+    assert torch.equal(fast.sizes, slow.sizes) and torch.equal(fast.offsets, slow.offsets)
+    assert torch.equal(fast.data[: fast.total_bytes()], slow.data[: slow.total_bytes()])
+    out_slow = cd.decompress(fast)
+    monkeypatch.delenv("SPRINTZ_MI355X_NO_FAST")
+    out_fast = cd.decompress(slow)
+    assert torch.equal(out_slow, out_fast) and np.array_equal(out_fast.cpu().numpy(), data)
