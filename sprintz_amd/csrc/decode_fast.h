@@ -137,8 +137,9 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     // instead of faulting -- the read-ahead needs no bounds test.
     const uint64_t wave_first = (((uint64_t)blockIdx.x * kThreads + (threadIdx.x & ~63u)) >> LOG2DP) * (uint64_t)a.chunks_per_group;
     uint64_t wave_base = a.offsets[wave_first < a.nchunks ? wave_first : 0] & ~(uint64_t)15;
-    wave_base = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(wave_base >> 32)) << 32) |
-                (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)wave_base);
+    // (the builtin returns int: go through uint32_t, or a low word >= 2^31 sign-extends into the high one)
+    wave_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(wave_base >> 32)) << 32) |
+                (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wave_base);
     // rounded up to whole 16-byte pieces (gfx950 zeroes a dwordx4 whose END is out of range);
     // the <= 15 extra bytes are inside the SPRINTZ_MI355X_READ_SLACK the API asks for
     const uint64_t wave_span = ((a.offsets[a.nchunks] - wave_base) + 15) & ~(uint64_t)15;

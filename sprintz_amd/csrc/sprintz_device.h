@@ -131,6 +131,9 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-constexpr int kThreads = 256;        // 4 wavefronts per workgroup
+#ifndef SPRINTZ_THREADS
+#define SPRINTZ_THREADS 256
+#endif
+constexpr int kThreads = SPRINTZ_THREADS;        // wavefronts per workgroup x 64
 
 }  // namespace sprintz

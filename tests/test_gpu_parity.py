@@ -416,3 +416,31 @@ def test_generic_kernels_agree_with_the_fast_ones(sz, monkeypatch, name, codec, 
     monkeypatch.delenv("SPRINTZ_MI355X_NO_FAST")
     out_fast = cd.decompress(slow)
     assert torch.equal(out_slow, out_fast) and np.array_equal(out_fast.cpu().numpy(), data)
+
+
+def test_containers_beyond_4_GiB(sz):
+    """520 000 chunks of mostly incompressible data: the container offsets pass 2^31 and 2^32, the output
+    passes 2^32 bytes (a sign-extended 32-bit word in the decoder's wave base once broke this);
+    also through the Huffman stage and the reduce-only query"""
+    import torch
+    n, chunk_len, ndims = 520000, 5120, 8
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    x = torch.randint(0, 65536, (n * chunk_len,), generator=g, device="cuda", dtype=torch.int32).to(torch.uint16)
+    xv = x.view(torch.int16).view(n, chunk_len)
+    xv[::4] = xv[::4] & 0x00ff                                   # every 4th chunk compresses 2:1 (coded Huffman records too)
+    cd = sz.ChunkedCodec("xff", 2, ndims, chunk_len)
+    batch = cd.compress(x)
+    assert batch.total_bytes() > (1 << 32) + (1 << 28)
+    rets = torch.empty(n, dtype=torch.int64, device="cuda")
+    out = cd.decompress(batch, rets=rets)
+    assert bool((rets == chunk_len).all()) and torch.equal(out, x)
+    del out
+    res, _ = cd.query(batch, "sum")
+    want = x.view(torch.int16).to(torch.int64).bitwise_and(0xffff).view(-1, ndims).sum(dim=0)
+    assert torch.equal(res, want)
+    hb = sz.huf_compress(batch)
+    back = sz.huf_decompress(hb, batch.total_bytes(), rets=rets)
+    assert torch.equal(back.sizes, batch.sizes) and torch.equal(back.offsets, batch.offsets)
+    out = cd.decompress(back)
+    assert torch.equal(out, x)
