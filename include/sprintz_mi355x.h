@@ -241,6 +241,35 @@ int64_t sprintz_mi355x_query_xff_8b(const int8_t* src, uint8_t* dest, int op, in
 int64_t sprintz_mi355x_query_xff_16b(const int16_t* src, uint16_t* dest, int op, int materialize, uint32_t flags, uint64_t* result);
 
 /* ------------------------------------------------------------------------
+ * Stand-alone transforms.  Replace
+ *   encode_delta_rowmajor_{8b,16b} / decode_delta_rowmajor_{8b,16b}              cpp/Compress/delta.h:17-24,53-60
+ *   encode_doubledelta_rowmajor_{8b,16b} / decode_doubledelta_rowmajor_{8b,16b}  cpp/Compress/delta.h:36-43,63-68
+ * Per column (element index mod ndims), state starting at zero, arithmetic
+ * wrapping at the element width: delta y[r] = x[r] - x[r-1]; double delta
+ * y[r] = x[r] - 2 x[r-1] + x[r-2].  One call transforms ONE stream of any
+ * length; the decode is a multi-level scan over its rows (transforms.hip).
+ *   kind        : SPRINTZ_TRANSFORM_DELTA / SPRINTZ_TRANSFORM_DOUBLEDELTA
+ * Device forms: len elements in, len elements out, no header;
+ *   d_tmp: sprintz_mi355x_transform_tmp_bytes(kind, elem_bytes, len, ndims).
+ * Host forms: the reference's container -- a 6-byte header {u32 len; u16 ndims}
+ * (format.h:65-86) before the transformed elements; encode returns len + header
+ * length in elements (6 @8b, 3 @16b; delta.cpp:120), decode returns len.  decode
+ * with raw_len == raw_ndims == 0 reads the header; otherwise src is headerless
+ * (the reference's 4-argument form, delta.h:19).
+ * ---------------------------------------------------------------------- */
+#define SPRINTZ_TRANSFORM_DELTA 0
+#define SPRINTZ_TRANSFORM_DOUBLEDELTA 1
+size_t sprintz_mi355x_transform_tmp_bytes(int kind, int elem_bytes, uint64_t len, uint16_t ndims);
+int sprintz_mi355x_transform_encode_device(int kind, int elem_bytes, const void* d_src, uint64_t len, uint16_t ndims, void* d_dest,
+                                           void* hip_stream);
+int sprintz_mi355x_transform_decode_device(int kind, int elem_bytes, const void* d_src, uint64_t len, uint16_t ndims, void* d_dest,
+                                           void* d_tmp, void* hip_stream);
+int64_t sprintz_mi355x_transform_encode(int kind, int elem_bytes, const void* src, uint32_t len, void* dest, uint16_t ndims,
+                                        int write_size);
+int64_t sprintz_mi355x_transform_decode(int kind, int elem_bytes, const void* src, void* dest, uint32_t raw_len, uint16_t raw_ndims);
+const char* sprintz_mi355x_transform_last_error(void);
+
+/* ------------------------------------------------------------------------
  * Host convenience: chunked codec over host buffers (what lzbench does per
  * block).  Stages through device memory; PCIe-inclusive by construction.
  * comp layout: chunk streams concatenated byte-dense; offsets[nchunks+1].

@@ -14,6 +14,7 @@
 #include "sprintz.h"   /* -I/root/reference/cpp/Compress : sprintz.h:16-32 */
 #include "sprintz_delta.h"   /* compress_rowmajor_delta_rle_*: :49-51,68-70; query_rowmajor_delta_rle_*: :95-98 */
 #include "sprintz_xff.h"     /* compress_rowmajor_xff_rle_*: :45-55; query_rowmajor_xff_rle_*: :90-93 */
+#include "delta.h"           /* encode/decode_{delta,doubledelta}_rowmajor_{8b,16b}: :17-68 */
 
 extern "C" {
 
@@ -104,6 +105,29 @@ int64_t ref_query(int codec, int elem_bytes, const void* src, void* dest, int op
     }
     return codec ? query_rowmajor_xff_rle_16b((const int16_t*)src, (uint16_t*)dest, qp)
                  : query_rowmajor_delta_rle_16b((const int16_t*)src, (uint16_t*)dest, qp);
+}
+
+/* stand-alone transforms (delta.h:17-68); kind 0 = delta, 1 = double delta */
+uint32_t ref_transform_encode(int kind, int elem_bytes, const void* src, uint32_t len, void* dest, uint16_t ndims, int write_size)
+{
+    const bool ws = write_size != 0;
+    if (elem_bytes == 1) {
+        return kind ? encode_doubledelta_rowmajor_8b((const uint8_t*)src, len, (int8_t*)dest, ndims, ws)
+                    : encode_delta_rowmajor_8b((const uint8_t*)src, len, (int8_t*)dest, ndims, ws);
+    }
+    return kind ? encode_doubledelta_rowmajor_16b((const uint16_t*)src, len, (int16_t*)dest, ndims, ws)
+                : encode_delta_rowmajor_16b((const uint16_t*)src, len, (int16_t*)dest, ndims, ws);
+}
+
+/* src carries the 6-byte header (format.h:65-86) */
+uint32_t ref_transform_decode(int kind, int elem_bytes, const void* src, void* dest)
+{
+    if (elem_bytes == 1) {
+        return kind ? decode_doubledelta_rowmajor_8b((const int8_t*)src, (uint8_t*)dest)
+                    : decode_delta_rowmajor_8b((const int8_t*)src, (uint8_t*)dest);
+    }
+    return kind ? decode_doubledelta_rowmajor_16b((const int16_t*)src, (uint16_t*)dest)
+                : decode_delta_rowmajor_16b((const int16_t*)src, (uint16_t*)dest);
 }
 
 }  // extern "C"

@@ -10,6 +10,9 @@ from .codec import (ChunkedCodec, CompressedBatch, HufBatch, compress_chunked, d
                     huf_compress, huf_decompress, QueryParams, QueryTypes,
                     query_rowmajor_delta_rle_8b, query_rowmajor_delta_rle_16b, query_rowmajor_xff_rle_8b,
                     query_rowmajor_xff_rle_16b,
+                    encode_delta_rowmajor_8b, encode_delta_rowmajor_16b, encode_doubledelta_rowmajor_8b,
+                    encode_doubledelta_rowmajor_16b, decode_delta_rowmajor_8b, decode_delta_rowmajor_16b,
+                    decode_doubledelta_rowmajor_8b, decode_doubledelta_rowmajor_16b, transform_device,
                     sprintz_compress_delta_8b, sprintz_compress_delta_16b, sprintz_compress_xff_8b,
                     sprintz_compress_xff_16b, sprintz_decompress_delta_8b, sprintz_decompress_delta_16b,
                     sprintz_decompress_xff_8b, sprintz_decompress_xff_16b)
@@ -17,6 +20,9 @@ from .codec import (ChunkedCodec, CompressedBatch, HufBatch, compress_chunked, d
 __all__ = [
     "SprintzError", "abi_version", "last_error", "ChunkedCodec", "CompressedBatch", "HufBatch", "huf_compress", "huf_decompress",
     "compress_chunked", "decompress_chunked", "decompress_noheader", "QueryParams", "QueryTypes",
+    "encode_delta_rowmajor_8b", "encode_delta_rowmajor_16b", "encode_doubledelta_rowmajor_8b", "encode_doubledelta_rowmajor_16b",
+    "decode_delta_rowmajor_8b", "decode_delta_rowmajor_16b", "decode_doubledelta_rowmajor_8b", "decode_doubledelta_rowmajor_16b",
+    "transform_device",
     "query_rowmajor_delta_rle_8b", "query_rowmajor_delta_rle_16b", "query_rowmajor_xff_rle_8b", "query_rowmajor_xff_rle_16b",
     "sprintz_compress_delta_8b", "sprintz_compress_delta_16b", "sprintz_compress_xff_8b", "sprintz_compress_xff_16b",
     "sprintz_decompress_delta_8b", "sprintz_decompress_delta_16b", "sprintz_decompress_xff_8b",

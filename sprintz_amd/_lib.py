@@ -98,6 +98,15 @@ query = {
 compress_batch_colmajor = _sig("sprintz_mi355x_compress_batch_colmajor", _i, _i, _i, _vp, _u64, _u64, _u32, _u16, _vp, _sz, _vp, _vp, _vp)
 decompress_batch_colmajor = _sig("sprintz_mi355x_decompress_batch_colmajor", _i, _i, _i, _vp, _vp, _u64, _u32, _u16, _u64, _vp, _vp, _vp)
 
+# (6) stand-alone transforms (delta.h:17-68)
+TRANSFORM_DELTA, TRANSFORM_DOUBLEDELTA = 0, 1
+transform_tmp_bytes = _sig("sprintz_mi355x_transform_tmp_bytes", _sz, _i, _i, _u64, _u16)
+transform_encode_device = _sig("sprintz_mi355x_transform_encode_device", _i, _i, _i, _vp, _u64, _u16, _vp, _vp)
+transform_decode_device = _sig("sprintz_mi355x_transform_decode_device", _i, _i, _i, _vp, _u64, _u16, _vp, _vp, _vp)
+transform_encode = _sig("sprintz_mi355x_transform_encode", _i64, _i, _i, _vp, _u32, _vp, _u16, _i)
+transform_decode = _sig("sprintz_mi355x_transform_decode", _i64, _i, _i, _vp, _vp, _u32, _u16)
+_transform_last_error = _sig("sprintz_mi355x_transform_last_error", C.c_char_p)
+
 # host convenience
 compress_chunked_host = _sig("sprintz_mi355x_compress_chunked_host", _i64, _i, _i, _vp, _u64, _u32, _u16, _vp, _sz, _vp)
 decompress_chunked_host = _sig("sprintz_mi355x_decompress_chunked_host", _i64, _i, _i, _vp, _vp, _u64, _u32, _u16, _vp)
@@ -119,11 +128,13 @@ EXPORTED_SYMBOLS = [
     "sprintz_mi355x_query_delta_8b", "sprintz_mi355x_query_xff_8b",
     "sprintz_mi355x_query_delta_16b", "sprintz_mi355x_query_xff_16b",
     "sprintz_mi355x_compress_batch_colmajor", "sprintz_mi355x_decompress_batch_colmajor",
+    "sprintz_mi355x_transform_tmp_bytes", "sprintz_mi355x_transform_encode_device", "sprintz_mi355x_transform_decode_device",
+    "sprintz_mi355x_transform_encode", "sprintz_mi355x_transform_decode", "sprintz_mi355x_transform_last_error",
 ]
 
 
 def last_error():
-    return _last_error().decode("utf-8", "replace")
+    return _last_error().decode("utf-8", "replace") or _transform_last_error().decode("utf-8", "replace")
 
 
 def check(rc):

@@ -295,6 +295,72 @@ def query_rowmajor_xff_rle_16b(src, dest, qp, general_layout=True):
     return _query("xff", 2, src, dest, qp, general_layout)
 
 
+# ---- stand-alone transforms (delta.h:17-68) -------------------------------------------------
+
+def _enc_t(kind, esz, src, length, dest, ndims, write_size):
+    src = np.ascontiguousarray(src)
+    if src.dtype.itemsize != esz or src.size < length:
+        raise ValueError("src dtype/size does not match the call")
+    if dest.nbytes < length * esz + (6 if write_size else 0):
+        raise ValueError("dest too small")
+    return int(_lib.transform_encode(kind, esz, _np_ptr(src), length, _np_ptr(dest), ndims, int(bool(write_size))))
+
+
+def _dec_t(kind, esz, src, dest, length=0, ndims=0):
+    src = np.ascontiguousarray(src)
+    return int(_lib.transform_decode(kind, esz, _np_ptr(src), _np_ptr(dest), length, ndims))
+
+
+def encode_delta_rowmajor_8b(src, len, dest, ndims, write_size=True):  # noqa: A002 - reference's name (delta.h:17)
+    return _enc_t(_lib.TRANSFORM_DELTA, 1, src, len, dest, ndims, write_size)
+
+
+def encode_delta_rowmajor_16b(src, len, dest, ndims, write_size=True):  # noqa: A002 (delta.h:53)
+    return _enc_t(_lib.TRANSFORM_DELTA, 2, src, len, dest, ndims, write_size)
+
+
+def encode_doubledelta_rowmajor_8b(src, len, dest, ndims, write_size=True):  # noqa: A002 (delta.h:36)
+    return _enc_t(_lib.TRANSFORM_DOUBLEDELTA, 1, src, len, dest, ndims, write_size)
+
+
+def encode_doubledelta_rowmajor_16b(src, len, dest, ndims, write_size=True):  # noqa: A002 (delta.h:63)
+    return _enc_t(_lib.TRANSFORM_DOUBLEDELTA, 2, src, len, dest, ndims, write_size)
+
+
+def decode_delta_rowmajor_8b(src, dest, len=0, ndims=0):  # noqa: A002 - both reference forms (delta.h:19-24)
+    return _dec_t(_lib.TRANSFORM_DELTA, 1, src, dest, len, ndims)
+
+
+def decode_delta_rowmajor_16b(src, dest, len=0, ndims=0):  # noqa: A002
+    return _dec_t(_lib.TRANSFORM_DELTA, 2, src, dest, len, ndims)
+
+
+def decode_doubledelta_rowmajor_8b(src, dest, len=0, ndims=0):  # noqa: A002
+    return _dec_t(_lib.TRANSFORM_DOUBLEDELTA, 1, src, dest, len, ndims)
+
+
+def decode_doubledelta_rowmajor_16b(src, dest, len=0, ndims=0):  # noqa: A002
+    return _dec_t(_lib.TRANSFORM_DOUBLEDELTA, 2, src, dest, len, ndims)
+
+
+def transform_device(kind, x, ndims, inverse=False, out=None):
+    """delta ("delta") / double delta ("doubledelta") of one row-major stream resident in HBM
+    (torch uint8/uint16 tensor); inverse=True undoes it (a multi-level scan over the rows)."""
+    import torch
+    k = {"delta": _lib.TRANSFORM_DELTA, "doubledelta": _lib.TRANSFORM_DOUBLEDELTA}[kind]
+    esz = x.dtype.itemsize
+    x = x.contiguous().reshape(-1)
+    if out is None:
+        out = torch.empty_like(x)
+    stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    if not inverse:
+        _lib.check(_lib.transform_encode_device(k, esz, x.data_ptr(), x.numel(), ndims, out.data_ptr(), stream))
+    else:
+        tmp = torch.empty(int(_lib.transform_tmp_bytes(k, esz, x.numel(), ndims)), dtype=torch.uint8, device=x.device)
+        _lib.check(_lib.transform_decode_device(k, esz, x.data_ptr(), x.numel(), ndims, out.data_ptr(), tmp.data_ptr(), stream))
+    return out
+
+
 # ---- optional Huffman stage (device) ------------------------------------------------
 
 @dataclass

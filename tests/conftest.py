@@ -46,6 +46,18 @@ def golden_rowmajor():
 
 
 @pytest.fixture(scope="session")
+def golden_transforms():
+    """containers of the reference's stand-alone transforms (oracle/gen_golden_transforms.py)"""
+    import json
+    import numpy as np
+    gdir = os.path.join(HERE, "golden")
+    with open(os.path.join(gdir, "golden_transforms_v1.json")) as f:
+        manifest = json.load(f)["cases"]
+    arrays = np.load(os.path.join(gdir, "golden_transforms_v1.npz"))
+    return manifest, arrays
+
+
+@pytest.fixture(scope="session")
 def golden():
     import json
     import numpy as np

@@ -154,6 +154,25 @@ class Oracle:
         ret = f(CODECS[codec], esz, padded.ctypes.data, out.ctypes.data, int(general), op, res.ctypes.data)
         return out[:max(int(ret), 0)].copy(), res[:ndims]
 
+    # ---- stand-alone transforms (oracle/transforms_oracle.c): kind 0 delta, 1 double delta
+    def transform_encode(self, kind, data, ndims, write_size=True):
+        """-> (container bytes, return value)"""
+        f = _bind(self.lib, "oracle_transform_encode", C.c_uint32,
+                  [C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint16, C.c_int])
+        data = np.ascontiguousarray(data)
+        esz = data.dtype.itemsize
+        out = np.full(data.size * esz + 6 + 64, 0xAB, np.uint8)
+        ret = f(kind, esz, data.ctypes.data, data.size, out.ctypes.data, ndims, int(write_size))
+        return out[: data.size * esz + (6 if write_size else 0)].copy(), int(ret)
+
+    def transform_decode(self, kind, container, esz):
+        f = _bind(self.lib, "oracle_transform_decode", C.c_uint32, [C.c_int, C.c_int, C.c_void_p, C.c_void_p])
+        container = np.ascontiguousarray(container, dtype=np.uint8)
+        n = int(np.frombuffer(container[:4].tobytes(), np.uint32)[0])
+        out = np.zeros(n + 64, DTYPES[esz])
+        ret = f(kind, esz, container.ctypes.data, out.ctypes.data)
+        return out[:n].copy(), int(ret)
+
     def compress_chunks(self, codec, data, chunk_len, ndims):
         """-> (list of per-chunk streams)"""
         data = np.ascontiguousarray(data)
@@ -199,6 +218,28 @@ class Reference:
 
     def has_query(self):
         return hasattr(self.lib, "ref_query")
+
+    def has_transforms(self):
+        return hasattr(self.lib, "ref_transform_encode")
+
+    def transform_encode(self, kind, data, ndims):
+        """encode_{delta,doubledelta}_rowmajor_{8b,16b}(write_size=true) -> (container bytes, return value)"""
+        f = _bind(self.lib, "ref_transform_encode", C.c_uint32,
+                  [C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint16, C.c_int])
+        data = np.ascontiguousarray(data)
+        esz = data.dtype.itemsize
+        src = np.concatenate([data.ravel(), np.zeros(128, data.dtype)])           # the vector loop reads past the end
+        out = np.full(data.size * esz + 6 + 512, 0xAB, np.uint8)
+        ret = f(kind, esz, src.ctypes.data, data.size, out.ctypes.data, ndims, 1)
+        return out[: data.size * esz + 6].copy(), int(ret)
+
+    def transform_decode(self, kind, container, esz):
+        f = _bind(self.lib, "ref_transform_decode", C.c_uint32, [C.c_int, C.c_int, C.c_void_p, C.c_void_p])
+        container = np.concatenate([np.ascontiguousarray(container, dtype=np.uint8), np.zeros(512, np.uint8)])
+        n = int(np.frombuffer(container[:4].tobytes(), np.uint32)[0])
+        out = np.zeros(n + 512, DTYPES[esz])
+        ret = f(kind, esz, container.ctypes.data, out.ctypes.data)
+        return out[:n].copy(), int(ret)
 
     def compress_rowmajor_raw(self, codec, data, ndims):
         """compress_rowmajor_{delta,xff}_rle_{8b,16b} (sprintz_delta.h:49, sprintz_xff.h:45-55):

@@ -1,0 +1,65 @@
+"""GPU tests (-m gpu): stand-alone transforms (delta.h:17-68) through the C-ABI, against the
+containers minted from the compiled reference, the oracle, and at sizes where the decode's
+multi-level scan has several levels.  Nothing here reads /root/reference."""
+import numpy as np
+import pytest
+
+from harness import DTYPES
+
+pytestmark = pytest.mark.gpu
+
+NAMES = {0: "delta", 1: "doubledelta"}
+
+
+@pytest.fixture(scope="module")
+def sz():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import sprintz_amd
+    return sprintz_amd
+
+
+def test_reference_containers_single_call(sz, golden_transforms):
+    """encode_* writes the reference's bytes and return value; decode_* (both forms) restores the input"""
+    manifest, arrays = golden_transforms
+    for m in manifest:
+        x, cont = arrays[m["name"] + "_in"], arrays[m["name"] + "_container"]
+        esz, D, n, kind = m["esz"], m["ndims"], m["n"], m["kind"]
+        enc = getattr(sz, f"encode_{NAMES[kind]}_rowmajor_{8 * esz}b")
+        dec = getattr(sz, f"decode_{NAMES[kind]}_rowmajor_{8 * esz}b")
+        dest = np.full(cont.size + 32, 0xAB, np.uint8)
+        ret = enc(x, n, dest, D)
+        assert ret == m["ret"], m
+        assert np.array_equal(dest[:cont.size], cont) and (dest[cont.size:] == 0xAB).all(), m
+        out = np.full(n + 16, 0xCD, DTYPES[esz])
+        assert dec(cont, out) == n and np.array_equal(out[:n], x) and (out[n:] == 0xCD).all(), m
+        out[:] = 0xCD
+        assert dec(cont[6:], out, n, D) == n and np.array_equal(out[:n], x), m       # headerless 4-argument form
+        dest2 = np.full(cont.size, 0xAB, np.uint8)
+        assert enc(x, n, dest2, D, False) == n and np.array_equal(dest2[:n * esz], cont[6:]), m   # write_size=false
+
+
+@pytest.mark.parametrize("kind", ["delta", "doubledelta"])
+@pytest.mark.parametrize("esz,ndims,n", [(2, 8, 8 * 1_000_003), (1, 80, 80 * 70_001 + 13), (2, 3, 3 * 5_000_000 + 1), (1, 1, 3_000_001),
+                                         (2, 300, 300 * 40_000), (2, 32, 32 * (1 << 20))])
+def test_long_streams_on_device(sz, oracle, kind, esz, ndims, n):
+    """one stream of millions of rows: element-wise encode, scan decode (3 to 6 levels)"""
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(n % 1000)
+    x = torch.randint(0, 1 << (8 * esz), (n,), generator=g, device="cuda", dtype=torch.int32).to(torch.uint8 if esz == 1 else torch.uint16)
+    y = sz.transform_device(kind, x, ndims)
+    # spot-check the encode against the oracle on the head and against the definition on the whole
+    head = x[: 64 * ndims + 5].cpu().numpy().view(DTYPES[esz])
+    cont, _ = oracle.transform_encode(0 if kind == "delta" else 1, head, ndims)
+    assert np.array_equal(y[: head.size].cpu().numpy().view(DTYPES[esz]), cont[6:].view(DTYPES[esz]))
+    xi = x.view(torch.int8 if esz == 1 else torch.int16).to(torch.int32)
+    p1 = torch.zeros_like(xi); p1[ndims:] = xi[:-ndims]
+    want = xi - p1
+    if kind == "doubledelta":
+        p2 = torch.zeros_like(xi); p2[2 * ndims:] = xi[:-2 * ndims]
+        want = xi - 2 * p1 + p2
+    mask = (1 << (8 * esz)) - 1
+    assert torch.equal(y.view(torch.int8 if esz == 1 else torch.int16).to(torch.int32) & mask, want & mask)
+    back = sz.transform_device(kind, y, ndims, inverse=True)
+    assert torch.equal(back, x)
