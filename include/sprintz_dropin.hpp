@@ -84,4 +84,25 @@ inline int64_t query_rowmajor_xff_rle_16b(const int16_t* src, uint16_t* dest, co
     return sprintz_mi355x_query_xff_16b(src, dest, (int)qp.op, qp.materialize ? 1 : 0, SPRINTZ_QUERY_GENERAL_LAYOUT, result);
 }
 
+// ================================================================ stand-alone transforms (delta.h:17-68)
+#define SPRINTZ_DROPIN_TRANSFORM(NAME, KIND, BITS, ESZ)                                                                       \
+    inline uint32_t encode_##NAME##_rowmajor_##BITS##b(const uint##BITS##_t* src, uint32_t len, int##BITS##_t* dest, uint16_t ndims,  \
+                                                       bool write_size = true)                                                \
+    {                                                                                                                         \
+        return (uint32_t)sprintz_mi355x_transform_encode(KIND, ESZ, src, len, dest, ndims, write_size ? 1 : 0);               \
+    }                                                                                                                         \
+    inline uint32_t decode_##NAME##_rowmajor_##BITS##b(const int##BITS##_t* src, uint32_t len, uint##BITS##_t* dest, uint16_t ndims)  \
+    {                                                                                                                         \
+        return ndims == 0 ? 0u : (uint32_t)sprintz_mi355x_transform_decode(KIND, ESZ, src, dest, len, ndims);                 \
+    }                                                                                                                         \
+    inline uint32_t decode_##NAME##_rowmajor_##BITS##b(const int##BITS##_t* src, uint##BITS##_t* dest)                        \
+    {                                                                                                                         \
+        return (uint32_t)sprintz_mi355x_transform_decode(KIND, ESZ, src, dest, 0, 0);                                         \
+    }
+SPRINTZ_DROPIN_TRANSFORM(delta, SPRINTZ_TRANSFORM_DELTA, 8, 1)
+SPRINTZ_DROPIN_TRANSFORM(delta, SPRINTZ_TRANSFORM_DELTA, 16, 2)
+SPRINTZ_DROPIN_TRANSFORM(doubledelta, SPRINTZ_TRANSFORM_DOUBLEDELTA, 8, 1)
+SPRINTZ_DROPIN_TRANSFORM(doubledelta, SPRINTZ_TRANSFORM_DOUBLEDELTA, 16, 2)
+#undef SPRINTZ_DROPIN_TRANSFORM
+
 #endif  // SPRINTZ_DROPIN_HPP

@@ -19,6 +19,7 @@
 
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -133,6 +134,109 @@ __global__ void __launch_bounds__(kTB) apply_kernel(Level<U> lo, uint64_t len, u
     }
 }
 
+// ---------------------------------------------------------------- decode, small rows: one wavefront scans a run of rows
+// When a row is a power-of-two number (<= 64) of 16-byte / 4-byte / element-sized pieces, the
+// lanes of a wavefront take CONSECUTIVE pieces (a coalesced 1 KB / 256 B / 64-element load =
+// 64/Dv rows), scan across lanes at stride Dv with the composition above (the right operand of
+// step s covers exactly 2^s rows), add the state carried from the rows before, store, and carry
+// the last row's state into the next load.  A run of kRunLoads loads per wavefront is one "row"
+// of level 1; the levels above it reuse reduce_kernel / apply_kernel on the summaries, which
+// have the layout of the stream's rows (packed lanes ARE elements).
+constexpr int kRunLoads = 16;
+
+struct P16 {                                            // 2 x u16 in a dword: v_pk_add_u16 / v_pk_mul_lo_u16
+    typedef uint32_t T;
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ T zero() { return 0; }
+    static __device__ __forceinline__ T add(T a, T b) { return __builtin_bit_cast(T, (us2)(__builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b))); }
+    static __device__ __forceinline__ T mul(T a, uint32_t n)
+    {
+        const us2 nn = {(unsigned short)n, (unsigned short)n};
+        return __builtin_bit_cast(T, (us2)(__builtin_bit_cast(us2, a) * nn));
+    }
+    static __device__ __forceinline__ T shfl(T v, int src) { return (T)__shfl((int)v, src); }
+};
+struct P8 {                                             // 4 x u8 in a dword
+    typedef uint32_t T;
+    static __device__ __forceinline__ T zero() { return 0; }
+    static __device__ __forceinline__ T add(T a, T b) { return ((a & 0x7f7f7f7fu) + (b & 0x7f7f7f7fu)) ^ ((a ^ b) & 0x80808080u); }
+    static __device__ __forceinline__ T mul(T a, uint32_t n)
+    {
+        n &= 0xffu;
+        return ((a & 0x00ff00ffu) * n & 0x00ff00ffu) | ((((a >> 8) & 0x00ff00ffu) * n & 0x00ff00ffu) << 8);
+    }
+    static __device__ __forceinline__ T shfl(T v, int src) { return (T)__shfl((int)v, src); }
+};
+template <typename U> struct S1x {                      // one element
+    typedef U T;
+    static __device__ __forceinline__ T zero() { return 0; }
+    static __device__ __forceinline__ T add(T a, T b) { return (T)(a + b); }
+    static __device__ __forceinline__ T mul(T a, uint32_t n) { return (T)(a * n); }
+    static __device__ __forceinline__ T shfl(T v, int src) { return (T)__shfl((int)v, src); }
+};
+template <typename P> struct V4 {                       // 4 packed dwords = 16 bytes
+    struct __attribute__((aligned(16))) T { uint32_t v[4]; };
+    static __device__ __forceinline__ T zero() { return T{{0, 0, 0, 0}}; }
+    static __device__ __forceinline__ T add(T a, T b) { T r; for (int k = 0; k < 4; k++) r.v[k] = P::add(a.v[k], b.v[k]); return r; }
+    static __device__ __forceinline__ T mul(T a, uint32_t n) { T r; for (int k = 0; k < 4; k++) r.v[k] = P::mul(a.v[k], n); return r; }
+    static __device__ __forceinline__ T shfl(T a, int src) { T r; for (int k = 0; k < 4; k++) r.v[k] = P::shfl(a.v[k], src); return r; }
+};
+
+// STORE = false: write the run's summary (S1 [, S2]) ; STORE = true: read the run's incoming state and write x
+template <typename E, int KIND, bool STORE>
+__global__ void __launch_bounds__(kTB) wave_scan_kernel(const typename E::T* y, uint64_t len_e, uint32_t log2_dv, uint64_t nruns,
+                                                        const typename E::T* xin, const typename E::T* din, typename E::T* s1_out,
+                                                        typename E::T* s2_out, typename E::T* dest)
+{
+    typedef typename E::T T;
+    const uint64_t run = ((uint64_t)blockIdx.x * kTB + threadIdx.x) >> 6;
+    if (run >= nruns) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t dv = 1u << log2_dv;
+    const int c = lane & (int)(dv - 1);                 // piece of the row this lane holds
+    const int r = lane >> log2_dv;                      // row of the load
+    const int rpw = 64 >> log2_dv;                      // rows per load
+    T x = E::zero(), d = E::zero();                     // state entering the next load (per column piece)
+    if (STORE && xin) {
+        x = xin[run * dv + c];
+        if (KIND) d = din[run * dv + c];
+    }
+    const uint64_t e0 = run * (uint64_t)kRunLoads * 64;
+    for (int j = 0; j < kRunLoads; j++) {
+        const uint64_t e = e0 + (uint64_t)j * 64 + lane;
+        if (e0 + (uint64_t)j * 64 >= len_e) break;      // wave-uniform
+        const bool have = e < len_e;
+        T s1 = have ? y[e] : E::zero();
+        T s2 = s1;
+        for (int st = 0; (1 << st) < rpw; st++) {       // inclusive scan over the rows of the load, stride dv lanes
+            const int src = lane - (int)(dv << st);
+            const T l1 = E::shfl(s1, src < 0 ? lane : src);
+            if (KIND) {
+                const T l2 = E::shfl(s2, src < 0 ? lane : src);
+                if (r >= (1 << st)) s2 = E::add(E::add(l2, E::mul(l1, 1u << st)), s2);
+            }
+            if (r >= (1 << st)) s1 = E::add(l1, s1);
+        }
+        // rows [0..r] of this load on top of the state before it
+        T xr, dr;
+        if (KIND) {
+            xr = E::add(E::add(x, E::mul(d, (uint32_t)(r + 1))), s2);
+            dr = E::add(d, s1);
+        } else {
+            xr = E::add(x, s1);
+            dr = E::zero();
+        }
+        if (STORE && have) dest[e] = xr;
+        const int last = (rpw - 1) * (int)dv + c;       // the load's last row, same column piece
+        x = E::shfl(xr, last);
+        if (KIND) d = E::shfl(dr, last);
+    }
+    if (!STORE && r == 0) {                             // the run's summary: the state it turns (0, 0) into
+        s1_out[run * dv + c] = KIND ? d : x;
+        if (KIND) s2_out[run * dv + c] = x;
+    }
+}
+
 thread_local std::string g_err;
 int fail(int code, const char* what)
 {
@@ -163,29 +267,31 @@ Plan make_plan(int kind, int esz, uint64_t len, uint32_t D)
     return p;
 }
 
+// levels above `base` (base.rows runs of base.span original rows each, summaries already in base.s1/s2):
+// fills base.xin / base.din with every run's incoming state.  With base = the input itself
+// (span 1) the last apply writes x into dest instead.
 template <typename U, int KIND>
-int decode_device(const U* y, uint64_t len, uint32_t D, U* dest, uint8_t* tmp, hipStream_t st)
+int scan_levels(Level<U> base, uint64_t len, uint32_t D, uint64_t rows0, U* dest, uint8_t* tmp, hipStream_t st)
 {
-    const Plan p = make_plan(KIND, sizeof(U), len, D);
-    const size_t L = p.rows.size();
-    std::vector<Level<U>> lv(L);
-    lv[0] = Level<U>{y, y, nullptr, nullptr, p.rows[0], 1};
+    std::vector<Level<U>> lv;
+    lv.push_back(base);
     uint8_t* t = tmp;
     auto take = [&](uint64_t n) { U* q = (U*)t; t += (n * D * sizeof(U) + 63) & ~(size_t)63; return q; };
-    for (size_t k = 1; k < L; k++) {
-        U* s1 = take(p.rows[k]);
-        U* s2 = KIND ? take(p.rows[k]) : nullptr;
-        U* xi = take(p.rows[k]);
-        U* di = KIND ? take(p.rows[k]) : nullptr;
-        lv[k] = Level<U>{s1, s2, xi, di, p.rows[k], p.span[k]};
+    while (lv.back().rows > 1) {
+        const uint64_t rows = (lv.back().rows + R - 1) / R;
+        U* s1 = take(rows);
+        U* s2 = KIND ? take(rows) : nullptr;
+        U* xi = take(rows);
+        U* di = KIND ? take(rows) : nullptr;
+        lv.push_back(Level<U>{s1, s2, xi, di, rows, lv.back().span * R});
     }
-    const uint64_t rows0 = p.rows[0];
+    const size_t L = lv.size();
     for (size_t k = 0; k + 1 < L; k++) {
         const uint64_t threads = lv[k + 1].rows * D;
         hipLaunchKernelGGL((reduce_kernel<U, KIND>), dim3((unsigned)((threads + kTB - 1) / kTB)), dim3(kTB), 0, st, lv[k], len, D, rows0,
                            (U*)lv[k + 1].s1, (U*)lv[k + 1].s2, lv[k + 1].rows);
     }
-    if (L == 1) {                                        // a single row: one pseudo-run above it
+    if (L == 1) {                                        // a single run: one pseudo-run above it, entering with the zero state
         hipLaunchKernelGGL((apply_kernel<U, KIND>), dim3((unsigned)((D + kTB - 1) / kTB)), dim3(kTB), 0, st, lv[0], len, D, rows0,
                            (const U*)nullptr, (const U*)nullptr, (uint64_t)1, dest);
     }
@@ -196,6 +302,69 @@ int decode_device(const U* y, uint64_t len, uint32_t D, U* dest, uint8_t* tmp, h
                            top ? (const U*)nullptr : (const U*)lv[k].xin, top ? (const U*)nullptr : (const U*)lv[k].din, lv[k].rows, dest);
     }
     return hipGetLastError() == hipSuccess ? 0 : fail(SPRINTZ_E_HIP, "transform decode launch");
+}
+
+// piece size of the wave-scan path for this stream: 16, 4 or sizeof(U) bytes -- the largest that
+// divides the row, the stream and the pointers' alignment, with a power-of-two piece count <= 64
+template <typename U>
+int wave_piece_bytes(const void* y, const void* dest, uint64_t len, uint32_t D)
+{
+    const uint64_t row_bytes = (uint64_t)D * sizeof(U), total = len * sizeof(U);
+    for (int pb : {16, 4, (int)sizeof(U)}) {
+        if (pb < (int)sizeof(U) || row_bytes % pb || total % pb) continue;
+        if (((uintptr_t)y | (uintptr_t)dest) % pb) continue;
+        const uint64_t dv = row_bytes / pb;
+        if (dv <= 64 && (dv & (dv - 1)) == 0) return pb;
+    }
+    return 0;
+}
+
+template <typename U, typename E, int KIND>
+int decode_wave(const U* y, uint64_t len, uint32_t D, U* dest, uint8_t* tmp, hipStream_t st)
+{
+    typedef typename E::T T;
+    const uint32_t dv = (uint32_t)((uint64_t)D * sizeof(U) / sizeof(T));
+    uint32_t log2_dv = 0;
+    while ((1u << log2_dv) < dv) log2_dv++;
+    const uint64_t len_e = len * sizeof(U) / sizeof(T);
+    const uint64_t rows0 = (len + D - 1) / D;
+    const uint64_t run_rows = (uint64_t)kRunLoads * (64 >> log2_dv);
+    const uint64_t nruns = (rows0 + run_rows - 1) / run_rows;
+    const unsigned grid = (unsigned)((nruns * 64 + kTB - 1) / kTB);
+    if (nruns == 1) {
+        hipLaunchKernelGGL((wave_scan_kernel<E, KIND, true>), dim3(grid), dim3(kTB), 0, st, (const T*)y, len_e, log2_dv, nruns,
+                           (const T*)nullptr, (const T*)nullptr, (T*)nullptr, (T*)nullptr, (T*)dest);
+        return hipGetLastError() == hipSuccess ? 0 : fail(SPRINTZ_E_HIP, "transform decode launch");
+    }
+    // level 1 = one summary per run, laid out like rows of the stream
+    uint8_t* t = tmp;
+    auto take = [&](uint64_t n) { U* q = (U*)t; t += (n * D * sizeof(U) + 63) & ~(size_t)63; return q; };
+    U* s1 = take(nruns);
+    U* s2 = KIND ? take(nruns) : nullptr;
+    U* xi = take(nruns);
+    U* di = KIND ? take(nruns) : nullptr;
+    hipLaunchKernelGGL((wave_scan_kernel<E, KIND, false>), dim3(grid), dim3(kTB), 0, st, (const T*)y, len_e, log2_dv, nruns, (const T*)nullptr,
+                       (const T*)nullptr, (T*)s1, (T*)s2, (T*)nullptr);
+    const Level<U> base{s1, s2, xi, di, nruns, run_rows};
+    int rc = scan_levels<U, KIND>(base, len, D, rows0, dest, t, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL((wave_scan_kernel<E, KIND, true>), dim3(grid), dim3(kTB), 0, st, (const T*)y, len_e, log2_dv, nruns, (const T*)xi,
+                       (const T*)di, (T*)nullptr, (T*)nullptr, (T*)dest);
+    return hipGetLastError() == hipSuccess ? 0 : fail(SPRINTZ_E_HIP, "transform decode launch");
+}
+
+template <typename U, int KIND>
+int decode_device(const U* y, uint64_t len, uint32_t D, U* dest, uint8_t* tmp, hipStream_t st)
+{
+    typedef typename std::conditional<sizeof(U) == 1, P8, P16>::type P;
+    switch (wave_piece_bytes<U>(y, dest, len, D)) {
+        case 16: return decode_wave<U, V4<P>, KIND>(y, len, D, dest, tmp, st);
+        case 4: return decode_wave<U, P, KIND>(y, len, D, dest, tmp, st);
+        case 1: case 2: return decode_wave<U, S1x<U>, KIND>(y, len, D, dest, tmp, st);
+        default: break;
+    }
+    const uint64_t rows0 = (len + D - 1) / D;
+    return scan_levels<U, KIND>(Level<U>{y, y, nullptr, nullptr, rows0, 1}, len, D, rows0, dest, tmp, st);
 }
 
 template <typename U, int KIND>
