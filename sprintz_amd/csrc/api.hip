@@ -263,7 +263,7 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
     while (fdp * fcpl < D) fcpl <<= 1;                         // 2 / 4 columns per lane for D in 65..256
     // (32-bit offsets inside one wavefront's span of the output)
     // and chunks not much shorter than the read-ahead ring (it is filled before the first header is parsed)
-    const size_t fring = decode_fast_lds_bytes(8 * esz, fdp, fcpl, D);
+    const size_t fring = decode_fast_lds_bytes(8 * esz, fdp, fcpl, D, cs != 0 && fcpl == 1);
     const bool fast_common = !lowdim && !noheader && D <= 256 && 2 * D > fdp * fcpl && (uint64_t)chunk_len * esz * 2 >= fring &&
                              !getenv("SPRINTZ_MI355X_NO_FAST");
     // column-major: a lane's 8 samples per block are one aligned 16-byte (8-byte) piece of its column
@@ -275,7 +275,7 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
         a.log2DP = 0;
         while ((1 << a.log2DP) < fdp) a.log2DP++;
         const size_t fgroups = kThreads / fdp;
-        const size_t fstride = decode_fast_lds_bytes(8 * esz, fdp, fcpl, D);
+        const size_t fstride = decode_fast_lds_bytes(8 * esz, fdp, fcpl, D, cs != 0 && fcpl == 1);
         a.lds_group_stride = (uint32_t)fstride;
         // consecutive chunks per lane group: aim at ONE resident generation of workgroups
         // (no second cold start of the read-ahead ring, no partial last round)

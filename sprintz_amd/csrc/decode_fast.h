@@ -274,6 +274,57 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
 #pragma unroll
         for (int s2 = 0; s2 < 2; s2++) { cheld[s2][k] = make_uint4(0, 0, 0, 0); cheld_vo[s2][k] = kDropStore; }
     }
+    auto store_col = [&](const uint4& t, uint32_t vo) {
+        if constexpr (W == 16) {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, t), orsrc, vo, 0, 0);
+        } else {
+            typedef __attribute__((__vector_size__(2 * sizeof(uint32_t)))) uint32_t v2u;
+            v2u h = {t.x, t.y};
+            __builtin_amdgcn_raw_buffer_store_b64(h, orsrc, vo, 0, 0);
+        }
+    };
+    // Column-major burst (one column per lane): a lone 16-byte store per lane per block costs
+    // more than the whole decode (0.36 vs 0.15 ms on 8M x 32; every request is its own cache
+    // line).  So four blocks (two group steps) of every column wait in LDS as
+    // cst[column][slot], and on every second step a QUAD of lanes stores one column's 64
+    // contiguous bytes -- whole 64-byte requests, as in the row-major path.
+    constexpr bool CMB = CM && CPL == 1;
+    constexpr uint32_t PB = W == 16 ? 16u : 8u;            // bytes of one block of one column
+    uint8_t* const cst = stage;
+    uint32_t* const cvo = (uint32_t*)(stage + 4u * DCAP * PB);   // row offset of staged block b, or kDropStore
+    uint32_t stepno = 0;
+    const uint32_t cs_bytes = CM ? (uint32_t)(a.col_stride * ESZ) : 0u;
+    // slot permutation: column c keeps block b at slot (b + c/4) % 4, which spreads both the
+    // per-column writes and the per-quad reads over the banks
+    auto cst_at = [&](uint32_t col, uint32_t blk) { return cst + (col * 4u + ((blk + (col >> 2)) & 3u)) * PB; };
+    if constexpr (CMB) {
+        if (lane_d < 4) cvo[lane_d] = kDropStore;
+        wave_lds_sync();
+    }
+    // `real` = false: the same four store instructions, all dropped (keeps the VMEM count of a step fixed)
+    auto cm_flush = [&](bool real) {
+        if constexpr (CMB) {
+            wave_lds_sync();
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t pid = (uint32_t)j * DP + (uint32_t)lane_d, col = pid >> 2, p = pid & 3u;
+                uint4 t = make_uint4(0, 0, 0, 0);
+                uint32_t vo = kDropStore;
+                if (real && col < (uint32_t)D) {
+                    const uint32_t rofs_b = cvo[p];
+                    if constexpr (W == 16) t = *(const uint4*)cst_at(col, p);
+                    else { const uint2 h = *(const uint2*)cst_at(col, p); t.x = h.x; t.y = h.y; }
+                    vo = rofs_b == kDropStore ? kDropStore : col * cs_bytes + rofs_b;
+                }
+                store_col(t, vo);
+            }
+            if (real) {
+                wave_lds_sync();
+                if (lane_d < 4) cvo[lane_d] = kDropStore;
+            }
+            wave_lds_sync();
+        }
+    };
     auto pack_row = [&](int k, int i) {                    // pv[k] is row i of the block
         if constexpr (CM) {
             if constexpr (W == 16) {
@@ -285,18 +336,24 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
             }
         }
     };
-    auto store_col = [&](const uint4& t, uint32_t vo) {
-        if constexpr (W == 16) {
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, t), orsrc, vo, 0, 0);
-        } else {
-            typedef __attribute__((__vector_size__(2 * sizeof(uint32_t)))) uint32_t v2u;
-            v2u h = {t.x, t.y};
-            __builtin_amdgcn_raw_buffer_store_b64(h, orsrc, vo, 0, 0);
-        }
-    };
     auto stage_out = [&](int slot) {
         if constexpr (Q == kQueryReduceOnly) return;
-        if constexpr (CM) {                                // ovo counts ROW bytes here
+        if constexpr (CMB) {                               // ovo counts ROW bytes here
+            if (slot >= 0) {
+                const uint32_t blk = (stepno & 1u) * 2u + (uint32_t)slot;
+                if (col_ok[0]) {
+                    if constexpr (W == 16) *(uint4*)cst_at((uint32_t)col0, blk) = make_uint4(pk[0][0], pk[0][1], pk[0][2], pk[0][3]);
+                    else *(uint2*)cst_at((uint32_t)col0, blk) = make_uint2(pk[0][0], pk[0][1]);
+                }
+                if (lane_d == 0) cvo[blk] = ovo;
+            } else {                                       // run blocks: straight from the registers
+                const uint4 t = W == 16 ? make_uint4(pk[0][0], pk[0][1], pk[0][2], pk[0][3]) : make_uint4(pk[0][0], pk[0][1], 0, 0);
+                store_col(t, col_ok[0] ? cbase[0] + ovo : kDropStore);
+            }
+            ovo += 8u * ESZ;
+            return;
+        }
+        if constexpr (CM) {
 #pragma unroll
             for (int k = 0; k < CPL; k++) {
                 const uint4 t = W == 16 ? make_uint4(pk[k][0], pk[k][1], pk[k][2], pk[k][3]) : make_uint4(pk[k][0], pk[k][1], 0, 0);
@@ -535,7 +592,10 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         // counter for loads and stores, so parking the loads must not wait for the stores
         // just issued: with every VMEM op of the common path unconditional, hipcc emits
         // s_waitcnt vmcnt(<number of stores>) here instead of vmcnt(0).
-        if constexpr (Q != kQueryReduceOnly && CM) {
+        if constexpr (Q != kQueryReduceOnly && CMB) {
+            cm_flush((stepno & 1u) != 0);
+            stepno++;
+        } else if constexpr (Q != kQueryReduceOnly && CM) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
@@ -553,6 +613,10 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         wave_lds_sync();
     }
 
+    if constexpr (CMB) {                                   // an odd number of steps leaves one step's blocks staged
+        if (stepno & 1u) cm_flush(true);
+        stepno = 0;
+    }
     // ---- verbatim tail (:1171), straight from HBM
     const uint32_t out_elems = a.chunk_len - out_left;
     if (!corrupt && remaining > out_left) corrupt = true;
@@ -596,7 +660,7 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
 }
 
 // bytes of LDS one group needs in decode_fast_kernel
-constexpr uint32_t decode_fast_lds_bytes(int W, int DP, int CPL, int D)
+constexpr uint32_t decode_fast_lds_bytes(int W, int DP, int CPL, int D, bool colmajor_burst = false)
 {
     const uint32_t unit = DP * 16 * CPL;
     const uint32_t hb = W == 8 ? 3 : 4;
@@ -605,7 +669,8 @@ constexpr uint32_t decode_fast_lds_bytes(int W, int DP, int CPL, int D)
     const uint32_t cg = hdrmax + 2 * blkmax + 4;
     const uint32_t rb = ((2 * (cg + 24) + 3 + unit - 1) / unit + 1) * unit;
     const uint32_t apron = (cg + 24 + 8 + 15) & ~15u;
-    const uint32_t stage = ((8u * D * (W / 8) + 15) & ~15u) + 16;   // +16: spread groups over banks
+    // column-major burst staging: 4 blocks of every column the group can hold + 4 row offsets
+    const uint32_t stage = colmajor_burst ? 4u * blkmax + 16 : ((8u * D * (W / 8) + 15) & ~15u) + 16;   // +16: spread groups over banks
     return rb + apron + stage;
 }
 
