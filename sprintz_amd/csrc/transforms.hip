@@ -136,13 +136,26 @@ __global__ void __launch_bounds__(kTB) apply_kernel(Level<U> lo, uint64_t len, u
 
 // ---------------------------------------------------------------- decode, small rows: one wavefront scans a run of rows
 // When a row is a power-of-two number (<= 64) of 16-byte / 4-byte / element-sized pieces, the
-// lanes of a wavefront take CONSECUTIVE pieces (a coalesced 1 KB / 256 B / 64-element load =
-// 64/Dv rows), scan across lanes at stride Dv with the composition above (the right operand of
-// step s covers exactly 2^s rows), add the state carried from the rows before, store, and carry
-// the last row's state into the next load.  A run of kRunLoads loads per wavefront is one "row"
+// lanes of a wavefront share a contiguous 4 KB / 1 KB / 256-element load: a lane folds
+// kRowsPerLane consecutive rows of its column piece in registers, the lane summaries are scanned
+// across lanes at stride Dv with the composition above (the right operand of step s covers exactly
+// kRowsPerLane * 2^s rows), every lane advances the carried state over the rows before its own,
+// finishes its rows, stores, and the last lane's state is carried into the next load.  A run of kRunLoads loads per wavefront is one "row"
 // of level 1; the levels above it reuse reduce_kernel / apply_kernel on the summaries, which
 // have the layout of the stream's rows (packed lanes ARE elements).
 constexpr int kRunLoads = 16;
+constexpr int kRowsPerLane = 4;
+
+// LDS hand-off between lanes of one wavefront (DS ops of a wave execute in issue order)
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// piece p of a load -> LDS slot: rotate within aligned groups of 4 by p/16, so that both "lane l takes
+// piece l" and "lane l takes pieces 4l .. 4l+3" spread over the banks
+__device__ __forceinline__ uint32_t swz(uint32_t p) { return (p & ~3u) | ((p + (p >> 4)) & 3u); }
 
 struct P16 {                                            // 2 x u16 in a dword: v_pk_add_u16 / v_pk_mul_lo_u16
     typedef uint32_t T;
@@ -201,35 +214,79 @@ __global__ void __launch_bounds__(kTB) wave_scan_kernel(const typename E::T* y, 
         x = xin[run * dv + c];
         if (KIND) d = din[run * dv + c];
     }
-    const uint64_t e0 = run * (uint64_t)kRunLoads * 64;
+    constexpr int K = kRowsPerLane;                     // consecutive rows a lane folds in registers before the cross-lane step
+    // With 1 or 2 pieces per row a lane's own rows are not next to its neighbours': loading them
+    // directly makes every 16-byte piece its own memory request.  So the wavefront loads (and
+    // stores) the 64*K pieces in order, lane l piece l, and the rows change hands in LDS.
+    __shared__ T xbuf[kTB / 64][64 * K];
+    T* const xb = xbuf[threadIdx.x >> 6];
+    const bool via_lds = dv < 4;
+    const uint64_t e0 = run * (uint64_t)kRunLoads * 64 * K;
     for (int j = 0; j < kRunLoads; j++) {
-        const uint64_t e = e0 + (uint64_t)j * 64 + lane;
-        if (e0 + (uint64_t)j * 64 >= len_e) break;      // wave-uniform
-        const bool have = e < len_e;
-        T s1 = have ? y[e] : E::zero();
-        T s2 = s1;
-        for (int st = 0; (1 << st) < rpw; st++) {       // inclusive scan over the rows of the load, stride dv lanes
-            const int src = lane - (int)(dv << st);
-            const T l1 = E::shfl(s1, src < 0 ? lane : src);
-            if (KIND) {
-                const T l2 = E::shfl(s2, src < 0 ? lane : src);
-                if (r >= (1 << st)) s2 = E::add(E::add(l2, E::mul(l1, 1u << st)), s2);
+        const uint64_t eb = e0 + (uint64_t)j * 64 * K;  // first piece of this load
+        if (eb >= len_e) break;                         // wave-uniform
+        const uint64_t el = eb + ((uint64_t)r * K << log2_dv) + (uint64_t)c;   // this lane's first piece; its rows are dv pieces apart
+        T yk[K];
+        T s1 = E::zero(), s2 = E::zero();               // summary of the lane's K rows
+        const uint32_t pl = (((uint32_t)r * K) << log2_dv) + (uint32_t)c;      // this lane's first piece within the load
+        if (via_lds) {
+#pragma unroll
+            for (int m = 0; m < K; m++) {
+                const uint64_t e = eb + (uint64_t)m * 64 + lane;
+                xb[swz((uint32_t)m * 64 + lane)] = e < len_e ? y[e] : E::zero();
             }
-            if (r >= (1 << st)) s1 = E::add(l1, s1);
+            wave_sync();
         }
-        // rows [0..r] of this load on top of the state before it
-        T xr, dr;
-        if (KIND) {
-            xr = E::add(E::add(x, E::mul(d, (uint32_t)(r + 1))), s2);
-            dr = E::add(d, s1);
-        } else {
-            xr = E::add(x, s1);
-            dr = E::zero();
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const uint64_t e = el + ((uint64_t)k << log2_dv);
+            if (via_lds) yk[k] = xb[swz(pl + ((uint32_t)k << log2_dv))];
+            else yk[k] = e < len_e ? y[e] : E::zero();
+            s1 = E::add(s1, yk[k]);
+            if (KIND) s2 = E::add(s2, s1);
         }
-        if (STORE && have) dest[e] = xr;
-        const int last = (rpw - 1) * (int)dv + c;       // the load's last row, same column piece
-        x = E::shfl(xr, last);
-        if (KIND) d = E::shfl(dr, last);
+        // inclusive scan of the lane summaries over the rows of the load (stride dv lanes); the right
+        // operand of step st covers K * 2^st rows
+        T i1 = s1, i2 = s2;
+        for (int st = 0; (1 << st) < rpw; st++) {
+            const int src = lane - (int)(dv << st);
+            const T l1 = E::shfl(i1, src < 0 ? lane : src);
+            if (KIND) {
+                const T l2 = E::shfl(i2, src < 0 ? lane : src);
+                if (r >= (1 << st)) i2 = E::add(E::add(l2, E::mul(l1, (uint32_t)K << st)), i2);
+            }
+            if (r >= (1 << st)) i1 = E::add(l1, i1);
+        }
+        // state entering this lane's rows: the carried state advanced over the r*K rows before them
+        const int prev = lane - (int)dv;
+        T p1 = E::shfl(i1, prev < 0 ? lane : prev), p2 = KIND ? E::shfl(i2, prev < 0 ? lane : prev) : E::zero();
+        T xl = x, dl = d;
+        if (r > 0) {
+            if (KIND) { xl = E::add(E::add(x, E::mul(d, (uint32_t)(r * K))), p2); dl = E::add(d, p1); }
+            else xl = E::add(x, p1);
+        }
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (KIND) { dl = E::add(dl, yk[k]); xl = E::add(xl, dl); }
+            else xl = E::add(xl, yk[k]);
+            const uint64_t e = el + ((uint64_t)k << log2_dv);
+            if (STORE) {
+                if (via_lds) xb[swz(pl + ((uint32_t)k << log2_dv))] = xl;
+                else if (e < len_e) dest[e] = xl;
+            }
+        }
+        if (STORE && via_lds) {
+            wave_sync();
+#pragma unroll
+            for (int m = 0; m < K; m++) {
+                const uint64_t e = eb + (uint64_t)m * 64 + lane;
+                if (e < len_e) dest[e] = xb[swz((uint32_t)m * 64 + lane)];
+            }
+        }
+        if (via_lds) wave_sync();
+        const int last = (rpw - 1) * (int)dv + c;       // the lane holding the load's last rows of this column piece
+        x = E::shfl(xl, last);
+        if (KIND) d = E::shfl(dl, last);
     }
     if (!STORE && r == 0) {                             // the run's summary: the state it turns (0, 0) into
         s1_out[run * dv + c] = KIND ? d : x;
@@ -328,7 +385,7 @@ int decode_wave(const U* y, uint64_t len, uint32_t D, U* dest, uint8_t* tmp, hip
     while ((1u << log2_dv) < dv) log2_dv++;
     const uint64_t len_e = len * sizeof(U) / sizeof(T);
     const uint64_t rows0 = (len + D - 1) / D;
-    const uint64_t run_rows = (uint64_t)kRunLoads * (64 >> log2_dv);
+    const uint64_t run_rows = (uint64_t)kRunLoads * kRowsPerLane * (64 >> log2_dv);
     const uint64_t nruns = (rows0 + run_rows - 1) / run_rows;
     const unsigned grid = (unsigned)((nruns * 64 + kTB - 1) / kTB);
     if (nruns == 1) {
