@@ -84,6 +84,28 @@ inline int64_t query_rowmajor_xff_rle_16b(const int16_t* src, uint16_t* dest, co
     return sprintz_mi355x_query_xff_16b(src, dest, (int)qp.op, qp.materialize ? 1 : 0, SPRINTZ_QUERY_GENERAL_LAYOUT, result);
 }
 
+// ================================================================ non-RLE codecs (sprintz_delta.h:26-76)
+inline int64_t compress_rowmajor_8b(const uint8_t* src, uint32_t len, int8_t* dest, uint16_t ndims, bool = true)
+{
+    return sprintz_mi355x_compress_norle(SPRINTZ_CODEC_BITPACK_NORLE, 1, src, len, dest, ndims);
+}
+inline int64_t compress_rowmajor_16b(const uint16_t* src, uint32_t len, int16_t* dest, uint16_t ndims, bool = true)
+{
+    return sprintz_mi355x_compress_norle(SPRINTZ_CODEC_BITPACK_NORLE, 2, src, len, dest, ndims);
+}
+inline int64_t compress_rowmajor_delta_8b(const uint8_t* src, uint32_t len, int8_t* dest, uint16_t ndims, bool = true)
+{
+    return sprintz_mi355x_compress_norle(SPRINTZ_CODEC_DELTA_NORLE, 1, src, len, dest, ndims);
+}
+inline int64_t compress_rowmajor_delta_16b(const uint16_t* src, uint32_t len, int16_t* dest, uint16_t ndims, bool = true)
+{
+    return sprintz_mi355x_compress_norle(SPRINTZ_CODEC_DELTA_NORLE, 2, src, len, dest, ndims);
+}
+inline int64_t decompress_rowmajor_8b(const int8_t* src, uint8_t* dest) { return sprintz_mi355x_decompress_norle(SPRINTZ_CODEC_BITPACK_NORLE, 1, src, dest); }
+inline int64_t decompress_rowmajor_16b(const int16_t* src, uint16_t* dest) { return sprintz_mi355x_decompress_norle(SPRINTZ_CODEC_BITPACK_NORLE, 2, src, dest); }
+inline int64_t decompress_rowmajor_delta_8b(const int8_t* src, uint8_t* dest) { return sprintz_mi355x_decompress_norle(SPRINTZ_CODEC_DELTA_NORLE, 1, src, dest); }
+inline int64_t decompress_rowmajor_delta_16b(const int16_t* src, uint16_t* dest) { return sprintz_mi355x_decompress_norle(SPRINTZ_CODEC_DELTA_NORLE, 2, src, dest); }
+
 // ================================================================ stand-alone transforms (delta.h:17-68)
 #define SPRINTZ_DROPIN_TRANSFORM(NAME, KIND, BITS, ESZ)                                                                       \
     inline uint32_t encode_##NAME##_rowmajor_##BITS##b(const uint##BITS##_t* src, uint32_t len, int##BITS##_t* dest, uint16_t ndims,  \

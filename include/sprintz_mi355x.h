@@ -43,6 +43,11 @@ extern "C" {
 /* codec ids */
 #define SPRINTZ_CODEC_DELTA 0   /* sprintz_*_delta_*  (sprintz_delta_rle.cpp / sprintz_delta_lowdim.cpp) */
 #define SPRINTZ_CODEC_XFF   1   /* sprintz_*_xff_*    (sprintz_xff_rle.cpp   / sprintz_xff_lowdim.cpp), FIRE */
+/* the reference's older codecs without run-length coding: 6-byte header
+ * {u32 len; u16 ndims}, general row-major layout for every ndims; accepted by every batched
+ * entry point; decoded by the generic kernels */
+#define SPRINTZ_CODEC_DELTA_NORLE   2   /* compress_rowmajor_delta_{8b,16b}  sprintz_delta.cpp:776-1391 */
+#define SPRINTZ_CODEC_BITPACK_NORLE 3   /* compress_rowmajor_{8b,16b}: bit-packing only  sprintz_delta.cpp:64-773 */
 
 /* error codes */
 #define SPRINTZ_E_INVALID    (-1)   /* bad argument; also what the reference returns for ndims == 0 (sprintz.cpp:36) */
@@ -239,6 +244,13 @@ int64_t sprintz_mi355x_query_delta_8b(const int8_t* src, uint8_t* dest, int op, 
 int64_t sprintz_mi355x_query_delta_16b(const int16_t* src, uint16_t* dest, int op, int materialize, uint32_t flags, uint64_t* result);
 int64_t sprintz_mi355x_query_xff_8b(const int8_t* src, uint8_t* dest, int op, int materialize, uint32_t flags, uint64_t* result);
 int64_t sprintz_mi355x_query_xff_16b(const int16_t* src, uint16_t* dest, int op, int materialize, uint32_t flags, uint64_t* result);
+
+/* single-call forms of the non-RLE codecs over host buffers; replace
+ *   compress_rowmajor_{8b,16b} / decompress_rowmajor_{8b,16b}                cpp/Compress/sprintz_delta.h:26-31,63-66
+ *   compress_rowmajor_delta_{8b,16b} / decompress_rowmajor_delta_{8b,16b}    cpp/Compress/sprintz_delta.h:37-42,72-76
+ * codec: SPRINTZ_CODEC_DELTA_NORLE or SPRINTZ_CODEC_BITPACK_NORLE; return values in elements as above */
+int64_t sprintz_mi355x_compress_norle(int codec, int elem_bytes, const void* src, uint32_t len, void* dest, uint16_t ndims);
+int64_t sprintz_mi355x_decompress_norle(int codec, int elem_bytes, const void* src, void* dest);
 
 /* ------------------------------------------------------------------------
  * Stand-alone transforms.  Replace

@@ -130,4 +130,25 @@ uint32_t ref_transform_decode(int kind, int elem_bytes, const void* src, void* d
                 : decode_delta_rowmajor_16b((const int16_t*)src, (uint16_t*)dest);
 }
 
+/* non-RLE codecs (sprintz_delta.h): raw = 1 compress_rowmajor_{8b,16b}, raw = 0 compress_rowmajor_delta_{8b,16b} */
+int64_t ref_compress_norle(int raw, int elem_bytes, const void* src, uint32_t len, void* dest, uint16_t ndims)
+{
+    if (elem_bytes == 1) {
+        return raw ? compress_rowmajor_8b((const uint8_t*)src, len, (int8_t*)dest, ndims, true)
+                   : compress_rowmajor_delta_8b((const uint8_t*)src, len, (int8_t*)dest, ndims, true);
+    }
+    return raw ? compress_rowmajor_16b((const uint16_t*)src, len, (int16_t*)dest, ndims, true)
+               : compress_rowmajor_delta_16b((const uint16_t*)src, len, (int16_t*)dest, ndims, true);
+}
+
+int64_t ref_decompress_norle(int raw, int elem_bytes, const void* src, void* dest)
+{
+    if (elem_bytes == 1) {
+        return raw ? decompress_rowmajor_8b((const int8_t*)src, (uint8_t*)dest)
+                   : decompress_rowmajor_delta_8b((const int8_t*)src, (uint8_t*)dest);
+    }
+    return raw ? decompress_rowmajor_16b((const int16_t*)src, (uint16_t*)dest)
+               : decompress_rowmajor_delta_16b((const int16_t*)src, (uint16_t*)dest);
+}
+
 }  // extern "C"

@@ -142,6 +142,20 @@ int64_t oracle_decompress_rowmajor_ex(int codec, int elem_bytes, const void* src
     return decompress_w16((const uint8_t*)src, (uint16_t*)dest, fire, quirk, 1, consumed_bytes);
 }
 
+/* ---- non-RLE codecs (sprintz_delta.cpp:64-1391): raw = 1 bit-packing only (compress_rowmajor_{8b,16b}),
+ * raw = 0 delta + bit-packing (compress_rowmajor_delta_{8b,16b}) */
+int64_t oracle_compress_norle(int raw, int elem_bytes, const void* src, uint32_t len, void* dest, uint16_t ndims, size_t* nbytes_out)
+{
+    if (elem_bytes == 1) return compress_norle_w8((const uint8_t*)src, len, (uint8_t*)dest, ndims, raw, nbytes_out);
+    return compress_norle_w16((const uint16_t*)src, len, (uint8_t*)dest, ndims, raw, nbytes_out);
+}
+
+int64_t oracle_decompress_norle(int raw, int elem_bytes, const void* src, void* dest, size_t* consumed_bytes)
+{
+    if (elem_bytes == 1) return decompress_norle_w8((const uint8_t*)src, (uint8_t*)dest, raw, consumed_bytes);
+    return decompress_norle_w16((const uint8_t*)src, (uint16_t*)dest, raw, consumed_bytes);
+}
+
 /* ---- query on compressed data (query.hpp:23-29).  The reference throws its reduction
  * away (sprintz_xff_rle_query.cpp:69-104) and its functors are unfinished (query.hpp:222,
  * :84-87), so the RESULT is defined here, by restating what the operation means: op over the

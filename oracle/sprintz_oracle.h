@@ -68,6 +68,8 @@ int64_t oracle_decompress_ex(int codec, int elem_bytes, const void* src, void* d
  * semantic definition of query-on-compressed; see sprintz_oracle.c */
 int64_t oracle_compress_rowmajor(int codec, int elem_bytes, const void* src, uint32_t len, void* dest, uint16_t ndims, size_t* nbytes_out);
 int64_t oracle_decompress_rowmajor_ex(int codec, int elem_bytes, const void* src, void* dest, int ref_rle16_quirk, size_t* consumed_bytes);
+int64_t oracle_compress_norle(int raw, int elem_bytes, const void* src, uint32_t len, void* dest, uint16_t ndims, size_t* nbytes_out);
+int64_t oracle_decompress_norle(int raw, int elem_bytes, const void* src, void* dest, size_t* consumed_bytes);
 int64_t oracle_query(int codec, int elem_bytes, const void* src, void* dest, int general, int op, uint64_t* result);
 
 size_t oracle_compress_bound(int elem_bytes, uint32_t len, uint16_t ndims);

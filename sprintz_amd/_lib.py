@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPRINTZ_MI355X_LIB") or os.path.join(_HERE, "libsprintz_mi355x.so")   # env override: A/B builds
 
 E_INVALID, E_NO_DEVICE, E_HIP, E_UNSUPPORTED, E_CORRUPT = -1, -2, -3, -4, -5
-CODEC_DELTA, CODEC_XFF = 0, 1
+CODEC_DELTA, CODEC_XFF, CODEC_DELTA_NORLE, CODEC_BITPACK_NORLE = 0, 1, 2, 3
 READ_SLACK = 16
 MAX_NDIMS = 512
 
@@ -107,6 +107,10 @@ transform_encode = _sig("sprintz_mi355x_transform_encode", _i64, _i, _i, _vp, _u
 transform_decode = _sig("sprintz_mi355x_transform_decode", _i64, _i, _i, _vp, _vp, _u32, _u16)
 _transform_last_error = _sig("sprintz_mi355x_transform_last_error", C.c_char_p)
 
+# (7) non-RLE codecs, single call (sprintz_delta.h:26-76)
+compress_norle = _sig("sprintz_mi355x_compress_norle", _i64, _i, _i, _vp, _u32, _vp, _u16)
+decompress_norle = _sig("sprintz_mi355x_decompress_norle", _i64, _i, _i, _vp, _vp)
+
 # host convenience
 compress_chunked_host = _sig("sprintz_mi355x_compress_chunked_host", _i64, _i, _i, _vp, _u64, _u32, _u16, _vp, _sz, _vp)
 decompress_chunked_host = _sig("sprintz_mi355x_decompress_chunked_host", _i64, _i, _i, _vp, _vp, _u64, _u32, _u16, _vp)
@@ -130,6 +134,7 @@ EXPORTED_SYMBOLS = [
     "sprintz_mi355x_compress_batch_colmajor", "sprintz_mi355x_decompress_batch_colmajor",
     "sprintz_mi355x_transform_tmp_bytes", "sprintz_mi355x_transform_encode_device", "sprintz_mi355x_transform_decode_device",
     "sprintz_mi355x_transform_encode", "sprintz_mi355x_transform_decode", "sprintz_mi355x_transform_last_error",
+    "sprintz_mi355x_compress_norle", "sprintz_mi355x_decompress_norle",
 ]
 
 

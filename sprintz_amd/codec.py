@@ -20,7 +20,8 @@ import numpy as np
 from . import _lib
 
 _NP = {1: np.uint8, 2: np.uint16}
-_CODEC_ID = {"delta": _lib.CODEC_DELTA, "xff": _lib.CODEC_XFF}
+_CODEC_ID = {"delta": _lib.CODEC_DELTA, "xff": _lib.CODEC_XFF,
+             "delta_norle": _lib.CODEC_DELTA_NORLE, "bitpack": _lib.CODEC_BITPACK_NORLE}   # the last two: sprintz_delta.cpp:64-1391
 
 
 def _np_ptr(a):
@@ -116,7 +117,7 @@ class ChunkedCodec:
     def __init__(self, codec, elem_bytes, ndims, chunk_len, device=None, align=16):
         import torch
         if codec not in _CODEC_ID:
-            raise ValueError("codec must be 'delta' or 'xff'")
+            raise ValueError("codec must be 'delta', 'xff', 'delta_norle' or 'bitpack'")
         if elem_bytes not in (1, 2):
             raise ValueError("elem_bytes must be 1 or 2")
         if not torch.cuda.is_available():
@@ -293,6 +294,47 @@ def query_rowmajor_xff_rle_8b(src, dest, qp, general_layout=True):
 
 def query_rowmajor_xff_rle_16b(src, dest, qp, general_layout=True):
     return _query("xff", 2, src, dest, qp, general_layout)
+
+
+# ---- non-RLE codecs, the reference's names (sprintz_delta.h:26-76) --------------------------------
+
+def _c_norle(codec, esz, src, length, dest, ndims):
+    src = np.ascontiguousarray(src)
+    if src.dtype.itemsize != esz or src.size < length:
+        raise ValueError("src dtype/size does not match the call")
+    return int(_lib.compress_norle(codec, esz, _np_ptr(src), length, _np_ptr(dest), ndims))
+
+
+def compress_rowmajor_8b(src, len, dest, ndims):  # noqa: A002
+    return _c_norle(_lib.CODEC_BITPACK_NORLE, 1, src, len, dest, ndims)
+
+
+def compress_rowmajor_16b(src, len, dest, ndims):  # noqa: A002
+    return _c_norle(_lib.CODEC_BITPACK_NORLE, 2, src, len, dest, ndims)
+
+
+def compress_rowmajor_delta_8b(src, len, dest, ndims):  # noqa: A002
+    return _c_norle(_lib.CODEC_DELTA_NORLE, 1, src, len, dest, ndims)
+
+
+def compress_rowmajor_delta_16b(src, len, dest, ndims):  # noqa: A002
+    return _c_norle(_lib.CODEC_DELTA_NORLE, 2, src, len, dest, ndims)
+
+
+def decompress_rowmajor_8b(src, dest):
+    return int(_lib.decompress_norle(_lib.CODEC_BITPACK_NORLE, 1, _np_ptr(np.ascontiguousarray(src)), _np_ptr(dest)))
+
+
+def decompress_rowmajor_16b(src, dest):
+    return int(_lib.decompress_norle(_lib.CODEC_BITPACK_NORLE, 2, _np_ptr(np.ascontiguousarray(src)), _np_ptr(dest)))
+
+
+def decompress_rowmajor_delta_8b(src, dest):
+    return int(_lib.decompress_norle(_lib.CODEC_DELTA_NORLE, 1, _np_ptr(np.ascontiguousarray(src)), _np_ptr(dest)))
+
+
+def decompress_rowmajor_delta_16b(src, dest):
+    return int(_lib.decompress_norle(_lib.CODEC_DELTA_NORLE, 2, _np_ptr(np.ascontiguousarray(src)), _np_ptr(dest)))
 
 
 # ---- stand-alone transforms (delta.h:17-68) -------------------------------------------------

@@ -199,7 +199,8 @@ namespace {
 
 int check_common(int codec, int esz, uint16_t ndims)
 {
-    if (codec != SPRINTZ_CODEC_DELTA && codec != SPRINTZ_CODEC_XFF) return fail(SPRINTZ_E_INVALID, "codec must be 0 (delta) or 1 (xff)");
+    if (codec < SPRINTZ_CODEC_DELTA || codec > SPRINTZ_CODEC_BITPACK_NORLE)
+        return fail(SPRINTZ_E_INVALID, "codec must be 0 (delta), 1 (xff), 2 (delta, no RLE) or 3 (bit-packing only)");
     if (esz != 1 && esz != 2) return fail(SPRINTZ_E_INVALID, "elem_bytes must be 1 or 2");
     if (ndims == 0) return fail(SPRINTZ_E_INVALID, "ndims == 0 (reference: sprintz.cpp:36 returns -1)");
     if (ndims > SPRINTZ_MI355X_MAX_NDIMS) return fail(SPRINTZ_E_UNSUPPORTED, "ndims above SPRINTZ_MI355X_MAX_NDIMS");
@@ -221,7 +222,8 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
 {
     if (nchunks == 0) return 0;
     const int D = ndims;
-    const bool lowdim = qs.general ? false : is_lowdim(esz, D);
+    const bool norle = codec >= SPRINTZ_CODEC_DELTA_NORLE;      // general layout for every ndims, generic kernels
+    const bool lowdim = (qs.general || norle) ? false : is_lowdim(esz, D);
     const Mapping m = choose_mapping(D, lowdim);
     const int DP = 1 << m.log2DP;
 
@@ -240,6 +242,8 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
     a.chunks_per_group = 1;
     a.qop = qs.qop;
     a.qres = qs.qres;
+    a.norle = norle ? 1 : 0;
+    a.raw = codec == SPRINTZ_CODEC_BITPACK_NORLE ? 1 : 0;
     a.col_stride = qs.col_stride;
     const uint64_t cs = qs.col_stride;
 
@@ -264,7 +268,7 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
     // (32-bit offsets inside one wavefront's span of the output)
     // and chunks not much shorter than the read-ahead ring (it is filled before the first header is parsed)
     const size_t fring = decode_fast_lds_bytes(8 * esz, fdp, fcpl, D, cs != 0 && fcpl == 1);
-    const bool fast_common = !lowdim && !noheader && D <= 256 && 2 * D > fdp * fcpl && (uint64_t)chunk_len * esz * 2 >= fring &&
+    const bool fast_common = !lowdim && !norle && !noheader && D <= 256 && 2 * D > fdp * fcpl && (uint64_t)chunk_len * esz * 2 >= fring &&
                              !getenv("SPRINTZ_MI355X_NO_FAST");
     // column-major: a lane's 8 samples per block are one aligned 16-byte (8-byte) piece of its column
     const bool fast = cs ? fast_common && qs.q == kQueryOff && cs % 8 == 0 && (chunk_len / (uint32_t)D) % 8 == 0 &&
@@ -319,7 +323,8 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     const uint64_t nchunks = sprintz_mi355x_num_chunks(total_len, chunk_len);
     if (nchunks == 0) return 0;
     const int D = ndims;
-    const bool lowdim = is_lowdim(esz, D);
+    const bool norle = codec >= SPRINTZ_CODEC_DELTA_NORLE;
+    const bool lowdim = norle ? false : is_lowdim(esz, D);
     const Mapping m = choose_mapping(D, lowdim);
     const int DP = 1 << m.log2DP;
 
@@ -336,6 +341,8 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     a.rets = d_rets;
     a.write_size = write_size;
     a.col_stride = col_stride;
+    a.norle = norle ? 1 : 0;
+    a.raw = codec == SPRINTZ_CODEC_BITPACK_NORLE ? 1 : 0;
     a.cap = next_pow2((uint32_t)group_bytes_max(esz, D) + 48u);
     const size_t shmem = (size_t)a.cap * (kThreads / DP);
     if (shmem > 160 * 1024) return fail(SPRINTZ_E_UNSUPPORTED, "ndims too large for the LDS output ring");
@@ -345,7 +352,7 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     int fdp = 4;
     while (fdp < D) fdp <<= 1;
     const size_t blk_bytes = (size_t)8 * D * esz;
-    const bool fast_common = !lowdim && D <= 64 && 2 * D > fdp && ((uintptr_t)d_src % 16) == 0 && !getenv("SPRINTZ_MI355X_NO_FAST");
+    const bool fast_common = !lowdim && !norle && D <= 64 && 2 * D > fdp && ((uintptr_t)d_src % 16) == 0 && !getenv("SPRINTZ_MI355X_NO_FAST");
     const bool fast = col_stride ? fast_common && col_stride % 8 == 0 && (chunk_len / (uint32_t)D) % 8 == 0
                                  : fast_common && blk_bytes % 16 == 0 && ((uint64_t)chunk_len * esz) % 16 == 0;
     hipError_t e;
@@ -382,7 +389,7 @@ struct DevBuf {
 // signature carries no length (sprintz.h:20) but an H2D copy must be sized.
 // Touches headers and run lengths only -- no sample is decoded here.
 void walk_stream(const uint8_t* s, int esz, int D, uint32_t ngroups, uint32_t remaining, bool lowdim,
-                 uint64_t* nbytes, uint64_t* nelems)
+                 uint64_t* nbytes, uint64_t* nelems, bool norle = false)
 {
     const int W = 8 * esz, HB = esz == 1 ? 3 : 4;
     const uint32_t hdr_bytes = (2u * D * HB + 7u) / 8u;
@@ -402,7 +409,9 @@ void walk_stream(const uint8_t* s, int esz, int D, uint32_t ngroups, uint32_t re
                 uint32_t f = field(h, slot * D + d);
                 total += (f == (uint32_t)(W - 1)) ? (uint32_t)W : f;
             }
-            if (total == 0) {
+            if (total == 0 && norle) {
+                blocks += 1;                                   // a block of zeros has no payload
+            } else if (total == 0) {
                 uint32_t b0 = s[pos++], len = b0 & 0x7f;
                 if (b0 & 0x80) len |= (uint32_t)s[pos++] << 7;
                 blocks += len;
@@ -433,6 +442,11 @@ int64_t compress_host(int codec, int esz, const void* src, uint32_t len, void* d
     int64_t* d_ret = (int64_t*)((uint8_t*)d_meta.p + 8);
     rc = encode_launch(codec, esz, d_src.p, len, len ? len : 1, ndims, d_slot.p, bound, d_size, d_ret, nullptr, write_size);
     if (rc) return rc;
+    if (len == 0 && codec >= SPRINTZ_CODEC_DELTA_NORLE) {   // {u32 0; u16 ndims} (format.h:65-72)
+        uint8_t h[6] = {0, 0, 0, 0, (uint8_t)(ndims & 0xff), (uint8_t)(ndims >> 8)};
+        memcpy(dest, h, 6);
+        return 6 / esz;
+    }
     if (len == 0) {   // zero elements: header only (reference: :116-124 with len == 0)
         uint8_t h[8] = {0};
         h[6] = (uint8_t)(ndims & 0xff); h[7] = (uint8_t)(ndims >> 8);
@@ -454,7 +468,15 @@ int64_t decompress_host(int codec, int esz, const void* src, void* dest, int noh
     const uint8_t* s = (const uint8_t*)src;
     uint32_t ngroups, remaining;
     uint16_t ndims;
-    if (!noheader) {
+    const bool norle = codec >= SPRINTZ_CODEC_DELTA_NORLE;
+    if (norle) {                                               // {u32 len; u16 ndims}; sprintz_delta.cpp:803-807, :832
+        uint32_t len;
+        memcpy(&len, s, 4);
+        memcpy(&ndims, s + 4, 2);
+        ngroups = (len < 128 || ndims == 0) ? 0 : len / (16u * ndims);
+        remaining = len - ngroups * 16u * ndims;
+        if (ndims == 0 && len == 0) return 0;
+    } else if (!noheader) {
         uint16_t r16;
         memcpy(&ngroups, s, 4);
         memcpy(&r16, s + 4, 2);
@@ -467,9 +489,9 @@ int64_t decompress_host(int codec, int esz, const void* src, void* dest, int noh
     int rc = check_common(codec, esz, ndims);
     if (rc) return rc;
     if ((rc = ensure_device())) return rc;
-    const uint32_t hlen = noheader ? 0 : 8;
+    const uint32_t hlen = norle ? 6 : (noheader ? 0 : 8);
     uint64_t nbytes = 0, nelems = 0;
-    walk_stream(s + hlen, esz, ndims, ngroups, remaining, is_lowdim(esz, ndims), &nbytes, &nelems);
+    walk_stream(s + hlen, esz, ndims, ngroups, remaining, norle ? false : is_lowdim(esz, ndims), &nbytes, &nelems, norle);
     nbytes += hlen;
     if (nelems == 0) return 0;
     if (nelems > (1ull << 31)) return fail(SPRINTZ_E_UNSUPPORTED, "single call limited to 2^31 elements");
@@ -833,6 +855,19 @@ int sprintz_mi355x_decompress_batch_colmajor(int codec, int elem_bytes, const vo
     qs.col_stride = col_stride;
     return decode_launch(codec, elem_bytes, d_comp, d_offsets, nchunks, rows_per_chunk * (uint32_t)ndims, ndims, d_out, d_rets,
                          (hipStream_t)hip_stream, 0, 0, 0, qs);
+}
+
+// ---------------------------------------------------------------- non-RLE codecs, single call (host pointers)
+int64_t sprintz_mi355x_compress_norle(int codec, int elem_bytes, const void* src, uint32_t len, void* dest, uint16_t ndims)
+{
+    if (codec != SPRINTZ_CODEC_DELTA_NORLE && codec != SPRINTZ_CODEC_BITPACK_NORLE) return fail(SPRINTZ_E_INVALID, "codec must be 2 or 3");
+    return compress_host(codec, elem_bytes, src, len, dest, ndims, 1);
+}
+
+int64_t sprintz_mi355x_decompress_norle(int codec, int elem_bytes, const void* src, void* dest)
+{
+    if (codec != SPRINTZ_CODEC_DELTA_NORLE && codec != SPRINTZ_CODEC_BITPACK_NORLE) return fail(SPRINTZ_E_INVALID, "codec must be 2 or 3");
+    return decompress_host(codec, elem_bytes, src, dest, 0, 0, 0, 0);
 }
 
 }  // extern "C"

@@ -36,6 +36,10 @@ struct DecodeArgs {
     // column-major destination (BASELINE config 5): element (row r, column d) at out[d*col_stride + r];
     // chunk c holds rows [c*chunk_len/D, ...).  0 = row-major.
     uint64_t col_stride;
+    // non-RLE codecs (sprintz_delta.cpp:64-1391; generic kernel only): 6-byte header {u32 len; u16 ndims},
+    // len/(16 D) groups, an all-zero block has no payload and no run length; raw: bit-packing only
+    int norle;
+    int raw;
     int qop;                    // 1: max, 2: sum (what lands in qres)
     uint64_t* qres;             // [nchunks][D] per-chunk, per-column partial results
 };
@@ -70,7 +74,17 @@ __global__ void __launch_bounds__(kThreads) decode_kernel(DecodeArgs a)
 
     // ---- 8-byte stream header (format.h:48-62)
     uint32_t groups_left, remaining, pos;
-    if (!a.noheader) {
+    if (a.norle) {                                   // format.h:65-86; sprintz_delta.cpp:803-807, :832
+        const uint32_t len = load_u32_any(s);
+        const uint32_t nd = load_u8(s + 4) | (load_u8(s + 5) << 8);
+        if ((int)nd != D || len > a.chunk_len) {
+            if (lane_d == 0 && a.rets) a.rets[chunk] = kErrCorrupt;
+            return;
+        }
+        groups_left = len < 128u ? 0u : len / (16u * (uint32_t)D);
+        remaining = len - groups_left * 16u * (uint32_t)D;
+        pos = 6;
+    } else if (!a.noheader) {
         const uint32_t w0 = load_u32_any(s), w1 = load_u32_any(s + 4);
         groups_left = w0;
         remaining = w1 & 0xffffu;
@@ -147,7 +161,11 @@ __global__ void __launch_bounds__(kThreads) decode_kernel(DecodeArgs a)
                     slot = 0;
                 }
                 const uint32_t total = slot ? tot1 : tot0;
-                if (total == 0) {                // RUN slot: varint length in blocks (:829-833)
+                if (total == 0 && a.norle) {     // a block of zeros: no payload at all
+                    slot++;
+                    have = true;
+                    break;
+                } else if (total == 0) {         // RUN slot: varint length in blocks (:829-833)
                     const uint32_t b0 = load_u8(s + pos);
                     uint32_t len = b0 & 0x7fu;
                     if (b0 & 0x80u) { len |= load_u8(s + pos + 1) << 7; pos += 2; }
@@ -208,7 +226,7 @@ __global__ void __launch_bounds__(kThreads) decode_kernel(DecodeArgs a)
                 if (FIRE && (i & 1)) grad += sign_times(err, pdk);
                 pvk = (pvk + (uint32_t)delta) & MASK;
                 pdk = delta;
-                v[i][k] = pvk;
+                v[i][k] = (!FIRE && a.raw) ? z[i][k] : pvk;     // raw: the packed bits ARE the samples (sprintz_delta.cpp:143-146)
             }
             pv[k] = pvk;
             pd[k] = pdk;

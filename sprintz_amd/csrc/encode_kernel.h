@@ -36,6 +36,9 @@ struct EncodeArgs {
     // chunk c covers rows [c*chunk_len/D, ...) and is coded as the reference codes the row-major
     // flattening of that row range.  0 = row-major.
     uint64_t col_stride;
+    // non-RLE codecs (generic kernel only), see DecodeArgs
+    int norle;
+    int raw;
 };
 
 template <int W, bool FIRE, bool LOWDIM, int CPL>
@@ -73,7 +76,7 @@ __global__ void __launch_bounds__(kThreads) encode_kernel(EncodeArgs a)
     for (uint32_t u = (uint32_t)lane_d; u < (cap >> 4); u += (uint32_t)DP) ((uint4*)ring)[u] = make_uint4(0, 0, 0, 0);
     wave_lds_sync();
 
-    uint32_t wpos = a.write_size ? 8u : 0u;   // stream write position (bytes)
+    uint32_t wpos = a.norle ? 6u : (a.write_size ? 8u : 0u);   // stream write position (bytes)
     uint32_t flushed = 0;                     // multiple of 16; ring holds [flushed, flushed + cap)
 
     // flush [flushed, upto) (upto multiple of 16) to HBM and re-zero it
@@ -152,7 +155,7 @@ __global__ void __launch_bounds__(kThreads) encode_kernel(EncodeArgs a)
                 const int delta = sext<W>((int)(x[i] - pvk));
                 const int pred = FIRE ? fire_predict<W, LOWDIM>(pdk, coef) : 0;
                 const int err = sext<W>(delta - pred);
-                const uint32_t zz = zigzag<W>(err);
+                const uint32_t zz = (!FIRE && a.raw) ? x[i] : zigzag<W>(err);   // raw: the samples themselves are packed
                 if (FIRE && (i & 1)) grad += sign_times(err, pdk);
                 mask |= zz;
                 z[i][k] = zz;
@@ -170,7 +173,7 @@ __global__ void __launch_bounds__(kThreads) encode_kernel(EncodeArgs a)
 
         // ---- RLE state machine (:350-456); everything here is group-uniform
         for (;;) {
-            if (total == 0 && run < 0x7fffu) {
+            if (total == 0 && run < 0x7fffu && !a.norle) {
                 run++;
                 pos_in += blk;
                 const bool more = TAIL_LE ? (pos_in <= limit) : (pos_in < limit);
@@ -246,7 +249,10 @@ __global__ void __launch_bounds__(kThreads) encode_kernel(EncodeArgs a)
 
     // ---- 8-byte stream header (format.h:36-45); lane 0 also wrote unit 0 in flush_to
     if (lane_d == 0) {
-        if (a.write_size) {
+        if (a.norle) {                                       // {u32 len; u16 ndims} (format.h:65-72); bytes 6.. are stream
+            ((uint32_t*)gdst)[0] = n;
+            ((uint16_t*)gdst)[2] = (uint16_t)D;
+        } else if (a.write_size) {
             ((uint32_t*)gdst)[0] = ngroups;
             ((uint32_t*)gdst)[1] = (remaining & 0xffffu) | ((uint32_t)D << 16);
         }

@@ -154,6 +154,25 @@ class Oracle:
         ret = f(CODECS[codec], esz, padded.ctypes.data, out.ctypes.data, int(general), op, res.ctypes.data)
         return out[:max(int(ret), 0)].copy(), res[:ndims]
 
+    # ---- non-RLE codecs (sprintz_delta.cpp:64-1391): raw = 1 bit-packing only, raw = 0 delta + bit-packing
+    def compress_norle(self, raw, data, ndims):
+        f = _bind(self.lib, "oracle_compress_norle", C.c_int64,
+                  [C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint16, C.POINTER(C.c_size_t)])
+        data = np.ascontiguousarray(data)
+        esz = data.dtype.itemsize
+        out = np.full(data.size * esz * 2 + 6 + 64 * max(ndims, 1) + 256, 0xAB, np.uint8)
+        nb = C.c_size_t(0)
+        ret = f(int(raw), esz, data.ctypes.data, data.size, out.ctypes.data, ndims, C.byref(nb))
+        return out[:nb.value].copy(), int(ret)
+
+    def decompress_norle(self, raw, stream, esz):
+        f = _bind(self.lib, "oracle_decompress_norle", C.c_int64, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p])
+        stream = np.concatenate([np.ascontiguousarray(stream, dtype=np.uint8), np.zeros(64, np.uint8)])
+        n = int(np.frombuffer(stream[:4].tobytes(), np.uint32)[0])
+        out = np.zeros(n + 64, DTYPES[esz])
+        ret = f(int(raw), esz, stream.ctypes.data, out.ctypes.data, None)
+        return out[:n].copy(), int(ret)
+
     # ---- stand-alone transforms (oracle/transforms_oracle.c): kind 0 delta, 1 double delta
     def transform_encode(self, kind, data, ndims, write_size=True):
         """-> (container bytes, return value)"""
@@ -221,6 +240,27 @@ class Reference:
 
     def has_transforms(self):
         return hasattr(self.lib, "ref_transform_encode")
+
+    def has_norle(self):
+        return hasattr(self.lib, "ref_compress_norle")
+
+    def compress_norle_raw(self, raw, data, ndims):
+        """compress_rowmajor[_delta]_{8b,16b}: -> (whole poison-filled output buffer, return value in elements)"""
+        f = _bind(self.lib, "ref_compress_norle", C.c_int64, [C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint16])
+        data = np.ascontiguousarray(data)
+        esz = data.dtype.itemsize
+        src = np.concatenate([data.ravel(), np.zeros(256, data.dtype)])
+        out = np.full(data.size * esz * 2 + 1024, 0xAB, np.uint8)
+        ret = f(int(raw), esz, src.ctypes.data, data.size, out.ctypes.data, ndims)
+        return out, int(ret)
+
+    def decompress_norle(self, raw, stream, esz):
+        f = _bind(self.lib, "ref_decompress_norle", C.c_int64, [C.c_int, C.c_int, C.c_void_p, C.c_void_p])
+        stream = np.concatenate([np.ascontiguousarray(stream, dtype=np.uint8), np.zeros(512, np.uint8)])
+        n = int(np.frombuffer(stream[:4].tobytes(), np.uint32)[0])
+        out = np.zeros(n + 512, DTYPES[esz])
+        ret = f(int(raw), esz, stream.ctypes.data, out.ctypes.data)
+        return out[:n].copy(), int(ret)
 
     def transform_encode(self, kind, data, ndims):
         """encode_{delta,doubledelta}_rowmajor_{8b,16b}(write_size=true) -> (container bytes, return value)"""
