@@ -442,6 +442,14 @@ __global__ void __launch_bounds__(256) huf_rawsize_kernel(const uint8_t* huf, co
     sizes[c] = n;
 }
 
+// LDS hand-off between lanes of one wavefront (DS ops of a wave execute in issue order)
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---------------------------------------------------------------- K5: decode
 __global__ void __launch_bounds__(256) huf_decode_kernel(const uint8_t* huf, const uint64_t* huf_offsets, const uint8_t* tables,
                                                          uint64_t nchunks, uint8_t* dense, const uint64_t* offsets,
@@ -615,34 +623,86 @@ __global__ void __launch_bounds__(256) huf_decode_kernel(const uint8_t* huf, con
         *(u32x4_a1*)(o + i) = sixteen();
         i += 16;
     }
-    while (i + 64 <= b) {
-        u32x4 v[4];
+    // The 64-byte body.  A lane's four 16-byte stores would be four separate memory requests;
+    // the four lanes of a quad (= the four sub-streams of one chunk) transpose their pieces in
+    // registers instead (two DPP butterfly stages), so that each store instruction writes one
+    // member's 64 bytes as ONE request: lane p of the quad stores piece p of member q in round q.
+    // The loop runs while any member of the quad has a body left (DPP reads 0 from lanes that
+    // are switched off, so the exchange must run with the whole quad enabled).
+    {
+        const int lane = t & 63;
+        const bool odd1 = (t & 1) != 0, odd2 = (t & 2) != 0;
+        const uint32_t p = (uint32_t)t & 3u;
+        for (;;) {
+            const bool work = i + 64 <= b;
+            const uint64_t any = __ballot(work);
+            if (((any >> (lane & ~3)) & 0xfull) == 0) break;                  // quad-uniform
+            uint32_t v[4][4];                                                 // [piece][dword]
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            // refill(), with the four loads of the piece spread over the period
-            if (have_pend) {
-                park(fpiece, pend);
-                fpiece++;
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int d = 0; d < 4; d++) v[q][d] = 0;
+            if (work) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    // refill(), with the four loads of the piece spread over the period
+                    if (have_pend) {
+                        park(fpiece, pend);
+                        fpiece++;
+                    }
+                    have_pend = fpiece - (bp >> 9) < 2u;
+                    const uint64_t q0 = (piece0 + fpiece) << 2;
+                    auto part = [&](int m) {
+                        uint64_t qq = q0 + m;
+                        qq = qq < last16 ? qq : last16;
+                        pend.v[m] = *(const u32x4_a4*)(have_pend ? huf + (qq << 4) : idle);
+                    };
+                    part(0);
+                    v[q][0] = four();
+                    part(1);
+                    v[q][1] = four();
+                    part(2);
+                    v[q][2] = four();
+                    part(3);
+                    v[q][3] = four();
+                }
             }
-            have_pend = fpiece - (bp >> 9) < 2u;
-            const uint64_t q0 = (piece0 + fpiece) << 2;
-            auto part = [&](int m) {
-                uint64_t qq = q0 + m;
-                qq = qq < last16 ? qq : last16;
-                pend.v[m] = *(const u32x4_a4*)(have_pend ? huf + (qq << 4) : idle);
-            };
-            part(0);
-            v[q].x = four();
-            part(1);
-            v[q].y = four();
-            part(2);
-            v[q].z = four();
-            part(3);
-            v[q].w = four();
-        }
+            // 4 x 4 transpose of 16-byte pieces across the quad: (member m, piece k) -> (lane k, slot m)
 #pragma unroll
-        for (int q = 0; q < 4; q++) *(u32x4_a1*)(o + i + 16 * q) = v[q];
-        i += 64;
+            for (int k = 0; k < 4; k += 2)                                    // stage 1: lanes l ^ 1 swap slots k+1 <-> k
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const uint32_t send = odd1 ? v[k][d] : v[k + 1][d];
+                    const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+                    if (odd1) v[k][d] = recv; else v[k + 1][d] = recv;
+                }
+#pragma unroll
+            for (int k = 0; k < 2; k++)                                       // stage 2: lanes l ^ 2 swap slots k+2 <-> k
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const uint32_t send = odd2 ? v[k][d] : v[k + 2][d];
+                    const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+                    if (odd2) v[k][d] = recv; else v[k + 2][d] = recv;
+                }
+            const uint64_t mine = work ? (uint64_t)(uintptr_t)(o + i) : 0ull;
+            const int mlo = (int)(uint32_t)mine, mhi = (int)(uint32_t)(mine >> 32);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {                                     // member q's 64 bytes, 16 from each lane
+                const int ctrl = q * 0x55;                                    // quad_perm [q,q,q,q]
+                uint32_t dlo, dhi;
+                if (q == 0) { dlo = (uint32_t)__builtin_amdgcn_mov_dpp(mlo, 0x00, 0xf, 0xf, true); dhi = (uint32_t)__builtin_amdgcn_mov_dpp(mhi, 0x00, 0xf, 0xf, true); }
+                else if (q == 1) { dlo = (uint32_t)__builtin_amdgcn_mov_dpp(mlo, 0x55, 0xf, 0xf, true); dhi = (uint32_t)__builtin_amdgcn_mov_dpp(mhi, 0x55, 0xf, 0xf, true); }
+                else if (q == 2) { dlo = (uint32_t)__builtin_amdgcn_mov_dpp(mlo, 0xAA, 0xf, 0xf, true); dhi = (uint32_t)__builtin_amdgcn_mov_dpp(mhi, 0xAA, 0xf, 0xf, true); }
+                else { dlo = (uint32_t)__builtin_amdgcn_mov_dpp(mlo, 0xFF, 0xf, 0xf, true); dhi = (uint32_t)__builtin_amdgcn_mov_dpp(mhi, 0xFF, 0xf, 0xf, true); }
+                (void)ctrl;
+                const uint64_t dst = ((uint64_t)dhi << 32) | dlo;
+                if (dst) {
+                    u32x4 piece = {v[q][0], v[q][1], v[q][2], v[q][3]};
+                    *(u32x4_a1*)(uintptr_t)(dst + 16u * p) = piece;
+                }
+            }
+            if (work) i += 64;
+        }
     }
     while (i + 16 <= b) {
         *(u32x4_a1*)(o + i) = sixteen();
