@@ -106,6 +106,12 @@ inline int64_t decompress_rowmajor_16b(const int16_t* src, uint16_t* dest) { ret
 inline int64_t decompress_rowmajor_delta_8b(const int8_t* src, uint8_t* dest) { return sprintz_mi355x_decompress_norle(SPRINTZ_CODEC_DELTA_NORLE, 1, src, dest); }
 inline int64_t decompress_rowmajor_delta_16b(const int16_t* src, uint16_t* dest) { return sprintz_mi355x_decompress_norle(SPRINTZ_CODEC_DELTA_NORLE, 2, src, dest); }
 
+inline int64_t compress8b_rowmajor_xff(const uint8_t* src, uint64_t len, int8_t* dest, uint16_t ndims, bool = true)   // sprintz_xff.h:28
+{
+    return len >> 32 ? -1 : sprintz_mi355x_compress_norle(SPRINTZ_CODEC_XFF_NORLE, 1, src, (uint32_t)len, dest, ndims);
+}
+inline int64_t decompress8b_rowmajor_xff(const int8_t* src, uint8_t* dest) { return sprintz_mi355x_decompress_norle(SPRINTZ_CODEC_XFF_NORLE, 1, src, dest); }
+
 // ================================================================ stand-alone transforms (delta.h:17-68)
 #define SPRINTZ_DROPIN_TRANSFORM(NAME, KIND, BITS, ESZ)                                                                       \
     inline uint32_t encode_##NAME##_rowmajor_##BITS##b(const uint##BITS##_t* src, uint32_t len, int##BITS##_t* dest, uint16_t ndims,  \

@@ -48,6 +48,7 @@ extern "C" {
  * entry point; decoded by the generic kernels */
 #define SPRINTZ_CODEC_DELTA_NORLE   2   /* compress_rowmajor_delta_{8b,16b}  sprintz_delta.cpp:776-1391 */
 #define SPRINTZ_CODEC_BITPACK_NORLE 3   /* compress_rowmajor_{8b,16b}: bit-packing only  sprintz_delta.cpp:64-773 */
+#define SPRINTZ_CODEC_XFF_NORLE     4   /* compress8b_rowmajor_xff (8-bit only; 8-byte header)  sprintz_xff.cpp:35-626 */
 
 /* error codes */
 #define SPRINTZ_E_INVALID    (-1)   /* bad argument; also what the reference returns for ndims == 0 (sprintz.cpp:36) */
@@ -248,7 +249,8 @@ int64_t sprintz_mi355x_query_xff_16b(const int16_t* src, uint16_t* dest, int op,
 /* single-call forms of the non-RLE codecs over host buffers; replace
  *   compress_rowmajor_{8b,16b} / decompress_rowmajor_{8b,16b}                cpp/Compress/sprintz_delta.h:26-31,63-66
  *   compress_rowmajor_delta_{8b,16b} / decompress_rowmajor_delta_{8b,16b}    cpp/Compress/sprintz_delta.h:37-42,72-76
- * codec: SPRINTZ_CODEC_DELTA_NORLE or SPRINTZ_CODEC_BITPACK_NORLE; return values in elements as above */
+ *   compress8b_rowmajor_xff / decompress8b_rowmajor_xff                      cpp/Compress/sprintz_xff.h:28-31
+ * codec: SPRINTZ_CODEC_DELTA_NORLE, SPRINTZ_CODEC_BITPACK_NORLE or SPRINTZ_CODEC_XFF_NORLE; return values in elements as above */
 int64_t sprintz_mi355x_compress_norle(int codec, int elem_bytes, const void* src, uint32_t len, void* dest, uint16_t ndims);
 int64_t sprintz_mi355x_decompress_norle(int codec, int elem_bytes, const void* src, void* dest);
 

@@ -27,7 +27,7 @@ def main():
     idx = 0
     for esz in (1, 2):
         top = 1 << (8 * esz)
-        for raw in (0, 1):
+        for raw in ((0, 1, 2) if esz == 1 else (0, 1)):      # 2: compress8b_rowmajor_xff (sprintz_xff.cpp), 8-bit only
             for D in (1, 2, 3, 4, 5, 8, 17, 33, 80):
                 for n in (1, 17, 127, 128, 129, 16 * D, 16 * D + 1, 48 * D + 5, 1000, 4113):
                     for kind in ("fuzz", "walk", "walk_zero", "small"):

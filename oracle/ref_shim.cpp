@@ -133,6 +133,7 @@ uint32_t ref_transform_decode(int kind, int elem_bytes, const void* src, void* d
 /* non-RLE codecs (sprintz_delta.h): raw = 1 compress_rowmajor_{8b,16b}, raw = 0 compress_rowmajor_delta_{8b,16b} */
 int64_t ref_compress_norle(int raw, int elem_bytes, const void* src, uint32_t len, void* dest, uint16_t ndims)
 {
+    if (raw == 2) return compress8b_rowmajor_xff((const uint8_t*)src, len, (int8_t*)dest, ndims, true);   /* sprintz_xff.h:28 */
     if (elem_bytes == 1) {
         return raw ? compress_rowmajor_8b((const uint8_t*)src, len, (int8_t*)dest, ndims, true)
                    : compress_rowmajor_delta_8b((const uint8_t*)src, len, (int8_t*)dest, ndims, true);
@@ -143,6 +144,7 @@ int64_t ref_compress_norle(int raw, int elem_bytes, const void* src, uint32_t le
 
 int64_t ref_decompress_norle(int raw, int elem_bytes, const void* src, void* dest)
 {
+    if (raw == 2) return decompress8b_rowmajor_xff((const int8_t*)src, (uint8_t*)dest);
     if (elem_bytes == 1) {
         return raw ? decompress_rowmajor_8b((const int8_t*)src, (uint8_t*)dest)
                    : decompress_rowmajor_delta_8b((const int8_t*)src, (uint8_t*)dest);

@@ -15,6 +15,7 @@ from .codec import (ChunkedCodec, CompressedBatch, HufBatch, compress_chunked, d
                     decode_doubledelta_rowmajor_8b, decode_doubledelta_rowmajor_16b, transform_device,
                     compress_rowmajor_8b, compress_rowmajor_16b, compress_rowmajor_delta_8b, compress_rowmajor_delta_16b,
                     decompress_rowmajor_8b, decompress_rowmajor_16b, decompress_rowmajor_delta_8b, decompress_rowmajor_delta_16b,
+                    compress8b_rowmajor_xff, decompress8b_rowmajor_xff,
                     sprintz_compress_delta_8b, sprintz_compress_delta_16b, sprintz_compress_xff_8b,
                     sprintz_compress_xff_16b, sprintz_decompress_delta_8b, sprintz_decompress_delta_16b,
                     sprintz_decompress_xff_8b, sprintz_decompress_xff_16b)
@@ -27,6 +28,7 @@ __all__ = [
     "transform_device",
     "compress_rowmajor_8b", "compress_rowmajor_16b", "compress_rowmajor_delta_8b", "compress_rowmajor_delta_16b",
     "decompress_rowmajor_8b", "decompress_rowmajor_16b", "decompress_rowmajor_delta_8b", "decompress_rowmajor_delta_16b",
+    "compress8b_rowmajor_xff", "decompress8b_rowmajor_xff",
     "query_rowmajor_delta_rle_8b", "query_rowmajor_delta_rle_16b", "query_rowmajor_xff_rle_8b", "query_rowmajor_xff_rle_16b",
     "sprintz_compress_delta_8b", "sprintz_compress_delta_16b", "sprintz_compress_xff_8b", "sprintz_compress_xff_16b",
     "sprintz_decompress_delta_8b", "sprintz_decompress_delta_16b", "sprintz_decompress_xff_8b",

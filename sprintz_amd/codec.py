@@ -21,7 +21,8 @@ from . import _lib
 
 _NP = {1: np.uint8, 2: np.uint16}
 _CODEC_ID = {"delta": _lib.CODEC_DELTA, "xff": _lib.CODEC_XFF,
-             "delta_norle": _lib.CODEC_DELTA_NORLE, "bitpack": _lib.CODEC_BITPACK_NORLE}   # the last two: sprintz_delta.cpp:64-1391
+             "delta_norle": _lib.CODEC_DELTA_NORLE, "bitpack": _lib.CODEC_BITPACK_NORLE,    # sprintz_delta.cpp:64-1391
+             "xff_norle": _lib.CODEC_XFF_NORLE}                                             # sprintz_xff.cpp:35-626, 8-bit only
 
 
 def _np_ptr(a):
@@ -117,7 +118,7 @@ class ChunkedCodec:
     def __init__(self, codec, elem_bytes, ndims, chunk_len, device=None, align=16):
         import torch
         if codec not in _CODEC_ID:
-            raise ValueError("codec must be 'delta', 'xff', 'delta_norle' or 'bitpack'")
+            raise ValueError("codec must be 'delta', 'xff', 'delta_norle', 'bitpack' or 'xff_norle'")
         if elem_bytes not in (1, 2):
             raise ValueError("elem_bytes must be 1 or 2")
         if not torch.cuda.is_available():
@@ -319,6 +320,14 @@ def compress_rowmajor_delta_8b(src, len, dest, ndims):  # noqa: A002
 
 def compress_rowmajor_delta_16b(src, len, dest, ndims):  # noqa: A002
     return _c_norle(_lib.CODEC_DELTA_NORLE, 2, src, len, dest, ndims)
+
+
+def compress8b_rowmajor_xff(src, len, dest, ndims):  # noqa: A002 - sprintz_xff.h:28
+    return _c_norle(_lib.CODEC_XFF_NORLE, 1, src, len, dest, ndims)
+
+
+def decompress8b_rowmajor_xff(src, dest):
+    return int(_lib.decompress_norle(_lib.CODEC_XFF_NORLE, 1, _np_ptr(np.ascontiguousarray(src)), _np_ptr(dest)))
 
 
 def decompress_rowmajor_8b(src, dest):

@@ -199,8 +199,9 @@ namespace {
 
 int check_common(int codec, int esz, uint16_t ndims)
 {
-    if (codec < SPRINTZ_CODEC_DELTA || codec > SPRINTZ_CODEC_BITPACK_NORLE)
-        return fail(SPRINTZ_E_INVALID, "codec must be 0 (delta), 1 (xff), 2 (delta, no RLE) or 3 (bit-packing only)");
+    if (codec < SPRINTZ_CODEC_DELTA || codec > SPRINTZ_CODEC_XFF_NORLE)
+        return fail(SPRINTZ_E_INVALID, "codec must be 0 (delta), 1 (xff), 2 (delta, no RLE), 3 (bit-packing only) or 4 (xff, no RLE)");
+    if (codec == SPRINTZ_CODEC_XFF_NORLE && esz != 1) return fail(SPRINTZ_E_UNSUPPORTED, "the non-RLE xff codec exists for 8-bit elements only");
     if (esz != 1 && esz != 2) return fail(SPRINTZ_E_INVALID, "elem_bytes must be 1 or 2");
     if (ndims == 0) return fail(SPRINTZ_E_INVALID, "ndims == 0 (reference: sprintz.cpp:36 returns -1)");
     if (ndims > SPRINTZ_MI355X_MAX_NDIMS) return fail(SPRINTZ_E_UNSUPPORTED, "ndims above SPRINTZ_MI355X_MAX_NDIMS");
@@ -242,7 +243,7 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
     a.chunks_per_group = 1;
     a.qop = qs.qop;
     a.qres = qs.qres;
-    a.norle = norle ? 1 : 0;
+    a.norle = norle ? (codec == SPRINTZ_CODEC_XFF_NORLE ? 2 : 1) : 0;
     a.raw = codec == SPRINTZ_CODEC_BITPACK_NORLE ? 1 : 0;
     a.col_stride = qs.col_stride;
     const uint64_t cs = qs.col_stride;
@@ -310,8 +311,8 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
     const uint64_t threads = nchunks * (uint64_t)DP;
     const uint64_t grid = (threads + kThreads - 1) / kThreads;
     if (grid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
-    e = esz == 1 ? launch_decode_w8(codec == SPRINTZ_CODEC_XFF, lowdim, m.cpl, qs.q, (unsigned)grid, shmem, st, a)
-                 : launch_decode_w16(codec == SPRINTZ_CODEC_XFF, lowdim, m.cpl, qs.q, (unsigned)grid, shmem, st, a);
+    e = esz == 1 ? launch_decode_w8((codec == SPRINTZ_CODEC_XFF || codec == SPRINTZ_CODEC_XFF_NORLE), lowdim, m.cpl, qs.q, (unsigned)grid, shmem, st, a)
+                 : launch_decode_w16((codec == SPRINTZ_CODEC_XFF || codec == SPRINTZ_CODEC_XFF_NORLE), lowdim, m.cpl, qs.q, (unsigned)grid, shmem, st, a);
     if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "decode kernel launch", e);
     return 0;
 }
@@ -341,7 +342,7 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     a.rets = d_rets;
     a.write_size = write_size;
     a.col_stride = col_stride;
-    a.norle = norle ? 1 : 0;
+    a.norle = norle ? (codec == SPRINTZ_CODEC_XFF_NORLE ? 2 : 1) : 0;
     a.raw = codec == SPRINTZ_CODEC_BITPACK_NORLE ? 1 : 0;
     a.cap = next_pow2((uint32_t)group_bytes_max(esz, D) + 48u);
     const size_t shmem = (size_t)a.cap * (kThreads / DP);
@@ -371,8 +372,8 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     const uint64_t threads = nchunks * (uint64_t)DP;
     const uint64_t grid = (threads + kThreads - 1) / kThreads;
     if (grid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
-    e = esz == 1 ? launch_encode_w8(codec == SPRINTZ_CODEC_XFF, lowdim, m.cpl, (unsigned)grid, shmem, st, a)
-                 : launch_encode_w16(codec == SPRINTZ_CODEC_XFF, lowdim, m.cpl, (unsigned)grid, shmem, st, a);
+    e = esz == 1 ? launch_encode_w8((codec == SPRINTZ_CODEC_XFF || codec == SPRINTZ_CODEC_XFF_NORLE), lowdim, m.cpl, (unsigned)grid, shmem, st, a)
+                 : launch_encode_w16((codec == SPRINTZ_CODEC_XFF || codec == SPRINTZ_CODEC_XFF_NORLE), lowdim, m.cpl, (unsigned)grid, shmem, st, a);
     if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "encode kernel launch", e);
     return 0;
 }
@@ -442,6 +443,11 @@ int64_t compress_host(int codec, int esz, const void* src, uint32_t len, void* d
     int64_t* d_ret = (int64_t*)((uint8_t*)d_meta.p + 8);
     rc = encode_launch(codec, esz, d_src.p, len, len ? len : 1, ndims, d_slot.p, bound, d_size, d_ret, nullptr, write_size);
     if (rc) return rc;
+    if (len == 0 && codec == SPRINTZ_CODEC_XFF_NORLE) {     // u64 0 with ndims in bytes 6..7 (sprintz_xff.cpp:58-63)
+        uint8_t h[8] = {0, 0, 0, 0, 0, 0, (uint8_t)(ndims & 0xff), (uint8_t)(ndims >> 8)};
+        memcpy(dest, h, 8);
+        return 8;
+    }
     if (len == 0 && codec >= SPRINTZ_CODEC_DELTA_NORLE) {   // {u32 0; u16 ndims} (format.h:65-72)
         uint8_t h[6] = {0, 0, 0, 0, (uint8_t)(ndims & 0xff), (uint8_t)(ndims >> 8)};
         memcpy(dest, h, 6);
@@ -472,7 +478,7 @@ int64_t decompress_host(int codec, int esz, const void* src, void* dest, int noh
     if (norle) {                                               // {u32 len; u16 ndims}; sprintz_delta.cpp:803-807, :832
         uint32_t len;
         memcpy(&len, s, 4);
-        memcpy(&ndims, s + 4, 2);
+        memcpy(&ndims, s + (codec == SPRINTZ_CODEC_XFF_NORLE ? 6 : 4), 2);
         ngroups = (len < 128 || ndims == 0) ? 0 : len / (16u * ndims);
         remaining = len - ngroups * 16u * ndims;
         if (ndims == 0 && len == 0) return 0;
@@ -489,7 +495,7 @@ int64_t decompress_host(int codec, int esz, const void* src, void* dest, int noh
     int rc = check_common(codec, esz, ndims);
     if (rc) return rc;
     if ((rc = ensure_device())) return rc;
-    const uint32_t hlen = norle ? 6 : (noheader ? 0 : 8);
+    const uint32_t hlen = norle ? (codec == SPRINTZ_CODEC_XFF_NORLE ? 8 : 6) : (noheader ? 0 : 8);
     uint64_t nbytes = 0, nelems = 0;
     walk_stream(s + hlen, esz, ndims, ngroups, remaining, norle ? false : is_lowdim(esz, ndims), &nbytes, &nelems, norle);
     nbytes += hlen;
@@ -860,13 +866,13 @@ int sprintz_mi355x_decompress_batch_colmajor(int codec, int elem_bytes, const vo
 // ---------------------------------------------------------------- non-RLE codecs, single call (host pointers)
 int64_t sprintz_mi355x_compress_norle(int codec, int elem_bytes, const void* src, uint32_t len, void* dest, uint16_t ndims)
 {
-    if (codec != SPRINTZ_CODEC_DELTA_NORLE && codec != SPRINTZ_CODEC_BITPACK_NORLE) return fail(SPRINTZ_E_INVALID, "codec must be 2 or 3");
+    if (codec < SPRINTZ_CODEC_DELTA_NORLE || codec > SPRINTZ_CODEC_XFF_NORLE) return fail(SPRINTZ_E_INVALID, "codec must be 2, 3 or 4");
     return compress_host(codec, elem_bytes, src, len, dest, ndims, 1);
 }
 
 int64_t sprintz_mi355x_decompress_norle(int codec, int elem_bytes, const void* src, void* dest)
 {
-    if (codec != SPRINTZ_CODEC_DELTA_NORLE && codec != SPRINTZ_CODEC_BITPACK_NORLE) return fail(SPRINTZ_E_INVALID, "codec must be 2 or 3");
+    if (codec < SPRINTZ_CODEC_DELTA_NORLE || codec > SPRINTZ_CODEC_XFF_NORLE) return fail(SPRINTZ_E_INVALID, "codec must be 2, 3 or 4");
     return decompress_host(codec, elem_bytes, src, dest, 0, 0, 0, 0);
 }
 

@@ -75,15 +75,17 @@ __global__ void __launch_bounds__(kThreads) decode_kernel(DecodeArgs a)
     // ---- 8-byte stream header (format.h:48-62)
     uint32_t groups_left, remaining, pos;
     if (a.norle) {                                   // format.h:65-86; sprintz_delta.cpp:803-807, :832
+        // norle == 2: compress8b_rowmajor_xff's 8-byte header, a u64 len whose bytes 6..7 hold ndims (sprintz_xff.cpp:58-63)
         const uint32_t len = load_u32_any(s);
-        const uint32_t nd = load_u8(s + 4) | (load_u8(s + 5) << 8);
+        const uint32_t ndo = a.norle == 2 ? 6u : 4u;
+        const uint32_t nd = load_u8(s + ndo) | (load_u8(s + ndo + 1) << 8);
         if ((int)nd != D || len > a.chunk_len) {
             if (lane_d == 0 && a.rets) a.rets[chunk] = kErrCorrupt;
             return;
         }
         groups_left = len < 128u ? 0u : len / (16u * (uint32_t)D);
         remaining = len - groups_left * 16u * (uint32_t)D;
-        pos = 6;
+        pos = a.norle == 2 ? 8u : 6u;
     } else if (!a.noheader) {
         const uint32_t w0 = load_u32_any(s), w1 = load_u32_any(s + 4);
         groups_left = w0;

@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(kThreads) encode_kernel(EncodeArgs a)
     for (uint32_t u = (uint32_t)lane_d; u < (cap >> 4); u += (uint32_t)DP) ((uint4*)ring)[u] = make_uint4(0, 0, 0, 0);
     wave_lds_sync();
 
-    uint32_t wpos = a.norle ? 6u : (a.write_size ? 8u : 0u);   // stream write position (bytes)
+    uint32_t wpos = a.norle == 1 ? 6u : ((a.norle == 2 || a.write_size) ? 8u : 0u);   // stream write position (bytes)
     uint32_t flushed = 0;                     // multiple of 16; ring holds [flushed, flushed + cap)
 
     // flush [flushed, upto) (upto multiple of 16) to HBM and re-zero it
@@ -249,7 +249,10 @@ __global__ void __launch_bounds__(kThreads) encode_kernel(EncodeArgs a)
 
     // ---- 8-byte stream header (format.h:36-45); lane 0 also wrote unit 0 in flush_to
     if (lane_d == 0) {
-        if (a.norle) {                                       // {u32 len; u16 ndims} (format.h:65-72); bytes 6.. are stream
+        if (a.norle == 2) {                                  // u64 len with ndims in its bytes 6..7 (sprintz_xff.cpp:58-63)
+            ((uint32_t*)gdst)[0] = n;
+            ((uint32_t*)gdst)[1] = (uint32_t)D << 16;
+        } else if (a.norle) {                                // {u32 len; u16 ndims} (format.h:65-72); bytes 6.. are stream
             ((uint32_t*)gdst)[0] = n;
             ((uint16_t*)gdst)[2] = (uint16_t)D;
         } else if (a.write_size) {

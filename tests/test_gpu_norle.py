@@ -24,9 +24,12 @@ def test_reference_streams_single_call(sz, golden_norle):
     for m in manifest[::2]:
         x, stream = arrays[m["name"] + "_in"], arrays[m["name"] + "_stream"]
         esz, D, n = m["esz"], m["ndims"], m["n"]
-        name = ("" if m["raw"] else "delta_") + f"{8 * esz}b"
-        comp = getattr(sz, f"compress_rowmajor_{name}")
-        dec = getattr(sz, f"decompress_rowmajor_{name}")
+        if m["raw"] == 2:
+            comp, dec = sz.compress8b_rowmajor_xff, sz.decompress8b_rowmajor_xff
+        else:
+            name = ("" if m["raw"] else "delta_") + f"{8 * esz}b"
+            comp = getattr(sz, f"compress_rowmajor_{name}")
+            dec = getattr(sz, f"decompress_rowmajor_{name}")
         dest = np.full(stream.size + 64 + 4 * D, 0xAB, np.uint8)
         ret = comp(x, n, dest, D)
         assert ret == m["ret"], m
@@ -37,7 +40,8 @@ def test_reference_streams_single_call(sz, golden_norle):
 
 
 @pytest.mark.parametrize("codec,esz,ndims,chunk_len", [("delta_norle", 2, 8, 5120), ("bitpack", 2, 8, 5120), ("delta_norle", 1, 80, 10240),
-                                                       ("bitpack", 1, 3, 999), ("delta_norle", 2, 300, 9600 + 31), ("delta_norle", 1, 1, 1024)])
+                                                       ("bitpack", 1, 3, 999), ("delta_norle", 2, 300, 9600 + 31), ("delta_norle", 1, 1, 1024),
+                                                       ("xff_norle", 1, 8, 4096), ("xff_norle", 1, 80, 10240)])
 def test_batched_matches_oracle(sz, oracle, codec, esz, ndims, chunk_len):
     import torch
     rng = np.random.default_rng(zlib.crc32(f"{codec}{esz}{ndims}".encode()))
@@ -47,7 +51,7 @@ def test_batched_matches_oracle(sz, oracle, codec, esz, ndims, chunk_len):
     x = (np.cumsum(rng.integers(-5, 6, n)) % top).astype(DTYPES[esz])
     x[n // 4: n // 4 + 2 * chunk_len] = 0                          # all-zero blocks: no payload, no run length
     x[n - chunk_len // 2:] = rng.integers(0, top, chunk_len // 2)
-    raw = codec == "bitpack"
+    raw = {"delta_norle": 0, "bitpack": 1, "xff_norle": 2}[codec]
     cd = sz.ChunkedCodec(codec, esz, ndims, chunk_len, device="cuda:0")
     batch = cd.compress(torch.from_numpy(x.view(np.int8 if esz == 1 else np.int16)).cuda().view(cd.dtype))
     comp, offs, sizes = batch.data.cpu().numpy(), batch.offsets.cpu().numpy(), batch.sizes.cpu().numpy()
