@@ -111,3 +111,48 @@ def test_dropin_header_compiles_and_links(lib_path, tmp_path):
            "-L", libdir, "-lsprintz_mi355x", "-L/opt/rocm/lib", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
     assert exe.exists()
+
+
+def test_argument_checks_come_before_the_device_check(lib_path):
+    """bad arguments are E_INVALID / E_UNSUPPORTED on any machine; good ones need a device"""
+    import ctypes as C
+    import torch
+    from sprintz_amd import _lib
+    E = _lib
+    buf = (C.c_uint8 * 4096)()
+    p = C.addressof(buf)
+    p16 = (p + 15) & ~15
+    # batched codec entry points
+    assert _lib.compress_batch(9, 2, p16, 100, 50, 8, p16, 1024, p16, None, None) == E.E_INVALID          # codec
+    assert _lib.compress_batch(0, 3, p16, 100, 50, 8, p16, 1024, p16, None, None) == E.E_INVALID          # elem_bytes
+    assert _lib.compress_batch(0, 2, p16, 100, 50, 0, p16, 1024, p16, None, None) == E.E_INVALID          # ndims
+    assert _lib.compress_batch(0, 2, p16, 100, 50, 600, p16, 1 << 20, p16, None, None) == E.E_UNSUPPORTED  # ndims > MAX
+    assert _lib.compress_batch(4, 2, p16, 100, 50, 8, p16, 1024, p16, None, None) == E.E_UNSUPPORTED      # xff_norle is 8-bit only
+    assert _lib.compress_batch(0, 2, p16, 100, 0, 8, p16, 1024, p16, None, None) == E.E_INVALID           # chunk_len
+    assert _lib.compress_batch(0, 2, p16, 100, 50, 8, p16 + 4, 1024, p16, None, None) == E.E_INVALID      # slot alignment
+    assert _lib.compress_batch(0, 2, p16, 100, 50, 8, p16, 16, p16, None, None) == E.E_INVALID            # slot_stride < bound
+    assert _lib.decompress_batch(0, 2, None, p16, 1, 50, 8, p16, None, None) == E.E_INVALID               # null
+    # query
+    assert _lib.query_batch(1, 2, p16, p16, 1, 50, 8, 7, 0, 0, None, p16, None, None) == E.E_INVALID      # op
+    assert _lib.query_batch(1, 2, p16, p16, 1, 50, 8, 1, 1, 0, None, p16, None, None) == E.E_INVALID      # materialize without out
+    assert _lib.query_batch(1, 2, p16, p16, 1, 50, 8, 1, 0, 0, None, None, None, None) == E.E_INVALID     # op without partials
+    assert _lib.query_batch(1, 2, p16, p16, 1, 50, 8, 1, 0, 8, None, p16, None, None) == E.E_INVALID      # unknown flag
+    assert _lib.query_reduce(0, p16, 1, 8, p16, None) == E.E_INVALID
+    # column-major
+    assert _lib.compress_batch_colmajor(1, 2, p16, 100, 50, 10, 8, p16, 1024, p16, None, None) == E.E_INVALID   # col_stride < nrows
+    assert _lib.decompress_batch_colmajor(1, 2, p16, p16, 4, 10, 8, 30, p16, None, None) == E.E_INVALID          # col_stride < nchunks*rows
+    # transforms
+    assert _lib.transform_encode_device(2, 2, p16, 10, 8, p16, None) == E.E_INVALID
+    assert _lib.transform_encode_device(0, 4, p16, 10, 8, p16, None) == E.E_INVALID
+    assert _lib.transform_decode_device(0, 2, p16, 10, 0, p16, p16, None) == E.E_INVALID
+    assert _lib.transform_decode_device(0, 2, p16, 10, 8, p16, None, None) == E.E_INVALID
+    assert _lib.transform_tmp_bytes(0, 2, 1 << 30, 8) > 0 and _lib.transform_tmp_bytes(0, 2, 100, 0) == 0
+    # non-RLE single call
+    assert _lib.compress_norle(1, 1, p16, 10, p16, 3) == E.E_INVALID
+    # Huffman
+    assert _lib.huf_compress_batch(None, p16, p16, 1, p16, p16, p16, p16, None) == E.E_INVALID
+    assert _lib.huf_decompress_batch(p16, p16, p16, 1, 3, p16, 100, p16, p16, None, p16, None) == E.E_INVALID   # align not a power of two
+    if not torch.cuda.is_available():
+        assert _lib.compress_batch(0, 2, p16, 100, 50, 8, p16, 1024, p16, None, None) == E.E_NO_DEVICE
+        assert _lib.transform_encode_device(0, 2, p16, 10, 8, p16, None) == E.E_NO_DEVICE
+        assert _lib.query_batch(1, 2, p16, p16, 1, 50, 8, 1, 0, 0, None, p16, None, None) == E.E_NO_DEVICE
