@@ -126,6 +126,10 @@ inline int64_t decompress8b_rowmajor_xff(const int8_t* src, uint8_t* dest) { ret
     inline uint32_t decode_##NAME##_rowmajor_##BITS##b(const int##BITS##_t* src, uint##BITS##_t* dest)                        \
     {                                                                                                                         \
         return (uint32_t)sprintz_mi355x_transform_decode(KIND, ESZ, src, dest, 0, 0);                                         \
+    }                                                                                                                         \
+    inline uint32_t decode_##NAME##_rowmajor_inplace_##BITS##b(uint##BITS##_t* buff, uint32_t len, uint16_t ndims)            \
+    {   /* the device copy is the temporary the reference mallocs (delta.cpp:351-373) */                                      \
+        return ndims == 0 ? 0u : (uint32_t)sprintz_mi355x_transform_decode(KIND, ESZ, buff, buff, len, ndims);                \
     }
 SPRINTZ_DROPIN_TRANSFORM(delta, SPRINTZ_TRANSFORM_DELTA, 8, 1)
 SPRINTZ_DROPIN_TRANSFORM(delta, SPRINTZ_TRANSFORM_DELTA, 16, 2)

@@ -103,6 +103,10 @@ def test_dropin_header_compiles_and_links(lib_path, tmp_path):
         "  uint64_t res[8];\n"
         "  int64_t q = query_rowmajor_xff_rle_16b(c.data(), y.data(), qp);           // sprintz_xff.h:92\n"
         "  int64_t r = query_rowmajor_delta_rle_8b((const int8_t*)c.data(), (uint8_t*)y.data(), qp, res);\n"
+        "  uint32_t e = encode_doubledelta_rowmajor_16b(x.data(), 100, c.data(), 4);   // delta.h:63\n"
+        "  uint32_t d = decode_delta_rowmajor_inplace_8b((uint8_t*)y.data(), 64, 2);     // delta.h:21\n"
+        "  int64_t z = compress_rowmajor_delta_16b(x.data(), 4096, c.data(), 8) + decompress8b_rowmajor_xff((const int8_t*)c.data(), (uint8_t*)y.data());\n"
+        "  (void)e; (void)d; (void)z;\n"
         "  return (n < 0 && m < 0 && a < 0 && q < 0 && r < 0) ? 0 : 1;   // without a GPU every call fails loudly\n"
         "}\n")
     exe = tmp_path / "caller"
