@@ -30,6 +30,9 @@ CM_CONFIGS = [
     ("u16 D=8, unaligned stride (generic kernels)", "xff", 2, 8, 100, 100 * 9 + 3, 903),
     ("u8 D=2 low-dim", "delta", 1, 2, 512, 512 * 5 + 1, 0),
     ("u16 D=100 (2 columns per lane)", "xff", 2, 100, 64, 64 * 7 + 5, 64 * 8),
+    ("u16 D=6 (fast kernels, group not full)", "xff", 2, 6, 160, 160 * 9 + 48, 160 * 10),
+    ("u8 D=12 (fast kernels, group not full)", "delta", 1, 12, 256, 256 * 5 + 64, 256 * 6),
+    ("u16 D=48 delta (fast kernels, group not full)", "delta", 2, 48, 104, 104 * 11 + 16, 104 * 12),
 ]
 
 
