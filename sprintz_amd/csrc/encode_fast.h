@@ -129,12 +129,54 @@ __global__ void __launch_bounds__(kThreads) encode_fast_kernel(EncodeArgs a)
         return v;
     };
     static_assert(PIECES == 1, "one 16-byte piece per lane covers a block");
+    // Column-major source: a lone 16-byte load per lane per block makes every request its own cache
+    // line (see decode_fast.h).  So the blocks arrive four at a time: a QUAD of lanes loads one
+    // column's 64 contiguous bytes (= 4 blocks; 32 bytes at 8 bits) one burst ahead, the pieces wait
+    // in LDS as cst[buffer][column][slot] (slots rotated by column/4, as in the decoder), and every
+    // lane picks up its own column's block from there.
+    constexpr uint32_t PB = W == 16 ? 16u : 8u;
+    uint8_t* const cst = stage;                            // 2 buffers x 4 blocks x DP columns x PB bytes
+    auto cst_at = [&](uint32_t buf, uint32_t col, uint32_t b4) { return cst + ((buf * DP + col) * 4u + ((b4 + (col >> 2)) & 3u)) * PB; };
+    uint4 burst[4];                                        // this lane's share of the burst in flight
+    const uint32_t cs_elems = CM ? (uint32_t)a.col_stride : 0u;
+    const U* const cm0 = CM ? (const U*)a.src + first / (uint64_t)D : nullptr;
+    auto burst_load = [&](uint32_t k) {                    // blocks 4k .. 4k+3
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t pid = (uint32_t)j * DP + (uint32_t)lane_d, col = pid >> 2, part = pid & 3u;
+            const int64_t pos = ((int64_t)k * 4 + part) * (int64_t)blk;
+            burst[j] = make_uint4(0, 0, 0, 0);
+            if (col < (uint32_t)D && pos + (int64_t)blk <= (int64_t)n) {
+                const U* p = cm0 + (uint64_t)col * cs_elems + (uint32_t)pos / (uint32_t)D;
+                if constexpr (W == 16) burst[j] = *(const uint4*)p;
+                else { const uint2 t = *(const uint2*)p; burst[j].x = t.x; burst[j].y = t.y; }
+            }
+        }
+    };
+    auto burst_park = [&](uint32_t k) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t pid = (uint32_t)j * DP + (uint32_t)lane_d, col = pid >> 2, part = pid & 3u;
+            if (col < (uint32_t)D) {
+                if constexpr (W == 16) *(uint4*)cst_at(k & 1u, col, part) = burst[j];
+                else *(uint2*)cst_at(k & 1u, col, part) = make_uint2(burst[j].x, burst[j].y);
+            }
+        }
+    };
+    uint32_t bno = 0;                                      // blocks taken so far (= pos_in / blk)
 
     bool active = n >= 128u && limit >= 0;      // :116 and the loop guard :160
     uint4 nxt = make_uint4(0, 0, 0, 0);
     if (active) {
         start_group();
-        nxt = load_block(0);
+        if constexpr (CM) {
+            burst_load(0);
+            burst_park(0);
+            burst_load(1);
+            wave_lds_sync();
+        } else {
+            nxt = load_block(0);
+        }
     }
     uint8_t* const stage_col = stage + lane_d * ESZ;
     const uint32_t row_stride = (uint32_t)D * ESZ;
@@ -143,8 +185,18 @@ __global__ void __launch_bounds__(kThreads) encode_fast_kernel(EncodeArgs a)
         // ---- the block at pos_in is in `nxt`; transpose it through LDS, request the next one
         uint32_t x[8];
         if constexpr (CM) {
-            const uint4 cur = nxt;
-            nxt = load_block(pos_in + blk);
+            const uint32_t k = bno >> 2;
+            if ((bno & 3u) == 0 && bno != 0) {             // a new burst starts: park it, request the one after
+                wave_lds_sync();
+                burst_park(k);
+                burst_load(k + 1);
+                wave_lds_sync();
+            }
+            uint4 cur = make_uint4(0, 0, 0, 0);
+            if (col_ok) {
+                if constexpr (W == 16) cur = *(const uint4*)cst_at(k & 1u, (uint32_t)lane_d, bno & 3u);
+                else { const uint2 t = *(const uint2*)cst_at(k & 1u, (uint32_t)lane_d, bno & 3u); cur.x = t.x; cur.y = t.y; }
+            }
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 if constexpr (W == 16) {
@@ -196,6 +248,7 @@ __global__ void __launch_bounds__(kThreads) encode_fast_kernel(EncodeArgs a)
             if (total == 0 && run < 0x7fffu) {
                 run++;
                 pos_in += blk;
+                bno++;
                 const bool more = TAIL_LE ? (pos_in <= limit) : (pos_in < limit);
                 if (more) break;
                 slot++;
@@ -225,6 +278,7 @@ __global__ void __launch_bounds__(kThreads) encode_fast_kernel(EncodeArgs a)
             }
             wl += row_bits;                              // 8 rows * row_bytes
             pos_in += blk;
+            bno++;
             slot++;
             if (slot == 2) {
                 if (pos_in <= limit) start_group();
