@@ -68,22 +68,44 @@ __global__ void __launch_bounds__(256) huf_build_kernel(const uint8_t* dense, co
     if (t == 0) s_kraft = 0;
     __syncthreads();
     uint32_t* const hw = hist4[t >> 6];
-    for (uint64_t c = c0; c < c1; c++) {
-        const uint8_t* p = dense + offsets[c];
-        const uint32_t n = sizes[c];
-        const uint32_t np = n >> 4;
-        for (uint32_t i = t; i < np; i += 256) {
-            const u32x4 x = *(const u32x4_a1*)(p + (size_t)i * 16);
+    // chunk geometry once, coalesced; then two chunks' first pieces are in flight together (a
+    // chunk of the headline shape is < 256 pieces: one trip per thread, and the loop was two
+    // dependent memory latencies per chunk)
+    __shared__ uint64_t s_off[SEG];
+    __shared__ uint32_t s_sz[SEG];
+    if (t < SEG) {
+        const bool in = c0 + t < c1;
+        s_off[t] = in ? offsets[c0 + t] : 0;
+        s_sz[t] = in ? sizes[c0 + t] : 0;
+    }
+    __syncthreads();
+    auto tally = [&](const u32x4& x) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t d = k == 0 ? x.x : k == 1 ? x.y : k == 2 ? x.z : x.w;
-                atomicAdd(&hw[d & 255], 1u);
-                atomicAdd(&hw[(d >> 8) & 255], 1u);
-                atomicAdd(&hw[(d >> 16) & 255], 1u);
-                atomicAdd(&hw[d >> 24], 1u);
-            }
+        for (int k = 0; k < 4; k++) {
+            const uint32_t d = k == 0 ? x.x : k == 1 ? x.y : k == 2 ? x.z : x.w;
+            atomicAdd(&hw[d & 255], 1u);
+            atomicAdd(&hw[(d >> 8) & 255], 1u);
+            atomicAdd(&hw[(d >> 16) & 255], 1u);
+            atomicAdd(&hw[d >> 24], 1u);
         }
-        for (uint32_t i = (np << 4) + t; i < n; i += 256) atomicAdd(&hw[p[i]], 1u);
+    };
+    const int nc = (int)(c1 - c0);
+    for (int cc = 0; cc < nc; cc += 2) {
+        const uint8_t* p0 = dense + s_off[cc];
+        const uint32_t n0 = s_sz[cc], np0 = n0 >> 4;
+        const bool two = cc + 1 < nc;
+        const uint8_t* p1 = dense + s_off[two ? cc + 1 : cc];
+        const uint32_t n1 = two ? s_sz[cc + 1] : 0u, np1 = n1 >> 4;
+        u32x4 x0 = {0, 0, 0, 0}, x1 = {0, 0, 0, 0};
+        const bool h0 = (uint32_t)t < np0, h1 = (uint32_t)t < np1;
+        if (h0) x0 = *(const u32x4_a1*)(p0 + (size_t)t * 16);
+        if (h1) x1 = *(const u32x4_a1*)(p1 + (size_t)t * 16);
+        if (h0) tally(x0);
+        if (h1) tally(x1);
+        for (uint32_t i = t + 256; i < np0; i += 256) { const u32x4 x = *(const u32x4_a1*)(p0 + (size_t)i * 16); tally(x); }
+        for (uint32_t i = t + 256; i < np1; i += 256) { const u32x4 x = *(const u32x4_a1*)(p1 + (size_t)i * 16); tally(x); }
+        for (uint32_t i = (np0 << 4) + t; i < n0; i += 256) atomicAdd(&hw[p0[i]], 1u);
+        for (uint32_t i = (np1 << 4) + t; i < n1; i += 256) atomicAdd(&hw[p1[i]], 1u);
     }
     __syncthreads();
     hist[t] = hist4[0][t] + hist4[1][t] + hist4[2][t] + hist4[3][t];
@@ -237,28 +259,62 @@ __global__ void __launch_bounds__(256) huf_size_kernel(const uint8_t* dense, con
     cnt[t] = 0;
     __syncthreads();
     const uint64_t c0 = seg * SEG, c1 = (c0 + SEG < nchunks) ? c0 + SEG : nchunks;
-    for (uint64_t cc = c0; cc < c1; cc++) {
-        const uint32_t n = sizes[cc];
-        const uint8_t* s = dense + offsets[cc];
+    __shared__ uint64_t s_off[SEG];
+    __shared__ uint32_t s_sz[SEG];
+    if (t < SEG) {                                                          // chunk geometry once, coalesced
+        const bool in = c0 + t < c1;
+        s_off[t] = in ? offsets[c0 + t] : 0;
+        s_sz[t] = in ? sizes[c0 + t] : 0;
+    }
+    __syncthreads();
+    // piece i of local chunk cc: x already loaded when the piece lies inside one sub-stream
+    auto account = [&](int cc, uint32_t i, bool whole, const u32x4& x) {
+        const uint32_t n = s_sz[cc];
+        const uint8_t* s = dense + s_off[cc];
         const uint32_t q = (n + 3u) >> 2;
-        uint32_t* const my = cnt + (cc - c0) * 4;
+        uint32_t* const my = cnt + cc * 4;
         auto stream_of = [&](uint32_t pos) { return (uint32_t)(pos >= q) + (uint32_t)(pos >= 2 * q) + (uint32_t)(pos >= 3 * q); };
-        const uint32_t np = (n + 15u) >> 4;
-        for (uint32_t i = t; i < np; i += 256) {
-            const uint32_t pos0 = i * 16;
-            if (pos0 + 16 <= n && stream_of(pos0) == stream_of(pos0 + 15)) {
-                const u32x4 x = *(const u32x4_a1*)(s + pos0);
-                uint32_t bits = 0;
+        const uint32_t pos0 = i * 16;
+        if (whole) {
+            uint32_t bits = 0;
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t d = k == 0 ? x.x : k == 1 ? x.y : k == 2 ? x.z : x.w;
-                    bits += enc[d & 255] + enc[(d >> 8) & 255] + enc[(d >> 16) & 255] + enc[d >> 24];
-                }
-                atomicAdd(&my[stream_of(pos0)], bits);
-            } else {
-                const uint32_t end = pos0 + 16 < n ? pos0 + 16 : n;
-                for (uint32_t pos = pos0; pos < end; pos++) atomicAdd(&my[stream_of(pos)], enc[s[pos]]);
+            for (int k = 0; k < 4; k++) {
+                const uint32_t d = k == 0 ? x.x : k == 1 ? x.y : k == 2 ? x.z : x.w;
+                bits += enc[d & 255] + enc[(d >> 8) & 255] + enc[(d >> 16) & 255] + enc[d >> 24];
             }
+            atomicAdd(&my[stream_of(pos0)], bits);
+        } else {
+            const uint32_t end = pos0 + 16 < n ? pos0 + 16 : n;
+            for (uint32_t pos = pos0; pos < end; pos++) atomicAdd(&my[stream_of(pos)], enc[s[pos]]);
+        }
+    };
+    auto is_whole = [&](int cc, uint32_t i) {
+        const uint32_t n = s_sz[cc], q = (n + 3u) >> 2, pos0 = i * 16;
+        auto stream_of = [&](uint32_t pos) { return (uint32_t)(pos >= q) + (uint32_t)(pos >= 2 * q) + (uint32_t)(pos >= 3 * q); };
+        return pos0 + 16 <= n && stream_of(pos0) == stream_of(pos0 + 15);
+    };
+    const int nc = (int)(c1 - c0);
+    for (int cc = 0; cc < nc; cc += 2) {                                    // two chunks' first pieces in flight together
+        const int cd = cc + 1 < nc ? cc + 1 : cc;
+        const uint32_t np0 = (s_sz[cc] + 15u) >> 4, np1 = cd != cc ? (s_sz[cd] + 15u) >> 4 : 0u;
+        const bool h0 = t < np0, h1 = t < np1;
+        const bool w0 = h0 && is_whole(cc, t), w1 = h1 && is_whole(cd, t);
+        u32x4 x0 = {0, 0, 0, 0}, x1 = {0, 0, 0, 0};
+        if (w0) x0 = *(const u32x4_a1*)(dense + s_off[cc] + (size_t)t * 16);
+        if (w1) x1 = *(const u32x4_a1*)(dense + s_off[cd] + (size_t)t * 16);
+        if (h0) account(cc, t, w0, x0);
+        if (h1) account(cd, t, w1, x1);
+        for (uint32_t i = t + 256; i < np0; i += 256) {
+            const bool w = is_whole(cc, i);
+            u32x4 x = {0, 0, 0, 0};
+            if (w) x = *(const u32x4_a1*)(dense + s_off[cc] + (size_t)i * 16);
+            account(cc, i, w, x);
+        }
+        for (uint32_t i = t + 256; i < np1; i += 256) {
+            const bool w = is_whole(cd, i);
+            u32x4 x = {0, 0, 0, 0};
+            if (w) x = *(const u32x4_a1*)(dense + s_off[cd] + (size_t)i * 16);
+            account(cd, i, w, x);
         }
     }
     __syncthreads();
@@ -266,7 +322,7 @@ __global__ void __launch_bounds__(256) huf_size_kernel(const uint8_t* dense, con
     const int j = t & 3;
     uint32_t n = 0, sz = 0;
     if (c < nchunks) {
-        n = sizes[c];
+        n = s_sz[t >> 2];
         sz = (cnt[t] + 7u) >> 3;
     }
     // the four sizes of a chunk sit in one quad
@@ -281,40 +337,16 @@ __global__ void __launch_bounds__(256) huf_size_kernel(const uint8_t* dense, con
 }
 
 // ---------------------------------------------------------------- K3: encode
-// One lane per sub-stream.  HBM traffic is kept in whole 16-byte pieces per lane (a
-// lane-per-byte-stream kernel otherwise touches every 128-byte line 32+ times, far
-// apart in time, with 64K such lines open per XCD): the source bytes are read as
-// aligned 16-byte pieces one piece ahead, the coded dwords collect in a 16-byte
-// register window that is stored when full; only the first and last piece of a
-// sub-stream (shared with its neighbours) are written byte-wise.
-__device__ __forceinline__ uint32_t pick_dword(const u32x4& v, uint32_t k)
-{
-    return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
-}
-
-__device__ __forceinline__ void put_dword(u32x4& v, uint32_t k, uint32_t d)
-{
-    v.x = k == 0 ? d : v.x;
-    v.y = k == 1 ? d : v.y;
-    v.z = k == 2 ? d : v.z;
-    v.w = k == 3 ? d : v.w;
-}
-
-// bytes [lo, hi) of the 16-byte window v -> dst[lo..hi)
-__device__ __forceinline__ void store_window_bytes(uint8_t* dst, const u32x4& v, uint32_t lo, uint32_t hi)
-{
-#pragma unroll
-    for (uint32_t k = 0; k < 16; k++) {
-        const uint32_t d = k < 4 ? v.x : k < 8 ? v.y : k < 12 ? v.z : v.w;
-        if (k >= lo && k < hi) dst[k] = (uint8_t)(d >> (8 * (k & 3)));
-    }
-}
-
+// One lane per sub-stream.  A lane-per-byte-stream kernel touches every 128-byte line 32+
+// times, far apart in time, with 64K such lines open per XCD -- so both sides move in
+// 64-byte bursts: the source bytes are read four 16-byte loads at a time, one burst ahead;
+// the coded dwords collect in a 64-byte window in LDS that is stored when full.
 __global__ void __launch_bounds__(256) huf_encode_kernel(const uint8_t* dense, const uint64_t* offsets, const uint32_t* sizes,
                                                          uint64_t nchunks, const uint32_t* enc_tables, const uint64_t* meta,
                                                          uint8_t* huf, const uint64_t* huf_offsets)
 {
     __shared__ uint32_t enc[256];
+    __shared__ uint32_t wbuf[16 * 256];
     const uint64_t seg = blockIdx.x;
     enc[threadIdx.x] = enc_tables[seg * 256 + threadIdx.x];
     __syncthreads();
@@ -343,22 +375,47 @@ __global__ void __launch_bounds__(256) huf_encode_kernel(const uint8_t* dense, c
     uint32_t a, b;
     sub_range(n, j, a, b);
 
-    // output window = container bytes [wbase, wbase+16), wbase a multiple of 16
-    uint64_t wbase = poff & ~(uint64_t)15;
-    uint32_t wk = (uint32_t)(poff & 15) >> 2;                               // dword of the window the accumulator drains into
-    uint32_t wfirst = (uint32_t)(poff & 15);                                // first window: bytes below this belong to the neighbour
-    u32x4 win = {0, 0, 0, 0};
+    // Output window = container bytes [wbase, wbase+64), wbase a multiple of 64, kept in LDS as
+    // wbuf[dword][lane] (a lane's dwords sit in its own bank); a full window leaves as four
+    // 16-byte stores back to back, only the first and last window of a sub-stream (shared with
+    // its neighbours) are written piecemeal.  Same reasoning as in the decoder: touch memory in
+    // 64-byte bursts, or every 16-byte access pays for a whole cache line.
+    uint32_t* const wb = wbuf + threadIdx.x;
+    uint64_t wbase = poff & ~(uint64_t)63;
+    uint32_t wk = (uint32_t)(poff & 63) >> 2;                               // dword of the window the accumulator drains into
+    uint32_t wfirst = (uint32_t)(poff & 63);                                // first window: bytes below this belong to the neighbour
     uint64_t acc = 0;
     uint32_t nbits = (uint32_t)(poff & 3) * 8;                              // the accumulator starts inside a dword
+    auto store_range = [&](uint32_t lo, uint32_t hi) {                      // window bytes [lo, hi) -> container
+        uint8_t* const dst = huf + wbase;
+#pragma unroll
+        for (uint32_t m = 0; m < 16; m++) {
+            if (4 * m + 4 <= lo || 4 * m >= hi) continue;
+            const uint32_t d = wb[m * 256];
+            if (4 * m >= lo && 4 * m + 4 <= hi) {
+                *(uint32_t*)(dst + 4 * m) = d;                              // container and window are 4-byte aligned
+            } else {
+                for (uint32_t k = 0; k < 4; k++)
+                    if (4 * m + k >= lo && 4 * m + k < hi) dst[4 * m + k] = (uint8_t)(d >> (8 * k));
+            }
+        }
+    };
     auto flush = [&]() {                                                    // low 32 bits of acc -> window
-        put_dword(win, wk, (uint32_t)acc);
+        wb[wk * 256] = (uint32_t)acc;
         acc >>= 32;
         nbits -= 32;
-        if (++wk == 4) {
-            if (wfirst) store_window_bytes(huf + wbase, win, wfirst, 16);
-            else *(u32x4_a4*)(huf + wbase) = win;
+        if (++wk == 16) {
+            if (wfirst) {
+                store_range(wfirst, 64);
+            } else {
+                u32x4 p[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) p[q] = u32x4{wb[(4 * q) * 256], wb[(4 * q + 1) * 256], wb[(4 * q + 2) * 256], wb[(4 * q + 3) * 256]};
+#pragma unroll
+                for (int q = 0; q < 4; q++) *(u32x4_a4*)(huf + wbase + 16 * q) = p[q];
+            }
             wfirst = 0;
-            wbase += 16;
+            wbase += 64;
             wk = 0;
         }
     };
@@ -367,9 +424,23 @@ __global__ void __launch_bounds__(256) huf_encode_kernel(const uint8_t* dense, c
         acc |= (uint64_t)(e & 0xffffu) << nbits;
         nbits += e >> 16;
     };
+    auto put16 = [&](const u32x4& v) {                                      // 16 source bytes
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t d = q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w;
+            put(d & 255u);
+            put((d >> 8) & 255u);
+            if (nbits >= 32) flush();
+            put((d >> 16) & 255u);
+            put(d >> 24);
+            if (nbits >= 32) flush();
+        }
+    };
 
+    // source: bytes up to a 16-byte boundary, 16-byte steps up to a 64-byte boundary, 64-byte
+    // bursts (four loads back to back, one burst ahead), and the same in reverse at the end
     uint32_t i = a;
-    {                                                                       // byte-wise up to a 16-byte boundary of the source
+    {
         uint32_t pro = (16u - (uint32_t)((soff + a) & 15)) & 15u;
         if (pro > b - a) pro = b - a;
         for (uint32_t k = 0; k < pro; k++) {
@@ -377,36 +448,42 @@ __global__ void __launch_bounds__(256) huf_encode_kernel(const uint8_t* dense, c
             if (nbits >= 32) flush();
         }
     }
-    if (i + 16 <= b) {
-        u32x4 nxt = *(const u32x4_a1*)(s + i);
-        while (i + 16 <= b) {
-            const u32x4 cur = nxt;
-            i += 16;
-            if (i + 16 <= b) nxt = *(const u32x4_a1*)(s + i);
+    while (((soff + i) & 63) != 0 && i + 16 <= b) {
+        const u32x4 v = *(const u32x4_a1*)(s + i);
+        put16(v);
+        i += 16;
+    }
+    if (i + 64 <= b) {
+        u32x4 nxt[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t d = q == 0 ? cur.x : q == 1 ? cur.y : q == 2 ? cur.z : cur.w;
-                put(d & 255u);
-                put((d >> 8) & 255u);
-                if (nbits >= 32) flush();
-                put((d >> 16) & 255u);
-                put(d >> 24);
-                if (nbits >= 32) flush();
+        for (int q = 0; q < 4; q++) nxt[q] = *(const u32x4_a1*)(s + i + 16 * q);
+        while (i + 64 <= b) {
+            u32x4 cur[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) cur[q] = nxt[q];
+            i += 64;
+            if (i + 64 <= b) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) nxt[q] = *(const u32x4_a1*)(s + i + 16 * q);
             }
+#pragma unroll
+            for (int q = 0; q < 4; q++) put16(cur[q]);
         }
+    }
+    while (i + 16 <= b) {
+        const u32x4 v = *(const u32x4_a1*)(s + i);
+        put16(v);
+        i += 16;
     }
     for (; i < b; i++) {
         put(s[i]);
         if (nbits >= 32) flush();
     }
     // close: the rest of the accumulator (zero padded to a byte), then the partial window
-    const uint32_t endb = wk * 4 + ((nbits + 7u) >> 3);                     // bytes of the window in use (<= 16 + 3)
-    if (nbits > 0) {
-        put_dword(win, wk, (uint32_t)acc);                                  // wk < 4 here
-    }
-    const uint32_t lo = wfirst;
-    const uint32_t hi = endb < 16u ? endb : 16u;
-    if (hi > lo) store_window_bytes(huf + wbase, win, lo, hi);
+    const uint32_t endb = wk * 4 + ((nbits + 7u) >> 3);                     // bytes of the window in use (<= 64 + 3... wk < 16 here)
+    if (nbits > 0) wb[wk * 256] = (uint32_t)acc;
+    const uint32_t hi = endb < 64u ? endb : 64u;
+    if (hi > wfirst) store_range(wfirst, hi);
 }
 
 // ---------------------------------------------------------------- K4: raw sizes from the record headers
