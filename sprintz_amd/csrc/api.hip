@@ -308,6 +308,15 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
         if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "decode_fast kernel launch", e);
         return 0;
     }
+    // univariate streams: one lane per chunk, LDS ring in, quad-transposed 64-byte bursts out (decode_uni.h)
+    if (lowdim && D == 1 && !noheader && qs.q == kQueryOff && !cs && !getenv("SPRINTZ_MI355X_NO_FAST")) {
+        const uint64_t ugrid = (nchunks + 255) / 256;
+        if (ugrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
+        e = esz == 1 ? launch_decode_uni_w8(codec == SPRINTZ_CODEC_XFF, (unsigned)ugrid, st, a)
+                     : launch_decode_uni_w16(codec == SPRINTZ_CODEC_XFF, (unsigned)ugrid, st, a);
+        if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "decode_uni kernel launch", e);
+        return 0;
+    }
     const uint64_t threads = nchunks * (uint64_t)DP;
     const uint64_t grid = (threads + kThreads - 1) / kThreads;
     if (grid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");

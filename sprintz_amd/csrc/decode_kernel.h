@@ -259,6 +259,27 @@ __global__ void __launch_bounds__(kThreads) decode_kernel(DecodeArgs a)
                     for (int i = 0; i < 8; i++) cp[i] = (U)v[i][k];
                 }
             }
+        } else if (LOWDIM && D == 1) {
+            // one column: the block's 8 samples are contiguous -- one store, not eight
+            if (lane_d == 0) {
+                typedef uint32_t v2 __attribute__((ext_vector_type(2)));
+                typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+                typedef v2 __attribute__((aligned(1), may_alias)) v2u;
+                typedef v4 __attribute__((aligned(1), may_alias)) v4u;
+                if constexpr (W == 8) {
+                    v2 t;
+                    t.x = v[0][0] | (v[1][0] << 8) | (v[2][0] << 16) | (v[3][0] << 24);
+                    t.y = v[4][0] | (v[5][0] << 8) | (v[6][0] << 16) | (v[7][0] << 24);
+                    *(v2u*)ob = t;
+                } else {
+                    v4 t;
+                    t.x = v[0][0] | (v[1][0] << 16);
+                    t.y = v[2][0] | (v[3][0] << 16);
+                    t.z = v[4][0] | (v[5][0] << 16);
+                    t.w = v[6][0] | (v[7][0] << 16);
+                    *(v4u*)ob = t;
+                }
+            }
         } else if (a.vec_store) {
             U* const l = (U*)lds;
 #pragma unroll

@@ -1,0 +1,261 @@
+// decode_uni.h -- batched decoder for UNIVARIATE streams (ndims == 1: the low-dim layout of
+// sprintz_delta_lowdim.cpp:398-794 / sprintz_xff_lowdim.cpp:414-1119 with one column; the UCR
+// archive of the paper is univariate).  One lane per chunk.
+//
+// The generic kernel already maps a chunk of one column to one lane, but it walks memory a field
+// at a time: with 64 K lanes each trailing its own stream and its own output, every dword read
+// and every 8-byte write is a cache line of its own (0.1 - 0.17 TB/s).  Here, as in huf.hip's
+// decoder:
+//   * the stream waits in a per-lane LDS ring ring[dword][lane] (conflict-free for per-lane
+//     cursors), refilled by 64-byte bursts on a fixed cadence with unconditionally issued loads;
+//   * all lanes produce exactly one 8-sample block per step, so 64 bytes of output collect in
+//     registers at compile-time positions, the four lanes of a quad transpose their 16-byte
+//     pieces with DPP and every store writes one chunk's 64 contiguous bytes as one request.
+#pragma once
+
+#include "decode_kernel.h"
+#include "decode_fast.h"
+
+namespace sprintz {
+
+template <int W, bool FIRE>
+__global__ void __launch_bounds__(256) decode_uni_kernel(DecodeArgs a)
+{
+    constexpr int HB = Elem<W>::HB;
+    constexpr int ESZ = W / 8;
+    constexpr uint32_t MASK = Elem<W>::MASK;
+    constexpr int BW = 64 / (8 * ESZ);                     // blocks per 64-byte window: 8 (u8) or 4 (u16)
+    constexpr int BD = 2 * ESZ;                            // dwords per block
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    typedef v4 __attribute__((aligned(1), may_alias)) v4a1;
+    typedef uint32_t v2 __attribute__((ext_vector_type(2)));
+    typedef v2 __attribute__((aligned(1), may_alias)) v2a1;
+
+    __shared__ uint32_t ring[32 * 256];                    // 128 bytes per lane
+    const int t = threadIdx.x;
+    const uint64_t chunk = (uint64_t)blockIdx.x * 256 + t;
+    const bool exists = chunk < a.nchunks;
+    uint32_t* const my = ring + t;
+
+    const uint64_t total = a.offsets[a.nchunks];
+    const uint64_t last16 = total ? (total - 1) >> 4 : 0;
+    const uint64_t off = exists ? a.offsets[chunk] : 0;
+    const uint64_t stream_len = exists ? a.offsets[chunk + 1] - off : 0;
+    const uint64_t piece0 = off >> 6;
+    const uint8_t* const idle = a.comp;                    // what a lane with no free slot reads instead (one hot line)
+    struct Piece { v4 v[4]; };
+    auto load_piece = [&](uint32_t k, bool wanted) -> Piece {
+        Piece pc;
+        const uint64_t q0 = (piece0 + k) << 2;
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            uint64_t q = q0 + m;
+            q = q < last16 ? q : last16;
+            pc.v[m] = *(const v4a1*)(wanted ? a.comp + (q << 4) : idle);
+        }
+        return pc;
+    };
+    auto park = [&](uint32_t k, const Piece& pc) {
+        uint32_t* q = my + ((k & 1u) << 12);
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            q[(4 * m + 0) * 256] = pc.v[m].x;
+            q[(4 * m + 1) * 256] = pc.v[m].y;
+            q[(4 * m + 2) * 256] = pc.v[m].z;
+            q[(4 * m + 3) * 256] = pc.v[m].w;
+        }
+    };
+    park(0, load_piece(0, exists));
+    park(1, load_piece(1, exists));
+    uint32_t fpiece = 2;
+    Piece pend = {};
+    bool have_pend = false;
+    uint32_t c = (uint32_t)(off & 63);                     // byte cursor, from the start of piece0
+    const uint32_t c_begin = c;
+    // Every step takes at most 1 header + 2 run-length + 16 payload bytes; a piece is 64: when the
+    // cursor leaves a slot the other one is full, and the refill lands within two steps.
+    auto refill = [&]() {
+        if (have_pend) {
+            park(fpiece, pend);
+            fpiece++;
+        }
+        have_pend = exists && fpiece - (c >> 6) < 2u;
+        pend = load_piece(fpiece, have_pend);
+    };
+    auto rd_dw = [&](uint32_t dw) -> uint32_t { return my[(dw & 31u) << 8]; };
+    auto rd8 = [&](uint32_t at) -> uint32_t { return (rd_dw(at >> 2) >> ((at & 3u) * 8u)) & 0xffu; };
+    auto rd32 = [&](uint32_t at) -> uint32_t { return __builtin_amdgcn_alignbyte(rd_dw((at >> 2) + 1u), rd_dw(at >> 2), at); };
+
+    // ---- 8-byte stream header (format.h:48-62)
+    uint32_t groups_left = 0, remaining = 0;
+    bool corrupt = false, alive = exists;
+    if (exists) {
+        const uint32_t w0 = rd32(c), w1 = rd32(c + 4);
+        groups_left = w0;
+        remaining = w1 & 0xffffu;
+        c += 8;
+        corrupt = (w1 >> 16) != 1u || groups_left > a.chunk_len / 8u + 2u || stream_len < 8;
+        if (corrupt) { groups_left = 0; alive = false; }
+    }
+
+    uint32_t pv = 0;
+    int pd = 0, ctr = 0;
+    uint32_t nb0 = 0, nb1 = 0, run_left = 0, out_elems = 0;
+    int slot = 2;
+    uint8_t* const obase = (uint8_t*)a.out + chunk * (uint64_t)a.chunk_len * ESZ;
+    const bool odd1 = (t & 1) != 0, odd2 = (t & 2) != 0;
+    const uint32_t part = (uint32_t)t & 3u;
+
+    for (;;) {
+        uint32_t win[BW][BD];                              // the 64-byte window: block b at compile-time position b
+        uint32_t valid = 0;                                // bit b: block b of the window was produced
+        const uint32_t win_elems = out_elems;              // output position of the window's first block
+        bool wave_done = false;
+#pragma unroll
+        for (int b = 0; b < BW; b++) {
+#pragma unroll
+            for (int d = 0; d < BD; d++) win[b][d] = 0;
+            refill();
+            // ---- this lane's next block: inside a run, or the next slot of the stream
+            bool have = false;
+            uint32_t nb = 0, cfield = 0;
+            if (alive) {
+                if (run_left > 0) {
+                    run_left--;
+                    have = true;
+                } else {
+                    for (int tries = 0; tries < 4 && !have && alive; tries++) {   // <= 2 padding slots in a row in a valid stream
+                        if (slot == 2) {
+                            if (groups_left == 0) { alive = false; break; }
+                            groups_left--;
+                            const uint32_t h = rd8(c);                          // 2 fields of HB bits (:713-735)
+                            c += 1;
+                            const uint32_t f0 = h & ((1u << HB) - 1u), f1 = (h >> HB) & ((1u << HB) - 1u);
+                            nb0 = f0 == (uint32_t)(W - 1) ? (uint32_t)W : f0;
+                            nb1 = f1 == (uint32_t)(W - 1) ? (uint32_t)W : f1;
+                            slot = 0;
+                        }
+                        const uint32_t nbs = slot ? nb1 : nb0;
+                        slot++;
+                        if (nbs == 0) {                                         // RUN slot: varint length in blocks
+                            const uint32_t b0 = rd8(c);
+                            uint32_t len = b0 & 0x7fu;
+                            c += 1;
+                            if (b0 & 0x80u) { len |= rd8(c) << 7; c += 1; }
+                            if (len > 0) { run_left = len - 1; have = true; }
+                        } else {
+                            nb = nbs;
+                            cfield = c;
+                            c += nbs;                                           // 8 fields of nbs bits = nbs bytes
+                            have = true;
+                        }
+                    }
+                    if (!have && alive) { corrupt = true; alive = false; }
+                }
+                if ((uint64_t)(c - c_begin) > stream_len + 2 || (have && out_elems + 8 > a.chunk_len)) {
+                    corrupt = true; alive = false; have = false;
+                }
+            }
+            if (__ballot(alive || have) == 0) { wave_done = true; }
+            // ---- the block: zigzag^-1 + forecast recurrence down the column
+            if (have) {
+                const int coef = FIRE ? fire_coef<W, true>(ctr) : 0;
+                int grad = 0;
+                uint32_t x[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    uint32_t z = 0;
+                    if (nb != 0) {
+                        const uint32_t bit = (cfield & 3u) * 8u + (uint32_t)i * nb;
+                        const uint32_t dw = (cfield >> 2) + (bit >> 5);
+                        z = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(rd_dw(dw + 1u), rd_dw(dw), bit & 31u), 0, nb);
+                    }
+                    const int err = unzigzag(z);
+                    const int pred = FIRE ? fire_predict<W, true>(pd, coef) : 0;
+                    const int delta = sext<W>(err + pred);
+                    if (FIRE && (i & 1)) grad += sign_times(err, pd);
+                    pv = (pv + (uint32_t)delta) & MASK;
+                    pd = delta;
+                    x[i] = pv;
+                }
+                if (FIRE && nb != 0) ctr = wrap_counter<W>(ctr + (sext<W>(grad) >> 2));   // counters only move on real blocks
+                if constexpr (W == 8) {
+                    win[b][0] = x[0] | (x[1] << 8) | (x[2] << 16) | (x[3] << 24);
+                    win[b][1] = x[4] | (x[5] << 8) | (x[6] << 16) | (x[7] << 24);
+                } else {
+                    win[b][0] = x[0] | (x[1] << 16);
+                    win[b][1] = x[2] | (x[3] << 16);
+                    win[b][2] = x[4] | (x[5] << 16);
+                    win[b][3] = x[6] | (x[7] << 16);
+                }
+                valid |= 1u << b;
+                out_elems += 8;
+            }
+        }
+        // ---- the window leaves.  Full windows: the quad transposes its 16-byte pieces (two DPP
+        // butterfly stages: (member m, piece k) -> (lane k, slot m)) and stores one member's 64
+        // bytes per instruction.  A partly filled window (the chunk's end) is stored block by block.
+        const bool full = valid == (1u << BW) - 1u;
+        uint32_t v[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int d = 0; d < 4; d++) v[k][d] = W == 8 ? win[2 * k + (d >> 1)][d & 1] : win[k][d];
+#pragma unroll
+        for (int k = 0; k < 4; k += 2)
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const uint32_t send = odd1 ? v[k][d] : v[k + 1][d];
+                const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+                if (odd1) v[k][d] = recv; else v[k + 1][d] = recv;
+            }
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const uint32_t send = odd2 ? v[k][d] : v[k + 2][d];
+                const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+                if (odd2) v[k][d] = recv; else v[k + 2][d] = recv;
+            }
+        const uint64_t mine = full ? (uint64_t)(uintptr_t)(obase + (uint64_t)win_elems * ESZ) : 0ull;
+        const int mlo = (int)(uint32_t)mine, mhi = (int)(uint32_t)(mine >> 32);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t dlo, dhi;
+            if (q == 0) { dlo = (uint32_t)__builtin_amdgcn_mov_dpp(mlo, 0x00, 0xf, 0xf, true); dhi = (uint32_t)__builtin_amdgcn_mov_dpp(mhi, 0x00, 0xf, 0xf, true); }
+            else if (q == 1) { dlo = (uint32_t)__builtin_amdgcn_mov_dpp(mlo, 0x55, 0xf, 0xf, true); dhi = (uint32_t)__builtin_amdgcn_mov_dpp(mhi, 0x55, 0xf, 0xf, true); }
+            else if (q == 2) { dlo = (uint32_t)__builtin_amdgcn_mov_dpp(mlo, 0xAA, 0xf, 0xf, true); dhi = (uint32_t)__builtin_amdgcn_mov_dpp(mhi, 0xAA, 0xf, 0xf, true); }
+            else { dlo = (uint32_t)__builtin_amdgcn_mov_dpp(mlo, 0xFF, 0xf, 0xf, true); dhi = (uint32_t)__builtin_amdgcn_mov_dpp(mhi, 0xFF, 0xf, 0xf, true); }
+            const uint64_t dst = ((uint64_t)dhi << 32) | dlo;
+            if (dst) {
+                v4 piece = {v[q][0], v[q][1], v[q][2], v[q][3]};
+                *(v4a1*)(uintptr_t)(dst + 16u * part) = piece;
+            }
+        }
+        if (!full && valid) {
+            uint8_t* d = obase + (uint64_t)win_elems * ESZ;
+#pragma unroll
+            for (int b = 0; b < BW; b++) {
+                if ((valid >> b) & 1u) {                   // blocks are produced in order: the valid ones are a prefix
+                    if constexpr (W == 8) { v2 p = {win[b][0], win[b][1]}; *(v2a1*)(d + 8 * b) = p; }
+                    else { v4 p = {win[b][0], win[b][1], win[b][2], win[b][3]}; *(v4a1*)(d + 16 * b) = p; }
+                }
+            }
+        }
+        if (wave_done) break;
+    }
+
+    // ---- verbatim tail (:1171), straight from HBM
+    if (exists) {
+        if (!corrupt && out_elems + remaining > a.chunk_len) corrupt = true;
+        if (!corrupt && (uint64_t)(c - c_begin) + (uint64_t)remaining * ESZ > stream_len + 2) corrupt = true;
+        if (!corrupt) {
+            const uint8_t* src = a.comp + off + (c - c_begin);
+            uint8_t* d = obase + (uint64_t)out_elems * ESZ;
+            for (uint32_t j = 0; j < remaining * ESZ; j++) d[j] = src[j];
+        }
+        if (a.rets) a.rets[chunk] = corrupt ? kErrCorrupt : (int64_t)out_elems + remaining;
+    }
+}
+
+}  // namespace sprintz

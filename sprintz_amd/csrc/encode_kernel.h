@@ -142,6 +142,24 @@ __global__ void __launch_bounds__(kThreads) encode_kernel(EncodeArgs a)
                 const U* const cp = cm0 + (uint64_t)col * cs + (uint32_t)pos_in / (uint32_t)D;
 #pragma unroll
                 for (int i = 0; i < 8; i++) x[i] = (col < D) ? (uint32_t)cp[i] : 0u;
+            } else if (LOWDIM && D == 1) {
+                // one column: the block's 8 samples are contiguous -- one load, not eight
+                typedef uint32_t v2 __attribute__((ext_vector_type(2)));
+                typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+                typedef v2 __attribute__((aligned(1), may_alias)) v2u;
+                typedef v4 __attribute__((aligned(1), may_alias)) v4u;
+                if constexpr (W == 8) {
+                    const v2 t = *(const v2u*)(sc + pos_in);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) x[i] = ((i < 4 ? t.x : t.y) >> (8 * (i & 3))) & 0xffu;
+                } else {
+                    const v4 t = *(const v4u*)(sc + pos_in);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const uint32_t d = (i >> 1) == 0 ? t.x : (i >> 1) == 1 ? t.y : (i >> 1) == 2 ? t.z : t.w;
+                        x[i] = (i & 1) ? d >> 16 : d & 0xffffu;
+                    }
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < 8; i++) x[i] = (col < D) ? (uint32_t)sc[pos_in + (int64_t)i * D + col] : 0u;

@@ -127,6 +127,10 @@ CONFIGS = [
     ("odd_d", "xff", 2, 5, 5000),               # chunk not a multiple of the block: ragged tails, scalar store path
     ("lowdim16", "xff", 2, 2, 4096),
     ("lowdim8", "xff", 1, 3, 3000),
+    ("uni16_xff", "xff", 2, 1, 2048),           # univariate: decode_uni.h
+    ("uni8_xff_ragged", "xff", 1, 1, 1003),
+    ("uni16_delta_ragged", "delta", 2, 1, 777),
+    ("uni8_tiny", "delta", 1, 1, 100),          # chunks below 128 elements: verbatim
 ]
 
 
@@ -249,12 +253,13 @@ def test_full_size_cfg2_roundtrip_and_size_checksum(sz, oracle):
     assert 2.0 < x.numel() * 2 / sizes.sum() < 6.0
 
 
-def test_corrupt_streams_do_not_hang_or_overrun(sz, oracle):
+@pytest.mark.parametrize("codec,esz,ndims,chunk_len,nchunks", [("xff", 2, 8, 5120, 64), ("xff", 1, 1, 1024, 300), ("delta", 2, 1, 2000, 300),
+                                                               ("xff", 1, 3, 3000, 64)])
+def test_corrupt_streams_do_not_hang_or_overrun(sz, oracle, codec, esz, ndims, chunk_len, nchunks):
     """bit-flipped / truncated / header-damaged streams: the decoder must terminate, stay inside
     each chunk's output slot and either decode something or report SPRINTZ_E_CORRUPT"""
     import torch
     rng = np.random.default_rng(77)
-    codec, esz, ndims, chunk_len, nchunks = "xff", 2, 8, 5120, 64
     data = gen_walk(rng, nchunks * chunk_len, ndims, esz, 8, flat_every=4)
     cd = sz.ChunkedCodec(codec, esz, ndims, chunk_len, device="cuda:0")
     batch = cd.compress(torch.from_numpy(data).cuda())
@@ -273,13 +278,13 @@ def test_corrupt_streams_do_not_hang_or_overrun(sz, oracle):
             idx = rng.integers(0, comp.size, comp.size // 50)
             comp[idx] ^= rng.integers(1, 256, idx.size).astype(np.uint8)
         guard = 4096
-        out = torch.full((nchunks * chunk_len + guard,), 0x5A5A, dtype=torch.int16, device="cuda:0")
+        out = torch.full((nchunks * chunk_len + guard,), 0x5A, dtype=torch.int16 if esz == 2 else torch.int8, device="cuda:0")
         rets = torch.zeros(nchunks, dtype=torch.int64, device="cuda:0")
         cd.decompress_into(torch.from_numpy(comp).cuda(), batch.offsets, nchunks, out, rets)
         torch.cuda.synchronize()
         r = rets.cpu().numpy()
         assert ((r == sz._lib.E_CORRUPT) | ((r >= 0) & (r <= chunk_len))).all(), (trial, r[:8])
-        assert (out[nchunks * chunk_len:].cpu().numpy() == 0x5A5A).all(), trial
+        assert (out[nchunks * chunk_len:].cpu().numpy() == 0x5A).all(), trial
 
 
 # ------------------------------------------------ optional Huffman stage (format: oracle/huf_oracle.c)
