@@ -68,6 +68,31 @@ __global__ void __launch_bounds__(kThreads) encode_kernel(EncodeArgs a)
         return cs ? (uint32_t)cm0[(uint64_t)(e % (uint32_t)D) * cs + e / (uint32_t)D] : (uint32_t)sc[e];
     };
 
+    // A chunk too short for one group (n < 128 or n < 16 D: BASELINE config 3 at 1 KB chunks) is
+    // stored verbatim behind its header (sprintz_xff_rle.cpp:116-124, :158-160): straight copy,
+    // 8 bytes per lane, instead of the byte-wise trip through the LDS ring below.
+    if (!a.norle && !cs && !(n >= 128u && (int64_t)n - 16 * (int64_t)D >= 0)) {
+        const uint32_t hdr = a.write_size ? 8u : 0u;
+        const uint8_t* src = (const uint8_t*)sc;
+        uint8_t* dst = gdst + hdr;
+        const uint32_t nbytes = n * ESZ;
+        uint32_t done = 0;
+        if ((((uintptr_t)src | (uintptr_t)dst) & 7u) == 0) {
+            for (uint32_t j = (uint32_t)lane_d; j < (nbytes >> 3); j += (uint32_t)DP) ((uint2*)dst)[j] = ((const uint2*)src)[j];
+            done = nbytes & ~7u;
+        }
+        for (uint32_t j = done + (uint32_t)lane_d; j < nbytes; j += (uint32_t)DP) dst[j] = src[j];
+        if (lane_d == 0) {
+            if (a.write_size) {
+                ((uint32_t*)gdst)[0] = 0;
+                ((uint32_t*)gdst)[1] = (n & 0xffffu) | ((uint32_t)D << 16);
+            }
+            a.sizes[chunk] = hdr + nbytes;
+            if (a.rets) a.rets[chunk] = (int64_t)((hdr + nbytes) / ESZ);
+        }
+        return;
+    }
+
     const uint32_t cap = a.cap, capm = cap - 1;
     uint8_t* const ring = smem + (size_t)(threadIdx.x >> a.log2DP) * cap;
     uint32_t* const ring32 = (uint32_t*)ring;
