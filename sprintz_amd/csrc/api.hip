@@ -354,7 +354,7 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     a.norle = norle ? (codec == SPRINTZ_CODEC_XFF_NORLE ? 2 : 1) : 0;
     a.raw = codec == SPRINTZ_CODEC_BITPACK_NORLE ? 1 : 0;
     a.cap = next_pow2((uint32_t)group_bytes_max(esz, D) + 48u);
-    const size_t shmem = (size_t)a.cap * (kThreads / DP);
+    const size_t shmem = ((size_t)a.cap + 16) * (kThreads / DP);
     if (shmem > 160 * 1024) return fail(SPRINTZ_E_UNSUPPORTED, "ndims too large for the LDS output ring");
 
     // Fast path (encode_fast.h): general layout, one column per lane, every 8 x D input
@@ -378,6 +378,15 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
         e = esz == 1 ? launch_encode_fast_w8(codec == SPRINTZ_CODEC_XFF, fdp, D == fdp, (unsigned)fgrid, fshmem, st, a)
                      : launch_encode_fast_w16(codec == SPRINTZ_CODEC_XFF, fdp, D == fdp, (unsigned)fgrid, fshmem, st, a);
         if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "encode_fast kernel launch", e);
+        return 0;
+    }
+    // univariate streams: one lane per chunk, quad-loaded 64-byte input windows, 64-byte output units (encode_uni.h)
+    if (lowdim && D == 1 && !col_stride && !getenv("SPRINTZ_MI355X_NO_FAST")) {
+        const uint64_t ugrid = (nchunks + 255) / 256;
+        if (ugrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
+        e = esz == 1 ? launch_encode_uni_w8(codec == SPRINTZ_CODEC_XFF, (unsigned)ugrid, st, a)
+                     : launch_encode_uni_w16(codec == SPRINTZ_CODEC_XFF, (unsigned)ugrid, st, a);
+        if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "encode_uni kernel launch", e);
         return 0;
     }
     const uint64_t threads = nchunks * (uint64_t)DP;

@@ -94,7 +94,9 @@ __global__ void __launch_bounds__(kThreads) encode_kernel(EncodeArgs a)
     }
 
     const uint32_t cap = a.cap, capm = cap - 1;
-    uint8_t* const ring = smem + (size_t)(threadIdx.x >> a.log2DP) * cap;
+    // +16 per group: with few lanes per group (univariate: one) a power-of-two stride puts every
+    // group's ring on the same banks
+    uint8_t* const ring = smem + (size_t)(threadIdx.x >> a.log2DP) * (cap + 16u);
     uint32_t* const ring32 = (uint32_t*)ring;
 
     // zero this group's ring

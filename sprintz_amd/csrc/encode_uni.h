@@ -1,0 +1,238 @@
+// encode_uni.h -- batched encoder for UNIVARIATE streams (ndims == 1: the low-dim layout of
+// sprintz_delta_lowdim.cpp:39-384 / sprintz_xff_lowdim.cpp:44-400 with one column).  One lane
+// per chunk; same stream bytes as encode_kernel.h, which it follows step for step (the RLE state
+// machine of SURVEY.md A.5 included).
+//
+// Why a kernel of its own: see decode_uni.h -- a lane per chunk walking memory 8 bytes at a time
+// makes every access a cache line of its own.  Here every lane consumes exactly one 8-sample
+// block per step, so
+//   * INPUT arrives 64 bytes per lane at a time: the four lanes of a quad load one member's 64
+//     bytes as ONE request (16 bytes each), one window ahead, and a DPP 4 x 4 transpose hands
+//     every lane its own window in registers, at compile-time positions;
+//   * OUTPUT (variable length) is OR-ed into a 128-byte per-lane LDS ring out[dword][lane] -- the
+//     group header stays patchable until its second slot is known -- and leaves in 64-byte units,
+//     four 16-byte stores back to back.
+#pragma once
+
+#include "encode_kernel.h"
+#include "decode_fast.h"
+
+namespace sprintz {
+
+template <int W, bool FIRE>
+__global__ void __launch_bounds__(256) encode_uni_kernel(EncodeArgs a)
+{
+    constexpr int HB = Elem<W>::HB;
+    constexpr int ESZ = W / 8;
+    constexpr int BW = 64 / (8 * ESZ);                     // blocks per 64-byte input window: 8 (u8) or 4 (u16)
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    typedef v4 __attribute__((aligned(1), may_alias)) v4a1;
+
+    __shared__ uint32_t oring[32 * 256];                   // 128 bytes of output per lane
+    const int t = threadIdx.x;
+    const uint64_t chunk = (uint64_t)blockIdx.x * 256 + t;
+    const bool exists = chunk < a.nchunks;
+    uint32_t* const my = oring + t;
+#pragma unroll
+    for (int d = 0; d < 32; d++) my[d * 256] = 0;
+
+    const uint64_t first = chunk * (uint64_t)a.chunk_len;
+    const uint32_t n = exists ? (uint32_t)((a.total_len - first < a.chunk_len) ? (a.total_len - first) : a.chunk_len) : 0u;
+    const uint8_t* const sc = (const uint8_t*)a.src + first * ESZ;
+    uint8_t* const gdst = a.slots + chunk * a.slot_stride;
+    const uint32_t nbytes = n * ESZ;
+
+    // ---- output ring: stream bytes [flushed, flushed + 128), flushed a multiple of 64
+    uint32_t wpos = a.write_size ? 8u : 0u;
+    uint32_t flushed = 0;
+    auto or_bits = [&](uint32_t bp, uint32_t v, uint32_t nb) {           // low nb (<= 16) bits of v at stream bit bp
+        const uint32_t sh = bp & 31u;
+        uint32_t* q = my + (((bp >> 5) & 31u) << 8);
+        q[0] |= v << sh;
+        if (sh + nb > 32u) my[(((bp >> 5) + 1u) & 31u) << 8] |= v >> (32u - sh);
+    };
+    auto put_byte = [&](uint32_t pos, uint32_t v) { my[((pos >> 2) & 31u) << 8] |= v << ((pos & 3u) * 8u); };
+    auto flush_to = [&](uint32_t upto) {                                 // whole 64-byte units below upto -> HBM, re-zeroed
+        while (flushed < upto) {
+            const uint32_t d0 = (flushed >> 2) & 31u;                    // 0 or 16
+            v4 p[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                p[q] = v4{my[(d0 + 4 * q) << 8], my[(d0 + 4 * q + 1) << 8], my[(d0 + 4 * q + 2) << 8], my[(d0 + 4 * q + 3) << 8]};
+            }
+#pragma unroll
+            for (int d = 0; d < 16; d++) my[(d0 + d) << 8] = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) *(v4a1*)(gdst + flushed + 16 * q) = p[q];
+            flushed += 64;
+        }
+    };
+    auto put_run = [&](uint32_t run) {                                   // sprintz_xff_lowdim.cpp:246-253
+        put_byte(wpos, (run & 0x7fu) | (run > 0x7fu ? 0x80u : 0u));
+        if (run > 0x7fu) put_byte(wpos + 1, run >> 7);
+        wpos += run > 0x7fu ? 2u : 1u;
+    };
+
+    const int64_t limit = (int64_t)n - 16;                               // last_full_group_start
+    int64_t pos_in = 0;
+    uint32_t ngroups = 0, run = 0, hdr_pos = 0;
+    int slot = 0;
+    uint32_t pv = 0;
+    int pd = 0, ctr = 0;
+    auto start_group = [&]() {
+        ngroups++;
+        flush_to(wpos & ~63u);
+        hdr_pos = wpos;
+        wpos += 1;                                                       // 2 fields of HB bits: one byte
+        slot = 0;
+    };
+    bool active = exists && n >= 128u;
+    if (active) start_group();
+
+    // ---- input windows: a quad loads one member's 64 bytes per instruction, one window ahead
+    const bool odd1 = (t & 1) != 0, odd2 = (t & 2) != 0;
+    const uint32_t part = (uint32_t)t & 3u;
+    const uint64_t sa = (uint64_t)(uintptr_t)sc;
+    const int salo = (int)(uint32_t)sa, sahi = (int)(uint32_t)(sa >> 32);
+    auto bcast = [&](int x, int q) -> uint32_t {
+        if (q == 0) return (uint32_t)__builtin_amdgcn_mov_dpp(x, 0x00, 0xf, 0xf, true);
+        if (q == 1) return (uint32_t)__builtin_amdgcn_mov_dpp(x, 0x55, 0xf, 0xf, true);
+        if (q == 2) return (uint32_t)__builtin_amdgcn_mov_dpp(x, 0xAA, 0xf, 0xf, true);
+        return (uint32_t)__builtin_amdgcn_mov_dpp(x, 0xFF, 0xf, 0xf, true);
+    };
+    uint32_t nxt[4][4];
+    auto load_window = [&](uint32_t wi) {                                // nxt[q] = part `part` of member q's window wi
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint64_t base = ((uint64_t)bcast(sahi, q) << 32) | bcast(salo, q);
+            const uint32_t nb_q = bcast((int)nbytes, q);
+            const uint32_t o = wi * 64u + part * 16u;
+            v4 x = {0, 0, 0, 0};
+            if (o < nb_q) x = *(const v4a1*)(uintptr_t)(base + o);       // may run <= 15 bytes past the chunk (READ_SLACK)
+            nxt[q][0] = x.x; nxt[q][1] = x.y; nxt[q][2] = x.z; nxt[q][3] = x.w;
+        }
+    };
+    load_window(0);
+
+    for (uint32_t wi = 0;; wi++) {
+        if (__ballot(active) == 0) break;
+        // (member m, piece k) -> (lane k, slot m): two DPP butterfly stages, then this lane owns its window
+        uint32_t v[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int d = 0; d < 4; d++) v[q][d] = nxt[q][d];
+#pragma unroll
+        for (int k = 0; k < 4; k += 2)
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const uint32_t send = odd1 ? v[k][d] : v[k + 1][d];
+                const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xf, 0xf, true);
+                if (odd1) v[k][d] = recv; else v[k + 1][d] = recv;
+            }
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const uint32_t send = odd2 ? v[k][d] : v[k + 2][d];
+                const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xf, 0xf, true);
+                if (odd2) v[k][d] = recv; else v[k + 2][d] = recv;
+            }
+        load_window(wi + 1);
+
+#pragma unroll
+        for (int b = 0; b < BW; b++) {
+            if (!active) continue;
+            // ---- the block at pos_in (== (wi * BW + b) * 8): forecast + zigzag + OR-mask (sprintz_xff_lowdim.cpp:160-215)
+            uint32_t x[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if constexpr (W == 8) x[i] = (v[(b * 8 + i) / 16][((b * 8 + i) % 16) / 4] >> (8 * (i & 3))) & 0xffu;
+                else x[i] = (v[(b * 16 + 2 * i) / 16][((b * 16 + 2 * i) % 16) / 4] >> (16 * (i & 1))) & 0xffffu;
+            }
+            uint32_t z[8], mask = 0;
+            const int coef = FIRE ? fire_coef<W, true>(ctr) : 0;
+            int grad = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int delta = sext<W>((int)(x[i] - pv));
+                const int pred = FIRE ? fire_predict<W, true>(pd, coef) : 0;
+                const int err = sext<W>(delta - pred);
+                const uint32_t zz = zigzag<W>(err);
+                if (FIRE && (i & 1)) grad += sign_times(err, pd);
+                mask |= zz;
+                z[i] = zz;
+                pv = x[i];
+                pd = delta;
+            }
+            if (FIRE) ctr = wrap_counter<W>(ctr + (sext<W>(grad) >> 2));
+            const uint32_t nb = nbits_of<W, true>(mask);
+
+            // ---- RLE state machine ("<" tail test: sprintz_delta_lowdim.cpp:190, sprintz_xff_lowdim.cpp:234)
+            for (;;) {
+                if (nb == 0 && run < 0x7fffu) {
+                    run++;
+                    pos_in += 8;
+                    if (pos_in < limit) break;                           // analyse the next block
+                    slot++;                                              // not enough input left: close the run
+                    put_run(run);
+                    wpos += (uint32_t)(2 - slot);                        // empty slots are one 0x00 byte each (ring is zero)
+                    run = 0;
+                    active = false;
+                    break;
+                }
+                if (run > 0) {                                           // a run just ended
+                    slot++;
+                    put_run(run);
+                    run = 0;
+                    if (slot == 2) start_group();
+                    continue;                                            // re-evaluate this block
+                }
+                const uint32_t f = nb == (uint32_t)W ? (uint32_t)(W - 1) : nb;
+                or_bits(hdr_pos * 8u + (uint32_t)slot * HB, f, HB);
+#pragma unroll
+                for (int i = 0; i < 8; i++) or_bits(wpos * 8u + (uint32_t)i * nb, z[i], nb);
+                wpos += nb;                                              // 8 fields of nb bits
+                pos_in += 8;
+                slot++;
+                if (slot == 2) {
+                    if (pos_in <= limit) start_group();
+                    else active = false;
+                }
+                break;
+            }
+        }
+    }
+
+    if (!exists) return;
+    // ---- verbatim tail (sprintz_xff_lowdim.cpp:398) through the ring, 16 source bytes at a time
+    const uint32_t remaining = (uint32_t)((int64_t)n - pos_in);
+    {
+        const uint8_t* const tp = sc + (size_t)pos_in * ESZ;
+        const uint32_t left = remaining * ESZ;
+        for (uint32_t o = 0; o < left; o += 16) {
+            flush_to(wpos & ~63u);                                       // >= 64 bytes of room
+            const v4 x = *(const v4a1*)(tp + o);                         // starts inside the chunk (READ_SLACK covers the end)
+            const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int r = (int)(left - o) - 4 * q;                   // tail bytes from this dword on
+                if (r > 0) or_bits((wpos + 4u * q) * 8u, r >= 4 ? xs[q] : xs[q] & ((1u << (8 * r)) - 1u), 32u);
+            }
+            wpos += left - o < 16u ? left - o : 16u;
+        }
+    }
+    flush_to(wpos & ~63u);
+    for (uint32_t p = flushed; p < wpos; p += 16) {                      // the last units, rounded up to 16 bytes (slot slack)
+        const uint32_t d0 = (p >> 2) & 31u;
+        *(v4a1*)(gdst + p) = v4{my[d0 << 8], my[(d0 + 1) << 8], my[(d0 + 2) << 8], my[(d0 + 3) << 8]};
+    }
+    if (a.write_size) {                                                  // format.h:36-45
+        ((uint32_t*)gdst)[0] = ngroups;
+        ((uint32_t*)gdst)[1] = (remaining & 0xffffu) | (1u << 16);
+    }
+    a.sizes[chunk] = wpos;
+    if (a.rets) a.rets[chunk] = (int64_t)(wpos / ESZ);
+}
+
+}  // namespace sprintz

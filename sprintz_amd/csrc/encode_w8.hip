@@ -9,4 +9,10 @@ hipError_t launch_encode_fast_w8(bool fire, int dp, bool exact, unsigned grid, s
 {
     SPRINTZ_DISPATCH_FAST(encode_fast_kernel, 8)
 }
+hipError_t launch_encode_uni_w8(bool fire, unsigned grid, hipStream_t st, const EncodeArgs& a)
+{
+    if (fire) hipLaunchKernelGGL((encode_uni_kernel<8, true>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((encode_uni_kernel<8, false>), dim3(grid), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
 }  // namespace sprintz

@@ -10,6 +10,7 @@
 #include "decode_uni.h"
 #include "encode_kernel.h"
 #include "encode_fast.h"
+#include "encode_uni.h"
 
 namespace sprintz {
 
@@ -24,6 +25,8 @@ hipError_t launch_decode_fast_w16(bool fire, int dp, int cpl, bool exact, int q,
 // univariate streams (ndims == 1), one lane per chunk (decode_uni.h)
 hipError_t launch_decode_uni_w8(bool fire, unsigned grid, hipStream_t st, const DecodeArgs& a);
 hipError_t launch_decode_uni_w16(bool fire, unsigned grid, hipStream_t st, const DecodeArgs& a);
+hipError_t launch_encode_uni_w8(bool fire, unsigned grid, hipStream_t st, const EncodeArgs& a);
+hipError_t launch_encode_uni_w16(bool fire, unsigned grid, hipStream_t st, const EncodeArgs& a);
 hipError_t launch_encode_fast_w8(bool fire, int dp, bool exact, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
 hipError_t launch_encode_fast_w16(bool fire, int dp, bool exact, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
 hipError_t launch_encode_w8(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);

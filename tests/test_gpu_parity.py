@@ -93,7 +93,7 @@ def test_write_size_false_and_headerless_decode(sz, oracle):
 
 def test_long_runs(sz, oracle):
     """> 127 blocks (2-byte varint) and > 32767 blocks (run cap, sprintz_xff_rle.cpp:71,455)"""
-    for esz, codec, nd in [(1, "delta", 5), (2, "xff", 8), (1, "xff", 2), (2, "delta", 1)]:
+    for esz, codec, nd in [(1, "delta", 5), (2, "xff", 8), (1, "xff", 2), (2, "delta", 1), (1, "xff", 1)]:
         for nblocks in (130, 32767 + 5):
             n = nblocks * 8 * nd + 3
             d = np.zeros(n, DTYPES[esz])
@@ -404,7 +404,7 @@ def test_huffman_decoder_survives_damaged_containers(sz):
     assert np.array_equal(r, sizes.astype(np.int64))
 
 
-@pytest.mark.parametrize("name,codec,esz,ndims,chunk_len", [c for c in CONFIGS if c[0] in ("cfg2", "cfg3_10k", "cfg5", "xff8")])
+@pytest.mark.parametrize("name,codec,esz,ndims,chunk_len", [c for c in CONFIGS if c[0] in ("cfg2", "cfg3_10k", "cfg5", "xff8", "cfg1", "uni16_xff", "uni16_delta_ragged")])
 def test_generic_kernels_agree_with_the_fast_ones(sz, monkeypatch, name, codec, esz, ndims, chunk_len):
     """SPRINTZ_MI355X_NO_FAST routes the same calls to decode_kernel.h / encode_kernel.h: same bytes, same samples"""
     import torch
