@@ -79,7 +79,10 @@ __global__ void __launch_bounds__(256) encode_uni_kernel(EncodeArgs a)
     int slot = 0;
     uint32_t pv = 0;
     int pd = 0, ctr = 0;
+    uint32_t hdr = 0;                                                    // this group's header byte, written when it closes
     auto start_group = [&]() {
+        if (ngroups) put_byte(hdr_pos, hdr);
+        hdr = 0;
         ngroups++;
         flush_to(wpos & ~63u);
         hdr_pos = wpos;
@@ -189,10 +192,36 @@ __global__ void __launch_bounds__(256) encode_uni_kernel(EncodeArgs a)
                     continue;                                            // re-evaluate this block
                 }
                 const uint32_t f = nb == (uint32_t)W ? (uint32_t)(W - 1) : nb;
-                or_bits(hdr_pos * 8u + (uint32_t)slot * HB, f, HB);
+                hdr |= f << ((uint32_t)slot * HB);
+                {   // 8 fields of nb bits = nb bytes, assembled in registers, OR-ed in dword by dword
+                    uint64_t lo = 0, hi = 0;
 #pragma unroll
-                for (int i = 0; i < 8; i++) or_bits(wpos * 8u + (uint32_t)i * nb, z[i], nb);
-                wpos += nb;                                              // 8 fields of nb bits
+                    for (int i = 0; i < 4; i++) {
+                        lo |= (uint64_t)z[i] << (i * nb);
+                        hi |= (uint64_t)z[4 + i] << (i * nb);
+                    }
+                    const uint32_t half = 4u * nb;                       // 4 .. 64 bits
+                    uint32_t acc[5];
+                    if constexpr (W == 8) {                              // half <= 32
+                        lo |= hi << half;
+                        acc[0] = (uint32_t)lo; acc[1] = (uint32_t)(lo >> 32); acc[2] = acc[3] = acc[4] = 0;
+                    } else {
+                        const uint64_t top = half == 64u ? hi : (hi >> (64u - half));
+                        if (half != 64u) lo |= hi << half;
+                        acc[0] = (uint32_t)lo; acc[1] = (uint32_t)(lo >> 32); acc[2] = (uint32_t)top; acc[3] = (uint32_t)(top >> 32); acc[4] = 0;
+                    }
+                    const uint32_t sh = (wpos & 3u) * 8u, d0 = wpos >> 2, span = (wpos & 3u) + nb;   // bytes from dword d0 on
+                    constexpr int ND = W == 8 ? 3 : 5;
+                    uint32_t prev = 0;
+#pragma unroll
+                    for (int k = 0; k < ND; k++) {
+                        const uint32_t cur = k < (W == 8 ? 2 : 4) ? acc[k] : 0u;
+                        const uint32_t dw = (uint32_t)(((((uint64_t)cur << 32) | prev) << sh) >> 32);
+                        if ((uint32_t)(4 * k) < span) my[((d0 + k) & 31u) << 8] |= dw;
+                        prev = cur;
+                    }
+                }
+                wpos += nb;
                 pos_in += 8;
                 slot++;
                 if (slot == 2) {
@@ -205,6 +234,7 @@ __global__ void __launch_bounds__(256) encode_uni_kernel(EncodeArgs a)
     }
 
     if (!exists) return;
+    if (ngroups) put_byte(hdr_pos, hdr);
     // ---- verbatim tail (sprintz_xff_lowdim.cpp:398) through the ring, 16 source bytes at a time
     const uint32_t remaining = (uint32_t)((int64_t)n - pos_in);
     {
