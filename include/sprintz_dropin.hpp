@@ -112,7 +112,7 @@ inline int64_t compress8b_rowmajor_xff(const uint8_t* src, uint64_t len, int8_t*
 }
 inline int64_t decompress8b_rowmajor_xff(const int8_t* src, uint8_t* dest) { return sprintz_mi355x_decompress_norle(SPRINTZ_CODEC_XFF_NORLE, 1, src, dest); }
 
-// ================================================================ stand-alone transforms (delta.h:17-68)
+// ================================================================ stand-alone transforms (delta.h:17-68, predict.h:15-30)
 #define SPRINTZ_DROPIN_TRANSFORM(NAME, KIND, BITS, ESZ)                                                                       \
     inline uint32_t encode_##NAME##_rowmajor_##BITS##b(const uint##BITS##_t* src, uint32_t len, int##BITS##_t* dest, uint16_t ndims,  \
                                                        bool write_size = true)                                                \
@@ -135,6 +135,8 @@ SPRINTZ_DROPIN_TRANSFORM(delta, SPRINTZ_TRANSFORM_DELTA, 8, 1)
 SPRINTZ_DROPIN_TRANSFORM(delta, SPRINTZ_TRANSFORM_DELTA, 16, 2)
 SPRINTZ_DROPIN_TRANSFORM(doubledelta, SPRINTZ_TRANSFORM_DOUBLEDELTA, 8, 1)
 SPRINTZ_DROPIN_TRANSFORM(doubledelta, SPRINTZ_TRANSFORM_DOUBLEDELTA, 16, 2)
+SPRINTZ_DROPIN_TRANSFORM(xff, SPRINTZ_TRANSFORM_XFF, 8, 1)
+SPRINTZ_DROPIN_TRANSFORM(xff, SPRINTZ_TRANSFORM_XFF, 16, 2)
 #undef SPRINTZ_DROPIN_TRANSFORM
 
 #endif  // SPRINTZ_DROPIN_HPP

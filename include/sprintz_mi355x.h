@@ -258,11 +258,17 @@ int64_t sprintz_mi355x_decompress_norle(int codec, int elem_bytes, const void* s
  * Stand-alone transforms.  Replace
  *   encode_delta_rowmajor_{8b,16b} / decode_delta_rowmajor_{8b,16b}              cpp/Compress/delta.h:17-24,53-60
  *   encode_doubledelta_rowmajor_{8b,16b} / decode_doubledelta_rowmajor_{8b,16b}  cpp/Compress/delta.h:36-43,63-68
+ *   encode_xff_rowmajor_{8b,16b} / decode_xff_rowmajor_{8b,16b}                  cpp/Compress/predict.h:15-30
  * Per column (element index mod ndims), state starting at zero, arithmetic
  * wrapping at the element width: delta y[r] = x[r] - x[r-1]; double delta
  * y[r] = x[r] - 2 x[r-1] + x[r-2].  One call transforms ONE stream of any
  * length; the decode is a multi-level scan over its rows (transforms.hip).
- *   kind        : SPRINTZ_TRANSFORM_DELTA / SPRINTZ_TRANSFORM_DOUBLEDELTA
+ * SPRINTZ_TRANSFORM_XFF is the FIRE forecaster with no packing (errors out), with
+ * predict.cpp's own constants (not the codec's); only whole 8-row blocks that its
+ * vector stores cannot spill past the end are forecast, the rest is plain delta
+ * (predict.cpp:96-103, :266-273).  Its counters make the rows of one stream strictly
+ * sequential in both directions: a lane per column, latency-bound (transforms.hip).
+ *   kind        : SPRINTZ_TRANSFORM_DELTA / SPRINTZ_TRANSFORM_DOUBLEDELTA / SPRINTZ_TRANSFORM_XFF
  * Device forms: len elements in, len elements out, no header;
  *   d_tmp: sprintz_mi355x_transform_tmp_bytes(kind, elem_bytes, len, ndims).
  * Host forms: the reference's container -- a 6-byte header {u32 len; u16 ndims}
@@ -273,6 +279,7 @@ int64_t sprintz_mi355x_decompress_norle(int codec, int elem_bytes, const void* s
  * ---------------------------------------------------------------------- */
 #define SPRINTZ_TRANSFORM_DELTA 0
 #define SPRINTZ_TRANSFORM_DOUBLEDELTA 1
+#define SPRINTZ_TRANSFORM_XFF 2
 size_t sprintz_mi355x_transform_tmp_bytes(int kind, int elem_bytes, uint64_t len, uint16_t ndims);
 int sprintz_mi355x_transform_encode_device(int kind, int elem_bytes, const void* d_src, uint64_t len, uint16_t ndims, void* d_dest,
                                            void* hip_stream);

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Mint golden vectors for the stand-alone transforms (delta.h:17-68) from the COMPILED
+"""Mint golden vectors for the stand-alone transforms (delta.h:17-68, predict.h:15-30) from the COMPILED
 REFERENCE.  TEST INFRASTRUCTURE ONLY; run in the build container after `make -C oracle ref`:
 
     python oracle/gen_golden_transforms.py
 
-Writes tests/golden/golden_transforms_v1.npz (+ .json): input, the container the reference's
-encode_{delta,doubledelta}_rowmajor_{8b,16b} wrote (6-byte header + len elements), its return
+Writes tests/golden/golden_transforms_v2.npz (+ .json): input, the container the reference's
+encode_{delta,doubledelta,xff}_rowmajor_{8b,16b} wrote (6-byte header + len elements), its return
 value, and what its decoder returns for that container.  Only data is stored."""
 import json
 import os
@@ -26,9 +26,9 @@ def main():
     idx = 0
     for esz in (1, 2):
         top = 1 << (8 * esz)
-        for kind in (0, 1):
+        for kind in (0, 1, 2):
             for D in (1, 2, 3, 8, 17, 32, 33, 80, 200):
-                for n in (1, D, D + 1, 2 * D + 1, 8 * D, 8 * D + 3, 16 * D + 5, 1000, 4113):
+                for n in (1, D, D + 1, 2 * D + 1, 8 * D, 8 * D + 3, 16 * D + 5, 1000, 4113) + ((40 * D + 7, 20000) if kind == 2 else ()):
                     x = (rng.integers(0, top, n) if (idx % 2) else np.cumsum(rng.integers(-5, 6, n)) % top).astype(DTYPES[esz])
                     cont, ret = ref.transform_encode(kind, x, D)
                     back, dret = ref.transform_decode(kind, cont, esz)
@@ -38,9 +38,9 @@ def main():
                     arrays[name + "_container"] = cont
                     manifest.append({"name": name, "kind": kind, "esz": esz, "ndims": D, "n": n, "ret": ret})
                     idx += 1
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "golden_transforms_v1.npz"), **arrays)
-    with open(os.path.join(ROOT, "tests", "golden", "golden_transforms_v1.json"), "w") as f:
-        json.dump({"version": 1, "cases": manifest}, f, indent=0)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "golden_transforms_v2.npz"), **arrays)
+    with open(os.path.join(ROOT, "tests", "golden", "golden_transforms_v2.json"), "w") as f:
+        json.dump({"version": 2, "cases": manifest}, f, indent=0)
     print(len(manifest), "cases")
 
 

@@ -15,6 +15,7 @@
 #include "sprintz_delta.h"   /* compress_rowmajor_delta_rle_*: :49-51,68-70; query_rowmajor_delta_rle_*: :95-98 */
 #include "sprintz_xff.h"     /* compress_rowmajor_xff_rle_*: :45-55; query_rowmajor_xff_rle_*: :90-93 */
 #include "delta.h"           /* encode/decode_{delta,doubledelta}_rowmajor_{8b,16b}: :17-68 */
+#include "predict.h"         /* encode/decode_xff_rowmajor_{8b,16b}: :15-30 */
 
 extern "C" {
 
@@ -107,10 +108,14 @@ int64_t ref_query(int codec, int elem_bytes, const void* src, void* dest, int op
                  : query_rowmajor_delta_rle_16b((const int16_t*)src, (uint16_t*)dest, qp);
 }
 
-/* stand-alone transforms (delta.h:17-68); kind 0 = delta, 1 = double delta */
+/* stand-alone transforms (delta.h:17-68, predict.h:15-30); kind 0 = delta, 1 = double delta, 2 = xff */
 uint32_t ref_transform_encode(int kind, int elem_bytes, const void* src, uint32_t len, void* dest, uint16_t ndims, int write_size)
 {
     const bool ws = write_size != 0;
+    if (kind == 2) {
+        return elem_bytes == 1 ? encode_xff_rowmajor_8b((const uint8_t*)src, len, (int8_t*)dest, ndims, ws)
+                               : encode_xff_rowmajor_16b((const uint16_t*)src, len, (int16_t*)dest, ndims, ws);
+    }
     if (elem_bytes == 1) {
         return kind ? encode_doubledelta_rowmajor_8b((const uint8_t*)src, len, (int8_t*)dest, ndims, ws)
                     : encode_delta_rowmajor_8b((const uint8_t*)src, len, (int8_t*)dest, ndims, ws);
@@ -122,6 +127,10 @@ uint32_t ref_transform_encode(int kind, int elem_bytes, const void* src, uint32_
 /* src carries the 6-byte header (format.h:65-86) */
 uint32_t ref_transform_decode(int kind, int elem_bytes, const void* src, void* dest)
 {
+    if (kind == 2) {
+        return elem_bytes == 1 ? decode_xff_rowmajor_8b((const int8_t*)src, (uint8_t*)dest)
+                               : decode_xff_rowmajor_16b((const int16_t*)src, (uint16_t*)dest);
+    }
     if (elem_bytes == 1) {
         return kind ? decode_doubledelta_rowmajor_8b((const int8_t*)src, (uint8_t*)dest)
                     : decode_delta_rowmajor_8b((const int8_t*)src, (uint8_t*)dest);

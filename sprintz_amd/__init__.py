@@ -13,6 +13,7 @@ from .codec import (ChunkedCodec, CompressedBatch, HufBatch, compress_chunked, d
                     encode_delta_rowmajor_8b, encode_delta_rowmajor_16b, encode_doubledelta_rowmajor_8b,
                     encode_doubledelta_rowmajor_16b, decode_delta_rowmajor_8b, decode_delta_rowmajor_16b,
                     decode_doubledelta_rowmajor_8b, decode_doubledelta_rowmajor_16b, transform_device,
+                    encode_xff_rowmajor_8b, encode_xff_rowmajor_16b, decode_xff_rowmajor_8b, decode_xff_rowmajor_16b,
                     compress_rowmajor_8b, compress_rowmajor_16b, compress_rowmajor_delta_8b, compress_rowmajor_delta_16b,
                     decompress_rowmajor_8b, decompress_rowmajor_16b, decompress_rowmajor_delta_8b, decompress_rowmajor_delta_16b,
                     compress8b_rowmajor_xff, decompress8b_rowmajor_xff,
@@ -25,7 +26,7 @@ __all__ = [
     "compress_chunked", "decompress_chunked", "decompress_noheader", "QueryParams", "QueryTypes",
     "encode_delta_rowmajor_8b", "encode_delta_rowmajor_16b", "encode_doubledelta_rowmajor_8b", "encode_doubledelta_rowmajor_16b",
     "decode_delta_rowmajor_8b", "decode_delta_rowmajor_16b", "decode_doubledelta_rowmajor_8b", "decode_doubledelta_rowmajor_16b",
-    "transform_device",
+    "transform_device", "encode_xff_rowmajor_8b", "encode_xff_rowmajor_16b", "decode_xff_rowmajor_8b", "decode_xff_rowmajor_16b",
     "compress_rowmajor_8b", "compress_rowmajor_16b", "compress_rowmajor_delta_8b", "compress_rowmajor_delta_16b",
     "decompress_rowmajor_8b", "decompress_rowmajor_16b", "decompress_rowmajor_delta_8b", "decompress_rowmajor_delta_16b",
     "compress8b_rowmajor_xff", "decompress8b_rowmajor_xff",

@@ -99,7 +99,7 @@ compress_batch_colmajor = _sig("sprintz_mi355x_compress_batch_colmajor", _i, _i,
 decompress_batch_colmajor = _sig("sprintz_mi355x_decompress_batch_colmajor", _i, _i, _i, _vp, _vp, _u64, _u32, _u16, _u64, _vp, _vp, _vp)
 
 # (6) stand-alone transforms (delta.h:17-68)
-TRANSFORM_DELTA, TRANSFORM_DOUBLEDELTA = 0, 1
+TRANSFORM_DELTA, TRANSFORM_DOUBLEDELTA, TRANSFORM_XFF = 0, 1, 2
 transform_tmp_bytes = _sig("sprintz_mi355x_transform_tmp_bytes", _sz, _i, _i, _u64, _u16)
 transform_encode_device = _sig("sprintz_mi355x_transform_encode_device", _i, _i, _i, _vp, _u64, _u16, _vp, _vp)
 transform_decode_device = _sig("sprintz_mi355x_transform_decode_device", _i, _i, _i, _vp, _u64, _u16, _vp, _vp, _vp)

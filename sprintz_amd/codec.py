@@ -394,11 +394,28 @@ def decode_doubledelta_rowmajor_16b(src, dest, len=0, ndims=0):  # noqa: A002
     return _dec_t(_lib.TRANSFORM_DOUBLEDELTA, 2, src, dest, len, ndims)
 
 
+def encode_xff_rowmajor_8b(src, len, dest, ndims, write_size=True):  # noqa: A002 (predict.h:15)
+    return _enc_t(_lib.TRANSFORM_XFF, 1, src, len, dest, ndims, write_size)
+
+
+def encode_xff_rowmajor_16b(src, len, dest, ndims, write_size=True):  # noqa: A002 (predict.h:24)
+    return _enc_t(_lib.TRANSFORM_XFF, 2, src, len, dest, ndims, write_size)
+
+
+def decode_xff_rowmajor_8b(src, dest, len=0, ndims=0):  # noqa: A002 (predict.h:17-21)
+    return _dec_t(_lib.TRANSFORM_XFF, 1, src, dest, len, ndims)
+
+
+def decode_xff_rowmajor_16b(src, dest, len=0, ndims=0):  # noqa: A002 (predict.h:26-30)
+    return _dec_t(_lib.TRANSFORM_XFF, 2, src, dest, len, ndims)
+
+
 def transform_device(kind, x, ndims, inverse=False, out=None):
-    """delta ("delta") / double delta ("doubledelta") of one row-major stream resident in HBM
-    (torch uint8/uint16 tensor); inverse=True undoes it (a multi-level scan over the rows)."""
+    """delta ("delta") / double delta ("doubledelta") / FIRE errors ("xff", predict.h) of one
+    row-major stream resident in HBM (torch uint8/uint16 tensor); inverse=True undoes it (delta
+    kinds: a multi-level scan over the rows; xff: a lane per column, sequential in the rows)."""
     import torch
-    k = {"delta": _lib.TRANSFORM_DELTA, "doubledelta": _lib.TRANSFORM_DOUBLEDELTA}[kind]
+    k = {"delta": _lib.TRANSFORM_DELTA, "doubledelta": _lib.TRANSFORM_DOUBLEDELTA, "xff": _lib.TRANSFORM_XFF}[kind]
     esz = x.dtype.itemsize
     x = x.contiguous().reshape(-1)
     if out is None:

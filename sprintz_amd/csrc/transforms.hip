@@ -1,6 +1,7 @@
 // transforms.hip -- the reference's stand-alone transforms on the GPU:
 //   kind 0  delta         encode/decode_delta_rowmajor        cpp/Compress/delta.cpp:35-121, :133-397
 //   kind 1  double delta  encode/decode_doubledelta_rowmajor  delta.cpp:405-529, :532-693
+//   kind 2  xff (FIRE)    encode/decode_xff_rowmajor          cpp/Compress/predict.cpp:57-289, :302-517
 // Per column c (element index mod ndims), state starting at zero, arithmetic wrapping at the
 // element width:   delta  y[r] = x[r] - x[r-1];   double delta  y[r] = x[r] - 2 x[r-1] + x[r-2].
 //
@@ -13,6 +14,14 @@
 // Level k of the scan holds one summary per R^k rows; `reduce` builds level k+1 from level k,
 // `apply` walks back down handing every run its incoming state, and at level 0 writes x.
 // Everything is modulo 2^W, so the summaries are stored in the element type.
+//
+// XFF (the FIRE forecaster without packing, with predict.cpp's own constants) is different in
+// kind: the counter a block leaves depends non-linearly (>> truncation, sign()) on the counter
+// it entered with, so ONE stream offers no parallelism along the rows in either direction --
+// only across its columns.  xff_kernel is therefore a lane per column walking the rows, the
+// next block's samples in flight while one is forecast; it is latency-bound by construction
+// ("replicas only") and is here so that the whole transform surface of the
+// reference exists behind one boundary.  Many independent series belong in the batched codec.
 #include "../../include/sprintz_mi355x.h"
 
 #include <hip/hip_runtime.h>
@@ -433,11 +442,117 @@ int encode_device(const U* x, uint64_t len, uint32_t D, U* y, hipStream_t st)
     return hipGetLastError() == hipSuccess ? 0 : fail(SPRINTZ_E_HIP, "transform encode launch");
 }
 
+// ---------------------------------------------------------------- xff: a lane per column (predict.cpp:121-262, :372-497)
+template <int W> __device__ __forceinline__ int sx(int v) { return W == 8 ? (int)(int8_t)v : (int)(int16_t)v; }
+
+template <typename U, bool DECODE>
+__global__ void __launch_bounds__(64) xff_kernel(const U* __restrict__ in, uint64_t len, uint32_t D, uint32_t nblocks, U* __restrict__ out)
+{
+    constexpr int W = 8 * (int)sizeof(U);
+    const uint32_t col = blockIdx.x * 64u + threadIdx.x;
+    if (col >= D) return;
+    const bool odd_col = (col & 1u) != 0;
+    uint32_t pv = 0;
+    int pd = 0, ctr = 0;                                  // ctr: int16 at 8 bits, int32 at 16 (predict.cpp:84-87)
+    const U* p = in + col;
+    U* q = out + col;
+    // the next block's samples are in flight while one is forecast.  (Fetching 8 blocks ahead buys
+    // nothing: the walk is bound by ONE wave's dependent-instruction latency, ~20 dependent
+    // VALU ops = ~150 cycles a row, not by the loads.)
+    constexpr int PF = 1;
+    U cur[PF * 8], nxt[PF * 8];
+    const uint32_t Dv = D;
+    auto fetch = [&](U* v, uint32_t b0) {
+        const U* pb = p + (uint64_t)b0 * 8ull * Dv;
+#pragma unroll
+        for (int j = 0; j < PF; j++) {
+            const bool in_range = b0 + j < nblocks;              // wave-uniform
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                v[j * 8 + i] = in_range ? *pb : (U)0;
+                pb += Dv;
+            }
+        }
+    };
+    fetch(cur, 0);
+    for (uint32_t b0 = 0; b0 < nblocks; b0 += PF) {
+        fetch(nxt, b0 + PF);
+#pragma unroll
+        for (int j = 0; j < PF; j++) {
+            if (b0 + j >= nblocks) break;
+            int coef;
+            if constexpr (W == 8) coef = (int)(int16_t)((ctr >> 5) << 4);          // :140-145
+            else coef = (int)(int16_t)((uint32_t)(ctr >> 15) << 12);               // :224-232
+            int grad = 0;
+            U* const qb = q + (uint64_t)(b0 + j) * 8ull * Dv;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                int pred;
+                if constexpr (W == 8) {
+                    // byte 1 of the 16-bit product; the previous delta is taken unsigned in even columns (:163-168)
+                    const int m = odd_col ? pd : (pd & 0xff);
+                    pred = (int)(int8_t)(((uint32_t)(m * coef) >> 8) & 0xffu);
+                } else {
+                    pred = (int)(int16_t)((uint32_t)((pd * coef) >> 16) << 2);     // mulhi, << 2 (:240-242)
+                }
+                int delta, err;
+                uint32_t x;
+                if (DECODE) {
+                    err = sx<W>((int)cur[j * 8 + i]);
+                    delta = sx<W>(err + pred);
+                    x = (pv + (uint32_t)delta) & ((1u << W) - 1u);
+                    qb[(uint64_t)i * Dv] = (U)x;
+                } else {
+                    x = cur[j * 8 + i];
+                    delta = sx<W>((int)(x - pv));
+                    err = sx<W>(delta - pred);
+                    qb[(uint64_t)i * Dv] = (U)err;
+                }
+                if (i & 1) grad = sx<W>(grad + (err > 0 ? pd : err < 0 ? sx<W>(-pd) : 0));   // _mm256_sign_epi8/16 (:173, :247)
+                pv = x;
+                pd = delta;
+            }
+            ctr += grad >> 2;                                                      // :195-206, :255-262
+            if constexpr (W == 8) ctr = (int)(int16_t)ctr;
+        }
+#pragma unroll
+        for (int k = 0; k < PF * 8; k++) cur[k] = nxt[k];
+    }
+    // the rows the vector code leaves alone: plain delta against the previous row (:266-273, :500)
+    for (uint64_t i = (uint64_t)nblocks * 8ull * D + col; i < len; i += D) {
+        const uint32_t v = in[i];
+        if (DECODE) { pv = (pv + v) & ((1u << W) - 1u); out[i] = (U)pv; }
+        else { out[i] = (U)(v - pv); pv = v; }
+    }
+}
+
+// blocks the reference forecasts: rows / 8, less what its 32-byte stores would spill past the end (predict.cpp:96-103)
+uint32_t xff_nblocks(uint64_t len, uint32_t D, int esz)
+{
+    const uint32_t V = 32u / (uint32_t)esz;
+    const uint64_t blk = 8ull * D;
+    int64_t nblocks = (int64_t)((len / D) / 8u);
+    const uint32_t overrun = V - (D % V);
+    if (overrun > len % blk) nblocks -= (int64_t)((overrun + blk - 1) / blk);
+    return nblocks < 0 ? 0u : (uint32_t)nblocks;
+}
+
+template <typename U>
+int xff_device(bool decode, const U* in, uint64_t len, uint32_t D, U* out, hipStream_t st)
+{
+    const uint32_t nb = xff_nblocks(len, D, (int)sizeof(U));
+    const unsigned grid = (D + 63u) / 64u;
+    if (decode) hipLaunchKernelGGL((xff_kernel<U, true>), dim3(grid), dim3(64), 0, st, in, len, D, nb, out);
+    else hipLaunchKernelGGL((xff_kernel<U, false>), dim3(grid), dim3(64), 0, st, in, len, D, nb, out);
+    return hipGetLastError() == hipSuccess ? 0 : fail(SPRINTZ_E_HIP, "xff transform launch");
+}
+
 int check(int kind, int esz, uint64_t len, uint16_t ndims)
 {
-    if (kind != SPRINTZ_TRANSFORM_DELTA && kind != SPRINTZ_TRANSFORM_DOUBLEDELTA) return fail(SPRINTZ_E_INVALID, "kind must be 0 (delta) or 1 (double delta)");
+    if (kind < 0 || kind > SPRINTZ_TRANSFORM_XFF) return fail(SPRINTZ_E_INVALID, "kind must be 0 (delta), 1 (double delta) or 2 (xff)");
     if (esz != 1 && esz != 2) return fail(SPRINTZ_E_INVALID, "elem_bytes must be 1 or 2");
     if (ndims == 0) return fail(SPRINTZ_E_INVALID, "ndims == 0");
+    if (kind == SPRINTZ_TRANSFORM_XFF && len > 0xffffffffull) return fail(SPRINTZ_E_INVALID, "xff: len is 32 bits in the reference (predict.h:15)");
     if (len / 64 > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "len too large for one launch");
     return 0;
 }
@@ -457,6 +572,7 @@ const char* sprintz_mi355x_transform_last_error(void) { return g_err.c_str(); }
 size_t sprintz_mi355x_transform_tmp_bytes(int kind, int elem_bytes, uint64_t len, uint16_t ndims)
 {
     if (ndims == 0 || (elem_bytes != 1 && elem_bytes != 2)) return 0;
+    if (kind == SPRINTZ_TRANSFORM_XFF) return 64;              // no scratch: a lane per column
     return make_plan(kind, elem_bytes, len, ndims).tmp_bytes + 64;
 }
 
@@ -469,6 +585,10 @@ int sprintz_mi355x_transform_encode_device(int kind, int elem_bytes, const void*
     if (!have_device()) return fail(SPRINTZ_E_NO_DEVICE, "no HIP device; there is no CPU fallback");
     if (len == 0) return 0;
     hipStream_t st = (hipStream_t)hip_stream;
+    if (kind == SPRINTZ_TRANSFORM_XFF) {
+        return elem_bytes == 1 ? xff_device<uint8_t>(false, (const uint8_t*)d_src, len, ndims, (uint8_t*)d_dest, st)
+                               : xff_device<uint16_t>(false, (const uint16_t*)d_src, len, ndims, (uint16_t*)d_dest, st);
+    }
     if (elem_bytes == 1) return kind ? encode_device<uint8_t, 1>((const uint8_t*)d_src, len, ndims, (uint8_t*)d_dest, st)
                                      : encode_device<uint8_t, 0>((const uint8_t*)d_src, len, ndims, (uint8_t*)d_dest, st);
     return kind ? encode_device<uint16_t, 1>((const uint16_t*)d_src, len, ndims, (uint16_t*)d_dest, st)
@@ -484,6 +604,10 @@ int sprintz_mi355x_transform_decode_device(int kind, int elem_bytes, const void*
     if (!have_device()) return fail(SPRINTZ_E_NO_DEVICE, "no HIP device; there is no CPU fallback");
     if (len == 0) return 0;
     hipStream_t st = (hipStream_t)hip_stream;
+    if (kind == SPRINTZ_TRANSFORM_XFF) {
+        return elem_bytes == 1 ? xff_device<uint8_t>(true, (const uint8_t*)d_src, len, ndims, (uint8_t*)d_dest, st)
+                               : xff_device<uint16_t>(true, (const uint16_t*)d_src, len, ndims, (uint16_t*)d_dest, st);
+    }
     if (elem_bytes == 1) return kind ? decode_device<uint8_t, 1>((const uint8_t*)d_src, len, ndims, (uint8_t*)d_dest, (uint8_t*)d_tmp, st)
                                      : decode_device<uint8_t, 0>((const uint8_t*)d_src, len, ndims, (uint8_t*)d_dest, (uint8_t*)d_tmp, st);
     return kind ? decode_device<uint16_t, 1>((const uint16_t*)d_src, len, ndims, (uint16_t*)d_dest, (uint8_t*)d_tmp, st)
@@ -493,7 +617,7 @@ int sprintz_mi355x_transform_decode_device(int kind, int elem_bytes, const void*
 // host forms with the reference's container: 6-byte header {u32 len; u16 ndims} (format.h:65-86)
 int64_t sprintz_mi355x_transform_encode(int kind, int elem_bytes, const void* src, uint32_t len, void* dest, uint16_t ndims, int write_size)
 {
-    if (kind != 0 && kind != 1) return fail(SPRINTZ_E_INVALID, "kind must be 0 (delta) or 1 (double delta)");
+    if (kind < 0 || kind > SPRINTZ_TRANSFORM_XFF) return fail(SPRINTZ_E_INVALID, "kind must be 0 (delta), 1 (double delta) or 2 (xff)");
     if (elem_bytes != 1 && elem_bytes != 2) return fail(SPRINTZ_E_INVALID, "elem_bytes must be 1 or 2");
     if (!src || !dest) return fail(SPRINTZ_E_INVALID, "null pointer");
     if (!have_device()) return fail(SPRINTZ_E_NO_DEVICE, "no HIP device; there is no CPU fallback");
@@ -520,7 +644,7 @@ int64_t sprintz_mi355x_transform_encode(int kind, int elem_bytes, const void* sr
 // src carries the header unless len/ndims are given (the reference's 4-argument decode form, delta.h:19-21)
 int64_t sprintz_mi355x_transform_decode(int kind, int elem_bytes, const void* src, void* dest, uint32_t raw_len, uint16_t raw_ndims)
 {
-    if (kind != 0 && kind != 1) return fail(SPRINTZ_E_INVALID, "kind must be 0 (delta) or 1 (double delta)");
+    if (kind < 0 || kind > SPRINTZ_TRANSFORM_XFF) return fail(SPRINTZ_E_INVALID, "kind must be 0 (delta), 1 (double delta) or 2 (xff)");
     if (elem_bytes != 1 && elem_bytes != 2) return fail(SPRINTZ_E_INVALID, "elem_bytes must be 1 or 2");
     if (!src || !dest) return fail(SPRINTZ_E_INVALID, "null pointer");
     if (!have_device()) return fail(SPRINTZ_E_NO_DEVICE, "no HIP device; there is no CPU fallback");
@@ -532,7 +656,7 @@ int64_t sprintz_mi355x_transform_decode(int kind, int elem_bytes, const void* sr
         memcpy(&ndims, s + 4, 2);
         s += 6;
     }
-    if (ndims == 0) return 0;                                  // delta.cpp:191, :637
+    if (ndims == 0) return 0;                                  // delta.cpp:191, :637; predict.cpp:318
     if (len == 0) return 0;
     const size_t nb = (size_t)len * elem_bytes;
     const size_t tb = sprintz_mi355x_transform_tmp_bytes(kind, elem_bytes, len, ndims);

@@ -51,9 +51,9 @@ def golden_transforms():
     import json
     import numpy as np
     gdir = os.path.join(HERE, "golden")
-    with open(os.path.join(gdir, "golden_transforms_v1.json")) as f:
+    with open(os.path.join(gdir, "golden_transforms_v2.json")) as f:
         manifest = json.load(f)["cases"]
-    arrays = np.load(os.path.join(gdir, "golden_transforms_v1.npz"))
+    arrays = np.load(os.path.join(gdir, "golden_transforms_v2.npz"))
     return manifest, arrays
 
 

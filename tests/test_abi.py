@@ -105,6 +105,7 @@ def test_dropin_header_compiles_and_links(lib_path, tmp_path):
         "  int64_t r = query_rowmajor_delta_rle_8b((const int8_t*)c.data(), (uint8_t*)y.data(), qp, res);\n"
         "  uint32_t e = encode_doubledelta_rowmajor_16b(x.data(), 100, c.data(), 4);   // delta.h:63\n"
         "  uint32_t d = decode_delta_rowmajor_inplace_8b((uint8_t*)y.data(), 64, 2);     // delta.h:21\n"
+        "  e += encode_xff_rowmajor_16b(x.data(), 100, c.data(), 4) + decode_xff_rowmajor_8b((const int8_t*)c.data(), (uint8_t*)y.data());   // predict.h:24,21\n"
         "  int64_t z = compress_rowmajor_delta_16b(x.data(), 4096, c.data(), 8) + decompress8b_rowmajor_xff((const int8_t*)c.data(), (uint8_t*)y.data());\n"
         "  (void)e; (void)d; (void)z;\n"
         "  return (n < 0 && m < 0 && a < 0 && q < 0 && r < 0) ? 0 : 1;   // without a GPU every call fails loudly\n"
@@ -146,7 +147,7 @@ def test_argument_checks_come_before_the_device_check(lib_path):
     assert _lib.compress_batch_colmajor(1, 2, p16, 100, 50, 10, 8, p16, 1024, p16, None, None) == E.E_INVALID   # col_stride < nrows
     assert _lib.decompress_batch_colmajor(1, 2, p16, p16, 4, 10, 8, 30, p16, None, None) == E.E_INVALID          # col_stride < nchunks*rows
     # transforms
-    assert _lib.transform_encode_device(2, 2, p16, 10, 8, p16, None) == E.E_INVALID
+    assert _lib.transform_encode_device(3, 2, p16, 10, 8, p16, None) == E.E_INVALID
     assert _lib.transform_encode_device(0, 4, p16, 10, 8, p16, None) == E.E_INVALID
     assert _lib.transform_decode_device(0, 2, p16, 10, 0, p16, p16, None) == E.E_INVALID
     assert _lib.transform_decode_device(0, 2, p16, 10, 8, p16, None, None) == E.E_INVALID

@@ -1,4 +1,4 @@
-"""GPU tests (-m gpu): stand-alone transforms (delta.h:17-68) through the C-ABI, against the
+"""GPU tests (-m gpu): stand-alone transforms (delta.h:17-68, predict.h:15-30) through the C-ABI, against the
 containers minted from the compiled reference, the oracle, and at sizes where the decode's
 multi-level scan has several levels.  Nothing here reads /root/reference."""
 import numpy as np
@@ -8,7 +8,7 @@ from harness import DTYPES
 
 pytestmark = pytest.mark.gpu
 
-NAMES = {0: "delta", 1: "doubledelta"}
+NAMES = {0: "delta", 1: "doubledelta", 2: "xff"}
 
 
 @pytest.fixture(scope="module")
@@ -65,3 +65,21 @@ def test_long_streams_on_device(sz, oracle, kind, esz, ndims, n):
     assert torch.equal(y.view(torch.int8 if esz == 1 else torch.int16).to(torch.int32) & mask, want & mask)
     back = sz.transform_device(kind, y, ndims, inverse=True)
     assert torch.equal(back, x)
+
+
+@pytest.mark.parametrize("esz,ndims,n", [(2, 8, 8 * 200_003 + 5), (1, 80, 80 * 20_001 + 13), (1, 1, 100_001), (2, 300, 300 * 4_000 + 7),
+                                         (1, 33, 33 * 10_000), (2, 16, 16 * 8 * 5000)])
+def test_xff_long_streams_on_device(sz, oracle, esz, ndims, n):
+    """FIRE errors of one long stream (predict.cpp): device forms against the oracle, and back"""
+    import torch
+    rng = np.random.default_rng(n % 997)
+    top = 1 << (8 * esz)
+    x = ((np.cumsum(rng.integers(-6, 7, n)) + rng.integers(0, 3, n)) % top).astype(DTYPES[esz])
+    x[n // 3: n // 3 + 5000] = rng.integers(0, top, 5000).astype(DTYPES[esz])        # a noisy stretch: counters swing
+    want, _ = oracle.transform_encode(2, x, ndims)
+    xd = torch.from_numpy(x.view(np.uint8 if esz == 1 else np.int16)).cuda()
+    xd = xd if esz == 1 else xd.view(torch.uint16)
+    y = sz.transform_device("xff", xd, ndims)
+    assert np.array_equal(y.cpu().numpy().view(DTYPES[esz]), want[6:].view(DTYPES[esz]))
+    back = sz.transform_device("xff", y, ndims, inverse=True)
+    assert torch.equal(back, xd)

@@ -22,9 +22,9 @@ def test_oracle_vs_compiled_reference(oracle, reference):
         pytest.skip("oracle/_ref built before the transform shim was added")
     rng = np.random.default_rng(3)
     for esz in (1, 2):
-        for kind in (0, 1):
+        for kind in (0, 1, 2):
             for D in (1, 4, 7, 16, 31, 32, 65, 300):
-                for n in (1, 5, D, 2 * D - 1, 8 * D + 1, 777, 5000):
+                for n in (1, 5, D, 2 * D - 1, 8 * D + 1, 777, 5000, 24 * D + 3):
                     x = rng.integers(0, 1 << (8 * esz), n).astype(DTYPES[esz])
                     a, ra = oracle.transform_encode(kind, x, D)
                     b, rb = reference.transform_encode(kind, x, D)
