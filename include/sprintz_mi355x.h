@@ -255,6 +255,28 @@ int64_t sprintz_mi355x_compress_norle(int codec, int elem_bytes, const void* src
 int64_t sprintz_mi355x_decompress_norle(int codec, int elem_bytes, const void* src, void* dest);
 
 /* ------------------------------------------------------------------------
+ * Huff0 wire format.  The paper's entropy stage is Yann Collet's
+ * Huff0 (communicate/ubicomp/method.tex:293-297), a third-party coder the
+ * reference neither vendors nor pins; this entry point decodes GENUINE Huff0
+ * blocks -- what HUF_compress of zstd 1.4.x / lzbench's huff0 writes: tree
+ * description (4-bit or FSE-compressed weights), 3 x u16 jump table, 4 bit
+ * streams -- one block per chunk, so that a container entropy-coded by that
+ * library can be taken straight to sprintz_mi355x_decompress_batch.  Replaces
+ * HUF_decompress(dst, dstSize, cSrc, cSrcSize) per chunk, with its conventions:
+ * block bytes == decoded bytes means stored, 1 byte means one repeated byte.
+ *   d_blocks + d_block_offsets[c] .. [c+1] : chunk c's block
+ *   d_out + d_out_offsets[c] .. [c+1]      : where its bytes go (the sizes are
+ *                                            the caller's, as with HUF_decompress)
+ *   d_rets[c] (optional): decoded bytes, SPRINTZ_E_CORRUPT for a damaged block
+ *   (nothing is read or written outside the chunk's two ranges), or
+ *   SPRINTZ_E_UNSUPPORTED for a table log of 12 (HUF_compress caps it at 11).
+ * d_blocks must be readable 8 bytes past its end.  Format restated in
+ * oracle/huf0_oracle.c; kernel in sprintz_amd/csrc/huf0.hip.
+ * ---------------------------------------------------------------------- */
+int sprintz_mi355x_huf0_decompress_batch(const void* d_blocks, const uint64_t* d_block_offsets, uint64_t nchunks, void* d_out,
+                                         const uint64_t* d_out_offsets, int64_t* d_rets, void* hip_stream);
+
+/* ------------------------------------------------------------------------
  * Stand-alone transforms.  Replace
  *   encode_delta_rowmajor_{8b,16b} / decode_delta_rowmajor_{8b,16b}              cpp/Compress/delta.h:17-24,53-60
  *   encode_doubledelta_rowmajor_{8b,16b} / decode_doubledelta_rowmajor_{8b,16b}  cpp/Compress/delta.h:36-43,63-68

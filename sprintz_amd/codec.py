@@ -481,6 +481,22 @@ def huf_decompress(hb, dense_capacity, align=16, rets=None):
     return CompressedBatch(dense, offs, sizes, n, hb.total_len, hb.chunk_len, hb.ndims)
 
 
+def huf0_decompress(blocks, block_offsets, out_offsets, rets=None, out=None):
+    """Genuine Huff0 blocks (HUF_compress's output, one per chunk; torch uint8 tensor + int64 offsets
+    [nchunks+1]) -> the bytes they encode, chunk c at out_offsets[c] (int64 [nchunks+1], device).
+    `blocks` must carry 8 readable bytes past the last block.  Returns the uint8 output tensor
+    (READ_SLACK bytes longer than out_offsets[-1], ready for ChunkedCodec.decompress_into)."""
+    import torch
+    dev = blocks.device
+    n = block_offsets.numel() - 1
+    if out is None:
+        out = torch.zeros(int(out_offsets[-1].item()) + _lib.READ_SLACK, dtype=torch.uint8, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(_lib.huf0_decompress_batch(blocks.data_ptr(), block_offsets.data_ptr(), n, out.data_ptr(), out_offsets.data_ptr(),
+                                          rets.data_ptr() if rets is not None else None, stream))
+    return out
+
+
 # ---- host convenience (lzbench-style, PCIe inclusive) ---------------------------
 
 def compress_chunked(codec, data, ndims, chunk_len):

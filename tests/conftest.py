@@ -58,6 +58,18 @@ def golden_transforms():
 
 
 @pytest.fixture(scope="session")
+def golden_huf0():
+    """Huff0 blocks written by libzstd's HUF_compress (oracle/gen_golden_huf0.py)"""
+    import json
+    import numpy as np
+    gdir = os.path.join(HERE, "golden")
+    with open(os.path.join(gdir, "golden_huf0_v1.json")) as f:
+        manifest = json.load(f)["cases"]
+    arrays = np.load(os.path.join(gdir, "golden_huf0_v1.npz"))
+    return manifest, arrays
+
+
+@pytest.fixture(scope="session")
 def golden_norle():
     """streams of the reference's non-RLE codecs (oracle/gen_golden_norle.py)"""
     import json

@@ -101,6 +101,14 @@ class Oracle:
                             offs.ctypes.data, sizes.ctypes.data)
         return dense[:total].copy(), offs, sizes
 
+    def huf0_decompress(self, block, dst_size):
+        """one genuine Huff0 block (oracle/huf0_oracle.c = HUF_decompress): -> (bytes, return value)"""
+        f = _bind(self.lib, "oracle_huf0_decompress", C.c_int64, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t])
+        block = np.ascontiguousarray(block, dtype=np.uint8)
+        dst = np.zeros(max(dst_size, 1), np.uint8)
+        ret = f(dst.ctypes.data, dst_size, block.ctypes.data, block.size)
+        return dst[:dst_size], int(ret)
+
     def bound(self, esz, n, ndims):
         return int(self._bound(esz, n, ndims))
 
@@ -324,6 +332,43 @@ class Reference:
         out = np.full(capacity + 64 + 4 * max(ndims_hint, 32), 0xCD, dtype=DTYPES[esz])
         ret = self._decompress(CODECS[codec], esz, padded.ctypes.data, out.ctypes.data)
         return out[:max(int(ret), 0)].copy(), int(ret)
+
+
+class Zstd:
+    """The system libzstd's Huff0 (HUF_compress / HUF_decompress, zstd 1.4.x): the stand-in for the
+    un-vendored coder of the paper.  Test infrastructure; absent -> tests skip."""
+
+    def __init__(self):
+        z = C.CDLL("libzstd.so.1")
+        z.HUF_compress.restype = C.c_size_t
+        z.HUF_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        z.HUF_decompress.restype = C.c_size_t
+        z.HUF_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        z.HUF_compressBound.restype = C.c_size_t
+        z.HUF_compressBound.argtypes = [C.c_size_t]
+        z.HUF_isError.restype = C.c_uint
+        z.HUF_isError.argtypes = [C.c_size_t]
+        z.ZSTD_versionNumber.restype = C.c_uint
+        self.z = z
+        self.version = int(z.ZSTD_versionNumber())
+
+    def huf_compress(self, data):
+        """-> block bytes with HUF_decompress's conventions: the input itself when HUF_compress
+        declines (returns 0), one byte when it is a single repeated symbol"""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        if data.size == 0:
+            return data.copy()
+        out = np.zeros(self.z.HUF_compressBound(data.size) + 8, np.uint8)
+        r = self.z.HUF_compress(out.ctypes.data, out.size, data.ctypes.data, data.size)
+        if self.z.HUF_isError(r) or r == 0:
+            return data.copy()
+        return out[:r].copy()
+
+    def huf_decompress(self, block, dst_size):
+        block = np.ascontiguousarray(block, dtype=np.uint8)
+        dst = np.zeros(dst_size, np.uint8)
+        r = self.z.HUF_decompress(dst.ctypes.data, dst_size, block.ctypes.data, block.size)
+        return dst, (-1 if self.z.HUF_isError(r) else int(r))
 
 
 # ----------------------------------------------------------------- inputs

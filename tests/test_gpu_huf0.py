@@ -1,0 +1,113 @@
+"""GPU tests (-m gpu): genuine Huff0 blocks (written by libzstd's HUF_compress; committed under
+tests/golden/) through sprintz_mi355x_huf0_decompress_batch, against the plain bytes and the
+oracle, then on into the Sprintz decoder.  Nothing here needs libzstd or /root/reference."""
+import numpy as np
+import pytest
+
+from harness import DTYPES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sz():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import sprintz_amd
+    return sprintz_amd
+
+
+def pack(blocks, plains, align=1):
+    import torch
+    bo = np.zeros(len(blocks) + 1, np.int64)
+    bo[1:] = np.cumsum([b.size for b in blocks])
+    oo = np.zeros(len(plains) + 1, np.int64)
+    for i, p in enumerate(plains):
+        oo[i + 1] = oo[i] + p.size
+    data = np.concatenate(list(blocks) + [np.zeros(8, np.uint8)])
+    return torch.from_numpy(data).cuda(), torch.from_numpy(bo).cuda(), torch.from_numpy(oo).cuda(), oo
+
+
+def test_committed_blocks_decode(sz, golden_huf0):
+    import torch
+    manifest, arrays = golden_huf0
+    blocks = [arrays["b%04d" % m["idx"]] for m in manifest]
+    plains = [arrays["p%04d" % m["idx"]] for m in manifest]
+    d, bo, oo, oo_h = pack(blocks, plains)
+    rets = torch.full((len(blocks),), -99, dtype=torch.int64, device="cuda")
+    out = sz.huf0_decompress(d, bo, oo, rets=rets).cpu().numpy()
+    r = rets.cpu().numpy()
+    for i, m in enumerate(manifest):
+        assert r[i] == plains[i].size, (m, r[i])
+        assert np.array_equal(out[oo_h[i]:oo_h[i + 1]], plains[i]), m
+    assert not out[oo_h[-1]:].any()
+
+
+def test_damaged_blocks_are_contained(sz, oracle, golden_huf0):
+    """a damaged block decodes like the oracle says or is rejected; its neighbours are untouched"""
+    import torch
+    manifest, arrays = golden_huf0
+    rng = np.random.default_rng(12)
+    coded = [m for m in manifest if m["kind"] in ("fse", "nibbles") and m["n"] <= 5000][:80]
+    blocks, plains, want = [], [], []
+    for k, m in enumerate(coded):
+        plain, blk = arrays["p%04d" % m["idx"]], arrays["b%04d" % m["idx"]].copy()
+        if k % 2:
+            if k % 4 == 1:
+                blk[rng.integers(0, min(blk.size, 60))] ^= 1 << rng.integers(0, 8)
+            else:
+                blk = blk[: rng.integers(2, blk.size)]
+        got, ret = oracle.huf0_decompress(blk, plain.size)
+        blocks.append(blk)
+        plains.append(plain)
+        want.append((got, ret))
+    d, bo, oo, oo_h = pack(blocks, plains)
+    rets = torch.full((len(blocks),), -99, dtype=torch.int64, device="cuda")
+    out = sz.huf0_decompress(d, bo, oo, rets=rets).cpu().numpy()
+    r = rets.cpu().numpy()
+    rejected = 0
+    for k in range(len(blocks)):
+        got, ret = want[k]
+        if ret < 0:
+            assert r[k] < 0, (k, r[k])
+            rejected += 1
+        elif r[k] != -4:                                   # E_UNSUPPORTED: damage produced a table log of 12
+            assert r[k] == plains[k].size and np.array_equal(out[oo_h[k]:oo_h[k + 1]], got), k
+    assert rejected > 10
+
+
+def test_huff0_then_sprintz(sz, oracle, golden_huf0):
+    """the chain the paper describes: Huff0 blocks of Sprintz streams -> streams -> samples"""
+    import torch
+    manifest, arrays = golden_huf0
+    ms = [m for m in manifest if m["name"] == "sprintz_xff_16_8"]
+    assert len(ms) >= 20
+    blocks = [arrays["b%04d" % m["idx"]] for m in ms]
+    streams = [arrays["p%04d" % m["idx"]] for m in ms]
+    d, bo, oo, oo_h = pack(blocks, streams)
+    comp = sz.huf0_decompress(d, bo, oo)
+    cd = sz.ChunkedCodec("xff", 2, 8, 5120, device="cuda:0")
+    out = torch.empty(len(ms) * 5120, dtype=torch.uint16, device="cuda")
+    cd.decompress_into(comp, oo, len(ms), out)
+    want = np.concatenate([oracle.decompress("xff", s, 2, 5120)[0] for s in streams])
+    assert np.array_equal(out.cpu().numpy().view(np.uint16), want.view(np.uint16))
+
+
+def test_many_chunks(sz, golden_huf0):
+    """a batch that spans many workgroups, odd count, empty chunks in between"""
+    import torch
+    manifest, arrays = golden_huf0
+    base = [(arrays["b%04d" % m["idx"]], arrays["p%04d" % m["idx"]]) for m in manifest if m["n"] <= 11000]
+    blocks, plains = [], []
+    for k in range(5003):
+        if k % 97 == 5:
+            blocks.append(np.zeros(0, np.uint8)); plains.append(np.zeros(0, np.uint8))
+        else:
+            b, p = base[(k * 7) % len(base)]
+            blocks.append(b); plains.append(p)
+    d, bo, oo, oo_h = pack(blocks, plains)
+    rets = torch.full((len(blocks),), -99, dtype=torch.int64, device="cuda")
+    out = sz.huf0_decompress(d, bo, oo, rets=rets)
+    want = torch.from_numpy(np.concatenate(plains)).cuda()
+    assert torch.equal(out[: want.numel()], want)
+    assert torch.equal(rets.cpu(), torch.tensor([p.size for p in plains], dtype=torch.int64))
