@@ -18,6 +18,10 @@
 
 namespace sprintz {
 
+#ifndef SPRINTZ_ENC_PAIR_MERGE
+#define SPRINTZ_ENC_PAIR_MERGE 1
+#endif
+
 // CM: column-major source (EncodeArgs::col_stride): a lane's 8 samples of a block are
 // contiguous in ITS column -- one 16-byte (8-byte at W == 8) load per lane, no LDS transpose.
 template <int W, bool FIRE, int DP, bool EXACT, bool CM = false>
@@ -265,16 +269,42 @@ __global__ void __launch_bounds__(kThreads) encode_fast_kernel(EncodeArgs a)
                 if (slot == 2) start_group();            // :430-450
                 continue;
             }
-            if (col_ok) {
-                const uint32_t f = nb == (uint32_t)W ? (uint32_t)(W - 1) : nb;   // :296
-                or_bits(hdr_pos * 8u + (uint32_t)(slot * D + lane_d) * HB, f, HB);
+            {   // header fields: HB bits per column, eight adjacent lanes = one 24/32-bit word, merged the same way
+                uint32_t f = col_ok ? (nb == (uint32_t)W ? (uint32_t)(W - 1) : nb) : 0u;   // :296
+                const uint32_t hbp = hdr_pos * 8u + (uint32_t)(slot * D + lane_d) * HB;
+                if (SPRINTZ_ENC_PAIR_MERGE && DP >= 8) {
+                    f |= dpp<DPP_ROW_SHL(1)>(0, f) << HB;
+                    f |= dpp<DPP_ROW_SHL(2)>(0, f) << (2 * HB);
+                    f |= dpp<DPP_ROW_SHL(4)>(0, f) << (4 * HB);
+                    if ((lane_d & 7) == 0) or_bits(hbp, f, 8 * HB);
+                } else if (col_ok) {
+                    or_bits(hbp, f, HB);
+                }
             }
             const uint32_t row_bits = ((total + 7u) >> 3) << 3;
             uint32_t bp = wl * 8u + excl;
+            // Adjacent columns are adjacent bit fields of the same row: eight lanes OR-ing into the
+            // same one or two dwords serialise in the LDS (SQ_LDS_ADDR_CONFLICT was half of its busy
+            // cycles).  So a lane pair merges its two fields (<= 32 bits) in registers and only the
+            // even lane issues the OR: half the same-address collisions for 2 VALU per row (cfg2 compress
+            // + compact 1.45 -> 1.65 TB/s; merging a whole quad into 64 bits costs more VALU than it
+            // saves: 1.50).
+            if (SPRINTZ_ENC_PAIR_MERGE) {
+                const uint32_t nb_pair = nb + dpp<DPP_ROW_SHL(1)>(0, nb);
+                const bool even = (lane_d & 1) == 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const uint32_t zn = dpp<DPP_ROW_SHL(1)>(0, z[i]);
+                    const uint32_t zz = z[i] | (nb < 32u ? zn << nb : 0u);
+                    if (even) or_bits(bp, zz, nb_pair);
+                    bp += row_bits;
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 or_bits(bp, z[i], nb);
                 bp += row_bits;
+            }
             }
             wl += row_bits;                              // 8 rows * row_bytes
             pos_in += blk;

@@ -11,6 +11,7 @@ namespace sprintz {
 // dpp_ctrl encodings (AMDGPU ISA)
 constexpr int DPP_QUAD_PERM(int a, int b, int c, int d) { return a | (b << 2) | (c << 4) | (d << 6); }
 constexpr int DPP_ROW_SHR(int n) { return 0x110 + n; }
+constexpr int DPP_ROW_SHL(int n) { return 0x100 + n; }
 constexpr int DPP_ROW_HALF_MIRROR = 0x141;
 constexpr int DPP_ROW_MIRROR = 0x140;
 
