@@ -1,6 +1,7 @@
-// decode_uni.h -- batched decoder for UNIVARIATE streams (ndims == 1: the low-dim layout of
-// sprintz_delta_lowdim.cpp:398-794 / sprintz_xff_lowdim.cpp:414-1119 with one column; the UCR
-// archive of the paper is univariate).  One lane per chunk.
+// decode_uni.h -- batched decoder for the LOW-DIM layout (sprintz_delta_lowdim.cpp:398-794 /
+// sprintz_xff_lowdim.cpp:414-1119) with ND = 1, 2 or 4 columns (8 bits) / 1 or 2 (16 bits): the
+// univariate streams of the paper's UCR archive and their few-column neighbours.  One lane per
+// chunk (it carries all ND columns' predictor state).
 //
 // The generic kernel already maps a chunk of one column to one lane, but it walks memory a field
 // at a time: with 64 K lanes each trailing its own stream and its own output, every dword read
@@ -18,20 +19,27 @@
 
 namespace sprintz {
 
-template <int W, bool FIRE>
+template <int W, bool FIRE, int ND = 1>
 __global__ void __launch_bounds__(256) decode_uni_kernel(DecodeArgs a)
 {
     constexpr int HB = Elem<W>::HB;
     constexpr int ESZ = W / 8;
     constexpr uint32_t MASK = Elem<W>::MASK;
-    constexpr int BW = 64 / (8 * ESZ);                     // blocks per 64-byte window: 8 (u8) or 4 (u16)
-    constexpr int BD = 2 * ESZ;                            // dwords per block
+    constexpr int BW = 64 / (8 * ESZ * ND);                // blocks per 64-byte window: 8 .. 2
+    constexpr int BD = 2 * ESZ * ND;                       // dwords per block
+    constexpr int HBYTES = (2 * ND * HB + 7) / 8;          // group header: 2 slots x ND fields of HB bits
+    constexpr uint32_t STEPMAX = HBYTES + 2 + ND * W;      // most bytes one step takes: header + run length / payload
+    // ring pieces of 64 bytes: a piece requested in one step is usable in the next, and a step that starts
+    // up to STEPMAX - 1 bytes into a piece must not need the piece after the next resident one
+    constexpr int RP = (2 * STEPMAX + 4 <= 64) ? 2 : 4;    // pieces in the ring (128 or 256 bytes per lane)
+    constexpr uint32_t RDW = RP * 16;                      // ring dwords
+    static_assert(BW * BD == 16 && BW >= 1, "a window is 64 bytes");
     typedef uint32_t v4 __attribute__((ext_vector_type(4)));
     typedef v4 __attribute__((aligned(1), may_alias)) v4a1;
     typedef uint32_t v2 __attribute__((ext_vector_type(2)));
     typedef v2 __attribute__((aligned(1), may_alias)) v2a1;
 
-    __shared__ uint32_t ring[32 * 256];                    // 128 bytes per lane
+    __shared__ uint32_t ring[RDW * 256];                   // 128 / 256 bytes per lane
     const int t = threadIdx.x;
     const uint64_t chunk = (uint64_t)blockIdx.x * 256 + t;
     const bool exists = chunk < a.nchunks;
@@ -56,7 +64,7 @@ __global__ void __launch_bounds__(256) decode_uni_kernel(DecodeArgs a)
         return pc;
     };
     auto park = [&](uint32_t k, const Piece& pc) {
-        uint32_t* q = my + ((k & 1u) << 12);
+        uint32_t* q = my + ((k & (uint32_t)(RP - 1)) << 12);
 #pragma unroll
         for (int m = 0; m < 4; m++) {
             q[(4 * m + 0) * 256] = pc.v[m].x;
@@ -65,24 +73,24 @@ __global__ void __launch_bounds__(256) decode_uni_kernel(DecodeArgs a)
             q[(4 * m + 3) * 256] = pc.v[m].w;
         }
     };
-    park(0, load_piece(0, exists));
-    park(1, load_piece(1, exists));
-    uint32_t fpiece = 2;
+#pragma unroll
+    for (int k = 0; k < RP; k++) park((uint32_t)k, load_piece((uint32_t)k, exists));
+    uint32_t fpiece = RP;
     Piece pend = {};
     bool have_pend = false;
     uint32_t c = (uint32_t)(off & 63);                     // byte cursor, from the start of piece0
     const uint32_t c_begin = c;
-    // Every step takes at most 1 header + 2 run-length + 16 payload bytes; a piece is 64: when the
-    // cursor leaves a slot the other one is full, and the refill lands within two steps.
+    // A step takes at most STEPMAX bytes and a piece is 64: when the cursor leaves a slot its
+    // successors are full, and the refill requested in the next step is usable in the one after.
     auto refill = [&]() {
         if (have_pend) {
             park(fpiece, pend);
             fpiece++;
         }
-        have_pend = exists && fpiece - (c >> 6) < 2u;
+        have_pend = exists && fpiece - (c >> 6) < (uint32_t)RP;
         pend = load_piece(fpiece, have_pend);
     };
-    auto rd_dw = [&](uint32_t dw) -> uint32_t { return my[(dw & 31u) << 8]; };
+    auto rd_dw = [&](uint32_t dw) -> uint32_t { return my[(dw & (RDW - 1u)) << 8]; };
     auto rd8 = [&](uint32_t at) -> uint32_t { return (rd_dw(at >> 2) >> ((at & 3u) * 8u)) & 0xffu; };
     auto rd32 = [&](uint32_t at) -> uint32_t { return __builtin_amdgcn_alignbyte(rd_dw((at >> 2) + 1u), rd_dw(at >> 2), at); };
 
@@ -94,13 +102,16 @@ __global__ void __launch_bounds__(256) decode_uni_kernel(DecodeArgs a)
         groups_left = w0;
         remaining = w1 & 0xffffu;
         c += 8;
-        corrupt = (w1 >> 16) != 1u || groups_left > a.chunk_len / 8u + 2u || stream_len < 8;
+        corrupt = (w1 >> 16) != (uint32_t)ND || groups_left > a.chunk_len / (8u * ND) + 2u || stream_len < 8;
         if (corrupt) { groups_left = 0; alive = false; }
     }
 
-    uint32_t pv = 0;
-    int pd = 0, ctr = 0;
-    uint32_t nb0 = 0, nb1 = 0, run_left = 0, out_elems = 0;
+    uint32_t pv[ND];
+    int pd[ND], ctr[ND];
+    uint32_t nb0[ND], nb1[ND];
+#pragma unroll
+    for (int k = 0; k < ND; k++) { pv[k] = 0; pd[k] = 0; ctr[k] = 0; nb0[k] = 0; nb1[k] = 0; }
+    uint32_t run_left = 0, out_elems = 0;
     int slot = 2;
     uint8_t* const obase = (uint8_t*)a.out + chunk * (uint64_t)a.chunk_len * ESZ;
     const bool odd1 = (t & 1) != 0, odd2 = (t & 2) != 0;
@@ -118,7 +129,9 @@ __global__ void __launch_bounds__(256) decode_uni_kernel(DecodeArgs a)
             refill();
             // ---- this lane's next block: inside a run, or the next slot of the stream
             bool have = false;
-            uint32_t nb = 0, cfield = 0;
+            uint32_t nb[ND], cfield = 0, nbsum = 0;
+#pragma unroll
+            for (int k = 0; k < ND; k++) nb[k] = 0;
             if (alive) {
                 if (run_left > 0) {
                     run_left--;
@@ -128,68 +141,73 @@ __global__ void __launch_bounds__(256) decode_uni_kernel(DecodeArgs a)
                         if (slot == 2) {
                             if (groups_left == 0) { alive = false; break; }
                             groups_left--;
-                            const uint32_t h = rd8(c);                          // 2 fields of HB bits (:713-735)
-                            c += 1;
-                            const uint32_t f0 = h & ((1u << HB) - 1u), f1 = (h >> HB) & ((1u << HB) - 1u);
-                            nb0 = f0 == (uint32_t)(W - 1) ? (uint32_t)W : f0;
-                            nb1 = f1 == (uint32_t)(W - 1) ? (uint32_t)W : f1;
+                            const uint32_t h = rd32(c);                         // 2 x ND fields of HB bits (:713-735)
+                            c += HBYTES;
+#pragma unroll
+                            for (int k = 0; k < ND; k++) {
+                                const uint32_t f0 = (h >> (k * HB)) & ((1u << HB) - 1u), f1 = (h >> ((ND + k) * HB)) & ((1u << HB) - 1u);
+                                nb0[k] = f0 == (uint32_t)(W - 1) ? (uint32_t)W : f0;
+                                nb1[k] = f1 == (uint32_t)(W - 1) ? (uint32_t)W : f1;
+                            }
                             slot = 0;
                         }
-                        const uint32_t nbs = slot ? nb1 : nb0;
+                        uint32_t sum = 0;
+#pragma unroll
+                        for (int k = 0; k < ND; k++) { nb[k] = slot ? nb1[k] : nb0[k]; sum += nb[k]; }
                         slot++;
-                        if (nbs == 0) {                                         // RUN slot: varint length in blocks
+                        if (sum == 0) {                                         // RUN slot: varint length in blocks
                             const uint32_t b0 = rd8(c);
                             uint32_t len = b0 & 0x7fu;
                             c += 1;
                             if (b0 & 0x80u) { len |= rd8(c) << 7; c += 1; }
                             if (len > 0) { run_left = len - 1; have = true; }
                         } else {
-                            nb = nbs;
+                            nbsum = sum;
                             cfield = c;
-                            c += nbs;                                           // 8 fields of nbs bits = nbs bytes
+                            c += sum;                                           // per column 8 fields of nb bits = nb bytes
                             have = true;
                         }
                     }
                     if (!have && alive) { corrupt = true; alive = false; }
                 }
-                if ((uint64_t)(c - c_begin) > stream_len + 2 || (have && out_elems + 8 > a.chunk_len)) {
+                if ((uint64_t)(c - c_begin) > stream_len + 2 || (have && out_elems + 8 * ND > a.chunk_len)) {
                     corrupt = true; alive = false; have = false;
                 }
             }
             if (__ballot(alive || have) == 0) { wave_done = true; }
             // ---- the block: zigzag^-1 + forecast recurrence down the column
             if (have) {
-                const int coef = FIRE ? fire_coef<W, true>(ctr) : 0;
-                int grad = 0;
-                uint32_t x[8];
+                uint32_t x[ND][8];
+                uint32_t cf = cfield;
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    uint32_t z = 0;
-                    if (nb != 0) {
-                        const uint32_t bit = (cfield & 3u) * 8u + (uint32_t)i * nb;
-                        const uint32_t dw = (cfield >> 2) + (bit >> 5);
-                        z = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(rd_dw(dw + 1u), rd_dw(dw), bit & 31u), 0, nb);
+                for (int k = 0; k < ND; k++) {
+                    const int coef = FIRE ? fire_coef<W, true>(ctr[k]) : 0;
+                    const uint32_t nbk = nbsum ? nb[k] : 0u;                 // inside a run every field is empty
+                    int grad = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        uint32_t z = 0;
+                        if (nbk != 0) {
+                            const uint32_t bit = (cf & 3u) * 8u + (uint32_t)i * nbk;
+                            const uint32_t dw = (cf >> 2) + (bit >> 5);
+                            z = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(rd_dw(dw + 1u), rd_dw(dw), bit & 31u), 0, nbk);
+                        }
+                        const int err = unzigzag(z);
+                        const int pred = FIRE ? fire_predict<W, true>(pd[k], coef) : 0;
+                        const int delta = sext<W>(err + pred);
+                        if (FIRE && (i & 1)) grad += sign_times(err, pd[k]);
+                        pv[k] = (pv[k] + (uint32_t)delta) & MASK;
+                        pd[k] = delta;
+                        x[k][i] = pv[k];
                     }
-                    const int err = unzigzag(z);
-                    const int pred = FIRE ? fire_predict<W, true>(pd, coef) : 0;
-                    const int delta = sext<W>(err + pred);
-                    if (FIRE && (i & 1)) grad += sign_times(err, pd);
-                    pv = (pv + (uint32_t)delta) & MASK;
-                    pd = delta;
-                    x[i] = pv;
+                    if (FIRE && nbsum != 0) ctr[k] = wrap_counter<W>(ctr[k] + (sext<W>(grad) >> 2));   // counters only move on real blocks
+                    cf += nbk;
                 }
-                if (FIRE && nb != 0) ctr = wrap_counter<W>(ctr + (sext<W>(grad) >> 2));   // counters only move on real blocks
-                if constexpr (W == 8) {
-                    win[b][0] = x[0] | (x[1] << 8) | (x[2] << 16) | (x[3] << 24);
-                    win[b][1] = x[4] | (x[5] << 8) | (x[6] << 16) | (x[7] << 24);
-                } else {
-                    win[b][0] = x[0] | (x[1] << 16);
-                    win[b][1] = x[2] | (x[3] << 16);
-                    win[b][2] = x[4] | (x[5] << 16);
-                    win[b][3] = x[6] | (x[7] << 16);
-                }
+                // row-major block: element e = row * ND + column at byte e * ESZ
+#pragma unroll
+                for (int e = 0; e < 8 * ND; e++) win[b][(e * ESZ) / 4] |= x[e % ND][e / ND] << (((e * ESZ) % 4) * 8);
                 valid |= 1u << b;
-                out_elems += 8;
+                out_elems += 8 * ND;
             }
         }
         // ---- the window leaves.  Full windows: the quad transposes its 16-byte pieces (two DPP
@@ -200,7 +218,7 @@ __global__ void __launch_bounds__(256) decode_uni_kernel(DecodeArgs a)
 #pragma unroll
         for (int k = 0; k < 4; k++)
 #pragma unroll
-            for (int d = 0; d < 4; d++) v[k][d] = W == 8 ? win[2 * k + (d >> 1)][d & 1] : win[k][d];
+            for (int d = 0; d < 4; d++) v[k][d] = win[(4 * k + d) / BD][(4 * k + d) % BD];
 #pragma unroll
         for (int k = 0; k < 4; k += 2)
 #pragma unroll
@@ -237,8 +255,11 @@ __global__ void __launch_bounds__(256) decode_uni_kernel(DecodeArgs a)
 #pragma unroll
             for (int b = 0; b < BW; b++) {
                 if ((valid >> b) & 1u) {                   // blocks are produced in order: the valid ones are a prefix
-                    if constexpr (W == 8) { v2 p = {win[b][0], win[b][1]}; *(v2a1*)(d + 8 * b) = p; }
-                    else { v4 p = {win[b][0], win[b][1], win[b][2], win[b][3]}; *(v4a1*)(d + 16 * b) = p; }
+                    if constexpr (BD == 2) { v2 p = {win[b][0], win[b][1]}; *(v2a1*)(d + 8 * b) = p; }
+                    else {
+#pragma unroll
+                        for (int j = 0; j < BD; j += 4) { v4 p = {win[b][j], win[b][j + 1], win[b][j + 2], win[b][j + 3]}; *(v4a1*)(d + 4 * BD * b + 4 * j) = p; }
+                    }
                 }
             }
         }

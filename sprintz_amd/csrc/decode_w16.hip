@@ -9,10 +9,19 @@ hipError_t launch_decode_fast_w16(bool fire, int dp, int cpl, bool exact, int q,
 {
     SPRINTZ_DISPATCH_DECODE_FAST(decode_fast_kernel, 16)
 }
-hipError_t launch_decode_uni_w16(bool fire, unsigned grid, hipStream_t st, const DecodeArgs& a)
+hipError_t launch_decode_uni_w16(bool fire, int nd, unsigned grid, hipStream_t st, const DecodeArgs& a)
 {
-    if (fire) hipLaunchKernelGGL((decode_uni_kernel<16, true>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((decode_uni_kernel<16, false>), dim3(grid), dim3(256), 0, st, a);
+    switch (nd) {
+        case 1:
+            if (fire) hipLaunchKernelGGL((decode_uni_kernel<16, true, 1>), dim3(grid), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((decode_uni_kernel<16, false, 1>), dim3(grid), dim3(256), 0, st, a);
+            break;
+        case 2:
+            if (fire) hipLaunchKernelGGL((decode_uni_kernel<16, true, 2>), dim3(grid), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((decode_uni_kernel<16, false, 2>), dim3(grid), dim3(256), 0, st, a);
+            break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 }  // namespace sprintz

@@ -131,6 +131,11 @@ CONFIGS = [
     ("uni8_xff_ragged", "xff", 1, 1, 1003),
     ("uni16_delta_ragged", "delta", 2, 1, 777),
     ("uni8_tiny", "delta", 1, 1, 100),          # chunks below 128 elements: verbatim
+    ("low8_d2", "delta", 1, 2, 2048),           # 2 and 4 columns per lane in decode_uni.h / encode_uni.h
+    ("low8_d2_xff_ragged", "xff", 1, 2, 1006),
+    ("low8_d4", "xff", 1, 4, 4000),
+    ("low8_d4_delta_ragged", "delta", 1, 4, 1500),
+    ("low16_d2_delta_ragged", "delta", 2, 2, 1002),
 ]
 
 
@@ -254,7 +259,7 @@ def test_full_size_cfg2_roundtrip_and_size_checksum(sz, oracle):
 
 
 @pytest.mark.parametrize("codec,esz,ndims,chunk_len,nchunks", [("xff", 2, 8, 5120, 64), ("xff", 1, 1, 1024, 300), ("delta", 2, 1, 2000, 300),
-                                                               ("xff", 1, 3, 3000, 64)])
+                                                               ("xff", 1, 3, 3000, 64), ("xff", 1, 4, 2000, 300), ("delta", 2, 2, 2000, 300)])
 def test_corrupt_streams_do_not_hang_or_overrun(sz, oracle, codec, esz, ndims, chunk_len, nchunks):
     """bit-flipped / truncated / header-damaged streams: the decoder must terminate, stay inside
     each chunk's output slot and either decode something or report SPRINTZ_E_CORRUPT"""
@@ -404,7 +409,7 @@ def test_huffman_decoder_survives_damaged_containers(sz):
     assert np.array_equal(r, sizes.astype(np.int64))
 
 
-@pytest.mark.parametrize("name,codec,esz,ndims,chunk_len", [c for c in CONFIGS if c[0] in ("cfg2", "cfg3_10k", "cfg5", "xff8", "cfg1", "uni16_xff", "uni16_delta_ragged")])
+@pytest.mark.parametrize("name,codec,esz,ndims,chunk_len", [c for c in CONFIGS if c[0] in ("cfg2", "cfg3_10k", "cfg5", "xff8", "cfg1", "uni16_xff", "uni16_delta_ragged", "low8_d2", "low8_d4", "lowdim16", "low16_d2_delta_ragged")])
 def test_generic_kernels_agree_with_the_fast_ones(sz, monkeypatch, name, codec, esz, ndims, chunk_len):
     """SPRINTZ_MI355X_NO_FAST routes the same calls to decode_kernel.h / encode_kernel.h: same bytes, same samples"""
     import torch
