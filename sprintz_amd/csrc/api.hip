@@ -385,11 +385,12 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
         return 0;
     }
     // univariate streams: one lane per chunk, quad-loaded 64-byte input windows, 64-byte output units (encode_uni.h)
-    if (lowdim && D == 1 && !col_stride && !getenv("SPRINTZ_MI355X_NO_FAST")) {
+    // (and the 2- and 4-column low-dim shapes)
+    if (lowdim && (D == 1 || D == 2 || (D == 4 && esz == 1)) && !col_stride && !getenv("SPRINTZ_MI355X_NO_FAST")) {
         const uint64_t ugrid = (nchunks + 255) / 256;
         if (ugrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
-        e = esz == 1 ? launch_encode_uni_w8(codec == SPRINTZ_CODEC_XFF, (unsigned)ugrid, st, a)
-                     : launch_encode_uni_w16(codec == SPRINTZ_CODEC_XFF, (unsigned)ugrid, st, a);
+        e = esz == 1 ? launch_encode_uni_w8(codec == SPRINTZ_CODEC_XFF, D, (unsigned)ugrid, st, a)
+                     : launch_encode_uni_w16(codec == SPRINTZ_CODEC_XFF, D, (unsigned)ugrid, st, a);
         if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "encode_uni kernel launch", e);
         return 0;
     }

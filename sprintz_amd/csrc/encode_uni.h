@@ -1,5 +1,5 @@
-// encode_uni.h -- batched encoder for UNIVARIATE streams (ndims == 1: the low-dim layout of
-// sprintz_delta_lowdim.cpp:39-384 / sprintz_xff_lowdim.cpp:44-400 with one column).  One lane
+// encode_uni.h -- batched encoder for the LOW-DIM layout (sprintz_delta_lowdim.cpp:39-384 /
+// sprintz_xff_lowdim.cpp:44-400) with ND = 1, 2 or 4 columns (8 bits) / 1 or 2 (16 bits).  One lane
 // per chunk; same stream bytes as encode_kernel.h, which it follows step for step (the RLE state
 // machine of SURVEY.md A.5 included).
 //
@@ -19,22 +19,27 @@
 
 namespace sprintz {
 
-template <int W, bool FIRE>
+template <int W, bool FIRE, int ND = 1>
 __global__ void __launch_bounds__(256) encode_uni_kernel(EncodeArgs a)
 {
     constexpr int HB = Elem<W>::HB;
     constexpr int ESZ = W / 8;
-    constexpr int BW = 64 / (8 * ESZ);                     // blocks per 64-byte input window: 8 (u8) or 4 (u16)
+    constexpr int BW = 64 / (8 * ESZ * ND);                // blocks per 64-byte input window: 8 .. 2
+    constexpr int HBYTES = (2 * ND * HB + 7) / 8;          // group header: 2 slots x ND fields of HB bits
+    constexpr uint32_t GROUPMAX = HBYTES + 2 * ND * W + 4; // most bytes between two flushes: header, two blocks, close-out
+    constexpr uint32_t RDW = (63 + GROUPMAX <= 128) ? 32 : 64;   // ring dwords per lane (128 or 256 bytes)
+    constexpr uint32_t RM = RDW - 1;
+    static_assert(BW >= 1 && BW * 8 * ESZ * ND == 64, "a window is 64 bytes");
     typedef uint32_t v4 __attribute__((ext_vector_type(4)));
     typedef v4 __attribute__((aligned(1), may_alias)) v4a1;
 
-    __shared__ uint32_t oring[32 * 256];                   // 128 bytes of output per lane
+    __shared__ uint32_t oring[RDW * 256];                  // 128 / 256 bytes of output per lane
     const int t = threadIdx.x;
     const uint64_t chunk = (uint64_t)blockIdx.x * 256 + t;
     const bool exists = chunk < a.nchunks;
     uint32_t* const my = oring + t;
 #pragma unroll
-    for (int d = 0; d < 32; d++) my[d * 256] = 0;
+    for (int d = 0; d < (int)RDW; d++) my[d * 256] = 0;
 
     const uint64_t first = chunk * (uint64_t)a.chunk_len;
     const uint32_t n = exists ? (uint32_t)((a.total_len - first < a.chunk_len) ? (a.total_len - first) : a.chunk_len) : 0u;
@@ -42,19 +47,19 @@ __global__ void __launch_bounds__(256) encode_uni_kernel(EncodeArgs a)
     uint8_t* const gdst = a.slots + chunk * a.slot_stride;
     const uint32_t nbytes = n * ESZ;
 
-    // ---- output ring: stream bytes [flushed, flushed + 128), flushed a multiple of 64
+    // ---- output ring: stream bytes [flushed, flushed + 4 * RDW), flushed a multiple of 64
     uint32_t wpos = a.write_size ? 8u : 0u;
     uint32_t flushed = 0;
     auto or_bits = [&](uint32_t bp, uint32_t v, uint32_t nb) {           // low nb (<= 16) bits of v at stream bit bp
         const uint32_t sh = bp & 31u;
-        uint32_t* q = my + (((bp >> 5) & 31u) << 8);
+        uint32_t* q = my + (((bp >> 5) & RM) << 8);
         q[0] |= v << sh;
-        if (sh + nb > 32u) my[(((bp >> 5) + 1u) & 31u) << 8] |= v >> (32u - sh);
+        if (sh + nb > 32u) my[(((bp >> 5) + 1u) & RM) << 8] |= v >> (32u - sh);
     };
-    auto put_byte = [&](uint32_t pos, uint32_t v) { my[((pos >> 2) & 31u) << 8] |= v << ((pos & 3u) * 8u); };
+    auto put_byte = [&](uint32_t pos, uint32_t v) { my[((pos >> 2) & RM) << 8] |= v << ((pos & 3u) * 8u); };
     auto flush_to = [&](uint32_t upto) {                                 // whole 64-byte units below upto -> HBM, re-zeroed
         while (flushed < upto) {
-            const uint32_t d0 = (flushed >> 2) & 31u;                    // 0 or 16
+            const uint32_t d0 = (flushed >> 2) & RM;                     // a multiple of 16
             v4 p[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -73,20 +78,27 @@ __global__ void __launch_bounds__(256) encode_uni_kernel(EncodeArgs a)
         wpos += run > 0x7fu ? 2u : 1u;
     };
 
-    const int64_t limit = (int64_t)n - 16;                               // last_full_group_start
+    constexpr uint32_t BLK = 8 * ND;                                     // elements per block
+    const int64_t limit = (int64_t)n - 2 * (int64_t)BLK;                 // last_full_group_start
     int64_t pos_in = 0;
     uint32_t ngroups = 0, run = 0, hdr_pos = 0;
     int slot = 0;
-    uint32_t pv = 0;
-    int pd = 0, ctr = 0;
-    uint32_t hdr = 0;                                                    // this group's header byte, written when it closes
+    uint32_t pv[ND];
+    int pd[ND], ctr[ND];
+#pragma unroll
+    for (int k = 0; k < ND; k++) { pv[k] = 0; pd[k] = 0; ctr[k] = 0; }
+    uint32_t hdr = 0;                                                    // this group's header (<= 24 bits), written when it closes
+    auto put_hdr = [&]() {
+#pragma unroll
+        for (int k = 0; k < HBYTES; k++) put_byte(hdr_pos + k, (hdr >> (8 * k)) & 0xffu);
+    };
     auto start_group = [&]() {
-        if (ngroups) put_byte(hdr_pos, hdr);
+        if (ngroups) put_hdr();
         hdr = 0;
         ngroups++;
         flush_to(wpos & ~63u);
         hdr_pos = wpos;
-        wpos += 1;                                                       // 2 fields of HB bits: one byte
+        wpos += HBYTES;                                                  // 2 x ND fields of HB bits
         slot = 0;
     };
     bool active = exists && n >= 128u;
@@ -146,36 +158,37 @@ __global__ void __launch_bounds__(256) encode_uni_kernel(EncodeArgs a)
 #pragma unroll
         for (int b = 0; b < BW; b++) {
             if (!active) continue;
-            // ---- the block at pos_in (== (wi * BW + b) * 8): forecast + zigzag + OR-mask (sprintz_xff_lowdim.cpp:160-215)
-            uint32_t x[8];
+            // ---- the block at pos_in (== (wi * BW + b) * 8 * ND): forecast + zigzag + OR-mask (sprintz_xff_lowdim.cpp:160-215)
+            uint32_t z[ND][8], nb[ND], total = 0;
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                if constexpr (W == 8) x[i] = (v[(b * 8 + i) / 16][((b * 8 + i) % 16) / 4] >> (8 * (i & 3))) & 0xffu;
-                else x[i] = (v[(b * 16 + 2 * i) / 16][((b * 16 + 2 * i) % 16) / 4] >> (16 * (i & 1))) & 0xffffu;
-            }
-            uint32_t z[8], mask = 0;
-            const int coef = FIRE ? fire_coef<W, true>(ctr) : 0;
-            int grad = 0;
+            for (int k = 0; k < ND; k++) {
+                uint32_t mask = 0;
+                const int coef = FIRE ? fire_coef<W, true>(ctr[k]) : 0;
+                int grad = 0;
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int delta = sext<W>((int)(x[i] - pv));
-                const int pred = FIRE ? fire_predict<W, true>(pd, coef) : 0;
-                const int err = sext<W>(delta - pred);
-                const uint32_t zz = zigzag<W>(err);
-                if (FIRE && (i & 1)) grad += sign_times(err, pd);
-                mask |= zz;
-                z[i] = zz;
-                pv = x[i];
-                pd = delta;
+                for (int i = 0; i < 8; i++) {
+                    const int byte = (b * 8 * ND + i * ND + k) * ESZ;        // row-major element (row i, column k) inside the window
+                    const uint32_t x = (v[byte / 16][(byte % 16) / 4] >> (8 * (byte % 4))) & Elem<W>::MASK;
+                    const int delta = sext<W>((int)(x - pv[k]));
+                    const int pred = FIRE ? fire_predict<W, true>(pd[k], coef) : 0;
+                    const int err = sext<W>(delta - pred);
+                    const uint32_t zz = zigzag<W>(err);
+                    if (FIRE && (i & 1)) grad += sign_times(err, pd[k]);
+                    mask |= zz;
+                    z[k][i] = zz;
+                    pv[k] = x;
+                    pd[k] = delta;
+                }
+                if (FIRE) ctr[k] = wrap_counter<W>(ctr[k] + (sext<W>(grad) >> 2));
+                nb[k] = nbits_of<W, true>(mask);
+                total += nb[k];
             }
-            if (FIRE) ctr = wrap_counter<W>(ctr + (sext<W>(grad) >> 2));
-            const uint32_t nb = nbits_of<W, true>(mask);
 
             // ---- RLE state machine ("<" tail test: sprintz_delta_lowdim.cpp:190, sprintz_xff_lowdim.cpp:234)
             for (;;) {
-                if (nb == 0 && run < 0x7fffu) {
+                if (total == 0 && run < 0x7fffu) {
                     run++;
-                    pos_in += 8;
+                    pos_in += BLK;
                     if (pos_in < limit) break;                           // analyse the next block
                     slot++;                                              // not enough input left: close the run
                     put_run(run);
@@ -191,16 +204,20 @@ __global__ void __launch_bounds__(256) encode_uni_kernel(EncodeArgs a)
                     if (slot == 2) start_group();
                     continue;                                            // re-evaluate this block
                 }
-                const uint32_t f = nb == (uint32_t)W ? (uint32_t)(W - 1) : nb;
-                hdr |= f << ((uint32_t)slot * HB);
-                {   // 8 fields of nb bits = nb bytes, assembled in registers, OR-ed in dword by dword
+#pragma unroll
+                for (int k = 0; k < ND; k++) {
+                    const uint32_t nbk = nb[k];
+                    const uint32_t f = nbk == (uint32_t)W ? (uint32_t)(W - 1) : nbk;
+                    hdr |= f << ((uint32_t)(slot * ND + k) * HB);
+                    if (nbk == 0) continue;
+                    // 8 fields of nbk bits = nbk bytes, assembled in registers, OR-ed in dword by dword
                     uint64_t lo = 0, hi = 0;
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        lo |= (uint64_t)z[i] << (i * nb);
-                        hi |= (uint64_t)z[4 + i] << (i * nb);
+                        lo |= (uint64_t)z[k][i] << (i * nbk);
+                        hi |= (uint64_t)z[k][4 + i] << (i * nbk);
                     }
-                    const uint32_t half = 4u * nb;                       // 4 .. 64 bits
+                    const uint32_t half = 4u * nbk;                      // 4 .. 64 bits
                     uint32_t acc[5];
                     if constexpr (W == 8) {                              // half <= 32
                         lo |= hi << half;
@@ -210,19 +227,19 @@ __global__ void __launch_bounds__(256) encode_uni_kernel(EncodeArgs a)
                         if (half != 64u) lo |= hi << half;
                         acc[0] = (uint32_t)lo; acc[1] = (uint32_t)(lo >> 32); acc[2] = (uint32_t)top; acc[3] = (uint32_t)(top >> 32); acc[4] = 0;
                     }
-                    const uint32_t sh = (wpos & 3u) * 8u, d0 = wpos >> 2, span = (wpos & 3u) + nb;   // bytes from dword d0 on
-                    constexpr int ND = W == 8 ? 3 : 5;
+                    const uint32_t sh = (wpos & 3u) * 8u, d0 = wpos >> 2, span = (wpos & 3u) + nbk;   // bytes from dword d0 on
+                    constexpr int NDW = W == 8 ? 3 : 5;
                     uint32_t prev = 0;
 #pragma unroll
-                    for (int k = 0; k < ND; k++) {
-                        const uint32_t cur = k < (W == 8 ? 2 : 4) ? acc[k] : 0u;
+                    for (int q = 0; q < NDW; q++) {
+                        const uint32_t cur = q < (W == 8 ? 2 : 4) ? acc[q] : 0u;
                         const uint32_t dw = (uint32_t)(((((uint64_t)cur << 32) | prev) << sh) >> 32);
-                        if ((uint32_t)(4 * k) < span) my[((d0 + k) & 31u) << 8] |= dw;
+                        if ((uint32_t)(4 * q) < span) my[((d0 + q) & RM) << 8] |= dw;
                         prev = cur;
                     }
+                    wpos += nbk;
                 }
-                wpos += nb;
-                pos_in += 8;
+                pos_in += BLK;
                 slot++;
                 if (slot == 2) {
                     if (pos_in <= limit) start_group();
@@ -234,7 +251,7 @@ __global__ void __launch_bounds__(256) encode_uni_kernel(EncodeArgs a)
     }
 
     if (!exists) return;
-    if (ngroups) put_byte(hdr_pos, hdr);
+    if (ngroups) put_hdr();
     // ---- verbatim tail (sprintz_xff_lowdim.cpp:398) through the ring, 16 source bytes at a time
     const uint32_t remaining = (uint32_t)((int64_t)n - pos_in);
     {
@@ -254,12 +271,12 @@ __global__ void __launch_bounds__(256) encode_uni_kernel(EncodeArgs a)
     }
     flush_to(wpos & ~63u);
     for (uint32_t p = flushed; p < wpos; p += 16) {                      // the last units, rounded up to 16 bytes (slot slack)
-        const uint32_t d0 = (p >> 2) & 31u;
+        const uint32_t d0 = (p >> 2) & RM;
         *(v4a1*)(gdst + p) = v4{my[d0 << 8], my[(d0 + 1) << 8], my[(d0 + 2) << 8], my[(d0 + 3) << 8]};
     }
     if (a.write_size) {                                                  // format.h:36-45
         ((uint32_t*)gdst)[0] = ngroups;
-        ((uint32_t*)gdst)[1] = (remaining & 0xffffu) | (1u << 16);
+        ((uint32_t*)gdst)[1] = (remaining & 0xffffu) | ((uint32_t)ND << 16);
     }
     a.sizes[chunk] = wpos;
     if (a.rets) a.rets[chunk] = (int64_t)(wpos / ESZ);

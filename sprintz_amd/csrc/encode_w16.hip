@@ -9,10 +9,19 @@ hipError_t launch_encode_fast_w16(bool fire, int dp, bool exact, unsigned grid, 
 {
     SPRINTZ_DISPATCH_FAST(encode_fast_kernel, 16)
 }
-hipError_t launch_encode_uni_w16(bool fire, unsigned grid, hipStream_t st, const EncodeArgs& a)
+hipError_t launch_encode_uni_w16(bool fire, int nd, unsigned grid, hipStream_t st, const EncodeArgs& a)
 {
-    if (fire) hipLaunchKernelGGL((encode_uni_kernel<16, true>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((encode_uni_kernel<16, false>), dim3(grid), dim3(256), 0, st, a);
+    switch (nd) {
+        case 1:
+            if (fire) hipLaunchKernelGGL((encode_uni_kernel<16, true, 1>), dim3(grid), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((encode_uni_kernel<16, false, 1>), dim3(grid), dim3(256), 0, st, a);
+            break;
+        case 2:
+            if (fire) hipLaunchKernelGGL((encode_uni_kernel<16, true, 2>), dim3(grid), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((encode_uni_kernel<16, false, 2>), dim3(grid), dim3(256), 0, st, a);
+            break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 }  // namespace sprintz

@@ -9,10 +9,23 @@ hipError_t launch_encode_fast_w8(bool fire, int dp, bool exact, unsigned grid, s
 {
     SPRINTZ_DISPATCH_FAST(encode_fast_kernel, 8)
 }
-hipError_t launch_encode_uni_w8(bool fire, unsigned grid, hipStream_t st, const EncodeArgs& a)
+hipError_t launch_encode_uni_w8(bool fire, int nd, unsigned grid, hipStream_t st, const EncodeArgs& a)
 {
-    if (fire) hipLaunchKernelGGL((encode_uni_kernel<8, true>), dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((encode_uni_kernel<8, false>), dim3(grid), dim3(256), 0, st, a);
+    switch (nd) {
+        case 1:
+            if (fire) hipLaunchKernelGGL((encode_uni_kernel<8, true, 1>), dim3(grid), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((encode_uni_kernel<8, false, 1>), dim3(grid), dim3(256), 0, st, a);
+            break;
+        case 2:
+            if (fire) hipLaunchKernelGGL((encode_uni_kernel<8, true, 2>), dim3(grid), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((encode_uni_kernel<8, false, 2>), dim3(grid), dim3(256), 0, st, a);
+            break;
+        case 4:
+            if (fire) hipLaunchKernelGGL((encode_uni_kernel<8, true, 4>), dim3(grid), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((encode_uni_kernel<8, false, 4>), dim3(grid), dim3(256), 0, st, a);
+            break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 }  // namespace sprintz

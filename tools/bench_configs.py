@@ -65,6 +65,9 @@ def main():
         ("      u16 D=16 xff 10KB", "xff", 2, 16, 5120, "walk8"),
         ("      u16 D=64 xff 16KB", "xff", 2, 64, 8192, "walk8"),
         ("      u16 D=2  xff 8KB (low-dim)", "xff", 2, 2, 4096, "walk8"),
+        ("      u8  D=4  xff 4KB (low-dim)", "xff", 1, 4, 4096, "walk2"),
+        ("      u8  D=2  delta 2KB (low-dim)", "delta", 1, 2, 2048, "walk2"),
+        ("      u8  D=3  xff 3KB (low-dim, generic kernels)", "xff", 1, 3, 3072, "walk2"),
     ]
     print("| config | ratio | compress GB/s | decompress GB/s | decode ms |")
     print("|---|---|---|---|---|")
