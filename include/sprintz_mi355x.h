@@ -267,9 +267,8 @@ int64_t sprintz_mi355x_decompress_norle(int codec, int elem_bytes, const void* s
  *   d_blocks + d_block_offsets[c] .. [c+1] : chunk c's block
  *   d_out + d_out_offsets[c] .. [c+1]      : where its bytes go (the sizes are
  *                                            the caller's, as with HUF_decompress)
- *   d_rets[c] (optional): decoded bytes, SPRINTZ_E_CORRUPT for a damaged block
- *   (nothing is read or written outside the chunk's two ranges), or
- *   SPRINTZ_E_UNSUPPORTED for a table log of 12 (HUF_compress caps it at 11).
+ *   d_rets[c] (optional): decoded bytes, or SPRINTZ_E_CORRUPT for a damaged block
+ *   (nothing is read or written outside the chunk's two ranges).
  * d_blocks must be readable 8 bytes past its end.  Format restated in
  * oracle/huf0_oracle.c; kernel in sprintz_amd/csrc/huf0.hip.
  * ---------------------------------------------------------------------- */

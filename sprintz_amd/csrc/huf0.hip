@@ -5,15 +5,22 @@
 // container.  The format is restated, with the library citations, in oracle/huf0_oracle.c;
 // parity is pinned against the system libzstd's HUF_compress / HUF_decompress by the tests.
 //
-// A Huff0 block is 4-way parallel by construction and its code table is private to the block:
-// a wave takes 16 chunks, lane = (chunk, stream).  Per chunk in LDS: the 2^tableLog-entry
-// decoding table (tableLog <= 11, HUF_compress's default cap) whose 4 KB first serve as scratch
-// for the FSE-compressed weights.  Phase A (first lane of each quad, serial): tree description
-// -> weights.  Phase B (the quad): weights -> table, entries interleaved over its 4 lanes.
-// Phase C (every lane): its stream, read from the last byte down through a 64-bit window,
-// 4 symbols per refill, the next refill's 16 bytes requested a step ahead.  This is the interoperability path, not the fast one: the tables cap
-// the occupancy at two waves per CU.  Measured on the headline shape (131 072 blocks of ~3.4 KB):
-// 4.6 ms, of which phase A 1.9 (a quarter of the lanes, serial FSE), B 0.6, C 2.1.
+// A Huff0 block is 4-way parallel by construction and its code is private to the block: a wave
+// takes 16 chunks, lane = (chunk, stream).  The library's decoder looks codes up in a
+// 2^tableLog-entry table; 16 such tables are 64 KB of LDS and leave a CU two waves (measured:
+// 4.6 ms on the headline shape, every phase latency-bound).  The code is canonical -- per code
+// length ascending symbols, the longest codes lowest (HUF_readDTableX1's fill order) -- so the
+// table is not needed: with start[w] = the first table index of weight w, a look-ahead value
+// idx has weight w = 1 + #{k >= 2 : start[k] <= idx} (11 compare-and-adds on per-lane
+// registers), its symbol is sorted[symoff[w] + ((idx - start[w]) >> (w - 1))] and it is
+// tableLog + 1 - w bits long.  Per chunk that is 256 bytes of sorted symbols and 13 words in
+// LDS instead of 4 KB, a dozen waves per CU instead of two, and every table log the format
+// allows (12 included).  Headline shape (131 072 blocks of ~3.4 KB): 1.6 ms, of which phases
+// A + B 0.5 and C 1.1 (its ~185 VALU per 4 symbols bound it at ~0.6).
+// Phase A (first lane of each quad, serial): tree description -> weights; the FSE-compressed form
+// is decoded with a 64-entry table in LDS.  Phase B (same lane): counting sort of the symbols by
+// weight.  Phase C (every lane): its stream, read from the last byte down through a 64-bit
+// window, 4 symbols per refill, the next refill's 16 bytes requested a step ahead.
 #include "../../include/sprintz_mi355x.h"
 
 #include <hip/hip_runtime.h>
@@ -22,11 +29,9 @@
 
 namespace {
 
-constexpr int kTL = 11;                          // largest table log decoded (HUF_TABLELOG_DEFAULT); the format allows 12
-constexpr int kDtStride = (1 << kTL) + 8;        // u16 entries per chunk, padded off the bank stride
-constexpr int kWStride = 256 + 4;
+constexpr int kWStride = 256 + 4;                // weights per chunk, padded off the bank stride
+constexpr int kRStride = 480 + 4;                // per chunk: header copy 144 | norm 32 | next 32 | fse 256; later the sorted symbols
 constexpr int64_t kCorrupt = SPRINTZ_E_CORRUPT;
-constexpr int64_t kUnsupported = SPRINTZ_E_UNSUPPORTED;
 
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 typedef v2u __attribute__((aligned(1), may_alias)) v2u_a1;
@@ -51,7 +56,8 @@ __device__ __forceinline__ uint32_t back_look(const uint8_t* h, int P, int nb)
 }
 
 // HUF_readStats (entropy_common.c) over the header bytes h[0..n) (zero padded); weights[0..nsym).
-// Scratch s: int16 norm[256] | u16 next[256] | u32 fse[64].  Returns header bytes, 0 if damaged.
+// Scratch s: int16 norm[16] | u16 next[16] | u32 fse[64]: weights are < 12, so a description that
+// gives probability to a symbol >= 16 is damaged.  Returns header bytes, 0 if damaged.
 __device__ uint32_t read_stats(const uint8_t* h, uint32_t n, uint8_t* weights, uint8_t* s, uint32_t& nsym, uint32_t& tl_out)
 {
     if (n < 1) return 0;
@@ -68,9 +74,9 @@ __device__ uint32_t read_stats(const uint8_t* h, uint32_t n, uint8_t* weights, u
         if (isize + 1 > n) return 0;
         const uint8_t* const f = h + 1;
         int16_t* const norm = (int16_t*)s;
-        uint16_t* const next = (uint16_t*)(s + 512);
-        uint32_t* const fse = (uint32_t*)(s + 1024);              // symbol | nbits << 8 | new_state << 16
-        for (int k = 0; k < 256; k++) norm[k] = 0;
+        uint16_t* const next = (uint16_t*)(s + 32);
+        uint32_t* const fse = (uint32_t*)(s + 64);                // symbol | nbits << 8 | new_state << 16
+        for (int k = 0; k < 16; k++) norm[k] = 0;
         // FSE_readNCount
         uint32_t bp = 0;
         int nb = (int)(fwd32(f, bp) & 0xf) + 5;
@@ -106,12 +112,13 @@ __device__ uint32_t read_stats(const uint8_t* h, uint32_t n, uint8_t* weights, u
             count--;
             remaining -= count < 0 ? -count : count;
             if (charnum > 255u || bp > bit_end) return 0;
-            norm[charnum++] = (int16_t)count;
+            if (charnum >= 16u) { if (count != 0) return 0; charnum++; }
+            else norm[charnum++] = (int16_t)count;
             previous0 = count == 0;
             while (remaining < threshold) { nb--; threshold >>= 1; }
         }
         if (remaining != 1 || bp > bit_end || charnum == 0) return 0;
-        const uint32_t max_sv = charnum - 1, hl = (bp + 7) >> 3;
+        const uint32_t max_sv = (charnum < 16u ? charnum : 16u) - 1, hl = (bp + 7) >> 3;
         if (hl >= isize) return 0;
         // FSE_buildDTable
         const uint32_t size = 1u << tl;
@@ -184,14 +191,21 @@ __device__ uint32_t read_stats(const uint8_t* h, uint32_t n, uint8_t* weights, u
 }
 
 __device__ __forceinline__ int quad_bcast0(int v) { return __builtin_amdgcn_mov_dpp(v, 0x00, 0xf, 0xf, true); }
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 __global__ void __launch_bounds__(64) huf0_decode_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restrict__ boffs,
                                                          uint64_t nchunks, uint8_t* __restrict__ out,
                                                          const uint64_t* __restrict__ ooffs, int64_t* __restrict__ rets)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t s_dt[16 * kDtStride];
     __shared__ __attribute__((aligned(16))) uint8_t s_w[16 * kWStride];
-    __shared__ uint16_t s_start[16][16];
+    __shared__ __attribute__((aligned(16))) uint8_t s_r[16 * kRStride];
+    __shared__ uint32_t s_tab[16][17];                            // [w]: start[w] | symoff[w] << 16; [16]: running offsets are in s_run
+    __shared__ uint16_t s_run[16][16];
     const int t = threadIdx.x, q = t >> 2, j = t & 3;
     const uint64_t chunk = (uint64_t)blockIdx.x * 16 + (uint64_t)q;
     const bool exists = chunk < nchunks;
@@ -200,8 +214,9 @@ __global__ void __launch_bounds__(64) huf0_decode_kernel(const uint8_t* __restri
     const uint8_t* const src = blocks + b0;
     uint8_t* const dst = out + o0;
     const uint64_t csize = b1 - b0, dsize = o1 - o0;
-    uint16_t* const dt = s_dt + q * kDtStride;
     uint8_t* const wts = s_w + q * kWStride;
+    uint8_t* const scratch = s_r + q * kRStride;
+    uint8_t* const sorted = scratch;                              // phase B on: the symbols by (weight, symbol)
 
     // ---- HUF_decompress's conventions (huf_decompress.c): stored, one repeated byte, or a coded block
     int mode = 0;                                                 // 0 nothing / damaged, 1 stored, 2 repeated byte, 3 coded
@@ -216,57 +231,55 @@ __global__ void __launch_bounds__(64) huf0_decode_kernel(const uint8_t* __restri
     if (mode == 1) for (uint64_t k = (uint64_t)j; k < dsize; k += 4) dst[k] = src[k];
     if (mode == 2) { const uint8_t v = src[0]; for (uint64_t k = (uint64_t)j; k < dsize; k += 4) dst[k] = v; }
 
-    // ---- phase A: tree description -> weights (first lane of the quad); the table's bytes are the scratch
-    uint8_t* const scratch = (uint8_t*)dt;
+    // ---- phase A: tree description -> weights (first lane of the quad)
     const uint32_t hcopy = mode == 3 ? (uint32_t)(csize < 129 ? csize : 129) : 0u;
     for (uint32_t k = (uint32_t)j; k < 144u; k += 4) scratch[k] = k < hcopy ? src[k] : (uint8_t)0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    wave_sync();
     uint32_t hl = 0, nsym = 0, tl = 0;
     if (mode == 3 && j == 0) {
-        hl = read_stats(scratch, hcopy, wts, scratch + 160, nsym, tl);
+        hl = read_stats(scratch, hcopy, wts, scratch + 144, nsym, tl);
         if (hl == 0 || hl >= csize) { hl = 0; ret = kCorrupt; }
-        else if (tl > (uint32_t)kTL) { hl = 0; ret = kUnsupported; }
-        if (hl) {                                                 // HUF_readDTableX1: per weight ascending symbols, weight 1 lowest
+        if (hl) {
+            // ---- phase B: start[w] (first table index of weight w), symoff[w], and the symbols sorted by (weight, symbol)
             uint32_t cnt[13];
 #pragma unroll
             for (int w = 0; w < 13; w++) cnt[w] = 0;
-            for (uint32_t s = 0; s < nsym; s++) {
-                const uint32_t w = wts[s];
+            for (uint32_t sy = 0; sy < nsym; sy++) {
+                const uint32_t w = wts[sy];
 #pragma unroll
                 for (int ww = 1; ww < 13; ww++) cnt[ww] += (uint32_t)(w == (uint32_t)ww);
             }
-            uint32_t at = 0;
+            uint32_t at = 0, so = 0;
 #pragma unroll
-            for (int w = 1; w < 13; w++) { s_start[q][w] = (uint16_t)at; at += cnt[w] << (w - 1); }
+            for (int w = 1; w < 13; w++) {
+                s_tab[q][w] = at | (so << 16);
+                s_run[q][w] = (uint16_t)so;
+                at += cnt[w] << (w - 1);
+                so += cnt[w];
+            }
+            for (uint32_t sy = 0; sy < nsym; sy++) {
+                const uint32_t w = wts[sy];
+                if (w) { const uint32_t pos = s_run[q][w]; s_run[q][w] = (uint16_t)(pos + 1); sorted[pos] = (uint8_t)sy; }
+            }
         }
     }
     hl = (uint32_t)quad_bcast0((int)hl);
-    nsym = (uint32_t)quad_bcast0((int)nsym);
     tl = (uint32_t)quad_bcast0((int)tl);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    wave_sync();
     const bool coded = mode == 3 && hl != 0;
 
-    // ---- phase B: the decoding table, entries interleaved over the quad
-    if (coded) {
-        for (uint32_t s = 0; s < nsym; s++) {
-            const uint32_t w = wts[s];
-            if (w == 0) continue;                                 // quad-uniform
-            const uint32_t len = (1u << w) >> 1, st = s_start[q][w];
-            const uint16_t e = (uint16_t)(s | ((tl + 1u - w) << 8));
-            for (uint32_t u = st + (uint32_t)j; u < st + len; u += 4) dt[u] = e;
-            if (j == 0) s_start[q][w] = (uint16_t)(st + len);
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    // ---- phase C: lane j decodes stream j (HUF_decompress4X1_usingDTable_internal)
+    // ---- phase C: lane j decodes stream j (HUF_decompress4X1_usingDTable_internal).  Set-up per lane, then ONE
+    // wave-uniform loop: the quad exchanges of the output path need every lane, streamless ones included.
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    typedef v4u __attribute__((aligned(1), may_alias)) v4u_a1;
     bool bad = false;
+    uint32_t T[13];                                               // T[k] = start[k]: thresholds of the weight search (k > tableLog: never reached)
+#pragma unroll
+    for (int k = 2; k < 13; k++) T[k] = (coded && (uint32_t)k <= tl) ? (s_tab[q][k] & 0xffffu) : 0xffffu;
+    const uint8_t* sp = blocks;                                   // this lane's stream
+    int64_t P = 0, floor_b = 0;
+    uint8_t* op = dst;
+    uint64_t left = 0;
     if (coded) {
         const uint8_t* const ip = src + hl;
         const uint64_t n = csize - hl;
@@ -285,67 +298,132 @@ __global__ void __launch_bounds__(64) huf0_decode_kernel(const uint8_t* __restri
 #pragma unroll
             for (int k = 0; k < 3; k++) so += k < j ? l[k] : 0;
             const uint64_t slen = j == 0 ? l[0] : j == 1 ? l[1] : j == 2 ? l[2] : l[3];
-            const uint8_t* const sp = ip + so;
             uint64_t w0 = seg * (uint64_t)j;
             w0 = w0 < dsize ? w0 : dsize;
             const uint64_t w1 = j == 3 ? dsize : (w0 + seg < dsize ? w0 + seg : dsize);
-            if (slen < 1 || sp[slen - 1] == 0) bad = true;
+            if (slen < 1 || ip[so + slen - 1] == 0) bad = true;
             if (!bad) {
-                int64_t P = 8 * (int64_t)(slen - 1) + highbit(sp[slen - 1]);
-                const uint32_t look_shift = 64u - tl;
-                uint8_t* op = dst + w0;
-                uint64_t left = w1 - w0;
-                // 16 bytes ending at the byte that holds bit P-1 are requested one step AHEAD: four symbols
-                // take at most 44 bits, so the next step's 8-byte window lies inside them (clamped to the
-                // block's first byte -- at least 7 bytes precede every stream, not always 15)
-                typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-                typedef v4u __attribute__((aligned(1), may_alias)) v4u_a1;
-                const int64_t floor_b = -(int64_t)(hl + so);                 // the block's first byte, relative to sp
-                auto fetch = [&](int64_t Pn, int64_t& base) -> v4u {
-                    const int64_t tb = Pn > 0 ? (Pn - 1) >> 3 : 0;
-                    base = tb - 15 > floor_b ? tb - 15 : floor_b;
-                    return *(const v4u_a1*)(sp + base);
-                };
-                int64_t base = 0;
-                v4u buf = fetch(P, base);
-                while (left > 0) {
-                    uint64_t win = 0;
-                    const v4u cur = buf;
-                    const int64_t cur_base = base;
-                    const int64_t Pc = P;
-                    if (Pc > 0) {
-                        const int64_t tb = (Pc - 1) >> 3;
-                        const uint32_t o = (uint32_t)(tb - 7 - cur_base);    // 0 .. 8: the window's first byte inside cur
-                        const uint32_t d0 = o < 4 ? cur.x : o < 8 ? cur.y : cur.z;
-                        const uint32_t d1 = o < 4 ? cur.y : o < 8 ? cur.z : cur.w;
-                        const uint32_t d2 = o < 4 ? cur.z : o < 8 ? cur.w : 0u;
-                        const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, o & 3u), hi = __builtin_amdgcn_alignbyte(d2, d1, o & 3u);
-                        win = (((uint64_t)hi << 32) | lo) << (7 - (int)((Pc - 1) & 7));
-                        if (Pc < 64) win &= ~0ull << (64 - (int)Pc);         // nothing before the stream's first bit
-                    }
-                    buf = fetch(Pc, base);                                   // for the NEXT step; in flight during this one's lookups
-                    uint32_t word = 0;
-                    const uint32_t m = left < 4 ? (uint32_t)left : 4u;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        if ((uint32_t)k < m) {
-                            const uint32_t e = dt[win >> look_shift];
-                            const uint32_t nb = e >> 8;
-                            word |= (e & 0xffu) << (8 * k);
-                            win <<= nb;
-                            P -= (int64_t)nb;
-                        }
-                    }
-                    if (m == 4) *(u32_a1*)op = word;
-                    else for (uint32_t k = 0; k < m; k++) op[k] = (uint8_t)(word >> (8 * k));
-                    op += m;
-                    left -= m;
-                    if (P < -64) break;                                      // damaged: ran far past the start
-                }
-                if (P != 0) bad = true;                                      // every stream ends exactly (BIT_endOfDStream)
+                sp = ip + so;
+                P = 8 * (int64_t)(slen - 1) + highbit(sp[slen - 1]);
+                floor_b = -(int64_t)(hl + so);                    // the block's first byte, relative to sp
+                op = dst + w0;
+                left = w1 - w0;
             }
         }
     }
+    const bool streaming = left > 0 || (coded && !bad);           // has a stream whose end must be checked
+    const uint32_t look_shift = 32u - (tl ? tl : 1u);
+    // 16 bytes ending at the byte that holds bit P-1 are requested one step AHEAD: four symbols take at
+    // most 48 bits, so the next step's 8-byte window lies inside them (clamped to the block's first
+    // byte -- at least 7 bytes precede every stream, not always 15)
+    int64_t base = 0;
+    auto fetch = [&](int64_t Pn) -> v4u {
+        if (!streaming) return v4u{0, 0, 0, 0};
+        const int64_t tb = Pn > 0 ? (Pn - 1) >> 3 : 0;
+        base = tb - 15 > floor_b ? tb - 15 : floor_b;
+        return *(const v4u_a1*)(sp + base);
+    };
+    v4u buf = fetch(P);
+    // one step = 4 symbols = one dword of output
+    auto step = [&](uint32_t m) -> uint32_t {
+        uint64_t win = 0;
+        const v4u cur = buf;
+        const int64_t cur_base = base;
+        const int64_t Pc = P;
+        if (Pc > 0) {
+            const int64_t tb = (Pc - 1) >> 3;
+            const uint32_t o = (uint32_t)(tb - 7 - cur_base);    // 0 .. 8: the window's first byte inside cur
+            const uint32_t d0 = o < 4 ? cur.x : o < 8 ? cur.y : cur.z;
+            const uint32_t d1 = o < 4 ? cur.y : o < 8 ? cur.z : cur.w;
+            const uint32_t d2 = o < 4 ? cur.z : o < 8 ? cur.w : 0u;
+            const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, o & 3u), hi = __builtin_amdgcn_alignbyte(d2, d1, o & 3u);
+            win = (((uint64_t)hi << 32) | lo) << (7 - (int)((Pc - 1) & 7));
+            if (Pc < 64) win &= ~0ull << (64 - (int)Pc);         // nothing before the stream's first bit
+        }
+        buf = fetch(Pc);                                         // for the NEXT step; in flight during this one's symbols
+        uint32_t word = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if ((uint32_t)k < m) {
+                const uint32_t idx = (uint32_t)(win >> 32) >> look_shift;
+                uint32_t w = 1;
+#pragma unroll
+                for (int kk = 2; kk < 13; kk++) w += (uint32_t)(idx >= T[kk]);
+                const uint32_t e = s_tab[q][w];
+                const uint32_t sym = sorted[(e >> 16) + ((idx - (e & 0xffffu)) >> (w - 1u))];
+                const uint32_t nb = tl + 1u - w;
+                word |= sym << (8 * k);
+                win <<= nb;
+                P -= (int64_t)nb;
+            }
+        }
+        return word;
+    };
+    // The output leaves 64 bytes at a time: a lane collects 16 steps in registers, the quad transposes
+    // its 16-byte pieces (two DPP butterfly stages) and every store writes ONE stream's 64 contiguous
+    // bytes (4-byte stores per lane per step -- 524 288 open lines at the headline shape -- made this
+    // phase 3.2 ms of a 3.7 ms launch).  A stream's final partial burst goes out narrow.
+    const bool odd1 = (t & 1) != 0, odd2 = (t & 2) != 0;
+    const uint32_t part = (uint32_t)t & 3u;
+    for (;;) {
+        if (__ballot(left > 0) == 0) break;
+        const bool full = left >= 64;
+        uint32_t wb[16];
+#pragma unroll
+        for (int sN = 0; sN < 16; sN++) {
+            const uint32_t done = 4u * sN;
+            const uint32_t m = (left > done && P >= -64) ? (left - done < 4 ? (uint32_t)(left - done) : 4u) : 0u;
+            wb[sN] = m ? step(m) : 0u;
+        }
+        const uint32_t cnt = left < 64 ? (uint32_t)left : 64u;
+        uint32_t v[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int d = 0; d < 4; d++) v[k][d] = wb[4 * k + d];
+#pragma unroll
+        for (int k = 0; k < 4; k += 2)
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const uint32_t send = odd1 ? v[k][d] : v[k + 1][d];
+                const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+                if (odd1) v[k][d] = recv; else v[k + 1][d] = recv;
+            }
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const uint32_t send = odd2 ? v[k][d] : v[k + 2][d];
+                const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+                if (odd2) v[k][d] = recv; else v[k + 2][d] = recv;
+            }
+        const uint64_t mine = full ? (uint64_t)(uintptr_t)op : 0ull;
+        const int mlo = (int)(uint32_t)mine, mhi = (int)(uint32_t)(mine >> 32);
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) {
+            uint32_t dlo, dhi;
+            if (qq == 0) { dlo = (uint32_t)__builtin_amdgcn_mov_dpp(mlo, 0x00, 0xf, 0xf, true); dhi = (uint32_t)__builtin_amdgcn_mov_dpp(mhi, 0x00, 0xf, 0xf, true); }
+            else if (qq == 1) { dlo = (uint32_t)__builtin_amdgcn_mov_dpp(mlo, 0x55, 0xf, 0xf, true); dhi = (uint32_t)__builtin_amdgcn_mov_dpp(mhi, 0x55, 0xf, 0xf, true); }
+            else if (qq == 2) { dlo = (uint32_t)__builtin_amdgcn_mov_dpp(mlo, 0xAA, 0xf, 0xf, true); dhi = (uint32_t)__builtin_amdgcn_mov_dpp(mhi, 0xAA, 0xf, 0xf, true); }
+            else { dlo = (uint32_t)__builtin_amdgcn_mov_dpp(mlo, 0xFF, 0xf, 0xf, true); dhi = (uint32_t)__builtin_amdgcn_mov_dpp(mhi, 0xFF, 0xf, 0xf, true); }
+            const uint64_t da = ((uint64_t)dhi << 32) | dlo;
+            if (da) {
+                v4u piece = {v[qq][0], v[qq][1], v[qq][2], v[qq][3]};
+                *(v4u_a1*)(uintptr_t)(da + 16u * part) = piece;
+            }
+        }
+        if (!full && cnt) {
+#pragma unroll
+            for (int sN = 0; sN < 16; sN++) {
+                const uint32_t done = 4u * sN;
+                if (cnt >= done + 4) *(u32_a1*)(op + done) = wb[sN];
+                else if (cnt > done) for (uint32_t k = 0; k < cnt - done; k++) op[done + k] = (uint8_t)(wb[sN] >> (8 * k));
+            }
+        }
+        op += cnt;
+        left -= cnt;
+    }
+    if (streaming && P != 0) bad = true;                          // every stream ends exactly (BIT_endOfDStream)
     const bool any_bad = __builtin_amdgcn_mov_dpp((int)bad, 0x00, 0xf, 0xf, true) | __builtin_amdgcn_mov_dpp((int)bad, 0x55, 0xf, 0xf, true) |
                          __builtin_amdgcn_mov_dpp((int)bad, 0xAA, 0xf, 0xf, true) | __builtin_amdgcn_mov_dpp((int)bad, 0xFF, 0xf, 0xf, true);
     if (exists && j == 0 && rets) {
