@@ -38,9 +38,20 @@ def main():
                 p = 1.0 / np.arange(1, k + 1) ** skew
                 s = rng.choice(k, n, p=p / p.sum()).astype(np.uint8)
                 plains.append(("zipf_n%d_k%d_s%g" % (n, k, skew), s if (n + k) % 2 else (s * 7 + 3).astype(np.uint8)))
+    log12 = []
+    # HUF_compress2 with huffLog 12, the format's largest table.  (With a dominant symbol it emits a weight of
+    # 12, which the library's own HUF_readStats rejects -- and so do the oracle and the kernel; those are left out.)
+    for n in (12000, 20000):
+        for skew in (1.0, 1.2, 1.4):
+            p = 1.0 / np.arange(1, 257) ** skew
+            cand = rng.choice(256, n, p=p / p.sum()).astype(np.uint8)
+            if z.huf_decompress(z.huf_compress(cand, 12), n)[1] == n:
+                log12.append(("log12_n%d_s%g" % (n, skew), cand))
     arrays, manifest, kinds = {}, [], {"stored": 0, "rle": 0, "fse": 0, "nibbles": 0}
-    for i, (name, s) in enumerate(plains):
-        blk = z.huf_compress(s)
+    nlog12 = 0
+    for i, (name, s) in enumerate(plains + log12):
+        blk = z.huf_compress(s, 12 if name.startswith("log12") else None)
+        nlog12 += name.startswith("log12") and o.huf0_table_log(blk) == 12
         back, r = o.huf0_decompress(blk, s.size)
         assert r == s.size and np.array_equal(back, s), name
         kind = "stored" if blk.size == s.size else "rle" if blk.size == 1 else "fse" if blk[0] < 128 else "nibbles"
@@ -51,7 +62,8 @@ def main():
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "golden_huf0_v1.npz"), **arrays)
     with open(os.path.join(ROOT, "tests", "golden", "golden_huf0_v1.json"), "w") as f:
         json.dump({"version": 1, "zstd": z.version, "cases": manifest}, f, indent=0)
-    print(len(manifest), "cases", kinds)
+    assert nlog12 >= 3, nlog12
+    print(len(manifest), "cases", kinds, "table log 12:", nlog12)
 
 
 if __name__ == "__main__":

@@ -101,6 +101,15 @@ class Oracle:
                             offs.ctypes.data, sizes.ctypes.data)
         return dense[:total].copy(), offs, sizes
 
+    def huf0_table_log(self, block):
+        """table log of a coded Huff0 block's tree description (oracle_huf0_read_stats)"""
+        f = _bind(self.lib, "oracle_huf0_read_stats", C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t])
+        block = np.ascontiguousarray(block, dtype=np.uint8)
+        w = np.zeros(256, np.uint8)
+        nsym, tl = C.c_uint(0), C.c_uint(0)
+        r = f(w.ctypes.data, C.byref(nsym), C.byref(tl), block.ctypes.data, block.size)
+        return int(tl.value) if r > 0 else -1
+
     def huf0_decompress(self, block, dst_size):
         """one genuine Huff0 block (oracle/huf0_oracle.c = HUF_decompress): -> (bytes, return value)"""
         f = _bind(self.lib, "oracle_huf0_decompress", C.c_int64, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t])
@@ -352,14 +361,20 @@ class Zstd:
         self.z = z
         self.version = int(z.ZSTD_versionNumber())
 
-    def huf_compress(self, data):
+    def huf_compress(self, data, table_log=None):
         """-> block bytes with HUF_decompress's conventions: the input itself when HUF_compress
-        declines (returns 0), one byte when it is a single repeated symbol"""
+        declines (returns 0), one byte when it is a single repeated symbol.  table_log: HUF_compress2's
+        huffLog (the format's maximum is 12; HUF_compress itself asks for 11)"""
         data = np.ascontiguousarray(data, dtype=np.uint8)
         if data.size == 0:
             return data.copy()
         out = np.zeros(self.z.HUF_compressBound(data.size) + 8, np.uint8)
-        r = self.z.HUF_compress(out.ctypes.data, out.size, data.ctypes.data, data.size)
+        if table_log is None:
+            r = self.z.HUF_compress(out.ctypes.data, out.size, data.ctypes.data, data.size)
+        else:
+            self.z.HUF_compress2.restype = C.c_size_t
+            self.z.HUF_compress2.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_uint, C.c_uint]
+            r = self.z.HUF_compress2(out.ctypes.data, out.size, data.ctypes.data, data.size, 255, table_log)
         if self.z.HUF_isError(r) or r == 0:
             return data.copy()
         return out[:r].copy()
