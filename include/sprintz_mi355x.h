@@ -255,7 +255,7 @@ int64_t sprintz_mi355x_compress_norle(int codec, int elem_bytes, const void* src
 int64_t sprintz_mi355x_decompress_norle(int codec, int elem_bytes, const void* src, void* dest);
 
 /* ------------------------------------------------------------------------
- * Huff0 wire format.  The paper's entropy stage is Yann Collet's
+ * Huff0 wire format, both directions.  The paper's entropy stage is Yann Collet's
  * Huff0 (communicate/ubicomp/method.tex:293-297), a third-party coder the
  * reference neither vendors nor pins; this entry point decodes GENUINE Huff0
  * blocks -- what HUF_compress of zstd 1.4.x / lzbench's huff0 writes: tree
@@ -274,6 +274,19 @@ int64_t sprintz_mi355x_decompress_norle(int codec, int elem_bytes, const void* s
  * ---------------------------------------------------------------------- */
 int sprintz_mi355x_huf0_decompress_batch(const void* d_blocks, const uint64_t* d_block_offsets, uint64_t nchunks, void* d_out,
                                          const uint64_t* d_out_offsets, int64_t* d_rets, void* hip_stream);
+/* The other direction: container (d_dense, d_offsets[nchunks+1], d_sizes[nchunks] = exact stream bytes, as
+ * sprintz_mi355x_compact leaves them) -> one Huff0 block per chunk, byte-dense at d_blocks +
+ * d_block_offsets[c] (d_block_offsets[nchunks] = total), each one a block HUF_decompress(dst, size of
+ * the chunk, block, size of the block) decodes -- the write side of lzbench's huff0 stage.  The
+ * format leaves the encoder free; what is written is specified by oracle/huf0_oracle.c
+ * (oracle_huf0_compress_batch: one code table per 64 chunks repeated in every block, FSE-coded or 4-bit
+ * weights, stored / one-byte blocks under HUF_decompress's conventions) and the kernels are
+ * byte-exact with it.  d_blocks: sprintz_mi355x_huf0_bound(sum of sizes, nchunks) bytes; d_tmp:
+ * sprintz_mi355x_huf0_tmp_bytes(nchunks). */
+size_t sprintz_mi355x_huf0_tmp_bytes(uint64_t nchunks);
+size_t sprintz_mi355x_huf0_bound(uint64_t total_stream_bytes, uint64_t nchunks);
+int sprintz_mi355x_huf0_compress_batch(const void* d_dense, const uint64_t* d_offsets, const uint32_t* d_sizes, uint64_t nchunks,
+                                       void* d_blocks, uint64_t* d_block_offsets, void* d_tmp, void* hip_stream);
 
 /* ------------------------------------------------------------------------
  * Stand-alone transforms.  Replace

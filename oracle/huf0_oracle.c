@@ -246,3 +246,204 @@ int64_t oracle_huf0_decompress(uint8_t* dst, size_t dst_size, const uint8_t* src
     }
     return (int64_t)dst_size;
 }
+
+/* =====================================================================================
+ * WRITER.  Not a restatement of HUF_compress: the format leaves the encoder free (which code
+ * lengths, how the weight statistics are normalised), so this is the specification of the blocks
+ * sprintz_mi355x_huf0_compress_batch writes -- every one of them a block the library's
+ * HUF_decompress accepts (tests/test_huf0_cpu.py feeds them to it) -- and the GPU kernels are
+ * byte-exact with it.
+ *   * code lengths: one table per segment of 64 chunks (huf_oracle_lengths over the segment's
+ *     histogram, <= 11 bits), written into EVERY chunk's block; a table that is not Kraft-complete
+ *     or has fewer than two symbols makes the segment's chunks stored.
+ *   * codes: Huff0's canonical order (HUF_buildCTable: per length ascending symbols, values
+ *     descending with the length).
+ *   * tree description: the weights FSE-coded with table log 6 (counts scaled to 64, every present
+ *     weight >= 1, the remainder given to / taken from the most frequent one; FSE_writeNCount's bit
+ *     layout; states chosen by search in the decoder's table, the last symbol of each of the two
+ *     state chains on that symbol's smallest state as FSE_initCState2 does) when that is shorter
+ *     than the 4-bit form or the 4-bit form does not exist (> 128 weights).
+ *   * a chunk is stored when it is shorter than 12 bytes, a stream would not fit the 16-bit jump
+ *     table, or the block would not be smaller; a chunk of one repeated byte is that byte.
+ */
+void huf_oracle_lengths(const uint32_t counts[256], uint8_t lens[256]);
+
+typedef struct { uint8_t* p; uint64_t acc; int nbits; size_t n; } bitw_t;
+static void bw_add(bitw_t* b, uint32_t v, int nb)
+{
+    b->acc |= (uint64_t)v << b->nbits;
+    b->nbits += nb;
+    while (b->nbits >= 8) { b->p[b->n++] = (uint8_t)b->acc; b->acc >>= 8; b->nbits -= 8; }
+}
+static size_t bw_close(bitw_t* b, int end_mark)
+{
+    if (end_mark) bw_add(b, 1, 1);
+    if (b->nbits > 0) { b->p[b->n++] = (uint8_t)b->acc; b->acc = 0; b->nbits = 0; }
+    return b->n;
+}
+
+/* FSE-coded weights: out[0..) = NCount + state stream; returns its size, 0 if not applicable */
+static size_t fse_write_weights(const uint8_t* w, unsigned n, uint8_t* out)
+{
+    unsigned count[16] = {0}, maxw = 0;
+    if (n < 2) return 0;
+    for (unsigned k = 0; k < n; k++) { count[w[k]]++; if (w[k] > maxw) maxw = w[k]; }
+    unsigned present = 0, top = 0;
+    for (unsigned s = 0; s <= maxw; s++) { present += count[s] != 0; if (count[s] > count[top]) top = s; }
+    if (present < 2) return 0;                               /* one repeated weight: FSE cannot code it */
+    const unsigned tl = 6, size = 64;
+    int norm[16] = {0}, sum = 0;
+    for (unsigned s = 0; s <= maxw; s++) if (count[s]) { norm[s] = (int)((uint64_t)count[s] * size / n); if (norm[s] < 1) norm[s] = 1; sum += norm[s]; }
+    norm[top] += (int)size - sum;                            /* the most frequent weight absorbs the rounding */
+    if (norm[top] < 1) return 0;
+    /* FSE_writeNCount */
+    bitw_t b = {out, 0, 0, 0};
+    bw_add(&b, tl - 5, 4);
+    {
+        int remaining = (int)size + 1, threshold = (int)size, nb = (int)tl + 1, previous0 = 0;
+        unsigned sym = 0;
+        while (sym <= maxw && remaining > 1) {
+            if (previous0) {
+                unsigned start = sym;
+                while (sym <= maxw && !norm[sym]) sym++;
+                if (sym > maxw) return 0;
+                while (sym >= start + 24) { start += 24; bw_add(&b, 0xffff, 16); }
+                while (sym >= start + 3) { start += 3; bw_add(&b, 3, 2); }
+                bw_add(&b, sym - start, 2);
+            }
+            int c = norm[sym++];
+            const int max = (2 * threshold - 1) - remaining;
+            remaining -= c;
+            c++;
+            if (c >= threshold) c += max;
+            bw_add(&b, (uint32_t)c, nb - (c < max));
+            previous0 = c == 1;
+            if (remaining < 1) return 0;
+            while (remaining < threshold) { nb--; threshold >>= 1; }
+        }
+        if (remaining != 1) return 0;
+    }
+    const size_t hl = bw_close(&b, 0);
+    /* the decoder's table (FSE_buildDTable), then the states by search */
+    uint8_t tsym[64], tnb[64];
+    uint16_t tnew[64], next[16];
+    {
+        const unsigned mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+        unsigned pos = 0;
+        for (unsigned s = 0; s <= maxw; s++) {
+            next[s] = (uint16_t)norm[s];
+            for (int i = 0; i < norm[s]; i++) { tsym[pos] = (uint8_t)s; pos = (pos + step) & mask; }
+        }
+        for (unsigned u = 0; u < size; u++) {
+            const unsigned ns = next[tsym[u]]++;
+            tnb[u] = (uint8_t)(tl - (unsigned)highbit(ns));
+            tnew[u] = (uint16_t)((ns << tnb[u]) - size);
+        }
+    }
+    /* D[i] = decoder state when symbol i is emitted; chains i, i+2, ...; fields in reverse read order */
+    unsigned D[256];
+    for (int i = (int)n - 1; i >= 0; i--) {
+        int found = -1;
+        for (unsigned u = 0; u < size && found < 0; u++) {
+            if (tsym[u] != w[i]) continue;
+            if (i + 2 >= (int)n) found = (int)u;                           /* smallest state of the symbol: table order */
+            else if (D[i + 2] >= tnew[u] && D[i + 2] < (unsigned)tnew[u] + (1u << tnb[u])) found = (int)u;
+        }
+        if (found < 0) return 0;
+        D[i] = (unsigned)found;
+    }
+    bitw_t sb = {out + hl, 0, 0, 0};
+    for (int i = (int)n - 3; i >= 0; i--) bw_add(&sb, D[i + 2] - tnew[D[i]], tnb[D[i]]);
+    bw_add(&sb, D[1], (int)tl);
+    bw_add(&sb, D[0], (int)tl);
+    return hl + bw_close(&sb, 1);
+}
+
+/* tree description for code lengths lens[]: hdr[0..return); 0 when the table cannot be written */
+size_t oracle_huf0_write_header(const uint8_t lens[256], uint8_t* hdr, unsigned* tl_out)
+{
+    unsigned tl = 0, nz = 0;
+    int max_sym = -1;
+    for (int s = 0; s < 256; s++) if (lens[s]) { nz++; max_sym = s; if (lens[s] > tl) tl = lens[s]; }
+    if (nz < 2 || tl > 11) return 0;
+    uint32_t kraft = 0;
+    for (int s = 0; s < 256; s++) if (lens[s]) kraft += 1u << (tl - lens[s]);
+    if (kraft != (1u << tl)) return 0;
+    uint8_t w[256];
+    const unsigned nw = (unsigned)max_sym;                   /* the last symbol's weight is implied */
+    for (unsigned s = 0; s < nw; s++) w[s] = lens[s] ? (uint8_t)(tl + 1 - lens[s]) : 0;
+    *tl_out = tl;
+    uint8_t f[300];
+    const size_t fs = nw >= 2 ? fse_write_weights(w, nw, f) : 0;
+    const size_t raw = nw <= 128 ? 1 + (nw + 1) / 2 : 0;
+    if (fs > 1 && fs < 128 && (raw == 0 || fs + 1 < raw)) {
+        hdr[0] = (uint8_t)fs;
+        memcpy(hdr + 1, f, fs);
+        return fs + 1;
+    }
+    if (raw == 0 || nw == 0) return 0;
+    hdr[0] = (uint8_t)(127 + nw);
+    for (unsigned k = 0; k < nw; k += 2) hdr[1 + k / 2] = (uint8_t)((w[k] << 4) | (k + 1 < nw ? w[k + 1] : 0));
+    return raw;
+}
+
+/* Huff0's canonical code values (HUF_buildCTable) */
+static void huf0_codes(const uint8_t lens[256], unsigned tl, uint16_t val[256])
+{
+    uint32_t per[16] = {0}, start[16] = {0};
+    for (int s = 0; s < 256; s++) per[lens[s]]++;
+    uint32_t min = 0;
+    for (unsigned l = tl; l > 0; l--) { start[l] = min; min += per[l]; min >>= 1; }
+    for (int s = 0; s < 256; s++) val[s] = lens[s] ? (uint16_t)start[lens[s]]++ : 0;
+}
+
+/* container (dense, offsets, sizes) -> Huff0 blocks, one per chunk, byte-dense; returns total bytes */
+uint64_t oracle_huf0_compress_batch(const uint8_t* dense, const uint64_t* offsets, const uint32_t* sizes, uint64_t nchunks,
+                                    uint8_t* out, uint64_t* out_offsets)
+{
+    uint64_t at = 0;
+    for (uint64_t c0 = 0; c0 < nchunks; c0 += 64) {
+        const uint64_t c1 = c0 + 64 < nchunks ? c0 + 64 : nchunks;
+        uint32_t hist[256] = {0};
+        for (uint64_t c = c0; c < c1; c++) for (uint32_t k = 0; k < sizes[c]; k++) hist[dense[offsets[c] + k]]++;
+        uint8_t lens[256], hdr[160];
+        uint16_t val[256];
+        unsigned tl = 0;
+        huf_oracle_lengths(hist, lens);
+        const size_t hlen = oracle_huf0_write_header(lens, hdr, &tl);
+        if (hlen) huf0_codes(lens, tl, val);
+        for (uint64_t c = c0; c < c1; c++) {
+            const uint8_t* s = dense + offsets[c];
+            const uint32_t n = sizes[c];
+            out_offsets[c] = at;
+            if (n == 0) continue;
+            int same = 1;
+            for (uint32_t k = 1; k < n; k++) if (s[k] != s[0]) { same = 0; break; }
+            if (same) { out[at++] = s[0]; continue; }        /* n == 1 included: stored and repeated coincide */
+            const uint32_t seg = (n + 3) / 4;
+            uint64_t bits[4] = {0, 0, 0, 0}, bytes[4], total = hlen + 6;
+            int ok = hlen != 0 && n >= 12;
+            if (ok) {
+                for (uint32_t k = 0; k < n; k++) bits[k / seg] += lens[s[k]];
+                for (int j = 0; j < 4; j++) { bytes[j] = (bits[j] + 1 + 7) / 8; total += bytes[j]; if (j < 3 && bytes[j] > 65535) ok = 0; }
+                if (total >= n) ok = 0;
+            }
+            if (!ok) { memcpy(out + at, s, n); at += n; continue; }
+            uint8_t* o = out + at;
+            memcpy(o, hdr, hlen);
+            o += hlen;
+            for (int j = 0; j < 3; j++) { o[2 * j] = (uint8_t)bytes[j]; o[2 * j + 1] = (uint8_t)(bytes[j] >> 8); }
+            o += 6;
+            for (int j = 0; j < 4; j++) {
+                const uint32_t k0 = seg * (uint32_t)j, k1 = j == 3 ? n : k0 + seg;
+                bitw_t b = {o, 0, 0, 0};
+                for (uint32_t k = k1; k > k0; k--) bw_add(&b, val[s[k - 1]], lens[s[k - 1]]);   /* last symbol first */
+                bw_close(&b, 1);
+                o += bytes[j];
+            }
+            at += total;
+        }
+    }
+    out_offsets[nchunks] = at;
+    return at;
+}

@@ -7,7 +7,7 @@ reference's interface (cpp/Compress/sprintz.h) on top of it.
 from . import _lib
 from ._lib import SprintzError, abi_version, last_error
 from .codec import (ChunkedCodec, CompressedBatch, HufBatch, compress_chunked, decompress_chunked, decompress_noheader,
-                    huf_compress, huf_decompress, huf0_decompress, QueryParams, QueryTypes,
+                    huf_compress, huf_decompress, huf0_compress, huf0_decompress, QueryParams, QueryTypes,
                     query_rowmajor_delta_rle_8b, query_rowmajor_delta_rle_16b, query_rowmajor_xff_rle_8b,
                     query_rowmajor_xff_rle_16b,
                     encode_delta_rowmajor_8b, encode_delta_rowmajor_16b, encode_doubledelta_rowmajor_8b,
@@ -22,7 +22,7 @@ from .codec import (ChunkedCodec, CompressedBatch, HufBatch, compress_chunked, d
                     sprintz_decompress_xff_8b, sprintz_decompress_xff_16b)
 
 __all__ = [
-    "SprintzError", "abi_version", "last_error", "ChunkedCodec", "CompressedBatch", "HufBatch", "huf_compress", "huf_decompress", "huf0_decompress",
+    "SprintzError", "abi_version", "last_error", "ChunkedCodec", "CompressedBatch", "HufBatch", "huf_compress", "huf_decompress", "huf0_compress", "huf0_decompress",
     "compress_chunked", "decompress_chunked", "decompress_noheader", "QueryParams", "QueryTypes",
     "encode_delta_rowmajor_8b", "encode_delta_rowmajor_16b", "encode_doubledelta_rowmajor_8b", "encode_doubledelta_rowmajor_16b",
     "decode_delta_rowmajor_8b", "decode_delta_rowmajor_16b", "decode_doubledelta_rowmajor_8b", "decode_doubledelta_rowmajor_16b",

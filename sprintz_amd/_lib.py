@@ -80,6 +80,9 @@ decompress_batch = _sig("sprintz_mi355x_decompress_batch", _i, _i, _i, _vp, _vp,
 huf_tmp_bytes = _sig("sprintz_mi355x_huf_tmp_bytes", _sz, _u64)
 huf_bound = _sig("sprintz_mi355x_huf_bound", _sz, _u64, _u64)
 huf_compress_batch = _sig("sprintz_mi355x_huf_compress_batch", _i, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp)
+huf0_tmp_bytes = _sig("sprintz_mi355x_huf0_tmp_bytes", _sz, _u64)
+huf0_bound = _sig("sprintz_mi355x_huf0_bound", _sz, _u64, _u64)
+huf0_compress_batch = _sig("sprintz_mi355x_huf0_compress_batch", _i, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp)
 huf0_decompress_batch = _sig("sprintz_mi355x_huf0_decompress_batch", _i, _vp, _vp, _u64, _vp, _vp, _vp, _vp)
 huf_decompress_batch = _sig("sprintz_mi355x_huf_decompress_batch", _i, _vp, _vp, _vp, _u64, _u32, _vp, _u64, _vp, _vp, _vp, _vp, _vp)
 
@@ -129,6 +132,7 @@ EXPORTED_SYMBOLS = [
     "sprintz_mi355x_compress_chunked_host", "sprintz_mi355x_decompress_chunked_host",
     "sprintz_mi355x_huf_tmp_bytes", "sprintz_mi355x_huf_bound",
     "sprintz_mi355x_huf_compress_batch", "sprintz_mi355x_huf_decompress_batch", "sprintz_mi355x_huf0_decompress_batch",
+    "sprintz_mi355x_huf0_tmp_bytes", "sprintz_mi355x_huf0_bound", "sprintz_mi355x_huf0_compress_batch",
     "sprintz_mi355x_query_batch", "sprintz_mi355x_query_reduce",
     "sprintz_mi355x_query_delta_8b", "sprintz_mi355x_query_xff_8b",
     "sprintz_mi355x_query_delta_16b", "sprintz_mi355x_query_xff_16b",

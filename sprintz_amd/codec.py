@@ -481,6 +481,22 @@ def huf_decompress(hb, dense_capacity, align=16, rets=None):
     return CompressedBatch(dense, offs, sizes, n, hb.total_len, hb.chunk_len, hb.ndims)
 
 
+def huf0_compress(batch):
+    """CompressedBatch -> (blocks uint8 tensor, block_offsets int64 [nchunks+1]): one genuine Huff0 block per
+    chunk (readable by HUF_decompress / lzbench's huff0; format of the writer: oracle/huf0_oracle.c)"""
+    import torch
+    dev = batch.data.device
+    n = batch.nchunks
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    total = int(batch.sizes.sum().item())
+    blocks = torch.zeros(int(_lib.huf0_bound(total, n)), dtype=torch.uint8, device=dev)
+    boffs = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    tmp = torch.empty(int(_lib.huf0_tmp_bytes(n)), dtype=torch.uint8, device=dev)
+    _lib.check(_lib.huf0_compress_batch(batch.data.data_ptr(), batch.offsets.data_ptr(), batch.sizes.data_ptr(), n,
+                                        blocks.data_ptr(), boffs.data_ptr(), tmp.data_ptr(), stream))
+    return blocks, boffs
+
+
 def huf0_decompress(blocks, block_offsets, out_offsets, rets=None, out=None):
     """Genuine Huff0 blocks (HUF_compress's output, one per chunk; torch uint8 tensor + int64 offsets
     [nchunks+1]) -> the bytes they encode, chunk c at out_offsets[c] (int64 [nchunks+1], device).

@@ -794,6 +794,8 @@ __global__ void __launch_bounds__(256) huf_decode_kernel(const uint8_t* huf, con
 
 thread_local std::string g_huf_error;
 
+#include "huf0_write.h"
+
 }  // namespace
 
 extern "C" {
@@ -829,6 +831,47 @@ int sprintz_mi355x_huf_compress_batch(const void* d_dense, const uint64_t* d_off
     if (launch_size_scan(rec_sizes, nchunks, 4, d_huf_offsets, scan_tmp, st) != hipSuccess) return SPRINTZ_E_HIP;
     hipLaunchKernelGGL(huf_encode_kernel, dim3((unsigned)nseg), dim3(256), 0, st, (const uint8_t*)d_dense, d_offsets, d_sizes, nchunks,
                        (const uint32_t*)enc_tables, (const uint64_t*)meta, (uint8_t*)d_huf, (const uint64_t*)d_huf_offsets);
+    return hipGetLastError() == hipSuccess ? 0 : SPRINTZ_E_HIP;
+}
+
+// ---- Huff0-format writer (huf0_write.h).  tmp: K1's code tables | nibble tables | segment records | block sizes | meta | scan scratch
+size_t sprintz_mi355x_huf0_tmp_bytes(uint64_t nchunks)
+{
+    const uint64_t nseg = (nchunks + SEG - 1) / SEG;
+    return (size_t)(nseg * 1024 + nseg * 128 + nseg * kRecBytes + ((nchunks * 4 + 15) & ~(uint64_t)15) + nchunks * 8 +
+                    sprintz_mi355x_compact_tmp_bytes(nchunks) + 64);
+}
+
+size_t sprintz_mi355x_huf0_bound(uint64_t total_stream_bytes, uint64_t nchunks)
+{
+    (void)nchunks;                                        // a block is never larger than its chunk
+    return (size_t)(total_stream_bytes + SPRINTZ_MI355X_READ_SLACK);
+}
+
+int sprintz_mi355x_huf0_compress_batch(const void* d_dense, const uint64_t* d_offsets, const uint32_t* d_sizes, uint64_t nchunks,
+                                       void* d_blocks, uint64_t* d_block_offsets, void* d_tmp, void* hip_stream)
+{
+    if (!d_dense || !d_offsets || !d_sizes || !d_blocks || !d_block_offsets || !d_tmp) return SPRINTZ_E_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return SPRINTZ_E_NO_DEVICE;
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (nchunks == 0) return hipMemsetAsync(d_block_offsets, 0, 8, st) == hipSuccess ? 0 : SPRINTZ_E_HIP;
+    const uint64_t nseg = (nchunks + SEG - 1) / SEG;
+    uint8_t* tmp = (uint8_t*)d_tmp;
+    uint32_t* enc_tables = (uint32_t*)tmp;
+    uint8_t* nib = tmp + nseg * 1024;
+    uint8_t* recs = nib + nseg * 128;
+    uint32_t* bsizes = (uint32_t*)(recs + nseg * kRecBytes);
+    uint64_t* meta = (uint64_t*)((uint8_t*)bsizes + ((nchunks * 4 + 15) & ~(uint64_t)15));
+    void* scan_tmp = (uint8_t*)meta + nchunks * 8;
+    hipLaunchKernelGGL(huf_build_kernel, dim3((unsigned)nseg), dim3(256), 0, st, (const uint8_t*)d_dense, d_offsets, d_sizes, nchunks,
+                       enc_tables, nib);
+    hipLaunchKernelGGL(huf0_table_kernel, dim3((unsigned)nseg), dim3(64), 0, st, (const uint8_t*)nib, recs);
+    hipLaunchKernelGGL(huf0_size_kernel, dim3((unsigned)nseg), dim3(256), 0, st, (const uint8_t*)d_dense, d_offsets, d_sizes, nchunks,
+                       (const uint8_t*)recs, bsizes, meta);
+    if (launch_size_scan(bsizes, nchunks, 1, d_block_offsets, scan_tmp, st) != hipSuccess) return SPRINTZ_E_HIP;
+    hipLaunchKernelGGL(huf0_encode_kernel, dim3((unsigned)nseg), dim3(256), 0, st, (const uint8_t*)d_dense, d_offsets, d_sizes, nchunks,
+                       (const uint8_t*)recs, (const uint64_t*)meta, (uint8_t*)d_blocks, (const uint64_t*)d_block_offsets);
     return hipGetLastError() == hipSuccess ? 0 : SPRINTZ_E_HIP;
 }
 

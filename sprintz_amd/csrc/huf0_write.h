@@ -1,0 +1,312 @@
+// huf0_write.h -- writer of Huff0-format blocks (included by huf.hip inside its anonymous namespace:
+// it reuses K1, huf_build_kernel, for the per-segment code lengths).  The blocks are specified by
+// oracle/huf0_oracle.c's oracle_huf0_compress_batch (one code table per segment of 64 chunks,
+// written into every chunk's block; Huff0's canonical code order; FSE-coded weights with table log 6
+// or the 4-bit form) and are byte-exact with it; the library's HUF_decompress reads them.
+//   H1 huf0_table_kernel   per segment: lengths -> tree description bytes + code values (one wave;
+//                          the FSE state chain is searched 64 table entries at a time)
+//   H2 huf0_size_kernel    per chunk: the four streams' byte counts, stored / repeated / coded
+//   H3 huf0_encode_kernel  per chunk: description, jump table, four streams written last symbol
+//                          first through a per-lane LDS ring that leaves in 64-byte units
+#pragma once
+
+constexpr int kRecBytes = 1024;         // per segment: hlen u32 | tl u32 | hdr[<=160] @8 | (val | len << 16) u32[256] @... see below
+constexpr int kRecHdr = 8, kRecTab = 192;   // tab: 256 x u16 val @192, 256 x u8 len @704
+
+struct BitW {                           // bytes into LDS, LSB first (bitstream.h BIT_CStream_t)
+    uint8_t* p; uint64_t acc; int nbits; uint32_t n;
+    __device__ void add(uint32_t v, int nb)
+    {
+        acc |= (uint64_t)v << nbits;
+        nbits += nb;
+        while (nbits >= 8) { p[n++] = (uint8_t)acc; acc >>= 8; nbits -= 8; }
+    }
+    __device__ uint32_t close(bool end_mark)
+    {
+        if (end_mark) add(1, 1);
+        if (nbits > 0) { p[n++] = (uint8_t)acc; acc = 0; nbits = 0; }
+        return n;
+    }
+};
+
+__global__ void __launch_bounds__(64) huf0_table_kernel(const uint8_t* __restrict__ tables, uint8_t* __restrict__ recs)
+{
+    __shared__ uint8_t lens[256], w[256], f[320], hdr[192], tsym[64], tnb[64], D[256];
+    __shared__ uint16_t tnew[64], vals[256];
+    __shared__ uint32_t s_hl, s_hlen, s_tl, s_nw, s_ok;
+    const int t = threadIdx.x;
+    const uint64_t seg = blockIdx.x;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int s = 4 * t + e;
+        lens[s] = (uint8_t)((tables[seg * 128 + (s >> 1)] >> (4 * (s & 1))) & 15u);
+    }
+    if (t == 0) { s_hl = 0; s_hlen = 0; s_tl = 0; s_nw = 0; s_ok = 0; }
+    __syncthreads();
+    int norm[16];
+    uint32_t maxw = 0;
+    if (t == 0) {
+        uint32_t tl = 0, nz = 0, kraft = 0;
+        int max_sym = -1;
+        for (int s = 0; s < 256; s++) if (lens[s]) { nz++; max_sym = s; if (lens[s] > tl) tl = lens[s]; }
+        for (int s = 0; s < 256; s++) if (lens[s]) kraft += 1u << (tl - lens[s]);
+        if (nz >= 2 && tl <= 11 && kraft == (1u << tl)) {
+            const uint32_t nw = (uint32_t)max_sym;
+            for (uint32_t s = 0; s < nw; s++) w[s] = lens[s] ? (uint8_t)(tl + 1 - lens[s]) : 0;
+            s_tl = tl;
+            s_nw = nw;
+            s_ok = 1;
+            // ---- FSE statistics of the weights, NCount, decoder table (fse_write_weights)
+            uint32_t count[16];
+            for (int k = 0; k < 16; k++) { count[k] = 0; norm[k] = 0; }
+            bool fse = nw >= 2;
+            if (fse) {
+                for (uint32_t k = 0; k < nw; k++) { count[w[k]]++; if (w[k] > maxw) maxw = w[k]; }
+                uint32_t present = 0, top = 0;
+                for (uint32_t s = 0; s <= maxw; s++) { present += count[s] != 0; if (count[s] > count[top]) top = s; }
+                int sum = 0;
+                for (uint32_t s = 0; s <= maxw; s++) if (count[s]) { norm[s] = (int)((uint64_t)count[s] * 64u / nw); if (norm[s] < 1) norm[s] = 1; sum += norm[s]; }
+                norm[top] += 64 - sum;
+                if (present < 2 || norm[top] < 1) fse = false;
+            }
+            if (fse) {
+                BitW b{f, 0, 0, 0};
+                b.add(6 - 5, 4);
+                int remaining = 65, threshold = 64, nb = 7;
+                bool previous0 = false;
+                uint32_t sym = 0;
+                while (sym <= maxw && remaining > 1) {
+                    if (previous0) {
+                        uint32_t start = sym;
+                        while (sym <= maxw && !norm[sym]) sym++;
+                        if (sym > maxw) { fse = false; break; }
+                        while (sym >= start + 24) { start += 24; b.add(0xffff, 16); }
+                        while (sym >= start + 3) { start += 3; b.add(3, 2); }
+                        b.add(sym - start, 2);
+                    }
+                    int c = norm[sym++];
+                    const int max = (2 * threshold - 1) - remaining;
+                    remaining -= c;
+                    c++;
+                    if (c >= threshold) c += max;
+                    b.add((uint32_t)c, nb - (c < max));
+                    previous0 = c == 1;
+                    if (remaining < 1) { fse = false; break; }
+                    while (remaining < threshold) { nb--; threshold >>= 1; }
+                }
+                if (remaining != 1) fse = false;
+                if (fse) {
+                    s_hl = b.close(false);
+                    uint16_t next[16];
+                    uint32_t pos = 0;
+                    for (uint32_t s = 0; s <= maxw; s++) {
+                        next[s] = (uint16_t)norm[s];
+                        for (int i = 0; i < norm[s]; i++) { tsym[pos] = (uint8_t)s; pos = (pos + 43u) & 63u; }   // step = 32 + 8 + 3
+                    }
+                    for (uint32_t u = 0; u < 64; u++) {
+                        const uint32_t ns = next[tsym[u]]++;
+                        tnb[u] = (uint8_t)(6 - (31 - __clz((int)ns)));
+                        tnew[u] = (uint16_t)((ns << tnb[u]) - 64u);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the two state chains, last weight first: D[i] = decoder state when weight i is emitted; every lane
+    // tests one table entry, the lowest match wins (= the symbol's smallest state at the chain ends)
+    const uint32_t nw = s_nw, hl = s_hl;
+    bool chain_ok = hl != 0;
+    if (hl != 0) {
+        const uint32_t my_sym = tsym[t], lo = tnew[t], hi = (uint32_t)tnew[t] + (1u << tnb[t]);
+        uint32_t later[2] = {0, 0};                      // D[i + 2] of either parity
+        for (int i = (int)nw - 1; i >= 0; i--) {
+            const uint32_t target = later[i & 1];
+            const bool match = my_sym == w[i] && (i + 2 >= (int)nw || (target >= lo && target < hi));
+            const uint64_t m = __ballot(match);
+            if (m == 0) { chain_ok = false; break; }
+            const uint32_t found = (uint32_t)__builtin_ctzll(m);
+            later[i & 1] = found;
+            if (t == 0) D[i] = (uint8_t)found;
+        }
+    }
+    __syncthreads();
+    if (t == 0 && s_ok) {
+        uint32_t fs = 0;
+        if (hl != 0 && chain_ok) {
+            BitW sb{f + hl, 0, 0, 0};
+            for (int i = (int)nw - 3; i >= 0; i--) sb.add((uint32_t)D[i + 2] - tnew[D[i]], tnb[D[i]]);
+            sb.add(D[1], 6);
+            sb.add(D[0], 6);
+            fs = hl + sb.close(true);
+        }
+        const uint32_t raw = nw <= 128 ? 1 + (nw + 1) / 2 : 0;
+        uint32_t hlen = 0;
+        if (fs > 1 && fs < 128 && (raw == 0 || fs + 1 < raw)) {
+            hdr[0] = (uint8_t)fs;
+            for (uint32_t k = 0; k < fs; k++) hdr[1 + k] = f[k];
+            hlen = fs + 1;
+        } else if (raw != 0 && nw != 0) {
+            hdr[0] = (uint8_t)(127 + nw);
+            for (uint32_t k = 0; k < nw; k += 2) hdr[1 + k / 2] = (uint8_t)((w[k] << 4) | (k + 1 < nw ? w[k + 1] : 0));
+            hlen = raw;
+        }
+        s_hlen = hlen;
+        // Huff0's canonical code values (HUF_buildCTable): per length ascending symbols, the longest codes lowest
+        const uint32_t tl = s_tl;
+        uint32_t per[16], start[16];
+        for (int l = 0; l < 16; l++) { per[l] = 0; start[l] = 0; }
+        for (int s = 0; s < 256; s++) per[lens[s]]++;
+        uint32_t min = 0;
+        for (uint32_t l = tl; l > 0; l--) { start[l] = min; min += per[l]; min >>= 1; }
+        for (int s = 0; s < 256; s++) vals[s] = lens[s] ? (uint16_t)start[lens[s]]++ : (uint16_t)0;
+    }
+    __syncthreads();
+    uint8_t* const rec = recs + seg * kRecBytes;
+    if (t == 0) { ((uint32_t*)rec)[0] = s_hlen; ((uint32_t*)rec)[1] = s_tl; }
+    for (int k = t; k < 160; k += 64) rec[kRecHdr + k] = k < (int)s_hlen ? hdr[k] : (uint8_t)0;
+    for (int k = t; k < 256; k += 64) {
+        ((uint16_t*)(rec + kRecTab))[k] = s_hlen ? vals[k] : (uint16_t)0;
+        rec[kRecTab + 512 + k] = lens[k];
+    }
+}
+
+// H2.  One workgroup per segment = 64 chunks x 4 streams; lane = (chunk, stream).
+// meta[c] = bytes0 | bytes1 << 16 | bytes2 << 32 | mode << 48   (mode 0 empty, 1 stored, 2 repeated byte, 3 coded)
+__global__ void __launch_bounds__(256) huf0_size_kernel(const uint8_t* __restrict__ dense, const uint64_t* __restrict__ offsets,
+                                                        const uint32_t* __restrict__ sizes, uint64_t nchunks,
+                                                        const uint8_t* __restrict__ recs, uint32_t* __restrict__ bsizes,
+                                                        uint64_t* __restrict__ meta)
+{
+    __shared__ uint8_t lens[256];
+    const int t = threadIdx.x, j = t & 3;
+    const uint64_t seg = blockIdx.x, c = seg * SEG + (uint64_t)(t >> 2);
+    const uint8_t* const rec = recs + seg * kRecBytes;
+    const uint32_t hlen = ((const uint32_t*)rec)[0];
+    lens[t] = rec[kRecTab + 512 + t];
+    __syncthreads();
+    const bool exists = c < nchunks;
+    const uint32_t n = exists ? sizes[c] : 0u;
+    const uint8_t* const s = dense + (exists ? offsets[c] : 0);
+    uint32_t k0, k1;
+    sub_range(n, j, k0, k1);
+    if (j == 3) k1 = n;
+    const uint32_t first = n ? s[0] : 0u;
+    uint32_t bits = 0;
+    bool same = true;
+    uint32_t k = k0;
+    for (; k + 16 <= k1; k += 16) {
+        const u32x4 x = *(const u32x4_a1*)(s + k);
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const uint32_t v = d == 0 ? x.x : d == 1 ? x.y : d == 2 ? x.z : x.w;
+            bits += lens[v & 255] + lens[(v >> 8) & 255] + lens[(v >> 16) & 255] + lens[v >> 24];
+            same = same && v == first * 0x01010101u;
+        }
+    }
+    for (; k < k1; k++) { bits += lens[s[k]]; same = same && s[k] == first; }
+    const uint32_t bytes = (bits + 1 + 7) >> 3;
+    const int all_same = __builtin_amdgcn_mov_dpp((int)same, 0x00, 0xf, 0xf, true) & __builtin_amdgcn_mov_dpp((int)same, 0x55, 0xf, 0xf, true) &
+                         __builtin_amdgcn_mov_dpp((int)same, 0xAA, 0xf, 0xf, true) & __builtin_amdgcn_mov_dpp((int)same, 0xFF, 0xf, 0xf, true);
+    const uint32_t b0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)bytes, 0x00, 0xf, 0xf, true), b1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)bytes, 0x55, 0xf, 0xf, true),
+                   b2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)bytes, 0xAA, 0xf, 0xf, true), b3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)bytes, 0xFF, 0xf, 0xf, true);
+    if (exists && j == 0) {
+        uint32_t mode, size;
+        const uint64_t total = (uint64_t)hlen + 6 + b0 + b1 + b2 + b3;
+        if (n == 0) { mode = 0; size = 0; }
+        else if (all_same) { mode = 2; size = 1; }
+        else if (hlen != 0 && n >= 12 && b0 <= 65535 && b1 <= 65535 && b2 <= 65535 && total < n) { mode = 3; size = (uint32_t)total; }
+        else { mode = 1; size = n; }
+        bsizes[c] = size;
+        meta[c] = (uint64_t)(b0 & 0xffffu) | ((uint64_t)(b1 & 0xffffu) << 16) | ((uint64_t)(b2 & 0xffffu) << 32) | ((uint64_t)mode << 48);
+    }
+}
+
+// H3.  Same mapping.  A stream is written last symbol first; its bytes collect in a per-lane LDS ring
+// ring[dword][lane] and leave as 64-byte units (four 16-byte stores back to back), the rest narrow.
+__global__ void __launch_bounds__(256) huf0_encode_kernel(const uint8_t* __restrict__ dense, const uint64_t* __restrict__ offsets,
+                                                          const uint32_t* __restrict__ sizes, uint64_t nchunks,
+                                                          const uint8_t* __restrict__ recs, const uint64_t* __restrict__ meta,
+                                                          uint8_t* __restrict__ out, const uint64_t* __restrict__ boffs)
+{
+    __shared__ uint32_t ring[32 * 256];
+    __shared__ uint32_t tab[256];                        // val | len << 16
+    __shared__ uint8_t hdr[160];
+    const int t = threadIdx.x, j = t & 3;
+    const uint64_t seg = blockIdx.x, c = seg * SEG + (uint64_t)(t >> 2);
+    const uint8_t* const rec = recs + seg * kRecBytes;
+    const uint32_t hlen = ((const uint32_t*)rec)[0];
+    tab[t] = (uint32_t)((const uint16_t*)(rec + kRecTab))[t] | ((uint32_t)rec[kRecTab + 512 + t] << 16);
+    if (t < 160) hdr[t] = rec[kRecHdr + t];
+    __syncthreads();
+    if (c >= nchunks) return;
+    const uint32_t n = sizes[c];
+    const uint8_t* const s = dense + offsets[c];
+    uint8_t* const o = out + boffs[c];
+    const uint64_t m = meta[c];
+    const uint32_t mode = (uint32_t)(m >> 48);
+    if (mode == 0) return;
+    if (mode == 2) { if (j == 0) o[0] = s[0]; return; }
+    if (mode == 1) {                                      // stored: 16-byte pieces over the quad, then the odd bytes
+        uint32_t k = (uint32_t)j * 16u;
+        for (; k + 16 <= n; k += 64) *(u32x4_a1*)(o + k) = *(const u32x4_a1*)(s + k);
+        for (uint32_t r = (n & ~15u) + (uint32_t)j; r < n; r += 4) o[r] = s[r];
+        return;
+    }
+    const uint32_t b0 = (uint32_t)(m & 0xffffu), b1 = (uint32_t)((m >> 16) & 0xffffu), b2 = (uint32_t)((m >> 32) & 0xffffu);
+    for (uint32_t k = (uint32_t)j; k < hlen; k += 4) o[k] = hdr[k];
+    if (j == 0) {
+        uint8_t* const jt = o + hlen;
+        jt[0] = (uint8_t)b0; jt[1] = (uint8_t)(b0 >> 8); jt[2] = (uint8_t)b1; jt[3] = (uint8_t)(b1 >> 8); jt[4] = (uint8_t)b2; jt[5] = (uint8_t)(b2 >> 8);
+    }
+    uint8_t* const so = o + hlen + 6 + (j > 0 ? b0 : 0u) + (j > 1 ? b1 : 0u) + (j > 2 ? b2 : 0u);
+    uint32_t k0, k1;
+    sub_range(n, j, k0, k1);
+    if (j == 3) k1 = n;
+    uint32_t* const my = ring + t;
+    uint64_t acc = 0;
+    uint32_t nbits = 0, wd = 0, fd = 0;                   // dwords appended to / flushed from the ring
+    auto put = [&](uint32_t sym) {
+        const uint32_t e = tab[sym];
+        acc |= (uint64_t)(e & 0xffffu) << nbits;
+        nbits += e >> 16;
+    };
+    auto drain = [&]() {                                  // whole dwords of the accumulator -> ring; whole 64-byte units -> HBM
+        if (nbits >= 32) {
+            my[(wd & 31u) << 8] = (uint32_t)acc;
+            wd++;
+            acc >>= 32;
+            nbits -= 32;
+            if (wd - fd >= 16) {
+                const uint32_t d0 = fd & 31u;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const u32x4 p = {my[(d0 + 4 * q) << 8], my[(d0 + 4 * q + 1) << 8], my[(d0 + 4 * q + 2) << 8], my[(d0 + 4 * q + 3) << 8]};
+                    *(u32x4_a1*)(so + 4u * fd + 16u * q) = p;
+                }
+                fd += 16;
+            }
+        }
+    };
+    // the ragged end first, byte by byte, then 16 source bytes per load (last symbol first)
+    uint32_t k = k1;
+    const uint32_t r = (k1 - k0) & 15u;
+    for (uint32_t i = 0; i < r; i++) { put(s[--k]); drain(); }
+    while (k > k0) {
+        k -= 16;
+        const u32x4 x = *(const u32x4_a1*)(s + k);
+#pragma unroll
+        for (int d = 3; d >= 0; d--) {
+            const uint32_t v = d == 0 ? x.x : d == 1 ? x.y : d == 2 ? x.z : x.w;
+            put(v >> 24); put((v >> 16) & 255u); drain();
+            put((v >> 8) & 255u); put(v & 255u); drain();
+        }
+    }
+    acc |= 1ull << nbits;                                 // the closing 1 bit (BIT_closeCStream)
+    nbits += 1;
+    drain();
+    // what is left: ring dwords [fd, wd), then the accumulator's bytes
+    for (; fd < wd; fd++) *(u32_any*)(so + 4u * fd) = my[(fd & 31u) << 8];
+    uint8_t* tail = so + 4u * wd;
+    for (uint32_t b = 0; b < nbits; b += 8) *tail++ = (uint8_t)(acc >> b);
+}

@@ -101,6 +101,18 @@ class Oracle:
                             offs.ctypes.data, sizes.ctypes.data)
         return dense[:total].copy(), offs, sizes
 
+    def huf0_compress(self, dense, offsets, sizes):
+        """the Huff0-format writer's specification (oracle_huf0_compress_batch): -> (blocks, block_offsets[n+1])"""
+        f = _bind(self.lib, "oracle_huf0_compress_batch", C.c_uint64, [C.c_void_p] * 3 + [C.c_uint64] + [C.c_void_p] * 2)
+        dense = np.ascontiguousarray(dense, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
+        n = len(sizes)
+        out = np.zeros(int(sizes.astype(np.int64).sum()) + 64, np.uint8)
+        oo = np.zeros(n + 1, np.uint64)
+        total = f(dense.ctypes.data, offsets.ctypes.data, sizes.ctypes.data, n, out.ctypes.data, oo.ctypes.data)
+        return out[:total].copy(), oo
+
     def huf0_table_log(self, block):
         """table log of a coded Huff0 block's tree description (oracle_huf0_read_stats)"""
         f = _bind(self.lib, "oracle_huf0_read_stats", C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t])

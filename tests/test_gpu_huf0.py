@@ -111,3 +111,32 @@ def test_many_chunks(sz, golden_huf0):
     want = torch.from_numpy(np.concatenate(plains)).cuda()
     assert torch.equal(out[: want.numel()], want)
     assert torch.equal(rets.cpu(), torch.tensor([p.size for p in plains], dtype=torch.int64))
+
+
+@pytest.mark.parametrize("codec,esz,ndims,nchunks", [("xff", 2, 8, 333), ("delta", 1, 1, 200), ("delta", 1, 80, 130), ("xff", 2, 2, 65)])
+def test_writer_matches_its_specification(sz, oracle, codec, esz, ndims, nchunks):
+    """huf0_compress_batch writes oracle_huf0_compress_batch's bytes; the blocks decode (GPU and oracle) to the streams"""
+    import torch
+    from harness import gen_walk, gen_fuzz
+    rng = np.random.default_rng(nchunks)
+    chunk_len = 5120
+    data = np.concatenate([gen_walk(rng, (nchunks - 20) * chunk_len, ndims, esz, 8, flat_every=4), gen_fuzz(rng, 10 * chunk_len, esz, 0),
+                           np.zeros(10 * chunk_len - 7, DTYPES[esz])])
+    cd = sz.ChunkedCodec(codec, esz, ndims, chunk_len, device="cuda:0")
+    batch = cd.compress(torch.from_numpy(data).cuda())
+    blocks, bo = sz.huf0_compress(batch)
+    want, wo = oracle.huf0_compress(batch.data.cpu().numpy(), batch.offsets.cpu().numpy().astype(np.uint64), batch.sizes.cpu().numpy())
+    bo_h = bo.cpu().numpy()
+    assert np.array_equal(bo_h.astype(np.uint64), wo)
+    assert np.array_equal(blocks[: int(bo_h[-1])].cpu().numpy(), want)
+    # back through the GPU decoder into a byte-dense container, then to samples
+    sizes = batch.sizes.cpu().numpy().astype(np.int64)
+    oo = np.zeros(nchunks + 1, np.int64)
+    oo[1:] = np.cumsum(sizes)
+    oo_d = torch.from_numpy(oo).cuda()
+    rets = torch.empty(nchunks, dtype=torch.int64, device="cuda")
+    streams = sz.huf0_decompress(blocks, bo, oo_d, rets=rets)
+    assert np.array_equal(rets.cpu().numpy(), sizes)
+    out = torch.empty(nchunks * chunk_len, dtype=torch.uint8 if esz == 1 else torch.uint16, device="cuda")
+    cd.decompress_into(streams, oo_d, nchunks, out)
+    assert np.array_equal(out.cpu().numpy().view(DTYPES[esz])[: data.size], data)

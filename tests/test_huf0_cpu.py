@@ -59,3 +59,41 @@ def test_oracle_rejects_damaged_blocks(oracle, golden_huf0):
             assert ret == plain.size or ret < 0
             rejected += ret < 0
     assert rejected > 50
+
+
+def _streams(oracle, rng):
+    out = []
+    for esz, D, codec in ((2, 8, "xff"), (1, 1, "delta"), (1, 80, "delta")):
+        data = gen_walk(rng, 70 * 5120, D, esz, 8, flat_every=4)
+        out += [np.ascontiguousarray(s) for s in oracle.compress_chunks(codec, data, 5120, D)]
+    for n in (0, 1, 5, 11, 12, 13, 100, 1000, 5000, 70000):
+        for k in (1, 2, 3, 17, 129, 256):
+            p = 1.0 / np.arange(1, k + 1) ** 1.3
+            out.append(rng.choice(k, n, p=p / p.sum()).astype(np.uint8))
+    return out
+
+
+def test_writer_blocks_are_read_by_libzstd(oracle):
+    """what oracle_huf0_compress_batch (the writer's specification) emits is Huff0 to the library"""
+    try:
+        z = Zstd()
+    except (OSError, AttributeError):
+        pytest.skip("no libzstd with the HUF_* exports on this machine")
+    rng = np.random.default_rng(21)
+    streams = _streams(oracle, rng)
+    sizes = np.array([s.size for s in streams], np.uint32)
+    offs = np.zeros(len(streams) + 1, np.uint64)
+    offs[1:] = np.cumsum(sizes)
+    blocks, bo = oracle.huf0_compress(np.concatenate(streams + [np.zeros(8, np.uint8)]), offs, sizes)
+    coded = 0
+    for c, s in enumerate(streams):
+        blk = blocks[int(bo[c]):int(bo[c + 1])]
+        assert blk.size <= s.size
+        if 1 < blk.size < s.size:
+            back, r = z.huf_decompress(blk, s.size)
+            assert r == s.size and np.array_equal(back, s), c
+            coded += 1
+        ours, ro = oracle.huf0_decompress(blk, s.size) if s.size else (s, 0)
+        assert ro == s.size and np.array_equal(ours, s), c
+    assert coded > 150
+    assert blocks.size < 0.97 * sizes.sum()
