@@ -78,9 +78,22 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
 
+    raw_bytes = a.chunks * chunk_len * 2
     t_h = timeit(lambda: sprintz_amd.huf0_decompress(d, bo_d, oo_d, out=streams))
     t_s = timeit(lambda: cd.decompress_into(streams, oo_d, a.chunks, raw))
     raw_bytes = a.chunks * chunk_len * 2
+    # the GPU writer on the same container (tiled like the blocks above)
+    big = cd.compress(x.repeat(reps)[: a.chunks * chunk_len])
+    gb, gbo = sprintz_amd.huf0_compress(big)
+    t_w = timeit(lambda: sprintz_amd.huf0_compress(big), reps=5)
+    gtotal = int(gbo[-1].item())
+    goo = torch.zeros(a.chunks + 1, dtype=torch.int64, device=dev)
+    goo[1:] = torch.cumsum(big.sizes.to(torch.int64), 0)
+    gst = sprintz_amd.huf0_decompress(gb, gbo, goo, rets=rets)
+    assert bool((rets == big.sizes.to(torch.int64)).all())
+    t_gd = timeit(lambda: sprintz_amd.huf0_decompress(gb, gbo, goo, out=gst))
+    print(f"GPU writer: {t_w:.3f} ms = {int(goo[-1].item())/t_w/1e6:.0f} GB/s of stream bytes in, ratio {raw_bytes/gtotal:.3f}; "
+          f"its blocks decode in {t_gd:.3f} ms")
     print(f"chunks {a.chunks}  raw {raw_bytes/1e6:.0f} MB  sprintz {oo_dense[-1]/1e6:.0f} MB  huff0 {bo[-1]/1e6:.0f} MB  "
           f"ratio {raw_bytes/bo[-1]:.3f} (sprintz alone {raw_bytes/oo_dense[-1]:.3f})")
     print(f"libzstd HUF_compress on 1 host thread: {sizes.sum()/cpu_s/1e6:.0f} MB/s of stream bytes")
