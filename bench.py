@@ -259,6 +259,33 @@ def main():
     huf_bytes = sum_over_ranks(hb.total_bytes(), device)
     del h_buf, d_buf
 
+    # ---------------- the same stage in Huff0's wire format (the paper's coder; pinned against libzstd)
+    z_buf = torch.zeros(int(_lib.huf0_bound(total_comp, nchunks)), dtype=torch.uint8, device=device)
+    z_offs = torch.empty(nchunks + 1, dtype=torch.int64, device=device)
+    z_tmp = torch.empty(int(_lib.huf0_tmp_bytes(nchunks)), dtype=torch.uint8, device=device)
+    s_offs = torch.zeros(nchunks + 1, dtype=torch.int64, device=device)          # byte-dense stream starts
+    s_offs[1:] = torch.cumsum(ws["sizes"].to(torch.int64), 0)
+    s_buf = torch.zeros(total_comp + _lib.READ_SLACK, dtype=torch.uint8, device=device)
+    z_rets = torch.empty(nchunks, dtype=torch.int64, device=device)
+
+    def huf0_enc():
+        _lib.check(_lib.huf0_compress_batch(comp.data_ptr(), offsets.data_ptr(), ws["sizes"].data_ptr(), nchunks, z_buf.data_ptr(),
+                                            z_offs.data_ptr(), z_tmp.data_ptr(), st))
+
+    def huf0_dec():
+        _lib.check(_lib.huf0_decompress_batch(z_buf.data_ptr(), z_offs.data_ptr(), nchunks, s_buf.data_ptr(), s_offs.data_ptr(),
+                                              z_rets.data_ptr(), st))
+
+    huf0_enc_ms = timed(huf0_enc)
+    huf0_dec_ms = timed(huf0_dec)
+    if not args.no_verify:
+        assert torch.equal(z_rets, ws["sizes"].to(torch.int64)), "Huff0 decode: a block was rejected"
+        codec.decompress_into(s_buf, s_offs, nchunks, out)
+        torch.cuda.synchronize()
+        assert torch.equal(out, x), "Huff0 -> Sprintz decode != input"
+    huf0_bytes = sum_over_ranks(int(z_offs[-1].item()), device)
+    del z_buf, s_buf
+
     # ---------------- query on compressed data: per-column sum fused into the decode
     q_part = torch.empty((nchunks, ndims), dtype=torch.int64, device=device)
     q_res = torch.empty(ndims, dtype=torch.int64, device=device)
@@ -311,6 +338,10 @@ def main():
         "huffman_stage": {"ratio": round(total_raw / huf_bytes, 4), "encode_ms": round(huf_enc_ms, 3),
                           "decode_ms": round(huf_dec_ms, 3),
                           "chain_decompress_MBps": round(nchunks * chunk_bytes / ((huf_dec_ms + wall / args.steps * 1e3) * 1e-3) / 1e6, 1), "parity": "unpinned (no Huffman coder in the reference tree)"},
+        "huff0_wire_format": {"ratio": round(total_raw / huf0_bytes, 4), "encode_ms": round(huf0_enc_ms, 3),
+                              "decode_ms": round(huf0_dec_ms, 3),
+                              "chain_decompress_MBps": round(nchunks * chunk_bytes / ((huf0_dec_ms + wall / args.steps * 1e3) * 1e-3) / 1e6, 1),
+                              "parity": "reader pinned against libzstd 1.4.8 HUF_compress blocks; writer's blocks read by its HUF_decompress"},
         "query_on_compressed": {"op": "sum", "reduce_only_ms": round(query_ms, 3),
                                 "reduce_only_MBps": round(nchunks * chunk_bytes / (query_ms * 1e-3) / 1e6, 1),
                                 "materialize_ms": round(query_mat_ms, 3)},
