@@ -140,3 +140,54 @@ def test_writer_matches_its_specification(sz, oracle, codec, esz, ndims, nchunks
     out = torch.empty(nchunks * chunk_len, dtype=torch.uint8 if esz == 1 else torch.uint16, device="cuda")
     cd.decompress_into(streams, oo_d, nchunks, out)
     assert np.array_equal(out.cpu().numpy().view(DTYPES[esz])[: data.size], data)
+
+
+def test_writer_edge_chunks(sz, oracle):
+    """any byte container goes in: empty, 1-byte, 11/12/13-byte chunks, one repeated byte, incompressible
+    noise, streams too long for the 16-bit jump table (stored), a chunk count that is not a multiple of 64"""
+    import torch
+    from sprintz_amd import _lib
+    rng = np.random.default_rng(77)
+    chunks = []
+    for n in (0, 1, 2, 11, 12, 13, 40, 300, 4096, 70000, 300000):
+        for k in (1, 2, 5, 60, 256):
+            p = 1.0 / np.arange(1, k + 1) ** 1.5
+            chunks.append(rng.choice(k, n, p=p / p.sum()).astype(np.uint8))
+    chunks.append(rng.integers(0, 256, 5000).astype(np.uint8))
+    chunks.append(np.full(9000, 7, np.uint8))
+    order = rng.permutation(len(chunks))
+    chunks = [chunks[i] for i in order] * 3                                   # 171 chunks: 2 full segments + a partial one
+    n = len(chunks)
+    sizes = np.array([c.size for c in chunks], np.uint32)
+    offs = np.zeros(n + 1, np.uint64)
+    offs[1:] = np.cumsum((sizes.astype(np.int64) + 15) & ~15)               # 16-byte aligned starts, like the codec's container
+    dense = np.zeros(int(offs[-1]) + 16, np.uint8)
+    for c, o in zip(chunks, offs[:-1]):
+        dense[int(o):int(o) + c.size] = c
+    want, wo = oracle.huf0_compress(dense, offs, sizes)
+    d_dense = torch.from_numpy(dense).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    d_sizes = torch.from_numpy(sizes.view(np.int32)).cuda()
+    blocks = torch.full((int(_lib.huf0_bound(int(sizes.sum()), n)) + 64,), 0xEE, dtype=torch.uint8, device="cuda")
+    bo = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    tmp = torch.empty(int(_lib.huf0_tmp_bytes(n)), dtype=torch.uint8, device="cuda")
+    _lib.check(_lib.huf0_compress_batch(d_dense.data_ptr(), d_offs.data_ptr(), d_sizes.data_ptr(), n, blocks.data_ptr(), bo.data_ptr(),
+                                        tmp.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert np.array_equal(bo.cpu().numpy().astype(np.uint64), wo)
+    got = blocks.cpu().numpy()
+    assert np.array_equal(got[: want.size], want)
+    assert (got[want.size:] == 0xEE).all()                                    # nothing written past the last block
+    kinds = {"stored": 0, "one": 0, "coded": 0}
+    for c in range(n):
+        b = int(wo[c + 1] - wo[c])
+        if sizes[c]:
+            kinds["stored" if b == sizes[c] else "one" if b == 1 else "coded"] += 1
+    assert min(kinds.values()) > 5, kinds
+    # and back
+    oo = np.zeros(n + 1, np.int64)
+    oo[1:] = np.cumsum(sizes.astype(np.int64))
+    rets = torch.empty(n, dtype=torch.int64, device="cuda")
+    out = sz.huf0_decompress(blocks, bo, torch.from_numpy(oo).cuda(), rets=rets).cpu().numpy()
+    assert np.array_equal(rets.cpu().numpy(), sizes.astype(np.int64))
+    assert np.array_equal(out[: oo[-1]], np.concatenate(chunks))
