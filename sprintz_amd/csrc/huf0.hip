@@ -233,7 +233,12 @@ __global__ void __launch_bounds__(64) huf0_decode_kernel(const uint8_t* __restri
 
     // ---- phase A: tree description -> weights (first lane of the quad)
     const uint32_t hcopy = mode == 3 ? (uint32_t)(csize < 129 ? csize : 129) : 0u;
-    for (uint32_t k = (uint32_t)j; k < 144u; k += 4) scratch[k] = k < hcopy ? src[k] : (uint8_t)0;
+    for (uint32_t k = 4u * (uint32_t)j; k < 144u; k += 16) {     // a dword per lane per trip (byte loads cost the address path as much)
+        uint32_t v = 0;
+        if (k + 4 <= hcopy) v = *(const u32_a1*)(src + k);
+        else for (uint32_t b = 0; b < 4 && k + b < hcopy; b++) v |= (uint32_t)src[k + b] << (8 * b);
+        *(uint32_t*)(scratch + k) = v;
+    }
     wave_sync();
     uint32_t hl = 0, nsym = 0, tl = 0;
     if (mode == 3 && j == 0) {
