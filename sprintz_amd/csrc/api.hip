@@ -312,8 +312,8 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
         return 0;
     }
     // univariate streams: one lane per chunk, LDS ring in, quad-transposed 64-byte bursts out (decode_uni.h)
-    // (and the 2- and 4-column low-dim shapes; 3 columns, 24-byte blocks, stay on the generic kernel)
-    if (lowdim && (D == 1 || D == 2 || (D == 4 && esz == 1)) && !noheader && qs.q == kQueryOff && !cs && !getenv("SPRINTZ_MI355X_NO_FAST")) {
+    // (and the other low-dim shapes: 2 columns, 3 and 4 at 8 bits)
+    if (lowdim && (D <= 2 || esz == 1) && !noheader && qs.q == kQueryOff && !cs && !getenv("SPRINTZ_MI355X_NO_FAST")) {
         const uint64_t ugrid = (nchunks + 255) / 256;
         if (ugrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
         e = esz == 1 ? launch_decode_uni_w8(codec == SPRINTZ_CODEC_XFF, D, (unsigned)ugrid, st, a)
@@ -385,8 +385,8 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
         return 0;
     }
     // univariate streams: one lane per chunk, quad-loaded 64-byte input windows, 64-byte output units (encode_uni.h)
-    // (and the 2- and 4-column low-dim shapes)
-    if (lowdim && (D == 1 || D == 2 || (D == 4 && esz == 1)) && !col_stride && !getenv("SPRINTZ_MI355X_NO_FAST")) {
+    // (and the other low-dim shapes: 2 columns, 3 and 4 at 8 bits)
+    if (lowdim && (D <= 2 || esz == 1) && !col_stride && !getenv("SPRINTZ_MI355X_NO_FAST")) {
         const uint64_t ugrid = (nchunks + 255) / 256;
         if (ugrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
         e = esz == 1 ? launch_encode_uni_w8(codec == SPRINTZ_CODEC_XFF, D, (unsigned)ugrid, st, a)

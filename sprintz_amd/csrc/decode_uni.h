@@ -1,5 +1,5 @@
 // decode_uni.h -- batched decoder for the LOW-DIM layout (sprintz_delta_lowdim.cpp:398-794 /
-// sprintz_xff_lowdim.cpp:414-1119) with ND = 1, 2 or 4 columns (8 bits) / 1 or 2 (16 bits): the
+// sprintz_xff_lowdim.cpp:414-1119) with ND = 1 .. 4 columns (8 bits) / 1 or 2 (16 bits): the
 // univariate streams of the paper's UCR archive and their few-column neighbours.  One lane per
 // chunk (it carries all ND columns' predictor state).
 //
@@ -25,15 +25,16 @@ __global__ void __launch_bounds__(256) decode_uni_kernel(DecodeArgs a)
     constexpr int HB = Elem<W>::HB;
     constexpr int ESZ = W / 8;
     constexpr uint32_t MASK = Elem<W>::MASK;
-    constexpr int BW = 64 / (8 * ESZ * ND);                // blocks per 64-byte window: 8 .. 2
     constexpr int BD = 2 * ESZ * ND;                       // dwords per block
+    constexpr int WINS = (64 % (4 * BD) == 0) ? 1 : 3;     // 64-byte windows that hold a whole number of blocks (3 columns: 24-byte blocks)
+    constexpr int BW = 16 * WINS / BD;                     // blocks per such span: 8 .. 2
     constexpr int HBYTES = (2 * ND * HB + 7) / 8;          // group header: 2 slots x ND fields of HB bits
     constexpr uint32_t STEPMAX = HBYTES + 2 + ND * W;      // most bytes one step takes: header + run length / payload
     // ring pieces of 64 bytes: a piece requested in one step is usable in the next, and a step that starts
     // up to STEPMAX - 1 bytes into a piece must not need the piece after the next resident one
-    constexpr int RP = (2 * STEPMAX + 4 <= 64) ? 2 : 4;    // pieces in the ring (128 or 256 bytes per lane)
+    constexpr int RP = (2 * STEPMAX + HBYTES + 6 <= 64) ? 2 : 4;   // pieces in the ring (128 or 256 bytes per lane)
     constexpr uint32_t RDW = RP * 16;                      // ring dwords
-    static_assert(BW * BD == 16 && BW >= 1, "a window is 64 bytes");
+    static_assert(BW * BD == 16 * WINS && BW >= 1, "whole blocks per span of windows");
     typedef uint32_t v4 __attribute__((ext_vector_type(4)));
     typedef v4 __attribute__((aligned(1), may_alias)) v4a1;
     typedef uint32_t v2 __attribute__((ext_vector_type(2)));
@@ -118,7 +119,7 @@ __global__ void __launch_bounds__(256) decode_uni_kernel(DecodeArgs a)
     const uint32_t part = (uint32_t)t & 3u;
 
     for (;;) {
-        uint32_t win[BW][BD];                              // the 64-byte window: block b at compile-time position b
+        uint32_t win[BW][BD];                              // the span of 64-byte windows: block b at compile-time position b
         uint32_t valid = 0;                                // bit b: block b of the window was produced
         const uint32_t win_elems = out_elems;              // output position of the window's first block
         bool wave_done = false;
@@ -214,11 +215,13 @@ __global__ void __launch_bounds__(256) decode_uni_kernel(DecodeArgs a)
         // butterfly stages: (member m, piece k) -> (lane k, slot m)) and stores one member's 64
         // bytes per instruction.  A partly filled window (the chunk's end) is stored block by block.
         const bool full = valid == (1u << BW) - 1u;
+#pragma unroll
+        for (int wn = 0; wn < WINS; wn++) {
         uint32_t v[4][4];
 #pragma unroll
         for (int k = 0; k < 4; k++)
 #pragma unroll
-            for (int d = 0; d < 4; d++) v[k][d] = win[(4 * k + d) / BD][(4 * k + d) % BD];
+            for (int d = 0; d < 4; d++) v[k][d] = win[(16 * wn + 4 * k + d) / BD][(16 * wn + 4 * k + d) % BD];
 #pragma unroll
         for (int k = 0; k < 4; k += 2)
 #pragma unroll
@@ -235,7 +238,7 @@ __global__ void __launch_bounds__(256) decode_uni_kernel(DecodeArgs a)
                 const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
                 if (odd2) v[k][d] = recv; else v[k + 2][d] = recv;
             }
-        const uint64_t mine = full ? (uint64_t)(uintptr_t)(obase + (uint64_t)win_elems * ESZ) : 0ull;
+        const uint64_t mine = full ? (uint64_t)(uintptr_t)(obase + (uint64_t)win_elems * ESZ + 64u * wn) : 0ull;
         const int mlo = (int)(uint32_t)mine, mhi = (int)(uint32_t)(mine >> 32);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -250,13 +253,17 @@ __global__ void __launch_bounds__(256) decode_uni_kernel(DecodeArgs a)
                 *(v4a1*)(uintptr_t)(dst + 16u * part) = piece;
             }
         }
+        }
         if (!full && valid) {
             uint8_t* d = obase + (uint64_t)win_elems * ESZ;
 #pragma unroll
             for (int b = 0; b < BW; b++) {
                 if ((valid >> b) & 1u) {                   // blocks are produced in order: the valid ones are a prefix
                     if constexpr (BD == 2) { v2 p = {win[b][0], win[b][1]}; *(v2a1*)(d + 8 * b) = p; }
-                    else {
+                    else if constexpr (BD % 4 != 0) {
+#pragma unroll
+                        for (int j = 0; j < BD; j += 2) { v2 p = {win[b][j], win[b][j + 1]}; *(v2a1*)(d + 4 * BD * b + 4 * j) = p; }
+                    } else {
 #pragma unroll
                         for (int j = 0; j < BD; j += 4) { v4 p = {win[b][j], win[b][j + 1], win[b][j + 2], win[b][j + 3]}; *(v4a1*)(d + 4 * BD * b + 4 * j) = p; }
                     }

@@ -20,6 +20,10 @@ hipError_t launch_decode_uni_w8(bool fire, int nd, unsigned grid, hipStream_t st
             if (fire) hipLaunchKernelGGL((decode_uni_kernel<8, true, 2>), dim3(grid), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((decode_uni_kernel<8, false, 2>), dim3(grid), dim3(256), 0, st, a);
             break;
+        case 3:
+            if (fire) hipLaunchKernelGGL((decode_uni_kernel<8, true, 3>), dim3(grid), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((decode_uni_kernel<8, false, 3>), dim3(grid), dim3(256), 0, st, a);
+            break;
         case 4:
             if (fire) hipLaunchKernelGGL((decode_uni_kernel<8, true, 4>), dim3(grid), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((decode_uni_kernel<8, false, 4>), dim3(grid), dim3(256), 0, st, a);

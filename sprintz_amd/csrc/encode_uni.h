@@ -1,5 +1,5 @@
 // encode_uni.h -- batched encoder for the LOW-DIM layout (sprintz_delta_lowdim.cpp:39-384 /
-// sprintz_xff_lowdim.cpp:44-400) with ND = 1, 2 or 4 columns (8 bits) / 1 or 2 (16 bits).  One lane
+// sprintz_xff_lowdim.cpp:44-400) with ND = 1 .. 4 columns (8 bits) / 1 or 2 (16 bits).  One lane
 // per chunk; same stream bytes as encode_kernel.h, which it follows step for step (the RLE state
 // machine of SURVEY.md A.5 included).
 //
@@ -24,12 +24,14 @@ __global__ void __launch_bounds__(256) encode_uni_kernel(EncodeArgs a)
 {
     constexpr int HB = Elem<W>::HB;
     constexpr int ESZ = W / 8;
-    constexpr int BW = 64 / (8 * ESZ * ND);                // blocks per 64-byte input window: 8 .. 2
+    constexpr int BB = 8 * ESZ * ND;                       // bytes per block
+    constexpr int WINS = (64 % BB == 0) ? 1 : 3;           // 64-byte input windows that hold a whole number of blocks (3 columns: 24-byte blocks)
+    constexpr int BW = 64 * WINS / BB;                     // blocks per such span: 8 .. 2
     constexpr int HBYTES = (2 * ND * HB + 7) / 8;          // group header: 2 slots x ND fields of HB bits
     constexpr uint32_t GROUPMAX = HBYTES + 2 * ND * W + 4; // most bytes between two flushes: header, two blocks, close-out
     constexpr uint32_t RDW = (63 + GROUPMAX <= 128) ? 32 : 64;   // ring dwords per lane (128 or 256 bytes)
     constexpr uint32_t RM = RDW - 1;
-    static_assert(BW >= 1 && BW * 8 * ESZ * ND == 64, "a window is 64 bytes");
+    static_assert(BW >= 1 && BW * BB == 64 * WINS, "whole blocks per span of windows");
     typedef uint32_t v4 __attribute__((ext_vector_type(4)));
     typedef v4 __attribute__((aligned(1), may_alias)) v4a1;
 
@@ -115,28 +117,33 @@ __global__ void __launch_bounds__(256) encode_uni_kernel(EncodeArgs a)
         if (q == 2) return (uint32_t)__builtin_amdgcn_mov_dpp(x, 0xAA, 0xf, 0xf, true);
         return (uint32_t)__builtin_amdgcn_mov_dpp(x, 0xFF, 0xf, 0xf, true);
     };
-    uint32_t nxt[4][4];
-    auto load_window = [&](uint32_t wi) {                                // nxt[q] = part `part` of member q's window wi
+    uint32_t nxt[WINS][4][4];
+    auto load_window = [&](uint32_t wi) {                                // nxt[.][q] = part `part` of member q's windows WINS*wi ..
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint64_t base = ((uint64_t)bcast(sahi, q) << 32) | bcast(salo, q);
-            const uint32_t nb_q = bcast((int)nbytes, q);
-            const uint32_t o = wi * 64u + part * 16u;
-            v4 x = {0, 0, 0, 0};
-            if (o < nb_q) x = *(const v4a1*)(uintptr_t)(base + o);       // may run <= 15 bytes past the chunk (READ_SLACK)
-            nxt[q][0] = x.x; nxt[q][1] = x.y; nxt[q][2] = x.z; nxt[q][3] = x.w;
-        }
+        for (int wn = 0; wn < WINS; wn++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint64_t base = ((uint64_t)bcast(sahi, q) << 32) | bcast(salo, q);
+                const uint32_t nb_q = bcast((int)nbytes, q);
+                const uint32_t o = (wi * WINS + wn) * 64u + part * 16u;
+                v4 x = {0, 0, 0, 0};
+                if (o < nb_q) x = *(const v4a1*)(uintptr_t)(base + o);   // may run <= 15 bytes past the chunk (READ_SLACK)
+                nxt[wn][q][0] = x.x; nxt[wn][q][1] = x.y; nxt[wn][q][2] = x.z; nxt[wn][q][3] = x.w;
+            }
     };
     load_window(0);
 
     for (uint32_t wi = 0;; wi++) {
         if (__ballot(active) == 0) break;
         // (member m, piece k) -> (lane k, slot m): two DPP butterfly stages, then this lane owns its window
-        uint32_t v[4][4];
+        uint32_t vv[WINS][4][4];
+#pragma unroll
+        for (int wn = 0; wn < WINS; wn++) {
+        uint32_t (&v)[4][4] = vv[wn];
 #pragma unroll
         for (int q = 0; q < 4; q++)
 #pragma unroll
-            for (int d = 0; d < 4; d++) v[q][d] = nxt[q][d];
+            for (int d = 0; d < 4; d++) v[q][d] = nxt[wn][q][d];
 #pragma unroll
         for (int k = 0; k < 4; k += 2)
 #pragma unroll
@@ -153,6 +160,7 @@ __global__ void __launch_bounds__(256) encode_uni_kernel(EncodeArgs a)
                 const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xf, 0xf, true);
                 if (odd2) v[k][d] = recv; else v[k + 2][d] = recv;
             }
+        }
         load_window(wi + 1);
 
 #pragma unroll
@@ -167,8 +175,8 @@ __global__ void __launch_bounds__(256) encode_uni_kernel(EncodeArgs a)
                 int grad = 0;
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
-                    const int byte = (b * 8 * ND + i * ND + k) * ESZ;        // row-major element (row i, column k) inside the window
-                    const uint32_t x = (v[byte / 16][(byte % 16) / 4] >> (8 * (byte % 4))) & Elem<W>::MASK;
+                    const int byte = (b * 8 * ND + i * ND + k) * ESZ;        // row-major element (row i, column k) inside the span
+                    const uint32_t x = (vv[byte / 64][(byte % 64) / 16][(byte % 16) / 4] >> (8 * (byte % 4))) & Elem<W>::MASK;
                     const int delta = sext<W>((int)(x - pv[k]));
                     const int pred = FIRE ? fire_predict<W, true>(pd[k], coef) : 0;
                     const int err = sext<W>(delta - pred);

@@ -136,6 +136,8 @@ CONFIGS = [
     ("low8_d4", "xff", 1, 4, 4000),
     ("low8_d4_delta_ragged", "delta", 1, 4, 1500),
     ("low16_d2_delta_ragged", "delta", 2, 2, 1002),
+    ("low8_d3_delta", "delta", 1, 3, 3072),      # 24-byte blocks: spans of three 64-byte windows
+    ("low8_d3_xff_ragged", "xff", 1, 3, 1000),
 ]
 
 
@@ -409,7 +411,7 @@ def test_huffman_decoder_survives_damaged_containers(sz):
     assert np.array_equal(r, sizes.astype(np.int64))
 
 
-@pytest.mark.parametrize("name,codec,esz,ndims,chunk_len", [c for c in CONFIGS if c[0] in ("cfg2", "cfg3_10k", "cfg5", "xff8", "cfg1", "uni16_xff", "uni16_delta_ragged", "low8_d2", "low8_d4", "lowdim16", "low16_d2_delta_ragged")])
+@pytest.mark.parametrize("name,codec,esz,ndims,chunk_len", [c for c in CONFIGS if c[0] in ("cfg2", "cfg3_10k", "cfg5", "xff8", "cfg1", "uni16_xff", "uni16_delta_ragged", "low8_d2", "low8_d4", "lowdim16", "low16_d2_delta_ragged", "lowdim8", "low8_d3_delta")])
 def test_generic_kernels_agree_with_the_fast_ones(sz, monkeypatch, name, codec, esz, ndims, chunk_len):
     """SPRINTZ_MI355X_NO_FAST routes the same calls to decode_kernel.h / encode_kernel.h: same bytes, same samples"""
     import torch

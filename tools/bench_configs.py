@@ -67,7 +67,7 @@ def main():
         ("      u16 D=2  xff 8KB (low-dim)", "xff", 2, 2, 4096, "walk8"),
         ("      u8  D=4  xff 4KB (low-dim)", "xff", 1, 4, 4096, "walk2"),
         ("      u8  D=2  delta 2KB (low-dim)", "delta", 1, 2, 2048, "walk2"),
-        ("      u8  D=3  xff 3KB (low-dim, generic kernels)", "xff", 1, 3, 3072, "walk2"),
+        ("      u8  D=3  xff 3KB (low-dim)", "xff", 1, 3, 3072, "walk2"),
     ]
     print("| config | ratio | compress GB/s | decompress GB/s | decode ms |")
     print("|---|---|---|---|---|")
