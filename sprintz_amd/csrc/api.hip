@@ -271,7 +271,7 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
     // (32-bit offsets inside one wavefront's span of the output)
     // and chunks not much shorter than the read-ahead ring (it is filled before the first header is parsed)
     const size_t fring = decode_fast_lds_bytes(8 * esz, fdp, fcpl, D, cs != 0 && fcpl == 1);
-    const bool fast_common = !lowdim && !norle && !noheader && D <= 256 && 2 * D > fdp * fcpl && (uint64_t)chunk_len * esz * 2 >= fring &&
+    const bool fast_common = !lowdim && !a.raw && !noheader && D <= 256 && 2 * D > fdp * fcpl && (uint64_t)chunk_len * esz * 2 >= fring &&
                              !getenv("SPRINTZ_MI355X_NO_FAST");
     // column-major: a lane's 8 samples per block are one aligned 16-byte (8-byte) piece of its column
     const bool fast = cs ? fast_common && qs.q == kQueryOff && cs % 8 == 0 && (chunk_len / (uint32_t)D) % 8 == 0 &&
@@ -306,8 +306,8 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
         const uint64_t fthreads = ngroups_launch * (uint64_t)fdp;
         const uint64_t fgrid = (fthreads + kThreads - 1) / kThreads;
         if (fgrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
-        e = esz == 1 ? launch_decode_fast_w8(codec == SPRINTZ_CODEC_XFF, fdp, fcpl, D == fdp * fcpl, qs.q, (unsigned)fgrid, fstride * fgroups, st, a)
-                     : launch_decode_fast_w16(codec == SPRINTZ_CODEC_XFF, fdp, fcpl, D == fdp * fcpl, qs.q, (unsigned)fgrid, fstride * fgroups, st, a);
+        e = esz == 1 ? launch_decode_fast_w8((codec == SPRINTZ_CODEC_XFF || codec == SPRINTZ_CODEC_XFF_NORLE), fdp, fcpl, D == fdp * fcpl, qs.q, (unsigned)fgrid, fstride * fgroups, st, a)
+                     : launch_decode_fast_w16((codec == SPRINTZ_CODEC_XFF || codec == SPRINTZ_CODEC_XFF_NORLE), fdp, fcpl, D == fdp * fcpl, qs.q, (unsigned)fgrid, fstride * fgroups, st, a);
         if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "decode_fast kernel launch", e);
         return 0;
     }
@@ -366,7 +366,7 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     int fdp = 4;
     while (fdp < D) fdp <<= 1;
     const size_t blk_bytes = (size_t)8 * D * esz;
-    const bool fast_common = !lowdim && !norle && D <= 64 && 2 * D > fdp && ((uintptr_t)d_src % 16) == 0 && !getenv("SPRINTZ_MI355X_NO_FAST");
+    const bool fast_common = !lowdim && !a.raw && D <= 64 && 2 * D > fdp && ((uintptr_t)d_src % 16) == 0 && !getenv("SPRINTZ_MI355X_NO_FAST");
     const bool fast = col_stride ? fast_common && col_stride % 8 == 0 && (chunk_len / (uint32_t)D) % 8 == 0
                                  : fast_common && blk_bytes % 16 == 0 && ((uint64_t)chunk_len * esz) % 16 == 0;
     hipError_t e;
@@ -379,8 +379,8 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
         const uint64_t fthreads = nchunks * (uint64_t)fdp;
         const uint64_t fgrid = (fthreads + kThreads - 1) / kThreads;
         if (fgrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
-        e = esz == 1 ? launch_encode_fast_w8(codec == SPRINTZ_CODEC_XFF, fdp, D == fdp, (unsigned)fgrid, fshmem, st, a)
-                     : launch_encode_fast_w16(codec == SPRINTZ_CODEC_XFF, fdp, D == fdp, (unsigned)fgrid, fshmem, st, a);
+        e = esz == 1 ? launch_encode_fast_w8((codec == SPRINTZ_CODEC_XFF || codec == SPRINTZ_CODEC_XFF_NORLE), fdp, D == fdp, (unsigned)fgrid, fshmem, st, a)
+                     : launch_encode_fast_w16((codec == SPRINTZ_CODEC_XFF || codec == SPRINTZ_CODEC_XFF_NORLE), fdp, D == fdp, (unsigned)fgrid, fshmem, st, a);
         if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "encode_fast kernel launch", e);
         return 0;
     }

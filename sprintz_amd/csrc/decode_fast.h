@@ -503,22 +503,30 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     uint32_t groups_left, remaining;
     {
         const uint32_t w0 = lds_rd32(ring + rofs), w1 = lds_rd32(ring + rofs + 4);
+        uint32_t hbytes = 8, nd_hdr = w1 >> 16;
         groups_left = w0;
         remaining = w1 & 0xffffu;
-        rp += 8;
-        rofs += 8;
+        if (a.norle) {                                     // {u32 len; u16 ndims} / u64 len with ndims in bytes 6..7 (decode_kernel.h)
+            const uint32_t len = w0 <= a.chunk_len ? w0 : 0u;
+            nd_hdr = w0 <= a.chunk_len ? (a.norle == 2 ? w1 >> 16 : w1 & 0xffffu) : 0xffffffffu;
+            hbytes = a.norle == 2 ? 8u : 6u;
+            groups_left = len < 128u ? 0u : len / (16u * (uint32_t)D);
+            remaining = len - groups_left * 16u * (uint32_t)D;
+        }
+        rp += hbytes;
+        rofs += hbytes;
         if (rofs >= RB) rofs -= RB;
-        ahead -= 8;
+        ahead -= hbytes;
 #pragma unroll
         for (int k = 0; k < CPL; k++) { pv[k] = 0; pd[k] = 0; ctr[k] = 0; qmax[k] = 0; qsum[k] = 0; }
         out_left = a.chunk_len;
         ovo = CM ? (uint32_t)((chunk - wave_first) * (uint64_t)rows_per_chunk * ESZ)
                  : (uint32_t)((chunk - wave_first) * (uint64_t)a.chunk_len * ESZ);
-        corrupt = (int)(w1 >> 16) != D;
+        corrupt = (int)nd_hdr != D;
         // a damaged header must not make the loop spin: every group takes at least its
-        // header and two slot bytes out of the stream
+        // header and two slot bytes (none in the run-less codecs) out of the stream
         const uint64_t stream_len = a.offsets[chunk + 1] - off_c;
-        if ((uint64_t)groups_left * (hdr_bytes + 2u) > stream_len || groups_left > a.chunk_len / blk_elems + 2u) corrupt = true;
+        if ((uint64_t)groups_left * (hdr_bytes + (a.norle ? 0u : 2u)) > stream_len || groups_left > a.chunk_len / blk_elems + 2u) corrupt = true;
         if (corrupt) groups_left = 0;
     }
 
@@ -571,9 +579,10 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         const uint32_t at0 = r + hdr_bytes;
         uint32_t len0 = 0, len1 = 0, bytes0, bytes1;
         const uint32_t rb0 = (tot0 + 7u) >> 3, rb1 = (tot1 + 7u) >> 3;
-        if (tot0 == 0) len0 = run_length(at0, bytes0); else bytes0 = rb0 * 8u;
+        // (run-less codecs: an all-zero block has no payload at all and stands for itself)
+        if (tot0 == 0) { if (a.norle) { len0 = 1; bytes0 = 0; } else len0 = run_length(at0, bytes0); } else bytes0 = rb0 * 8u;
         const uint32_t at1 = at0 + bytes0;
-        if (tot1 == 0) len1 = run_length(at1, bytes1); else bytes1 = rb1 * 8u;
+        if (tot1 == 0) { if (a.norle) { len1 = 1; bytes1 = 0; } else len1 = run_length(at1, bytes1); } else bytes1 = rb1 * 8u;
         const uint32_t used = hdr_bytes + bytes0 + bytes1;
         int z0[CPL][8], z1[CPL][8];
         if (tot0 != 0) fetch_rows(z0, at0, off0, nb0, rb0);

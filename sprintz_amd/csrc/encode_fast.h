@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(kThreads) encode_fast_kernel(EncodeArgs a)
     for (uint32_t u = (uint32_t)lane_d; u < (cap >> 4); u += DP) ((uint4*)win)[u] = make_uint4(0, 0, 0, 0);
     wave_lds_sync();
 
-    uint32_t wl = a.write_size ? 8u : 0u;     // write position inside the window (bytes)
+    uint32_t wl = a.norle == 1 ? 6u : ((a.norle == 2 || a.write_size) ? 8u : 0u);   // write position inside the window (bytes)
     uint32_t gpos = 0;                        // stream offset of the window start (multiple of 16)
 
     // whole 16-byte pieces below `upto` (window offset, multiple of 16) -> HBM; re-zero; slide
@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(kThreads) encode_fast_kernel(EncodeArgs a)
 
         // ---- RLE state machine (:350-456); group-uniform
         for (;;) {
-            if (total == 0 && run < 0x7fffu) {
+            if (total == 0 && run < 0x7fffu && !a.norle) {     // (run-less codecs: an all-zero block is two empty header fields)
                 run++;
                 pos_in += blk;
                 bno++;
@@ -347,7 +347,13 @@ __global__ void __launch_bounds__(kThreads) encode_fast_kernel(EncodeArgs a)
     drain((wl + 15u) & ~15u);
 
     if (lane_d == 0) {                                   // format.h:36-45; lane 0 also flushed unit 0
-        if (a.write_size) {
+        if (a.norle == 2) {                                  // u64 len with ndims in its bytes 6..7 (sprintz_xff.cpp:58-63)
+            ((uint32_t*)gdst)[0] = n;
+            ((uint32_t*)gdst)[1] = (uint32_t)D << 16;
+        } else if (a.norle) {                                // {u32 len; u16 ndims} (format.h:65-72); bytes 6.. are stream
+            ((uint32_t*)gdst)[0] = n;
+            ((uint16_t*)gdst)[2] = (uint16_t)D;
+        } else if (a.write_size) {
             ((uint32_t*)gdst)[0] = ngroups;
             ((uint32_t*)gdst)[1] = (remaining & 0xffffu) | ((uint32_t)D << 16);
         }

@@ -64,6 +64,8 @@ def main():
         ("cfg5  u16 D=32 xff 10KB", "xff", 2, 32, 5120, "walk8"),
         ("      u16 D=16 xff 10KB", "xff", 2, 16, 5120, "walk8"),
         ("      u16 D=64 xff 16KB", "xff", 2, 64, 8192, "walk8"),
+        ("      u16 D=8  delta, run-less codec 10KB", "delta_norle", 2, 8, 5120, "walk8"),
+        ("      u8  D=8  xff, run-less codec 8KB", "xff_norle", 1, 8, 8192, "walk2"),
         ("      u16 D=2  xff 8KB (low-dim)", "xff", 2, 2, 4096, "walk8"),
         ("      u8  D=4  xff 4KB (low-dim)", "xff", 1, 4, 4096, "walk2"),
         ("      u8  D=2  delta 2KB (low-dim)", "delta", 1, 2, 2048, "walk2"),
