@@ -153,19 +153,40 @@ __device__ uint32_t read_stats(const uint8_t* h, uint32_t n, uint8_t* weights, u
         uint32_t s1 = back_look(b, P, (int)tl); P -= (int)tl;
         uint32_t s2 = back_look(b, P, (int)tl); P -= (int)tl;
         osize = 0;
+        // the stream's next 64 bits ride in a register, refilled every 8 weights (8 x 6 bits <= the 57 a refill guarantees)
         for (;;) {
-            if (osize + 2 > 255u) return 0;
-            uint32_t e = fse[s1];
-            weights[osize++] = (uint8_t)e;
-            int nbt = (int)((e >> 8) & 0xffu);
-            s1 = (e >> 16) + back_look(b, P, nbt); P -= nbt;
-            if (P < 0) { weights[osize++] = (uint8_t)fse[s2]; break; }
-            if (osize + 2 > 255u) return 0;
-            e = fse[s2];
-            weights[osize++] = (uint8_t)e;
-            nbt = (int)((e >> 8) & 0xffu);
-            s2 = (e >> 16) + back_look(b, P, nbt); P -= nbt;
-            if (P < 0) { weights[osize++] = (uint8_t)fse[s1]; break; }
+            uint64_t win = 0;
+            if (P > 0) {
+                const int tb = (P - 1) >> 3;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int at = tb - 7 + k;
+                    win |= (uint64_t)(at >= 0 ? b[at] : (uint8_t)0) << (8 * k);
+                }
+                win <<= 7 - ((P - 1) & 7);
+                if (P < 64) win &= ~0ull << (64 - P);
+            }
+            bool done = false;
+#pragma unroll
+            for (int r = 0; r < 4 && !done; r++) {
+                if (osize + 2 > 255u) return 0;
+                uint32_t e = fse[s1];
+                weights[osize++] = (uint8_t)e;
+                uint32_t nbt = (e >> 8) & 0xffu;
+                s1 = (e >> 16) + (nbt ? (uint32_t)(win >> (64u - nbt)) : 0u);
+                win <<= nbt;
+                P -= (int)nbt;
+                if (P < 0) { weights[osize++] = (uint8_t)fse[s2]; done = true; break; }
+                if (osize + 2 > 255u) return 0;
+                e = fse[s2];
+                weights[osize++] = (uint8_t)e;
+                nbt = (e >> 8) & 0xffu;
+                s2 = (e >> 16) + (nbt ? (uint32_t)(win >> (64u - nbt)) : 0u);
+                win <<= nbt;
+                P -= (int)nbt;
+                if (P < 0) { weights[osize++] = (uint8_t)fse[s1]; done = true; break; }
+            }
+            if (done) break;
         }
     }
     // weight statistics; the last symbol's weight is implied
