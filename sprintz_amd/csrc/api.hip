@@ -384,6 +384,18 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
         if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "encode_fast kernel launch", e);
         return 0;
     }
+    // 8-bit streams of 65 .. 128 columns (BASELINE config 3): two columns per lane (encode_wide.h)
+    if (!lowdim && !a.raw && !col_stride && esz == 1 && D > 64 && D <= 128 && blk_bytes % 16 == 0 && (uint64_t)chunk_len % 16 == 0 && (uint64_t)chunk_len >= 2 * blk_bytes &&
+        ((uintptr_t)d_src % 16) == 0 && !getenv("SPRINTZ_MI355X_NO_FAST")) {
+        const size_t wgroups = kThreads / 64;
+        a.lds_group_stride = (uint32_t)(a.cap + ((blk_bytes + 15) & ~(size_t)15) + 16);
+        const uint64_t wgrid = (nchunks * 64ull + kThreads - 1) / kThreads;
+        if (wgrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
+        e = launch_encode_wide_w8((codec == SPRINTZ_CODEC_XFF || codec == SPRINTZ_CODEC_XFF_NORLE), D == 128, (unsigned)wgrid,
+                                  (size_t)a.lds_group_stride * wgroups, st, a);
+        if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "encode_wide kernel launch", e);
+        return 0;
+    }
     // univariate streams: one lane per chunk, quad-loaded 64-byte input windows, 64-byte output units (encode_uni.h)
     // (and the other low-dim shapes: 2 columns, 3 and 4 at 8 bits)
     if (lowdim && (D <= 2 || esz == 1) && !col_stride && !getenv("SPRINTZ_MI355X_NO_FAST")) {

@@ -1,0 +1,238 @@
+// encode_wide.h -- encode_fast.h's row-major path with TWO columns per lane, for 8-bit streams of
+// 65 .. 128 columns (BASELINE config 3 has 80): one 64-lane group per chunk, lane l owns columns 2l and
+// 2l + 1.  Same stream bytes as encode_kernel.h (sprintz_xff_rle.cpp:61-555,
+// sprintz_delta_rle.cpp:55-404).  An 8 x D block is at most 1 024 bytes, so the input side is
+// unchanged (one 16-byte piece per lane a block ahead, transposed through LDS); on the output side a
+// lane's two fields are adjacent in the row and are merged in registers for nothing, and a lane pair
+// merges its four (<= 32 bits) with one DPP move, so a quarter of the columns' worth of LDS ORs is
+// issued and same-address collisions shrink accordingly.
+#pragma once
+
+#include "encode_fast.h"
+
+namespace sprintz {
+
+template <bool FIRE, bool EXACT>
+__global__ void __launch_bounds__(kThreads) encode_wide_kernel(EncodeArgs a)
+{
+    constexpr int W = 8, DP = 64, CPL = 2, LOG2DP = 6;
+    using U = uint8_t;
+    constexpr int HB = Elem<W>::HB;
+    constexpr bool TAIL_LE = FIRE;               // "<=" at sprintz_xff_rle.cpp:362, "<" at sprintz_delta_rle.cpp:226
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const int D = EXACT ? DP * CPL : a.D;
+    const uint64_t gtid = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+    const uint64_t chunk = gtid >> LOG2DP;
+    const int lane_d = (int)(threadIdx.x & (uint32_t)(DP - 1));
+    if (chunk >= a.nchunks) return;
+
+    const uint64_t first = chunk * (uint64_t)a.chunk_len;
+    const uint32_t n = (uint32_t)((a.total_len - first < a.chunk_len) ? (a.total_len - first) : a.chunk_len);
+    const U* const sc = (const U*)a.src + first;
+    uint8_t* const gdst = a.slots + chunk * a.slot_stride;
+    const int col0 = lane_d * CPL;
+    bool col_ok[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; k++) col_ok[k] = EXACT ? true : (col0 + k) < D;
+
+    // LDS per group: [linear, zero-initialised output window cap | input block staging] (encode_fast.h)
+    const uint32_t cap = a.cap;
+    uint8_t* const win = smem + (size_t)(threadIdx.x >> LOG2DP) * a.lds_group_stride;
+    uint8_t* const stage = win + cap;
+    const uint32_t win_a = lds_addr(win);
+    for (uint32_t u = (uint32_t)lane_d; u < (cap >> 4); u += DP) ((uint4*)win)[u] = make_uint4(0, 0, 0, 0);
+    wave_lds_sync();
+
+    uint32_t wl = a.norle == 1 ? 6u : ((a.norle == 2 || a.write_size) ? 8u : 0u);
+    uint32_t gpos = 0;
+    auto drain = [&](uint32_t upto) {            // whole 16-byte pieces below `upto` -> HBM; re-zero; slide
+        wave_lds_sync();
+        for (uint32_t u = (uint32_t)lane_d * 16u; u < upto; u += DP * 16) {
+            uint4* r = (uint4*)(win + u);
+            *(uint4*)(gdst + gpos + u) = *r;
+            *r = make_uint4(0, 0, 0, 0);
+        }
+        wave_lds_sync();
+        if (upto != 0 && lane_d == 0 && upto < cap) {
+            const uint4 v = *(uint4*)(win + upto);
+            *(uint4*)(win + upto) = make_uint4(0, 0, 0, 0);
+            *(uint4*)win = v;
+        }
+        gpos += upto;
+        wl -= upto;
+        wave_lds_sync();
+    };
+    auto or_bits = [&](uint32_t bp, uint32_t v, uint32_t nb) {      // low nb (<= 32) bits of v at window bit bp
+        if (nb == 0) return;
+        const uint64_t x = (uint64_t)v << (bp & 31u);
+        __attribute__((address_space(3))) uint32_t* q =
+            (__attribute__((address_space(3))) uint32_t*)(uintptr_t)(win_a + ((bp >> 3) & ~3u));
+        __hip_atomic_fetch_or(q, (uint32_t)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if ((uint32_t)(x >> 32)) __hip_atomic_fetch_or(q + 1, (uint32_t)(x >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    };
+    auto put_run = [&](uint32_t run) {           // sprintz_xff_rle.cpp:377-384
+        if (lane_d == 0) {
+            win[wl] = (uint8_t)((run & 0x7fu) | (run > 0x7fu ? 0x80u : 0u));
+            if (run > 0x7fu) win[wl + 1] = (uint8_t)(run >> 7);
+        }
+        wl += run > 0x7fu ? 2u : 1u;
+    };
+
+    const uint32_t hdr_bytes = (2u * (uint32_t)D * HB + 7u) >> 3;
+    const uint32_t blk = 8u * (uint32_t)D;       // elements = bytes per block
+    const uint32_t lane16 = (uint32_t)lane_d * 16u;
+    const int64_t limit = (int64_t)n - 2 * (int64_t)blk;
+    int64_t pos_in = 0;
+    uint32_t ngroups = 0, run = 0, hdr_pos = 0;
+    int slot = 0;
+    uint32_t pv[CPL];
+    int pd[CPL], ctr[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; k++) { pv[k] = 0; pd[k] = 0; ctr[k] = 0; }
+    auto start_group = [&]() {
+        ngroups++;
+        drain(wl & ~15u);
+        hdr_pos = wl;
+        wl += hdr_bytes;
+        slot = 0;
+    };
+    auto load_block = [&](int64_t pos) -> uint4 {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (lane16 < blk && pos + (int64_t)blk <= (int64_t)n) v = *(const uint4*)(sc + pos + lane16);
+        return v;
+    };
+
+    bool active = n >= 128u && limit >= 0;
+    uint4 nxt = make_uint4(0, 0, 0, 0);
+    if (active) {
+        start_group();
+        nxt = load_block(0);
+    }
+    const uint32_t row_stride = (uint32_t)D;
+
+    while (active) {
+        // ---- the block at pos_in is in `nxt`: transpose it through LDS, request the next one
+        if (lane16 < blk) *(uint4*)(stage + lane16) = nxt;
+        wave_lds_sync();
+        nxt = load_block(pos_in + blk);
+        uint32_t z[CPL][8], nb[CPL], lane_bits = 0;
+#pragma unroll
+        for (int k = 0; k < CPL; k++) {
+            uint32_t x[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) x[i] = col_ok[k] ? (uint32_t)stage[(uint32_t)(col0 + k) + i * row_stride] : 0u;
+            const int coef = FIRE ? fire_coef<W, false>(ctr[k]) : 0;
+            int grad = 0;
+            uint32_t mask = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int delta = sext<W>((int)(x[i] - pv[k]));
+                int err;
+                if constexpr (FIRE) {
+                    const int pred = __builtin_amdgcn_sbfe(mad24(pd[k], coef, 0), W, W);
+                    err = sext<W>(delta - pred);
+                    if (i & 1) grad = mad24(sign_of(err), pd[k], grad);
+                } else {
+                    err = delta;
+                }
+                const uint32_t zz = zigzag<W>(err);
+                mask |= zz;
+                z[k][i] = zz;
+                pv[k] = x[i];
+                pd[k] = delta;
+            }
+            if constexpr (FIRE) ctr[k] = wrap_counter<W>(ctr[k] + __builtin_amdgcn_sbfe(grad, 2, W - 2));
+            nb[k] = col_ok[k] ? nbits_of<W, false>(mask) : 0u;
+            lane_bits += nb[k];
+        }
+        wave_lds_sync();
+        uint32_t total;
+        const uint32_t excl = group_scan<DP>(lane_bits, lane_d, total);
+
+        // ---- RLE state machine (:350-456); group-uniform
+        for (;;) {
+            if (total == 0 && run < 0x7fffu && !a.norle) {
+                run++;
+                pos_in += blk;
+                const bool more = TAIL_LE ? (pos_in <= limit) : (pos_in < limit);
+                if (more) break;
+                slot++;
+                put_run(run);
+                wl += (uint32_t)(2 - slot);
+                run = 0;
+                active = false;
+                break;
+            }
+            if (run > 0) {
+                slot++;
+                put_run(run);
+                run = 0;
+                if (slot == 2) start_group();
+                continue;
+            }
+            {   // header fields: the lane's two, then four lanes' eight = one 24-bit word (:296)
+                uint32_t f = 0;
+#pragma unroll
+                for (int k = 0; k < CPL; k++) f |= (col_ok[k] ? (nb[k] == (uint32_t)W ? (uint32_t)(W - 1) : nb[k]) : 0u) << (k * HB);
+                f |= dpp<DPP_ROW_SHL(1)>(0, f) << (2 * HB);
+                f |= dpp<DPP_ROW_SHL(2)>(0, f) << (4 * HB);
+                if ((lane_d & 3) == 0) or_bits(hdr_pos * 8u + (uint32_t)(slot * D + col0) * HB, f, 8 * HB);
+            }
+            const uint32_t row_bits = ((total + 7u) >> 3) << 3;
+            uint32_t bp = wl * 8u + excl;
+            const uint32_t nb_pair = lane_bits + dpp<DPP_ROW_SHL(1)>(0, lane_bits);   // this lane's and the next one's: 4 fields <= 32 bits
+            const bool even = (lane_d & 1) == 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t mine = z[0][i] | (z[1][i] << nb[0]);                  // <= 16 bits
+                const uint32_t theirs = dpp<DPP_ROW_SHL(1)>(0, mine);
+                if (even) or_bits(bp, mine | (theirs << lane_bits), nb_pair);
+                bp += row_bits;
+            }
+            wl += row_bits;
+            pos_in += blk;
+            slot++;
+            if (slot == 2) {
+                if (pos_in <= limit) start_group();
+                else active = false;
+            }
+            break;
+        }
+    }
+
+    // ---- verbatim tail through the window (:553)
+    const uint32_t remaining = (uint32_t)((int64_t)n - pos_in);
+    {
+        const uint8_t* tp = sc + pos_in;
+        uint32_t left = remaining;
+        while (left > 0) {
+            drain(wl & ~15u);
+            const uint32_t room = cap - 16u - wl;
+            const uint32_t m = left < room ? left : room;
+            for (uint32_t j = (uint32_t)lane_d; j < m; j += DP) win[wl + j] = tp[j];
+            wl += m;
+            tp += m;
+            left -= m;
+        }
+    }
+    const uint32_t total_bytes = gpos + wl;
+    drain((wl + 15u) & ~15u);
+
+    if (lane_d == 0) {                                   // format.h:36-45; lane 0 also flushed unit 0
+        if (a.norle == 2) {                              // u64 len with ndims in its bytes 6..7 (sprintz_xff.cpp:58-63)
+            ((uint32_t*)gdst)[0] = n;
+            ((uint32_t*)gdst)[1] = (uint32_t)D << 16;
+        } else if (a.norle) {                            // {u32 len; u16 ndims} (format.h:65-72)
+            ((uint32_t*)gdst)[0] = n;
+            ((uint16_t*)gdst)[2] = (uint16_t)D;
+        } else if (a.write_size) {
+            ((uint32_t*)gdst)[0] = ngroups;
+            ((uint32_t*)gdst)[1] = (remaining & 0xffffu) | ((uint32_t)D << 16);
+        }
+        a.sizes[chunk] = total_bytes;
+        if (a.rets) a.rets[chunk] = (int64_t)total_bytes;
+    }
+}
+
+}  // namespace sprintz

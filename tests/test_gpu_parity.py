@@ -138,6 +138,9 @@ CONFIGS = [
     ("low16_d2_delta_ragged", "delta", 2, 2, 1002),
     ("low8_d3_delta", "delta", 1, 3, 3072),      # 24-byte blocks: spans of three 64-byte windows
     ("low8_d3_xff_ragged", "xff", 1, 3, 1000),
+    ("wide8_d128_xff", "xff", 1, 128, 16384),    # two columns per lane: encode_wide.h
+    ("wide8_d100_delta", "delta", 1, 100, 8000),
+    ("wide8_d66_xff", "xff", 1, 66, 6336),
 ]
 
 
@@ -411,7 +414,7 @@ def test_huffman_decoder_survives_damaged_containers(sz):
     assert np.array_equal(r, sizes.astype(np.int64))
 
 
-@pytest.mark.parametrize("name,codec,esz,ndims,chunk_len", [c for c in CONFIGS if c[0] in ("cfg2", "cfg3_10k", "cfg5", "xff8", "cfg1", "uni16_xff", "uni16_delta_ragged", "low8_d2", "low8_d4", "lowdim16", "low16_d2_delta_ragged", "lowdim8", "low8_d3_delta")])
+@pytest.mark.parametrize("name,codec,esz,ndims,chunk_len", [c for c in CONFIGS if c[0] in ("cfg2", "cfg3_10k", "cfg5", "xff8", "cfg1", "uni16_xff", "uni16_delta_ragged", "low8_d2", "low8_d4", "lowdim16", "low16_d2_delta_ragged", "lowdim8", "low8_d3_delta", "wide8_d128_xff", "wide8_d100_delta", "wide8_d66_xff")])
 def test_generic_kernels_agree_with_the_fast_ones(sz, monkeypatch, name, codec, esz, ndims, chunk_len):
     """SPRINTZ_MI355X_NO_FAST routes the same calls to decode_kernel.h / encode_kernel.h: same bytes, same samples"""
     import torch
