@@ -459,3 +459,50 @@ def test_containers_beyond_4_GiB(sz):
     assert torch.equal(back.sizes, batch.sizes) and torch.equal(back.offsets, batch.offsets)
     out = cd.decompress(back)
     assert torch.equal(out, x)
+
+
+@pytest.mark.parametrize("seed", list(range(200)))
+def test_random_shapes(sz, oracle, seed):
+    """a sweep over the kernel variants' dispatch space: random element width, ndims, chunk length (multiples of
+    16 and not), codec (the five), data mix -- batched compress bytes == oracle's, decompress == input"""
+    import torch
+    rng = np.random.default_rng(1000 + seed)
+    esz = int(rng.choice([1, 2]))
+    codec = str(rng.choice(["delta", "xff", "delta_norle", "bitpack", "xff_norle"]))
+    if codec == "xff_norle":
+        esz = 1
+    ndims = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 16, 17, 31, 32, 33, 64, 65, 66, 80, 100, 127, 128, 129, 200]))
+    rows = int(rng.integers(3, 400))
+    chunk_len = rows * ndims + (int(rng.integers(0, ndims)) if rng.random() < 0.3 else 0)
+    if rng.random() < 0.5:
+        chunk_len = max(16, (chunk_len + 15) & ~15)
+    chunk_len = min(max(chunk_len, 8), 40000)
+    nchunks = int(rng.integers(3, 40))
+    total = nchunks * chunk_len - int(rng.integers(0, chunk_len))
+    top = 1 << (8 * esz)
+    kind = int(rng.integers(0, 4))
+    if kind == 0:
+        data = gen_walk(rng, total, ndims, esz, int(rng.integers(1, 40)), flat_every=int(rng.integers(2, 6)))
+    elif kind == 1:
+        data = gen_fuzz(rng, total, esz, int(rng.integers(0, 4)))
+    elif kind == 2:
+        data = (np.cumsum(rng.integers(-3, 4, total)) % top).astype(DTYPES[esz])
+        data[total // 3: total // 3 + 3 * chunk_len // 2] = data[total // 3]
+    else:
+        data = np.concatenate([gen_walk(rng, total // 2, ndims, esz, 300 if esz == 2 else 20, flat_every=3), gen_fuzz(rng, total - total // 2, esz, 1)])
+    data = np.ascontiguousarray(data[:total])
+    nchunks = (total + chunk_len - 1) // chunk_len
+    cd = sz.ChunkedCodec(codec, esz, ndims, chunk_len, device="cuda:0")
+    batch = cd.compress(torch.from_numpy(data.view(np.int8 if esz == 1 else np.int16)).cuda().view(cd.dtype))
+    comp, offs, sizes = batch.data.cpu().numpy(), batch.offsets.cpu().numpy(), batch.sizes.cpu().numpy()
+    if codec in ("delta", "xff"):
+        want = oracle.compress_chunks(codec, data, chunk_len, ndims)
+    else:
+        raw = {"delta_norle": 0, "bitpack": 1, "xff_norle": 2}[codec]
+        want = [oracle.compress_norle(raw, data[c * chunk_len:(c + 1) * chunk_len], ndims)[0] for c in range(nchunks)]
+    tag = (seed, codec, esz, ndims, chunk_len)
+    for c in range(nchunks):
+        assert sizes[c] == want[c].size, (tag, c)
+        assert np.array_equal(comp[offs[c]:offs[c] + sizes[c]], want[c]), (tag, c)
+    out = cd.decompress(batch)
+    assert np.array_equal(out.cpu().numpy().view(DTYPES[esz])[:total], data), tag
