@@ -177,6 +177,7 @@ struct P16 {                                            // 2 x u16 in a dword: v
         return __builtin_bit_cast(T, (us2)(__builtin_bit_cast(us2, a) * nn));
     }
     static __device__ __forceinline__ T shfl(T v, int src) { return (T)__shfl((int)v, src); }
+    static constexpr int M = 1;
 };
 struct P8 {                                             // 4 x u8 in a dword
     typedef uint32_t T;
@@ -188,6 +189,7 @@ struct P8 {                                             // 4 x u8 in a dword
         return ((a & 0x00ff00ffu) * n & 0x00ff00ffu) | ((((a >> 8) & 0x00ff00ffu) * n & 0x00ff00ffu) << 8);
     }
     static __device__ __forceinline__ T shfl(T v, int src) { return (T)__shfl((int)v, src); }
+    static constexpr int M = 1;
 };
 template <typename U> struct S1x {                      // one element
     typedef U T;
@@ -195,6 +197,7 @@ template <typename U> struct S1x {                      // one element
     static __device__ __forceinline__ T add(T a, T b) { return (T)(a + b); }
     static __device__ __forceinline__ T mul(T a, uint32_t n) { return (T)(a * n); }
     static __device__ __forceinline__ T shfl(T v, int src) { return (T)__shfl((int)v, src); }
+    static constexpr int M = 1;
 };
 template <typename P> struct V4 {                       // 4 packed dwords = 16 bytes
     struct __attribute__((aligned(16))) T { uint32_t v[4]; };
@@ -202,6 +205,39 @@ template <typename P> struct V4 {                       // 4 packed dwords = 16 
     static __device__ __forceinline__ T add(T a, T b) { T r; for (int k = 0; k < 4; k++) r.v[k] = P::add(a.v[k], b.v[k]); return r; }
     static __device__ __forceinline__ T mul(T a, uint32_t n) { T r; for (int k = 0; k < 4; k++) r.v[k] = P::mul(a.v[k], n); return r; }
     static __device__ __forceinline__ T shfl(T a, int src) { T r; for (int k = 0; k < 4; k++) r.v[k] = P::shfl(a.v[k], src); return r; }
+    static constexpr int M = 1;
+};
+// Rows SHORTER than a 16-byte piece (RB = 1, 2, 4 or 8 bytes: the univariate streams and their few-column
+// neighbours): a piece holds M = 16 / RB consecutive rows, so the scan runs over pieces -- a piece's summary is
+// the sum over its rows replicated into every row slot, the state is carried replicated -- and the rows inside a
+// piece are finished by an in-register prefix (shift by one row and add, log2(M) times).  Same 16-byte requests
+// as the wide rows instead of 1-, 2- or 4-byte ones.
+template <typename P, int RB> struct Sub : V4<P> {
+    typedef typename V4<P>::T T;
+    static constexpr int M = 16 / RB;
+    static __device__ __forceinline__ uint32_t rep_last(uint32_t a)      // the dword's last row in every row slot of a dword
+    {
+        if constexpr (RB == 1) return (a >> 24) * 0x01010101u;
+        else if constexpr (RB == 2) return (a >> 16) * 0x00010001u;
+        else return a;
+    }
+    static __device__ __forceinline__ T prefix(T a)                      // inclusive prefix over the piece's rows
+    {
+        if constexpr (RB == 8) { a.v[2] = P::add(a.v[2], a.v[0]); a.v[3] = P::add(a.v[3], a.v[1]); return a; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if constexpr (RB == 1) { a.v[k] = P::add(a.v[k], a.v[k] << 8); a.v[k] = P::add(a.v[k], a.v[k] << 16); }
+            if constexpr (RB == 2) a.v[k] = P::add(a.v[k], a.v[k] << 16);
+            if (k > 0) a.v[k] = P::add(a.v[k], rep_last(a.v[k - 1]));
+        }
+        return a;
+    }
+    static __device__ __forceinline__ T last(T a)                        // the piece's last row in every row slot
+    {
+        if constexpr (RB == 8) return T{{a.v[2], a.v[3], a.v[2], a.v[3]}};
+        const uint32_t r = rep_last(a.v[3]);
+        return T{{r, r, r, r}};
+    }
 };
 
 // STORE = false: write the run's summary (S1 [, S2]) ; STORE = true: read the run's incoming state and write x
@@ -251,8 +287,14 @@ __global__ void __launch_bounds__(kTB) wave_scan_kernel(const typename E::T* y, 
             const uint64_t e = el + ((uint64_t)k << log2_dv);
             if (via_lds) yk[k] = xb[swz(pl + ((uint32_t)k << log2_dv))];
             else yk[k] = e < len_e ? y[e] : E::zero();
-            s1 = E::add(s1, yk[k]);
-            if (KIND) s2 = E::add(s2, s1);
+            if constexpr (E::M > 1) {                   // a piece of M rows: (S1, S2, n) o (S1', S2', M)
+                const T p1 = E::prefix(yk[k]);
+                if (KIND) s2 = E::add(E::add(s2, E::mul(s1, (uint32_t)E::M)), E::last(E::prefix(p1)));
+                s1 = E::add(s1, E::last(p1));
+            } else {
+                s1 = E::add(s1, yk[k]);
+                if (KIND) s2 = E::add(s2, s1);
+            }
         }
         // inclusive scan of the lane summaries over the rows of the load (stride dv lanes); the right
         // operand of step st covers K * 2^st rows
@@ -262,7 +304,7 @@ __global__ void __launch_bounds__(kTB) wave_scan_kernel(const typename E::T* y, 
             const T l1 = E::shfl(i1, src < 0 ? lane : src);
             if (KIND) {
                 const T l2 = E::shfl(i2, src < 0 ? lane : src);
-                if (r >= (1 << st)) i2 = E::add(E::add(l2, E::mul(l1, (uint32_t)K << st)), i2);
+                if (r >= (1 << st)) i2 = E::add(E::add(l2, E::mul(l1, (uint32_t)(K * E::M) << st)), i2);
             }
             if (r >= (1 << st)) i1 = E::add(l1, i1);
         }
@@ -271,17 +313,32 @@ __global__ void __launch_bounds__(kTB) wave_scan_kernel(const typename E::T* y, 
         T p1 = E::shfl(i1, prev < 0 ? lane : prev), p2 = KIND ? E::shfl(i2, prev < 0 ? lane : prev) : E::zero();
         T xl = x, dl = d;
         if (r > 0) {
-            if (KIND) { xl = E::add(E::add(x, E::mul(d, (uint32_t)(r * K))), p2); dl = E::add(d, p1); }
+            if (KIND) { xl = E::add(E::add(x, E::mul(d, (uint32_t)(r * K * E::M))), p2); dl = E::add(d, p1); }
             else xl = E::add(x, p1);
         }
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            if (KIND) { dl = E::add(dl, yk[k]); xl = E::add(xl, dl); }
-            else xl = E::add(xl, yk[k]);
+            T outv;
+            if constexpr (E::M > 1) {                   // the rows inside the piece: x + (j + 1) d + prefix^2(y), d + prefix(y)
+                const T p1 = E::prefix(yk[k]);
+                if (KIND) {
+                    const T p2 = E::prefix(p1);
+                    outv = E::add(E::add(xl, E::prefix(dl)), p2);
+                    xl = E::add(E::add(xl, E::mul(dl, (uint32_t)E::M)), E::last(p2));
+                    dl = E::add(dl, E::last(p1));
+                } else {
+                    outv = E::add(xl, p1);
+                    xl = E::add(xl, E::last(p1));
+                }
+            } else {
+                if (KIND) { dl = E::add(dl, yk[k]); xl = E::add(xl, dl); }
+                else xl = E::add(xl, yk[k]);
+                outv = xl;
+            }
             const uint64_t e = el + ((uint64_t)k << log2_dv);
             if (STORE) {
-                if (via_lds) xb[swz(pl + ((uint32_t)k << log2_dv))] = xl;
-                else if (e < len_e) dest[e] = xl;
+                if (via_lds) xb[swz(pl + ((uint32_t)k << log2_dv))] = outv;
+                else if (e < len_e) dest[e] = outv;
             }
         }
         if (STORE && via_lds) {
@@ -386,15 +443,17 @@ int wave_piece_bytes(const void* y, const void* dest, uint64_t len, uint32_t D)
 }
 
 template <typename U, typename E, int KIND>
-int decode_wave(const U* y, uint64_t len, uint32_t D, U* dest, uint8_t* tmp, hipStream_t st)
+int decode_wave(const U* y, uint64_t len, uint32_t D_real, U* dest, uint8_t* tmp, hipStream_t st)
 {
     typedef typename E::T T;
-    const uint32_t dv = (uint32_t)((uint64_t)D * sizeof(U) / sizeof(T));
+    // (rows shorter than a piece, E::M > 1: the levels above see the replicated 16-byte pieces as rows of 16 / sizeof(U) columns)
+    const uint32_t D = E::M > 1 ? (uint32_t)(sizeof(T) / sizeof(U)) : D_real;
+    const uint32_t dv = E::M > 1 ? 1u : (uint32_t)((uint64_t)D * sizeof(U) / sizeof(T));
     uint32_t log2_dv = 0;
     while ((1u << log2_dv) < dv) log2_dv++;
     const uint64_t len_e = len * sizeof(U) / sizeof(T);
-    const uint64_t rows0 = (len + D - 1) / D;
-    const uint64_t run_rows = (uint64_t)kRunLoads * kRowsPerLane * (64 >> log2_dv);
+    const uint64_t rows0 = (len + D_real - 1) / D_real;                  // real rows
+    const uint64_t run_rows = (uint64_t)kRunLoads * kRowsPerLane * (64 >> log2_dv) * E::M;
     const uint64_t nruns = (rows0 + run_rows - 1) / run_rows;
     const unsigned grid = (unsigned)((nruns * 64 + kTB - 1) / kTB);
     if (nruns == 1) {
@@ -423,6 +482,16 @@ template <typename U, int KIND>
 int decode_device(const U* y, uint64_t len, uint32_t D, U* dest, uint8_t* tmp, hipStream_t st)
 {
     typedef typename std::conditional<sizeof(U) == 1, P8, P16>::type P;
+    const uint64_t rb = (uint64_t)D * sizeof(U);
+    if (rb < 16 && 16 % rb == 0 && (len * sizeof(U)) % 16 == 0 && (((uintptr_t)y | (uintptr_t)dest) % 16) == 0) {
+        switch ((int)rb) {                               // rows shorter than a piece
+            case 1: if constexpr (sizeof(U) == 1) return decode_wave<U, Sub<P, 1>, KIND>(y, len, D, dest, tmp, st); else break;
+            case 2: return decode_wave<U, Sub<P, 2>, KIND>(y, len, D, dest, tmp, st);
+            case 4: return decode_wave<U, Sub<P, 4>, KIND>(y, len, D, dest, tmp, st);
+            case 8: return decode_wave<U, Sub<P, 8>, KIND>(y, len, D, dest, tmp, st);
+            default: break;
+        }
+    }
     switch (wave_piece_bytes<U>(y, dest, len, D)) {
         case 16: return decode_wave<U, V4<P>, KIND>(y, len, D, dest, tmp, st);
         case 4: return decode_wave<U, P, KIND>(y, len, D, dest, tmp, st);
