@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(kTB) apply_kernel(Level<U> lo, uint64_t len, u
 }
 
 // ---------------------------------------------------------------- decode, small rows: one wavefront scans a run of rows
-// When a row is a power-of-two number (<= 64) of 16-byte / 4-byte / element-sized pieces, the
+// When a row is a whole number (<= 64) of 16-byte / 4-byte / element-sized pieces, the
 // lanes of a wavefront share a contiguous 4 KB / 1 KB / 256-element load: a lane folds
 // kRowsPerLane consecutive rows of its column piece in registers, the lane summaries are scanned
 // across lanes at stride Dv with the composition above (the right operand of step s covers exactly
@@ -242,7 +242,7 @@ template <typename P, int RB> struct Sub : V4<P> {
 
 // STORE = false: write the run's summary (S1 [, S2]) ; STORE = true: read the run's incoming state and write x
 template <typename E, int KIND, bool STORE>
-__global__ void __launch_bounds__(kTB) wave_scan_kernel(const typename E::T* y, uint64_t len_e, uint32_t log2_dv, uint64_t nruns,
+__global__ void __launch_bounds__(kTB) wave_scan_kernel(const typename E::T* y, uint64_t len_e, uint32_t dv, uint64_t nruns,
                                                         const typename E::T* xin, const typename E::T* din, typename E::T* s1_out,
                                                         typename E::T* s2_out, typename E::T* dest)
 {
@@ -250,10 +250,12 @@ __global__ void __launch_bounds__(kTB) wave_scan_kernel(const typename E::T* y, 
     const uint64_t run = ((uint64_t)blockIdx.x * kTB + threadIdx.x) >> 6;
     if (run >= nruns) return;
     const int lane = threadIdx.x & 63;
-    const uint32_t dv = 1u << log2_dv;
-    const int c = lane & (int)(dv - 1);                 // piece of the row this lane holds
-    const int r = lane >> log2_dv;                      // row of the load
-    const int rpw = 64 >> log2_dv;                      // rows per load
+    // dv pieces per row, any count <= 64: 64 / dv rows per load, the lanes past the last whole row idle
+    const int rpw = 64 / (int)dv;                       // rows per load
+    const int r = lane / (int)dv;                       // row of the load
+    const int c = lane - r * (int)dv;                   // piece of the row this lane holds
+    const bool act = r < rpw;
+    const uint32_t PL = (uint32_t)rpw * dv;             // pieces per row-step of a load (64 when dv divides 64)
     T x = E::zero(), d = E::zero();                     // state entering the next load (per column piece)
     if (STORE && xin) {
         x = xin[run * dv + c];
@@ -265,15 +267,15 @@ __global__ void __launch_bounds__(kTB) wave_scan_kernel(const typename E::T* y, 
     // stores) the 64*K pieces in order, lane l piece l, and the rows change hands in LDS.
     __shared__ T xbuf[kTB / 64][64 * K];
     T* const xb = xbuf[threadIdx.x >> 6];
-    const bool via_lds = dv < 4;
-    const uint64_t e0 = run * (uint64_t)kRunLoads * 64 * K;
+    const bool via_lds = dv < 3;                          // (1 or 2: powers of two, 64 pieces per row-step, which the hand-over is laid out for)
+    const uint64_t e0 = run * (uint64_t)kRunLoads * PL * K;
     for (int j = 0; j < kRunLoads; j++) {
-        const uint64_t eb = e0 + (uint64_t)j * 64 * K;  // first piece of this load
+        const uint64_t eb = e0 + (uint64_t)j * PL * K;  // first piece of this load
         if (eb >= len_e) break;                         // wave-uniform
-        const uint64_t el = eb + ((uint64_t)r * K << log2_dv) + (uint64_t)c;   // this lane's first piece; its rows are dv pieces apart
+        const uint64_t el = eb + (uint64_t)r * K * dv + (uint64_t)c;   // this lane's first piece; its rows are dv pieces apart
         T yk[K];
         T s1 = E::zero(), s2 = E::zero();               // summary of the lane's K rows
-        const uint32_t pl = (((uint32_t)r * K) << log2_dv) + (uint32_t)c;      // this lane's first piece within the load
+        const uint32_t pl = (uint32_t)r * K * dv + (uint32_t)c;      // this lane's first piece within the load
         if (via_lds) {
 #pragma unroll
             for (int m = 0; m < K; m++) {
@@ -284,9 +286,9 @@ __global__ void __launch_bounds__(kTB) wave_scan_kernel(const typename E::T* y, 
         }
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            const uint64_t e = el + ((uint64_t)k << log2_dv);
-            if (via_lds) yk[k] = xb[swz(pl + ((uint32_t)k << log2_dv))];
-            else yk[k] = e < len_e ? y[e] : E::zero();
+            const uint64_t e = el + (uint64_t)k * dv;
+            if (via_lds) yk[k] = xb[swz(pl + (uint32_t)k * dv)];
+            else yk[k] = (act && e < len_e) ? y[e] : E::zero();
             if constexpr (E::M > 1) {                   // a piece of M rows: (S1, S2, n) o (S1', S2', M)
                 const T p1 = E::prefix(yk[k]);
                 if (KIND) s2 = E::add(E::add(s2, E::mul(s1, (uint32_t)E::M)), E::last(E::prefix(p1)));
@@ -335,10 +337,10 @@ __global__ void __launch_bounds__(kTB) wave_scan_kernel(const typename E::T* y, 
                 else xl = E::add(xl, yk[k]);
                 outv = xl;
             }
-            const uint64_t e = el + ((uint64_t)k << log2_dv);
+            const uint64_t e = el + (uint64_t)k * dv;
             if (STORE) {
-                if (via_lds) xb[swz(pl + ((uint32_t)k << log2_dv))] = outv;
-                else if (e < len_e) dest[e] = outv;
+                if (via_lds) xb[swz(pl + (uint32_t)k * dv)] = outv;
+                else if (act && e < len_e) dest[e] = outv;
             }
         }
         if (STORE && via_lds) {
@@ -437,7 +439,8 @@ int wave_piece_bytes(const void* y, const void* dest, uint64_t len, uint32_t D)
         if (pb < (int)sizeof(U) || row_bytes % pb || total % pb) continue;
         if (((uintptr_t)y | (uintptr_t)dest) % pb) continue;
         const uint64_t dv = row_bytes / pb;
-        if (dv <= 64 && (dv & (dv - 1)) == 0) return pb;
+        // any piece count up to 64 (64 / dv whole rows per load); 1 and 2 go through the LDS hand-over, which is laid out for 64 pieces
+        if (dv <= 64 && ((dv & (dv - 1)) == 0 || dv >= 3)) return pb;
     }
     return 0;
 }
@@ -449,15 +452,13 @@ int decode_wave(const U* y, uint64_t len, uint32_t D_real, U* dest, uint8_t* tmp
     // (rows shorter than a piece, E::M > 1: the levels above see the replicated 16-byte pieces as rows of 16 / sizeof(U) columns)
     const uint32_t D = E::M > 1 ? (uint32_t)(sizeof(T) / sizeof(U)) : D_real;
     const uint32_t dv = E::M > 1 ? 1u : (uint32_t)((uint64_t)D * sizeof(U) / sizeof(T));
-    uint32_t log2_dv = 0;
-    while ((1u << log2_dv) < dv) log2_dv++;
     const uint64_t len_e = len * sizeof(U) / sizeof(T);
     const uint64_t rows0 = (len + D_real - 1) / D_real;                  // real rows
-    const uint64_t run_rows = (uint64_t)kRunLoads * kRowsPerLane * (64 >> log2_dv) * E::M;
+    const uint64_t run_rows = (uint64_t)kRunLoads * kRowsPerLane * (64 / dv) * E::M;
     const uint64_t nruns = (rows0 + run_rows - 1) / run_rows;
     const unsigned grid = (unsigned)((nruns * 64 + kTB - 1) / kTB);
     if (nruns == 1) {
-        hipLaunchKernelGGL((wave_scan_kernel<E, KIND, true>), dim3(grid), dim3(kTB), 0, st, (const T*)y, len_e, log2_dv, nruns,
+        hipLaunchKernelGGL((wave_scan_kernel<E, KIND, true>), dim3(grid), dim3(kTB), 0, st, (const T*)y, len_e, dv, nruns,
                            (const T*)nullptr, (const T*)nullptr, (T*)nullptr, (T*)nullptr, (T*)dest);
         return hipGetLastError() == hipSuccess ? 0 : fail(SPRINTZ_E_HIP, "transform decode launch");
     }
@@ -468,12 +469,12 @@ int decode_wave(const U* y, uint64_t len, uint32_t D_real, U* dest, uint8_t* tmp
     U* s2 = KIND ? take(nruns) : nullptr;
     U* xi = take(nruns);
     U* di = KIND ? take(nruns) : nullptr;
-    hipLaunchKernelGGL((wave_scan_kernel<E, KIND, false>), dim3(grid), dim3(kTB), 0, st, (const T*)y, len_e, log2_dv, nruns, (const T*)nullptr,
+    hipLaunchKernelGGL((wave_scan_kernel<E, KIND, false>), dim3(grid), dim3(kTB), 0, st, (const T*)y, len_e, dv, nruns, (const T*)nullptr,
                        (const T*)nullptr, (T*)s1, (T*)s2, (T*)nullptr);
     const Level<U> base{s1, s2, xi, di, nruns, run_rows};
     int rc = scan_levels<U, KIND>(base, len, D, rows0, dest, t, st);
     if (rc) return rc;
-    hipLaunchKernelGGL((wave_scan_kernel<E, KIND, true>), dim3(grid), dim3(kTB), 0, st, (const T*)y, len_e, log2_dv, nruns, (const T*)xi,
+    hipLaunchKernelGGL((wave_scan_kernel<E, KIND, true>), dim3(grid), dim3(kTB), 0, st, (const T*)y, len_e, dv, nruns, (const T*)xi,
                        (const T*)di, (T*)nullptr, (T*)nullptr, (T*)dest);
     return hipGetLastError() == hipSuccess ? 0 : fail(SPRINTZ_E_HIP, "transform decode launch");
 }

@@ -46,7 +46,9 @@ def test_reference_containers_single_call(sz, golden_transforms):
                                          (2, 8, 8 * 100_003 + 4), (2, 8, 8 * 100_003 + 3), (1, 16, 16 * 50_001 + 7), (2, 2, 2 * 70_001 + 1),
                                          # rows shorter than a 16-byte piece (several rows per piece, in-register prefix)
                                          (1, 1, 1 << 24), (1, 1, 16 * 4097), (1, 2, 16 * 300_001), (1, 4, 4 * 1_000_004), (1, 8, 8 * 500_002),
-                                         (2, 1, 8 * 700_001), (2, 2, 2 * 4_000_004), (2, 4, 4 * 600_002), (1, 1, 16), (2, 1, 65536 * 8 + 8)])
+                                         (2, 1, 8 * 700_001), (2, 2, 2 * 4_000_004), (2, 4, 4 * 600_002), (1, 1, 16), (2, 1, 65536 * 8 + 8),
+                                         # piece counts that are not powers of two: 5, 3, 9, 37 pieces a row
+                                         (1, 80, 80 * 300_001), (2, 24, 24 * 200_003), (1, 144, 144 * 70_001), (2, 296, 296 * 30_011), (2, 40, 40 * 17)])
 def test_long_streams_on_device(sz, oracle, kind, esz, ndims, n):
     """one stream of millions of rows: element-wise encode, scan decode (3 to 6 levels)"""
     import torch
