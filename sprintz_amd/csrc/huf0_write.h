@@ -10,8 +10,9 @@
 //                          first through a per-lane LDS ring that leaves in 64-byte units
 #pragma once
 
-constexpr int kRecBytes = 1024;         // per segment: hlen u32 | tl u32 | hdr[<=160] @8 | (val | len << 16) u32[256] @... see below
-constexpr int kRecHdr = 8, kRecTab = 192;   // tab: 256 x u16 val @192, 256 x u8 len @704
+// per-segment record (H1 -> H2, H3): hlen u32 @0 (0 = no table: the segment's chunks are stored) | tableLog u32 @4 |
+// tree description, <= 160 bytes @8 | code values 256 x u16 @192 | code lengths 256 x u8 @704
+constexpr int kRecBytes = 1024, kRecHdr = 8, kRecTab = 192;
 
 struct BitW {                           // bytes into LDS, LSB first (bitstream.h BIT_CStream_t)
     uint8_t* p; uint64_t acc; int nbits; uint32_t n;
