@@ -191,3 +191,48 @@ def test_writer_edge_chunks(sz, oracle):
     out = sz.huf0_decompress(blocks, bo, torch.from_numpy(oo).cuda(), rets=rets).cpu().numpy()
     assert np.array_equal(rets.cpu().numpy(), sizes.astype(np.int64))
     assert np.array_equal(out[: oo[-1]], np.concatenate(chunks))
+
+
+def test_reader_survives_garbage(sz, oracle, golden_huf0):
+    """2 000 blocks damaged in the tree description (where the FSE parser lives), the jump table or anywhere, and
+    blocks of pure noise: the launch ends, undamaged neighbours decode, verdicts agree with the oracle"""
+    import torch
+    manifest, arrays = golden_huf0
+    rng = np.random.default_rng(99)
+    coded = [m for m in manifest if m["kind"] in ("fse", "nibbles") and m["n"] <= 4200]
+    blocks, plains, clean = [], [], []
+    for k in range(2000):
+        m = coded[int(rng.integers(0, len(coded)))]
+        plain, blk = arrays["p%04d" % m["idx"]], arrays["b%04d" % m["idx"]].copy()
+        mode = k % 5
+        if mode == 0:
+            clean.append(k)
+        elif mode == 1:
+            for _ in range(int(rng.integers(1, 4))):
+                blk[rng.integers(0, min(blk.size, blk[0] + 2 if blk[0] < 128 else 70))] = rng.integers(0, 256)
+        elif mode == 2:
+            hl = (blk[0] + 1) if blk[0] < 128 else (1 + (blk[0] - 126) // 2)
+            at = min(int(hl) + int(rng.integers(0, 6)), blk.size - 1)
+            blk[at] = rng.integers(0, 256)
+        elif mode == 3:
+            blk[rng.integers(0, blk.size)] ^= 1 << rng.integers(0, 8)
+        else:
+            blk = rng.integers(0, 256, int(rng.integers(2, max(3, plain.size - 1)))).astype(np.uint8)
+        blocks.append(blk)
+        plains.append(plain)
+    d, bo, oo, oo_h = pack(blocks, plains)
+    rets = torch.full((len(blocks),), -99, dtype=torch.int64, device="cuda")
+    out = sz.huf0_decompress(d, bo, oo, rets=rets).cpu().numpy()
+    r = rets.cpu().numpy()
+    for k in clean:
+        assert r[k] == plains[k].size and np.array_equal(out[oo_h[k]:oo_h[k + 1]], plains[k]), k
+    agree = rejected = 0
+    for k in range(0, len(blocks), 7):                                        # the oracle is slow: a sample
+        got, ret = oracle.huf0_decompress(blocks[k], plains[k].size)
+        if ret < 0:
+            assert r[k] < 0, (k, r[k])
+            rejected += 1
+        else:
+            assert r[k] == plains[k].size and np.array_equal(out[oo_h[k]:oo_h[k + 1]], got), k
+        agree += 1
+    assert agree > 250 and rejected > 50
