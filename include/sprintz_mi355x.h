@@ -269,7 +269,7 @@ int64_t sprintz_mi355x_decompress_norle(int codec, int elem_bytes, const void* s
  *                                            the caller's, as with HUF_decompress)
  *   d_rets[c] (optional): decoded bytes, or SPRINTZ_E_CORRUPT for a damaged block
  *   (nothing is read or written outside the chunk's two ranges).
- * d_blocks must be readable 8 bytes past its end.  Format restated in
+ * d_blocks must be 16-byte aligned and readable 16 bytes past its end.  Format restated in
  * oracle/huf0_oracle.c; kernel in sprintz_amd/csrc/huf0.hip.
  * ---------------------------------------------------------------------- */
 int sprintz_mi355x_huf0_decompress_batch(const void* d_blocks, const uint64_t* d_block_offsets, uint64_t nchunks, void* d_out,

@@ -500,7 +500,7 @@ def huf0_compress(batch):
 def huf0_decompress(blocks, block_offsets, out_offsets, rets=None, out=None):
     """Genuine Huff0 blocks (HUF_compress's output, one per chunk; torch uint8 tensor + int64 offsets
     [nchunks+1]) -> the bytes they encode, chunk c at out_offsets[c] (int64 [nchunks+1], device).
-    `blocks` must carry 8 readable bytes past the last block.  Returns the uint8 output tensor
+    `blocks` must be 16-byte aligned and carry 16 readable bytes past the last block.  Returns the uint8 output tensor
     (READ_SLACK bytes longer than out_offsets[-1], ready for ChunkedCodec.decompress_into)."""
     import torch
     dev = blocks.device

@@ -15,12 +15,12 @@
 // registers), its symbol is sorted[symoff[w] + ((idx - start[w]) >> (w - 1))] and it is
 // tableLog + 1 - w bits long.  Per chunk that is 256 bytes of sorted symbols and 13 words in
 // LDS instead of 4 KB, a dozen waves per CU instead of two, and every table log the format
-// allows (12 included).  Headline shape (131 072 blocks of ~3.4 KB): 1.6 ms, of which phases
-// A + B 0.5 and C 1.1 (its ~185 VALU per 4 symbols bound it at ~0.6).
+// allows (12 included).  Headline shape (131 072 blocks of ~3.4 KB): 1.4 ms, of which phases
+// A + B 0.5 and C 0.9 (its ~200 VALU per 4 symbols bound it at ~0.6).
 // Phase A (first lane of each quad, serial): tree description -> weights; the FSE-compressed form
 // is decoded with a 64-entry table in LDS.  Phase B (same lane): counting sort of the symbols by
 // weight.  Phase C (every lane): its stream, read from the last byte down through a 64-bit
-// window, 4 symbols per refill, the next refill's 16 bytes requested a step ahead.
+// window, 4 symbols per refill, refilled from 16-byte aligned pieces held in registers.
 #include "../../include/sprintz_mi355x.h"
 
 #include <hip/hip_runtime.h>
@@ -30,7 +30,7 @@
 namespace {
 
 constexpr int kWStride = 256 + 4;                // weights per chunk, padded off the bank stride
-constexpr int kRStride = 480 + 4;                // per chunk: header copy 144 | norm 32 | next 32 | fse 256; later the sorted symbols
+constexpr int kRStride = 336 + 4;                // per chunk: header copy 144 | norm 32 | next 32 | fse 128; later the sorted symbols (256)
 constexpr int64_t kCorrupt = SPRINTZ_E_CORRUPT;
 
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
@@ -56,7 +56,7 @@ __device__ __forceinline__ uint32_t back_look(const uint8_t* h, int P, int nb)
 }
 
 // HUF_readStats (entropy_common.c) over the header bytes h[0..n) (zero padded); weights[0..nsym).
-// Scratch s: int16 norm[16] | u16 next[16] | u32 fse[64]: weights are < 12, so a description that
+// Scratch s: int16 norm[16] | u16 next[16] | u16 fse[64]: weights are < 12, so a description that
 // gives probability to a symbol >= 16 is damaged.  Returns header bytes, 0 if damaged.
 __device__ uint32_t read_stats(const uint8_t* h, uint32_t n, uint8_t* weights, uint8_t* s, uint32_t& nsym, uint32_t& tl_out)
 {
@@ -75,7 +75,7 @@ __device__ uint32_t read_stats(const uint8_t* h, uint32_t n, uint8_t* weights, u
         const uint8_t* const f = h + 1;
         int16_t* const norm = (int16_t*)s;
         uint16_t* const next = (uint16_t*)(s + 32);
-        uint32_t* const fse = (uint32_t*)(s + 64);                // symbol | nbits << 8 | new_state << 16
+        uint16_t* const fse = (uint16_t*)(s + 64);                // symbol | nbits << 4 | new_state << 8
         for (int k = 0; k < 16; k++) norm[k] = 0;
         // FSE_readNCount
         uint32_t bp = 0;
@@ -124,7 +124,7 @@ __device__ uint32_t read_stats(const uint8_t* h, uint32_t n, uint8_t* weights, u
         const uint32_t size = 1u << tl;
         uint32_t high = size - 1;
         for (uint32_t sy = 0; sy <= max_sv; sy++) {
-            if (norm[sy] == -1) { fse[high--] = sy; next[sy] = 1; }
+            if (norm[sy] == -1) { fse[high--] = (uint16_t)sy; next[sy] = 1; }
             else next[sy] = (uint16_t)norm[sy];
         }
         {
@@ -133,17 +133,17 @@ __device__ uint32_t read_stats(const uint8_t* h, uint32_t n, uint8_t* weights, u
             for (uint32_t sy = 0; sy <= max_sv; sy++)
                 for (int i = 0; i < norm[sy]; i++) {
                     if (++placed > size) return 0;
-                    fse[pos] = sy;
+                    fse[pos] = (uint16_t)sy;
                     pos = (pos + step) & mask;
                     while (pos > high) pos = (pos + step) & mask;
                 }
             if (pos != 0) return 0;
         }
         for (uint32_t u = 0; u < size; u++) {
-            const uint32_t sy = fse[u] & 0xffu, ns = next[sy]++;
+            const uint32_t sy = fse[u] & 0xfu, ns = next[sy]++;
             if (ns == 0 || ns >= 2 * size) return 0;
             const uint32_t nbits = tl - (uint32_t)highbit(ns);
-            fse[u] = sy | (nbits << 8) | (((ns << nbits) - size) << 16);
+            fse[u] = (uint16_t)(sy | (nbits << 4) | (((ns << nbits) - size) << 8));
         }
         // FSE_decompress_usingDTable: two interleaved states; the stream ends by running dry
         const uint8_t* const b = f + hl;
@@ -171,20 +171,20 @@ __device__ uint32_t read_stats(const uint8_t* h, uint32_t n, uint8_t* weights, u
             for (int r = 0; r < 4 && !done; r++) {
                 if (osize + 2 > 255u) return 0;
                 uint32_t e = fse[s1];
-                weights[osize++] = (uint8_t)e;
-                uint32_t nbt = (e >> 8) & 0xffu;
-                s1 = (e >> 16) + (nbt ? (uint32_t)(win >> (64u - nbt)) : 0u);
+                weights[osize++] = (uint8_t)(e & 0xfu);
+                uint32_t nbt = (e >> 4) & 0xfu;
+                s1 = (e >> 8) + (nbt ? (uint32_t)(win >> (64u - nbt)) : 0u);
                 win <<= nbt;
                 P -= (int)nbt;
-                if (P < 0) { weights[osize++] = (uint8_t)fse[s2]; done = true; break; }
+                if (P < 0) { weights[osize++] = (uint8_t)(fse[s2] & 0xfu); done = true; break; }
                 if (osize + 2 > 255u) return 0;
                 e = fse[s2];
-                weights[osize++] = (uint8_t)e;
-                nbt = (e >> 8) & 0xffu;
-                s2 = (e >> 16) + (nbt ? (uint32_t)(win >> (64u - nbt)) : 0u);
+                weights[osize++] = (uint8_t)(e & 0xfu);
+                nbt = (e >> 4) & 0xfu;
+                s2 = (e >> 8) + (nbt ? (uint32_t)(win >> (64u - nbt)) : 0u);
                 win <<= nbt;
                 P -= (int)nbt;
-                if (P < 0) { weights[osize++] = (uint8_t)fse[s1]; done = true; break; }
+                if (P < 0) { weights[osize++] = (uint8_t)(fse[s1] & 0xfu); done = true; break; }
             }
             if (done) break;
         }
@@ -298,12 +298,13 @@ __global__ void __launch_bounds__(64) huf0_decode_kernel(const uint8_t* __restri
     // wave-uniform loop: the quad exchanges of the output path need every lane, streamless ones included.
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     typedef v4u __attribute__((aligned(1), may_alias)) v4u_a1;
+    typedef v4u __attribute__((aligned(16), may_alias)) v4u_a16;
     bool bad = false;
     uint32_t T[13];                                               // T[k] = start[k]: thresholds of the weight search (k > tableLog: never reached)
 #pragma unroll
     for (int k = 2; k < 13; k++) T[k] = (coded && (uint32_t)k <= tl) ? (s_tab[q][k] & 0xffffu) : 0xffffu;
     const uint8_t* sp = blocks;                                   // this lane's stream
-    int64_t P = 0, floor_b = 0;
+    int64_t P = 0;
     uint8_t* op = dst;
     uint64_t left = 0;
     if (coded) {
@@ -331,7 +332,6 @@ __global__ void __launch_bounds__(64) huf0_decode_kernel(const uint8_t* __restri
             if (!bad) {
                 sp = ip + so;
                 P = 8 * (int64_t)(slen - 1) + highbit(sp[slen - 1]);
-                floor_b = -(int64_t)(hl + so);                    // the block's first byte, relative to sp
                 op = dst + w0;
                 left = w1 - w0;
             }
@@ -339,34 +339,43 @@ __global__ void __launch_bounds__(64) huf0_decode_kernel(const uint8_t* __restri
     }
     const bool streaming = left > 0 || (coded && !bad);           // has a stream whose end must be checked
     const uint32_t look_shift = 32u - (tl ? tl : 1u);
-    // 16 bytes ending at the byte that holds bit P-1 are requested one step AHEAD: four symbols take at
-    // most 48 bits, so the next step's 8-byte window lies inside them (clamped to the block's first
-    // byte -- at least 7 bytes precede every stream, not always 15)
-    int64_t base = 0;
-    auto fetch = [&](int64_t Pn) -> v4u {
-        if (!streaming) return v4u{0, 0, 0, 0};
-        const int64_t tb = Pn > 0 ? (Pn - 1) >> 3 : 0;
-        base = tb - 15 > floor_b ? tb - 15 : floor_b;
-        return *(const v4u_a1*)(sp + base);
+    // The stream reaches the lane as 16-byte ALIGNED pieces, three of them in registers: the one that holds the
+    // cursor's byte (pc0), the one below (pc1) and the one below that, in flight (pn).  A step takes at most 6
+    // bytes, so the cursor leaves a piece every ~3 steps: only then is a new piece requested -- a third of the
+    // requests of "16 unaligned bytes every step", which kept the address path 66 % busy -- and a piece has two
+    // crossings (>= 5 steps) to arrive.  Piece k covers bytes [16 k - s_al, 16 k - s_al + 16) of the stream.
+    const uint32_t s_al = (uint32_t)((uintptr_t)sp & 15u);
+    const uint8_t* const sp_al = sp - s_al;                       // >= blocks: the API asks for a 16-byte aligned buffer
+    auto load_piece = [&](int32_t k) -> v4u {
+        if (!streaming || k < 0) return v4u{0, 0, 0, 0};
+        return *(const v4u_a16*)(sp_al + 16 * (int64_t)k);
     };
-    v4u buf = fetch(P);
+    int32_t cur_k = (int32_t)(((P > 0 ? (P - 1) >> 3 : 0) + (int64_t)s_al) >> 4);
+    v4u pc0 = load_piece(cur_k), pc1 = load_piece(cur_k - 1), pn = load_piece(cur_k - 2);
     // one step = 4 symbols = one dword of output
     auto step = [&](uint32_t m) -> uint32_t {
         uint64_t win = 0;
-        const v4u cur = buf;
-        const int64_t cur_base = base;
         const int64_t Pc = P;
         if (Pc > 0) {
-            const int64_t tb = (Pc - 1) >> 3;
-            const uint32_t o = (uint32_t)(tb - 7 - cur_base);    // 0 .. 8: the window's first byte inside cur
-            const uint32_t d0 = o < 4 ? cur.x : o < 8 ? cur.y : cur.z;
-            const uint32_t d1 = o < 4 ? cur.y : o < 8 ? cur.z : cur.w;
-            const uint32_t d2 = o < 4 ? cur.z : o < 8 ? cur.w : 0u;
-            const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, o & 3u), hi = __builtin_amdgcn_alignbyte(d2, d1, o & 3u);
+            const uint32_t r = (uint32_t)((Pc - 1) >> 3) + s_al;  // the cursor's byte, counted from piece 0
+            if ((int32_t)(r >> 4) < cur_k) {                      // left pc0: shift the pieces up, request the next one down
+                pc0 = pc1;
+                pc1 = pn;
+                cur_k--;
+                pn = load_piece(cur_k - 2);
+            }
+            // the 8 bytes ending at byte r, out of the 32 of (pc1 | pc0): first byte at o = 9 .. 24
+            const uint32_t o = r - 7u - 16u * (uint32_t)(cur_k - 1);
+            const uint32_t t3 = (o >> 2) - 2u;                    // 0 .. 4: which dword the window starts in, minus 2
+            const bool b0 = (t3 & 1u) != 0, b1 = (t3 & 2u) != 0, b2 = (t3 & 4u) != 0;
+            const uint32_t D2 = pc1.z, D3 = pc1.w, D4 = pc0.x, D5 = pc0.y, D6 = pc0.z, D7 = pc0.w;
+            const uint32_t wa = b2 ? D6 : (b1 ? (b0 ? D5 : D4) : (b0 ? D3 : D2));
+            const uint32_t wb = b2 ? D7 : (b1 ? (b0 ? D6 : D5) : (b0 ? D4 : D3));
+            const uint32_t wc = b2 ? 0u : (b1 ? (b0 ? D7 : D6) : (b0 ? D5 : D4));
+            const uint32_t lo = __builtin_amdgcn_alignbyte(wb, wa, o & 3u), hi = __builtin_amdgcn_alignbyte(wc, wb, o & 3u);
             win = (((uint64_t)hi << 32) | lo) << (7 - (int)((Pc - 1) & 7));
             if (Pc < 64) win &= ~0ull << (64 - (int)Pc);         // nothing before the stream's first bit
         }
-        buf = fetch(Pc);                                         // for the NEXT step; in flight during this one's symbols
         uint32_t word = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -468,7 +477,7 @@ extern "C" {
 int sprintz_mi355x_huf0_decompress_batch(const void* d_blocks, const uint64_t* d_block_offsets, uint64_t nchunks, void* d_out,
                                          const uint64_t* d_out_offsets, int64_t* d_rets, void* hip_stream)
 {
-    if (!d_blocks || !d_block_offsets || !d_out || !d_out_offsets) return SPRINTZ_E_INVALID;
+    if (!d_blocks || !d_block_offsets || !d_out || !d_out_offsets || ((uintptr_t)d_blocks & 15)) return SPRINTZ_E_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return SPRINTZ_E_NO_DEVICE;
     if (nchunks == 0) return 0;

@@ -24,7 +24,7 @@ def pack(blocks, plains, align=1):
     oo = np.zeros(len(plains) + 1, np.int64)
     for i, p in enumerate(plains):
         oo[i + 1] = oo[i] + p.size
-    data = np.concatenate(list(blocks) + [np.zeros(8, np.uint8)])
+    data = np.concatenate(list(blocks) + [np.zeros(16, np.uint8)])
     return torch.from_numpy(data).cuda(), torch.from_numpy(bo).cuda(), torch.from_numpy(oo).cuda(), oo
 
 

@@ -58,7 +58,7 @@ def main():
     oo_dense = np.zeros(a.chunks + 1, np.int64)
     oo_dense[1:] = np.cumsum(plain_sizes)
     oo_d = torch.from_numpy(oo_dense).to(dev)
-    d = torch.from_numpy(np.concatenate(blocks + [np.zeros(8, np.uint8)])).to(dev)
+    d = torch.from_numpy(np.concatenate(blocks + [np.zeros(16, np.uint8)])).to(dev)
     bo_d = torch.from_numpy(bo).to(dev)
     rets = torch.empty(a.chunks, dtype=torch.int64, device=dev)
     streams = sprintz_amd.huf0_decompress(d, bo_d, oo_d, rets=rets)
