@@ -313,11 +313,11 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
     }
     // univariate streams: one lane per chunk, LDS ring in, quad-transposed 64-byte bursts out (decode_uni.h)
     // (and the other low-dim shapes: 2 columns, 3 and 4 at 8 bits)
-    if (lowdim && (D <= 2 || esz == 1) && !noheader && qs.q == kQueryOff && !cs && !getenv("SPRINTZ_MI355X_NO_FAST")) {
+    if (lowdim && (D <= 2 || esz == 1) && !noheader && !cs && !getenv("SPRINTZ_MI355X_NO_FAST")) {
         const uint64_t ugrid = (nchunks + 255) / 256;
         if (ugrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
-        e = esz == 1 ? launch_decode_uni_w8(codec == SPRINTZ_CODEC_XFF, D, (unsigned)ugrid, st, a)
-                     : launch_decode_uni_w16(codec == SPRINTZ_CODEC_XFF, D, (unsigned)ugrid, st, a);
+        e = esz == 1 ? launch_decode_uni_w8(codec == SPRINTZ_CODEC_XFF, D, qs.q, (unsigned)ugrid, st, a)
+                     : launch_decode_uni_w16(codec == SPRINTZ_CODEC_XFF, D, qs.q, (unsigned)ugrid, st, a);
         if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "decode_uni kernel launch", e);
         return 0;
     }

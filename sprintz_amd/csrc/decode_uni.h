@@ -19,7 +19,8 @@
 
 namespace sprintz {
 
-template <int W, bool FIRE, int ND = 1>
+// Q: query-on-compressed (decode_kernel.h): per-column max and sum ride along; reduce-only never stores samples
+template <int W, bool FIRE, int ND = 1, int Q = 0>
 __global__ void __launch_bounds__(256) decode_uni_kernel(DecodeArgs a)
 {
     constexpr int HB = Elem<W>::HB;
@@ -113,6 +114,10 @@ __global__ void __launch_bounds__(256) decode_uni_kernel(DecodeArgs a)
 #pragma unroll
     for (int k = 0; k < ND; k++) { pv[k] = 0; pd[k] = 0; ctr[k] = 0; nb0[k] = 0; nb1[k] = 0; }
     uint32_t run_left = 0, out_elems = 0;
+    uint32_t qmax[ND];
+    uint64_t qsum[ND];
+#pragma unroll
+    for (int k = 0; k < ND; k++) { qmax[k] = 0; qsum[k] = 0; }
     int slot = 2;
     uint8_t* const obase = (uint8_t*)a.out + chunk * (uint64_t)a.chunk_len * ESZ;
     const bool odd1 = (t & 1) != 0, odd2 = (t & 2) != 0;
@@ -200,6 +205,7 @@ __global__ void __launch_bounds__(256) decode_uni_kernel(DecodeArgs a)
                         pv[k] = (pv[k] + (uint32_t)delta) & MASK;
                         pd[k] = delta;
                         x[k][i] = pv[k];
+                        if constexpr (Q != 0) { qmax[k] = pv[k] > qmax[k] ? pv[k] : qmax[k]; qsum[k] += pv[k]; }
                     }
                     if (FIRE && nbsum != 0) ctr[k] = wrap_counter<W>(ctr[k] + (sext<W>(grad) >> 2));   // counters only move on real blocks
                     cf += nbk;
@@ -215,6 +221,7 @@ __global__ void __launch_bounds__(256) decode_uni_kernel(DecodeArgs a)
         // butterfly stages: (member m, piece k) -> (lane k, slot m)) and stores one member's 64
         // bytes per instruction.  A partly filled window (the chunk's end) is stored block by block.
         const bool full = valid == (1u << BW) - 1u;
+        if constexpr (Q != kQueryReduceOnly) {
 #pragma unroll
         for (int wn = 0; wn < WINS; wn++) {
         uint32_t v[4][4];
@@ -270,6 +277,7 @@ __global__ void __launch_bounds__(256) decode_uni_kernel(DecodeArgs a)
                 }
             }
         }
+        }   // Q != kQueryReduceOnly
         if (wave_done) break;
     }
 
@@ -279,8 +287,21 @@ __global__ void __launch_bounds__(256) decode_uni_kernel(DecodeArgs a)
         if (!corrupt && (uint64_t)(c - c_begin) + (uint64_t)remaining * ESZ > stream_len + 2) corrupt = true;
         if (!corrupt) {
             const uint8_t* src = a.comp + off + (c - c_begin);
-            uint8_t* d = obase + (uint64_t)out_elems * ESZ;
-            for (uint32_t j = 0; j < remaining * ESZ; j++) d[j] = src[j];
+            if constexpr (Q != kQueryReduceOnly) {
+                uint8_t* d = obase + (uint64_t)out_elems * ESZ;
+                for (uint32_t j = 0; j < remaining * ESZ; j++) d[j] = src[j];
+            }
+            if constexpr (Q != 0) {                      // the verbatim tail continues the row-major order: element e is column e % ND
+                for (uint32_t e = 0; e < remaining; e++) {
+                    const uint32_t x = ESZ == 1 ? (uint32_t)src[e] : ((uint32_t)src[2 * e] | ((uint32_t)src[2 * e + 1] << 8));
+#pragma unroll
+                    for (int k = 0; k < ND; k++)
+                        if (e % ND == (uint32_t)k) { qmax[k] = x > qmax[k] ? x : qmax[k]; qsum[k] += x; }
+                }
+#pragma unroll
+                for (int k = 0; k < ND; k++)
+                    if (a.qres) a.qres[chunk * (uint64_t)ND + (uint64_t)k] = a.qop == 1 ? (uint64_t)qmax[k] : qsum[k];
+            }
         }
         if (a.rets) a.rets[chunk] = corrupt ? kErrCorrupt : (int64_t)out_elems + remaining;
     }

@@ -9,27 +9,27 @@ hipError_t launch_decode_fast_w8(bool fire, int dp, int cpl, bool exact, int q, 
 {
     SPRINTZ_DISPATCH_DECODE_FAST(decode_fast_kernel, 8)
 }
-hipError_t launch_decode_uni_w8(bool fire, int nd, unsigned grid, hipStream_t st, const DecodeArgs& a)
-{
-    switch (nd) {
-        case 1:
-            if (fire) hipLaunchKernelGGL((decode_uni_kernel<8, true, 1>), dim3(grid), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((decode_uni_kernel<8, false, 1>), dim3(grid), dim3(256), 0, st, a);
-            break;
-        case 2:
-            if (fire) hipLaunchKernelGGL((decode_uni_kernel<8, true, 2>), dim3(grid), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((decode_uni_kernel<8, false, 2>), dim3(grid), dim3(256), 0, st, a);
-            break;
-        case 3:
-            if (fire) hipLaunchKernelGGL((decode_uni_kernel<8, true, 3>), dim3(grid), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((decode_uni_kernel<8, false, 3>), dim3(grid), dim3(256), 0, st, a);
-            break;
-        case 4:
-            if (fire) hipLaunchKernelGGL((decode_uni_kernel<8, true, 4>), dim3(grid), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((decode_uni_kernel<8, false, 4>), dim3(grid), dim3(256), 0, st, a);
-            break;
-        default: return hipErrorInvalidValue;
+#define SPRINTZ_UNI_CASE(NDV, QV)                                                                          \
+    if (nd == NDV && q == QV) {                                                                             \
+        if (fire) hipLaunchKernelGGL((decode_uni_kernel<8, true, NDV, QV>), dim3(grid), dim3(256), 0, st, a);   \
+        else hipLaunchKernelGGL((decode_uni_kernel<8, false, NDV, QV>), dim3(grid), dim3(256), 0, st, a);       \
+        return hipGetLastError();                                                                           \
     }
-    return hipGetLastError();
+hipError_t launch_decode_uni_w8(bool fire, int nd, int q, unsigned grid, hipStream_t st, const DecodeArgs& a)
+{
+    SPRINTZ_UNI_CASE(1, kQueryOff)
+    SPRINTZ_UNI_CASE(1, kQueryMaterialize)
+    SPRINTZ_UNI_CASE(1, kQueryReduceOnly)
+    SPRINTZ_UNI_CASE(2, kQueryOff)
+    SPRINTZ_UNI_CASE(2, kQueryMaterialize)
+    SPRINTZ_UNI_CASE(2, kQueryReduceOnly)
+    SPRINTZ_UNI_CASE(3, kQueryOff)
+    SPRINTZ_UNI_CASE(3, kQueryMaterialize)
+    SPRINTZ_UNI_CASE(3, kQueryReduceOnly)
+    SPRINTZ_UNI_CASE(4, kQueryOff)
+    SPRINTZ_UNI_CASE(4, kQueryMaterialize)
+    SPRINTZ_UNI_CASE(4, kQueryReduceOnly)
+    return hipErrorInvalidValue;
 }
+#undef SPRINTZ_UNI_CASE
 }  // namespace sprintz

@@ -84,6 +84,9 @@ QCONFIGS = [
     ("u8 D=8 xff", "xff", 1, 8, 4096),
     ("cfg1 u8 D=1 low-dim", "delta", 1, 1, 1024),
     ("u16 D=2 low-dim xff", "xff", 2, 2, 2048),
+    ("u8 D=4 low-dim xff", "xff", 1, 4, 2048),
+    ("u8 D=3 low-dim delta, ragged", "delta", 1, 3, 3001),
+    ("u16 D=1 low-dim xff", "xff", 2, 1, 777),
     ("u16 D=3 generic", "xff", 2, 3, 1001),
     ("u16 D=32", "xff", 2, 32, 5120),
     ("u8 D=200 (4 columns per lane)", "xff", 1, 200, 16000),
