@@ -24,4 +24,9 @@ hipError_t launch_encode_uni_w16(bool fire, int nd, unsigned grid, hipStream_t s
     }
     return hipGetLastError();
 }
+hipError_t launch_encode_wide_w16(bool fire, bool exact, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a)
+{
+    if (exact) return fire ? launch_one(encode_wide_kernel<16, true, true>, grid, shmem, st, a) : launch_one(encode_wide_kernel<16, false, true>, grid, shmem, st, a);
+    return fire ? launch_one(encode_wide_kernel<16, true, false>, grid, shmem, st, a) : launch_one(encode_wide_kernel<16, false, false>, grid, shmem, st, a);
+}
 }  // namespace sprintz

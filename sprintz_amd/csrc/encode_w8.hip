@@ -34,7 +34,7 @@ hipError_t launch_encode_uni_w8(bool fire, int nd, unsigned grid, hipStream_t st
 }
 hipError_t launch_encode_wide_w8(bool fire, bool exact, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a)
 {
-    if (exact) return fire ? launch_one(encode_wide_kernel<true, true>, grid, shmem, st, a) : launch_one(encode_wide_kernel<false, true>, grid, shmem, st, a);
-    return fire ? launch_one(encode_wide_kernel<true, false>, grid, shmem, st, a) : launch_one(encode_wide_kernel<false, false>, grid, shmem, st, a);
+    if (exact) return fire ? launch_one(encode_wide_kernel<8, true, true>, grid, shmem, st, a) : launch_one(encode_wide_kernel<8, false, true>, grid, shmem, st, a);
+    return fire ? launch_one(encode_wide_kernel<8, true, false>, grid, shmem, st, a) : launch_one(encode_wide_kernel<8, false, false>, grid, shmem, st, a);
 }
 }  // namespace sprintz

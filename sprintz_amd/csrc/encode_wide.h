@@ -1,23 +1,26 @@
-// encode_wide.h -- encode_fast.h's row-major path with TWO columns per lane, for 8-bit streams of
-// 65 .. 128 columns (BASELINE config 3 has 80): one 64-lane group per chunk, lane l owns columns 2l and
-// 2l + 1.  Same stream bytes as encode_kernel.h (sprintz_xff_rle.cpp:61-555,
-// sprintz_delta_rle.cpp:55-404).  An 8 x D block is at most 1 024 bytes, so the input side is
-// unchanged (one 16-byte piece per lane a block ahead, transposed through LDS); on the output side a
+// encode_wide.h -- encode_fast.h's row-major path with TWO columns per lane, for streams of
+// 65 .. 128 columns (BASELINE config 3 has 80; the paper's MSRC-12 has 80 at either width): one 64-lane
+// group per chunk, lane l owns columns 2l and 2l + 1.  Same stream bytes as encode_kernel.h (sprintz_xff_rle.cpp:61-555,
+// sprintz_delta_rle.cpp:55-404).  An 8 x D block is at most 1 024 bytes (2 048 at 16 bits: two pieces
+// per lane), so the input side is unchanged (16-byte pieces a block ahead, transposed through LDS); on the output side a
 // lane's two fields are adjacent in the row and are merged in registers for nothing, and a lane pair
-// merges its four (<= 32 bits) with one DPP move, so a quarter of the columns' worth of LDS ORs is
-// issued and same-address collisions shrink accordingly.
+// merges its four (<= 32 bits at 8 bits; at 16 bits a lane's own two already fill a dword) with one DPP
+// move, so a quarter (half) of the columns' worth of LDS ORs is issued and same-address collisions
+// shrink accordingly.
 #pragma once
 
 #include "encode_fast.h"
 
 namespace sprintz {
 
-template <bool FIRE, bool EXACT>
+template <int W, bool FIRE, bool EXACT>
 __global__ void __launch_bounds__(kThreads) encode_wide_kernel(EncodeArgs a)
 {
-    constexpr int W = 8, DP = 64, CPL = 2, LOG2DP = 6;
-    using U = uint8_t;
+    constexpr int DP = 64, CPL = 2, LOG2DP = 6;
+    using U = typename Elem<W>::U;
     constexpr int HB = Elem<W>::HB;
+    constexpr int ESZ = W / 8;
+    constexpr int PIECES = ESZ;                  // 16-byte pieces of a block per lane: 8 * 128 * ESZ bytes / (64 * 16)
     constexpr bool TAIL_LE = FIRE;               // "<=" at sprintz_xff_rle.cpp:362, "<" at sprintz_delta_rle.cpp:226
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
@@ -80,7 +83,8 @@ __global__ void __launch_bounds__(kThreads) encode_wide_kernel(EncodeArgs a)
     };
 
     const uint32_t hdr_bytes = (2u * (uint32_t)D * HB + 7u) >> 3;
-    const uint32_t blk = 8u * (uint32_t)D;       // elements = bytes per block
+    const uint32_t blk = 8u * (uint32_t)D;       // elements per block
+    const uint32_t blk_bytes = blk * ESZ;
     const uint32_t lane16 = (uint32_t)lane_d * 16u;
     const int64_t limit = (int64_t)n - 2 * (int64_t)blk;
     int64_t pos_in = 0;
@@ -97,31 +101,40 @@ __global__ void __launch_bounds__(kThreads) encode_wide_kernel(EncodeArgs a)
         wl += hdr_bytes;
         slot = 0;
     };
-    auto load_block = [&](int64_t pos) -> uint4 {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (lane16 < blk && pos + (int64_t)blk <= (int64_t)n) v = *(const uint4*)(sc + pos + lane16);
-        return v;
+    uint4 nxt[PIECES];
+    auto load_block = [&](int64_t pos) {
+#pragma unroll
+        for (int q = 0; q < PIECES; q++) {
+            const uint32_t u = lane16 + (uint32_t)q * DP * 16u;
+            nxt[q] = make_uint4(0, 0, 0, 0);
+            if (u < blk_bytes && pos + (int64_t)blk <= (int64_t)n) nxt[q] = *(const uint4*)((const uint8_t*)(sc + pos) + u);
+        }
     };
 
     bool active = n >= 128u && limit >= 0;
-    uint4 nxt = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < PIECES; q++) nxt[q] = make_uint4(0, 0, 0, 0);
     if (active) {
         start_group();
-        nxt = load_block(0);
+        load_block(0);
     }
-    const uint32_t row_stride = (uint32_t)D;
+    const uint32_t row_stride = (uint32_t)D;     // elements
 
     while (active) {
         // ---- the block at pos_in is in `nxt`: transpose it through LDS, request the next one
-        if (lane16 < blk) *(uint4*)(stage + lane16) = nxt;
+#pragma unroll
+        for (int q = 0; q < PIECES; q++) {
+            const uint32_t u = lane16 + (uint32_t)q * DP * 16u;
+            if (u < blk_bytes) *(uint4*)(stage + u) = nxt[q];
+        }
         wave_lds_sync();
-        nxt = load_block(pos_in + blk);
+        load_block(pos_in + blk);
         uint32_t z[CPL][8], nb[CPL], lane_bits = 0;
 #pragma unroll
         for (int k = 0; k < CPL; k++) {
             uint32_t x[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) x[i] = col_ok[k] ? (uint32_t)stage[(uint32_t)(col0 + k) + i * row_stride] : 0u;
+            for (int i = 0; i < 8; i++) x[i] = col_ok[k] ? (uint32_t)((const U*)stage)[(uint32_t)(col0 + k) + i * row_stride] : 0u;
             const int coef = FIRE ? fire_coef<W, false>(ctr[k]) : 0;
             int grad = 0;
             uint32_t mask = 0;
@@ -181,14 +194,22 @@ __global__ void __launch_bounds__(kThreads) encode_wide_kernel(EncodeArgs a)
             }
             const uint32_t row_bits = ((total + 7u) >> 3) << 3;
             uint32_t bp = wl * 8u + excl;
-            const uint32_t nb_pair = lane_bits + dpp<DPP_ROW_SHL(1)>(0, lane_bits);   // this lane's and the next one's: 4 fields <= 32 bits
-            const bool even = (lane_d & 1) == 0;
+            if constexpr (W == 8) {
+                const uint32_t nb_pair = lane_bits + dpp<DPP_ROW_SHL(1)>(0, lane_bits);   // this lane's and the next one's: 4 fields <= 32 bits
+                const bool even = (lane_d & 1) == 0;
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const uint32_t mine = z[0][i] | (z[1][i] << nb[0]);                  // <= 16 bits
-                const uint32_t theirs = dpp<DPP_ROW_SHL(1)>(0, mine);
-                if (even) or_bits(bp, mine | (theirs << lane_bits), nb_pair);
-                bp += row_bits;
+                for (int i = 0; i < 8; i++) {
+                    const uint32_t mine = z[0][i] | (z[1][i] << nb[0]);              // <= 16 bits
+                    const uint32_t theirs = dpp<DPP_ROW_SHL(1)>(0, mine);
+                    if (even) or_bits(bp, mine | (theirs << lane_bits), nb_pair);
+                    bp += row_bits;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    or_bits(bp, z[0][i] | (nb[0] < 32u ? z[1][i] << nb[0] : 0u), lane_bits);   // the lane's own two fields: <= 32 bits
+                    bp += row_bits;
+                }
             }
             wl += row_bits;
             pos_in += blk;
@@ -204,8 +225,8 @@ __global__ void __launch_bounds__(kThreads) encode_wide_kernel(EncodeArgs a)
     // ---- verbatim tail through the window (:553)
     const uint32_t remaining = (uint32_t)((int64_t)n - pos_in);
     {
-        const uint8_t* tp = sc + pos_in;
-        uint32_t left = remaining;
+        const uint8_t* tp = (const uint8_t*)(sc + pos_in);
+        uint32_t left = remaining * ESZ;
         while (left > 0) {
             drain(wl & ~15u);
             const uint32_t room = cap - 16u - wl;
@@ -231,7 +252,7 @@ __global__ void __launch_bounds__(kThreads) encode_wide_kernel(EncodeArgs a)
             ((uint32_t*)gdst)[1] = (remaining & 0xffffu) | ((uint32_t)D << 16);
         }
         a.sizes[chunk] = total_bytes;
-        if (a.rets) a.rets[chunk] = (int64_t)total_bytes;
+        if (a.rets) a.rets[chunk] = (int64_t)(total_bytes / ESZ);   // element units, floor (:554)
     }
 }
 

@@ -26,8 +26,9 @@ hipError_t launch_decode_fast_w16(bool fire, int dp, int cpl, bool exact, int q,
 // low-dim streams with 1, 2 or 4 columns (8 bits) / 1 or 2 (16 bits), one lane per chunk (decode_uni.h)
 hipError_t launch_decode_uni_w8(bool fire, int nd, int q, unsigned grid, hipStream_t st, const DecodeArgs& a);
 hipError_t launch_decode_uni_w16(bool fire, int nd, int q, unsigned grid, hipStream_t st, const DecodeArgs& a);
-// 8-bit streams of 65 .. 128 columns, two columns per lane (encode_wide.h)
+// streams of 65 .. 128 columns, two columns per lane (encode_wide.h)
 hipError_t launch_encode_wide_w8(bool fire, bool exact, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
+hipError_t launch_encode_wide_w16(bool fire, bool exact, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
 hipError_t launch_encode_uni_w8(bool fire, int nd, unsigned grid, hipStream_t st, const EncodeArgs& a);
 hipError_t launch_encode_uni_w16(bool fire, int nd, unsigned grid, hipStream_t st, const EncodeArgs& a);
 hipError_t launch_encode_fast_w8(bool fire, int dp, bool exact, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);

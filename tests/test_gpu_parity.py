@@ -141,6 +141,9 @@ CONFIGS = [
     ("wide8_d128_xff", "xff", 1, 128, 16384),    # two columns per lane: encode_wide.h
     ("wide8_d100_delta", "delta", 1, 100, 8000),
     ("wide8_d66_xff", "xff", 1, 66, 6336),
+    ("wide16_d80_xff", "xff", 2, 80, 10240),     # the same at 16 bits: two 16-byte pieces per lane and block
+    ("wide16_d128_delta", "delta", 2, 128, 8192),
+    ("wide16_d72_xff", "xff", 2, 72, 72 * 40),
 ]
 
 
@@ -414,7 +417,7 @@ def test_huffman_decoder_survives_damaged_containers(sz):
     assert np.array_equal(r, sizes.astype(np.int64))
 
 
-@pytest.mark.parametrize("name,codec,esz,ndims,chunk_len", [c for c in CONFIGS if c[0] in ("cfg2", "cfg3_10k", "cfg5", "xff8", "cfg1", "uni16_xff", "uni16_delta_ragged", "low8_d2", "low8_d4", "lowdim16", "low16_d2_delta_ragged", "lowdim8", "low8_d3_delta", "wide8_d128_xff", "wide8_d100_delta", "wide8_d66_xff")])
+@pytest.mark.parametrize("name,codec,esz,ndims,chunk_len", [c for c in CONFIGS if c[0] in ("cfg2", "cfg3_10k", "cfg5", "xff8", "cfg1", "uni16_xff", "uni16_delta_ragged", "low8_d2", "low8_d4", "lowdim16", "low16_d2_delta_ragged", "lowdim8", "low8_d3_delta", "wide8_d128_xff", "wide8_d100_delta", "wide8_d66_xff", "wide16_d80_xff", "wide16_d128_delta", "wide16_d72_xff")])
 def test_generic_kernels_agree_with_the_fast_ones(sz, monkeypatch, name, codec, esz, ndims, chunk_len):
     """SPRINTZ_MI355X_NO_FAST routes the same calls to decode_kernel.h / encode_kernel.h: same bytes, same samples"""
     import torch

@@ -61,6 +61,7 @@ def main():
         ("      u8  D=8  xff 8KB walk2", "xff", 1, 8, 8192, "walk2"),
         ("cfg3  u8  D=80 delta 1KB (raw passthrough)", "delta", 1, 80, 1024 + 16, "walk2"),
         ("cfg3  u8  D=80 delta 10KB", "delta", 1, 80, 10240, "walk2"),
+        ("      u16 D=80 xff 20KB (MSRC-12 shape at 16 bits)", "xff", 2, 80, 10240, "walk8"),
         ("cfg5  u16 D=32 xff 10KB", "xff", 2, 32, 5120, "walk8"),
         ("      u16 D=16 xff 10KB", "xff", 2, 16, 5120, "walk8"),
         ("      u16 D=64 xff 16KB", "xff", 2, 64, 8192, "walk8"),
