@@ -464,7 +464,7 @@ def test_containers_beyond_4_GiB(sz):
     assert torch.equal(out, x)
 
 
-@pytest.mark.parametrize("seed", list(range(200)))
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("SPRINTZ_SWEEP", "200")))))
 def test_random_shapes(sz, oracle, seed):
     """a sweep over the kernel variants' dispatch space: random element width, ndims, chunk length (multiples of
     16 and not), codec (the five), data mix -- batched compress bytes == oracle's, decompress == input"""
