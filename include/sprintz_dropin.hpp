@@ -1,12 +1,16 @@
-// sprintz_dropin.hpp -- the reference's public header, re-declared on top of
-// libsprintz_mi355x.so.  A caller written against dblalock/sprintz
-// cpp/Compress/sprintz.h (sprintz.h:16-32; e.g. the author's lzbench fork,
-// reference README.md:29) includes this file instead and links
-// -lsprintz_mi355x: same names, same C++ signatures (default argument
-// included), same units (ELEMENTS) and return values.
+// sprintz_dropin.hpp -- the reference's public prototypes, DECLARED here and DEFINED (non-inline,
+// C++ linkage, the reference's exact signatures and therefore its exact mangled names) in
+// libsprintz_mi355x.so (sprintz_amd/csrc/dropin.cpp).  An object file already compiled against
+// dblalock/sprintz cpp/Compress/sprintz.h (sprintz.h:16-32; e.g. the author's lzbench fork,
+// reference README.md:29) links against -lsprintz_mi355x unchanged; a caller being recompiled
+// may include this file instead of the reference's headers: same names, same default arguments,
+// same units (ELEMENTS) and return values.
 //
-// Host pointers in and out; every call is one chunk on the GPU (see
-// include/sprintz_mi355x.h for the batched device API that is actually fast).
+// Host pointers in and out; every call is one chunk on the GPU (see include/sprintz_mi355x.h for
+// the batched device API that is actually fast).  Error convention of the reference kept: the
+// int64_t functions return -1 for ndims == 0 (sprintz.cpp:36) and otherwise a negative
+// SPRINTZ_E_* code on failure (the reference has no other error path); the uint32_t transform
+// functions return 0 on failure (sprintz_mi355x_last_error() says why).
 #ifndef SPRINTZ_DROPIN_HPP
 #define SPRINTZ_DROPIN_HPP
 
@@ -15,44 +19,38 @@
 #include "sprintz_mi355x.h"
 
 // ================================================================ 8b  (sprintz.h:16-23)
-inline int64_t sprintz_compress_delta_8b(const uint8_t* src, uint32_t len, int8_t* dest, uint16_t ndims,
-                                         bool write_size = true)
-{
-    return sprintz_mi355x_compress_delta_8b(src, len, dest, ndims, write_size ? 1 : 0);
-}
-inline int64_t sprintz_decompress_delta_8b(const int8_t* src, uint8_t* dest)
-{
-    return sprintz_mi355x_decompress_delta_8b(src, dest);
-}
-inline int64_t sprintz_compress_xff_8b(const uint8_t* src, uint32_t len, int8_t* dest, uint16_t ndims,
-                                       bool write_size = true)
-{
-    return sprintz_mi355x_compress_xff_8b(src, len, dest, ndims, write_size ? 1 : 0);
-}
-inline int64_t sprintz_decompress_xff_8b(const int8_t* src, uint8_t* dest)
-{
-    return sprintz_mi355x_decompress_xff_8b(src, dest);
-}
+int64_t sprintz_compress_delta_8b(const uint8_t* src, uint32_t len, int8_t* dest, uint16_t ndims, bool write_size = true);
+int64_t sprintz_decompress_delta_8b(const int8_t* src, uint8_t* dest);
+int64_t sprintz_compress_xff_8b(const uint8_t* src, uint32_t len, int8_t* dest, uint16_t ndims, bool write_size = true);
+int64_t sprintz_decompress_xff_8b(const int8_t* src, uint8_t* dest);
 
 // ================================================================ 16b (sprintz.h:25-32)
-inline int64_t sprintz_compress_delta_16b(const uint16_t* src, uint32_t len, int16_t* dest, uint16_t ndims,
-                                          bool write_size = true)
-{
-    return sprintz_mi355x_compress_delta_16b(src, len, dest, ndims, write_size ? 1 : 0);
-}
-inline int64_t sprintz_decompress_delta_16b(const int16_t* src, uint16_t* dest)
-{
-    return sprintz_mi355x_decompress_delta_16b(src, dest);
-}
-inline int64_t sprintz_compress_xff_16b(const uint16_t* src, uint32_t len, int16_t* dest, uint16_t ndims,
-                                        bool write_size = true)
-{
-    return sprintz_mi355x_compress_xff_16b(src, len, dest, ndims, write_size ? 1 : 0);
-}
-inline int64_t sprintz_decompress_xff_16b(const int16_t* src, uint16_t* dest)
-{
-    return sprintz_mi355x_decompress_xff_16b(src, dest);
-}
+int64_t sprintz_compress_delta_16b(const uint16_t* src, uint32_t len, int16_t* dest, uint16_t ndims, bool write_size = true);
+int64_t sprintz_decompress_delta_16b(const int16_t* src, uint16_t* dest);
+int64_t sprintz_compress_xff_16b(const uint16_t* src, uint32_t len, int16_t* dest, uint16_t ndims, bool write_size = true);
+int64_t sprintz_decompress_xff_16b(const int16_t* src, uint16_t* dest);
+
+// ================================================================ the layer below sprintz.h
+// compress_rowmajor_{delta,xff}_rle[_lowdim]_{8b,16b} and their decoders (sprintz_delta.h:49-91,
+// sprintz_xff.h:43-85): the same four codecs with the payload layout chosen by NAME instead of by
+// ndims -- the plain names use the general row-major layout for every ndims, the _lowdim names the
+// column-major low-dim layout (ndims <= 4 at 8 bits, <= 2 at 16 bits; else -1 as
+// sprintz_delta_lowdim.cpp:64-70).  The 5-argument forms decode streams written with write_size = false.
+#define SPRINTZ_DROPIN_RLE(NAME, BITS)                                                                                          \
+    int64_t compress_rowmajor_##NAME##_##BITS##b(const uint##BITS##_t* src, uint32_t len, int##BITS##_t* dest, uint16_t ndims, \
+                                                 bool write_size = true);                                                     \
+    int64_t decompress_rowmajor_##NAME##_##BITS##b(const int##BITS##_t* src, uint##BITS##_t* dest);
+SPRINTZ_DROPIN_RLE(delta_rle, 8)
+SPRINTZ_DROPIN_RLE(delta_rle, 16)
+SPRINTZ_DROPIN_RLE(xff_rle, 8)
+SPRINTZ_DROPIN_RLE(xff_rle, 16)
+SPRINTZ_DROPIN_RLE(delta_rle_lowdim, 8)
+SPRINTZ_DROPIN_RLE(delta_rle_lowdim, 16)
+SPRINTZ_DROPIN_RLE(xff_rle_lowdim, 8)
+SPRINTZ_DROPIN_RLE(xff_rle_lowdim, 16)
+#undef SPRINTZ_DROPIN_RLE
+// (the reference's 5-argument decoders are force-inlined header code, sprintz_delta.h:52-54: no symbol to
+//  replace; the equivalent entry point is sprintz_mi355x_decompress_noheader)
 
 // ================================================================ query on compressed data
 // query.hpp:23-29 (QueryTypes, QueryParams); sprintz_delta.h:95-98, sprintz_xff.h:90-93.  Same names
@@ -67,76 +65,40 @@ typedef struct QueryParams {
     bool materialize;
 } QueryParams;
 
-inline int64_t query_rowmajor_delta_rle_8b(const int8_t* src, uint8_t* dest, const QueryParams& qp, uint64_t* result = nullptr)
-{
-    return sprintz_mi355x_query_delta_8b(src, dest, (int)qp.op, qp.materialize ? 1 : 0, SPRINTZ_QUERY_GENERAL_LAYOUT, result);
-}
-inline int64_t query_rowmajor_delta_rle_16b(const int16_t* src, uint16_t* dest, const QueryParams& qp, uint64_t* result = nullptr)
-{
-    return sprintz_mi355x_query_delta_16b(src, dest, (int)qp.op, qp.materialize ? 1 : 0, SPRINTZ_QUERY_GENERAL_LAYOUT, result);
-}
-inline int64_t query_rowmajor_xff_rle_8b(const int8_t* src, uint8_t* dest, const QueryParams& qp, uint64_t* result = nullptr)
-{
-    return sprintz_mi355x_query_xff_8b(src, dest, (int)qp.op, qp.materialize ? 1 : 0, SPRINTZ_QUERY_GENERAL_LAYOUT, result);
-}
-inline int64_t query_rowmajor_xff_rle_16b(const int16_t* src, uint16_t* dest, const QueryParams& qp, uint64_t* result = nullptr)
-{
-    return sprintz_mi355x_query_xff_16b(src, dest, (int)qp.op, qp.materialize ? 1 : 0, SPRINTZ_QUERY_GENERAL_LAYOUT, result);
-}
+int64_t query_rowmajor_delta_rle_8b(const int8_t* src, uint8_t* dest, const QueryParams& qp);
+int64_t query_rowmajor_delta_rle_16b(const int16_t* src, uint16_t* dest, const QueryParams& qp);
+int64_t query_rowmajor_xff_rle_8b(const int8_t* src, uint8_t* dest, const QueryParams& qp);
+int64_t query_rowmajor_xff_rle_16b(const int16_t* src, uint16_t* dest, const QueryParams& qp);
+int64_t query_rowmajor_delta_rle_8b(const int8_t* src, uint8_t* dest, const QueryParams& qp, uint64_t* result);
+int64_t query_rowmajor_delta_rle_16b(const int16_t* src, uint16_t* dest, const QueryParams& qp, uint64_t* result);
+int64_t query_rowmajor_xff_rle_8b(const int8_t* src, uint8_t* dest, const QueryParams& qp, uint64_t* result);
+int64_t query_rowmajor_xff_rle_16b(const int16_t* src, uint16_t* dest, const QueryParams& qp, uint64_t* result);
 
-// ================================================================ non-RLE codecs (sprintz_delta.h:26-76)
-inline int64_t compress_rowmajor_8b(const uint8_t* src, uint32_t len, int8_t* dest, uint16_t ndims, bool = true)
-{
-    return sprintz_mi355x_compress_norle(SPRINTZ_CODEC_BITPACK_NORLE, 1, src, len, dest, ndims);
-}
-inline int64_t compress_rowmajor_16b(const uint16_t* src, uint32_t len, int16_t* dest, uint16_t ndims, bool = true)
-{
-    return sprintz_mi355x_compress_norle(SPRINTZ_CODEC_BITPACK_NORLE, 2, src, len, dest, ndims);
-}
-inline int64_t compress_rowmajor_delta_8b(const uint8_t* src, uint32_t len, int8_t* dest, uint16_t ndims, bool = true)
-{
-    return sprintz_mi355x_compress_norle(SPRINTZ_CODEC_DELTA_NORLE, 1, src, len, dest, ndims);
-}
-inline int64_t compress_rowmajor_delta_16b(const uint16_t* src, uint32_t len, int16_t* dest, uint16_t ndims, bool = true)
-{
-    return sprintz_mi355x_compress_norle(SPRINTZ_CODEC_DELTA_NORLE, 2, src, len, dest, ndims);
-}
-inline int64_t decompress_rowmajor_8b(const int8_t* src, uint8_t* dest) { return sprintz_mi355x_decompress_norle(SPRINTZ_CODEC_BITPACK_NORLE, 1, src, dest); }
-inline int64_t decompress_rowmajor_16b(const int16_t* src, uint16_t* dest) { return sprintz_mi355x_decompress_norle(SPRINTZ_CODEC_BITPACK_NORLE, 2, src, dest); }
-inline int64_t decompress_rowmajor_delta_8b(const int8_t* src, uint8_t* dest) { return sprintz_mi355x_decompress_norle(SPRINTZ_CODEC_DELTA_NORLE, 1, src, dest); }
-inline int64_t decompress_rowmajor_delta_16b(const int16_t* src, uint16_t* dest) { return sprintz_mi355x_decompress_norle(SPRINTZ_CODEC_DELTA_NORLE, 2, src, dest); }
-
-inline int64_t compress8b_rowmajor_xff(const uint8_t* src, uint64_t len, int8_t* dest, uint16_t ndims, bool = true)   // sprintz_xff.h:28
-{
-    return len >> 32 ? -1 : sprintz_mi355x_compress_norle(SPRINTZ_CODEC_XFF_NORLE, 1, src, (uint32_t)len, dest, ndims);
-}
-inline int64_t decompress8b_rowmajor_xff(const int8_t* src, uint8_t* dest) { return sprintz_mi355x_decompress_norle(SPRINTZ_CODEC_XFF_NORLE, 1, src, dest); }
+// ================================================================ non-RLE codecs (sprintz_delta.h:26-44, sprintz_xff.h:28-31)
+int64_t compress_rowmajor_8b(const uint8_t* src, uint32_t len, int8_t* dest, uint16_t ndims, bool write_size = true);
+int64_t compress_rowmajor_16b(const uint16_t* src, uint32_t len, int16_t* dest, uint16_t ndims, bool write_size = true);
+int64_t compress_rowmajor_delta_8b(const uint8_t* src, uint32_t len, int8_t* dest, uint16_t ndims, bool write_size = true);
+int64_t compress_rowmajor_delta_16b(const uint16_t* src, uint32_t len, int16_t* dest, uint16_t ndims, bool write_size = true);
+int64_t decompress_rowmajor_8b(const int8_t* src, uint8_t* dest);
+int64_t decompress_rowmajor_16b(const int16_t* src, uint16_t* dest);
+int64_t decompress_rowmajor_delta_8b(const int8_t* src, uint8_t* dest);
+int64_t decompress_rowmajor_delta_16b(const int16_t* src, uint16_t* dest);
+int64_t compress8b_rowmajor_xff(const uint8_t* src, uint64_t len, int8_t* dest, uint16_t ndims, bool write_size = true);
+int64_t decompress8b_rowmajor_xff(const int8_t* src, uint8_t* dest);
 
 // ================================================================ stand-alone transforms (delta.h:17-68, predict.h:15-30)
-#define SPRINTZ_DROPIN_TRANSFORM(NAME, KIND, BITS, ESZ)                                                                       \
-    inline uint32_t encode_##NAME##_rowmajor_##BITS##b(const uint##BITS##_t* src, uint32_t len, int##BITS##_t* dest, uint16_t ndims,  \
-                                                       bool write_size = true)                                                \
-    {                                                                                                                         \
-        return (uint32_t)sprintz_mi355x_transform_encode(KIND, ESZ, src, len, dest, ndims, write_size ? 1 : 0);               \
-    }                                                                                                                         \
-    inline uint32_t decode_##NAME##_rowmajor_##BITS##b(const int##BITS##_t* src, uint32_t len, uint##BITS##_t* dest, uint16_t ndims)  \
-    {                                                                                                                         \
-        return ndims == 0 ? 0u : (uint32_t)sprintz_mi355x_transform_decode(KIND, ESZ, src, dest, len, ndims);                 \
-    }                                                                                                                         \
-    inline uint32_t decode_##NAME##_rowmajor_##BITS##b(const int##BITS##_t* src, uint##BITS##_t* dest)                        \
-    {                                                                                                                         \
-        return (uint32_t)sprintz_mi355x_transform_decode(KIND, ESZ, src, dest, 0, 0);                                         \
-    }                                                                                                                         \
-    inline uint32_t decode_##NAME##_rowmajor_inplace_##BITS##b(uint##BITS##_t* buff, uint32_t len, uint16_t ndims)            \
-    {   /* the device copy is the temporary the reference mallocs (delta.cpp:351-373) */                                      \
-        return ndims == 0 ? 0u : (uint32_t)sprintz_mi355x_transform_decode(KIND, ESZ, buff, buff, len, ndims);                \
-    }
-SPRINTZ_DROPIN_TRANSFORM(delta, SPRINTZ_TRANSFORM_DELTA, 8, 1)
-SPRINTZ_DROPIN_TRANSFORM(delta, SPRINTZ_TRANSFORM_DELTA, 16, 2)
-SPRINTZ_DROPIN_TRANSFORM(doubledelta, SPRINTZ_TRANSFORM_DOUBLEDELTA, 8, 1)
-SPRINTZ_DROPIN_TRANSFORM(doubledelta, SPRINTZ_TRANSFORM_DOUBLEDELTA, 16, 2)
-SPRINTZ_DROPIN_TRANSFORM(xff, SPRINTZ_TRANSFORM_XFF, 8, 1)
-SPRINTZ_DROPIN_TRANSFORM(xff, SPRINTZ_TRANSFORM_XFF, 16, 2)
+#define SPRINTZ_DROPIN_TRANSFORM(NAME, BITS)                                                                                   \
+    uint32_t encode_##NAME##_rowmajor_##BITS##b(const uint##BITS##_t* src, uint32_t len, int##BITS##_t* dest, uint16_t ndims, \
+                                                bool write_size = true);                                                      \
+    uint32_t decode_##NAME##_rowmajor_##BITS##b(const int##BITS##_t* src, uint32_t len, uint##BITS##_t* dest, uint16_t ndims); \
+    uint32_t decode_##NAME##_rowmajor_##BITS##b(const int##BITS##_t* src, uint##BITS##_t* dest);                              \
+    uint32_t decode_##NAME##_rowmajor_inplace_##BITS##b(uint##BITS##_t* buff, uint32_t len, uint16_t ndims);
+SPRINTZ_DROPIN_TRANSFORM(delta, 8)
+SPRINTZ_DROPIN_TRANSFORM(delta, 16)
+SPRINTZ_DROPIN_TRANSFORM(doubledelta, 8)
+SPRINTZ_DROPIN_TRANSFORM(doubledelta, 16)
+SPRINTZ_DROPIN_TRANSFORM(xff, 8)
+SPRINTZ_DROPIN_TRANSFORM(xff, 16)
 #undef SPRINTZ_DROPIN_TRANSFORM
 
 #endif  // SPRINTZ_DROPIN_HPP

@@ -10,9 +10,11 @@
  *      values (ELEMENTS, -1 for ndims == 0, floor'ed for odd 16-bit byte
  *      lengths -- sprintz_xff_rle.cpp:554), HOST pointers in and out.
  *      The reference's functions have C++ linkage (default argument
- *      `write_size=true`); include/sprintz_dropin.hpp re-declares them with
- *      exactly the reference's C++ signatures on top of these C symbols, so
- *      a caller such as the lzbench fork (reference README.md:29) relinks
+ *      `write_size=true`): the library ALSO exports them under exactly those
+ *      C++ signatures, i.e. the reference's own mangled names
+ *      (sprintz_amd/csrc/dropin.cpp, declared in include/sprintz_dropin.hpp),
+ *      so an object compiled against the reference's sprintz.h -- e.g. the
+ *      lzbench fork, reference README.md:29 -- links against this library
  *      unchanged.  One call = one chunk = one wavefront's worth of work: it
  *      is correct, not fast.  See (2).
  *
@@ -65,7 +67,17 @@ extern "C" {
 #define SPRINTZ_MI355X_READ_SLACK 16
 
 int         sprintz_mi355x_abi_version(void);
-const char* sprintz_mi355x_last_error(void);     /* thread-local, never NULL */
+const char* sprintz_mi355x_last_error(void);     /* thread-local, never NULL; describes the last call of
+                                                    this thread that returned a negative code */
+
+/* Tuning knobs (process-wide, atomic).  Their initial values come from the environment, read once:
+ *   SPRINTZ_OPT_NO_FAST           1 = route every call to the generic kernels (A/B runs, tests);
+ *                                 env SPRINTZ_MI355X_NO_FAST
+ *   SPRINTZ_OPT_CHUNKS_PER_GROUP  consecutive chunks one lane group of the headline decoder walks,
+ *                                 1..64, default 1; env SPRINTZ_MI355X_CHUNKS_PER_GROUP */
+#define SPRINTZ_OPT_NO_FAST 0
+#define SPRINTZ_OPT_CHUNKS_PER_GROUP 1
+int sprintz_mi355x_set_option(int option, int value);
 
 /* ------------------------------------------------------------------------
  * (1) Drop-in single-call API (host pointers).  Replaces, one to one:
@@ -98,6 +110,21 @@ int64_t sprintz_mi355x_decompress_xff_16b  (const int16_t* src, uint16_t* dest);
  * written with write_size == 0. */
 int64_t sprintz_mi355x_decompress_noheader(int codec, int elem_bytes, const void* src, void* dest,
                                            uint16_t ndims, uint32_t ngroups, uint16_t remaining_len);
+
+/* The layer below sprintz.h: the same four codecs with the payload layout chosen by the caller
+ * instead of by ndims.  Replaces compress_rowmajor_{delta,xff}_rle[_lowdim]_{8b,16b} and their
+ * 2-argument decoders (sprintz_delta.h:49-91, sprintz_xff.h:43-85):
+ *   SPRINTZ_LAYOUT_AUTO     what sprintz.h's dispatch picks (sprintz.cpp:34-50)
+ *   SPRINTZ_LAYOUT_GENERAL  row-major payload for every ndims (the *_rle_* names)
+ *   SPRINTZ_LAYOUT_LOWDIM   column-major low-dim payload; ndims <= 4 @8b / <= 2 @16b, else -1
+ *                           (sprintz_delta_lowdim.cpp:64-70)
+ * codec: SPRINTZ_CODEC_DELTA or SPRINTZ_CODEC_XFF. */
+#define SPRINTZ_LAYOUT_AUTO 0
+#define SPRINTZ_LAYOUT_GENERAL 1
+#define SPRINTZ_LAYOUT_LOWDIM 2
+int64_t sprintz_mi355x_compress_layout(int codec, int elem_bytes, const void* src, uint32_t len, void* dest, uint16_t ndims,
+                                       int write_size, int layout);
+int64_t sprintz_mi355x_decompress_layout(int codec, int elem_bytes, const void* src, void* dest, int layout);
 
 /* ------------------------------------------------------------------------
  * (2) Batched device API (device pointers, asynchronous on `hip_stream`).

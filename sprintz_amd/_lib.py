@@ -35,7 +35,7 @@ def _load():
         import torch  # noqa: F401
     except Exception:  # pragma: no cover - torch is optional for pure ctypes users
         pass
-    return C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    return C.CDLL(LIB_PATH)
 
 
 lib = _load()
@@ -52,6 +52,8 @@ def _sig(name, restype, *argtypes):
 
 abi_version = _sig("sprintz_mi355x_abi_version", _i)
 _last_error = _sig("sprintz_mi355x_last_error", C.c_char_p)
+OPT_NO_FAST, OPT_CHUNKS_PER_GROUP = 0, 1
+set_option = _sig("sprintz_mi355x_set_option", _i, _i, _i)
 
 # (1) drop-in single-call API, host pointers
 compress = {
@@ -67,6 +69,10 @@ decompress = {
     ("xff", 2): _sig("sprintz_mi355x_decompress_xff_16b", _i64, _vp, _vp),
 }
 decompress_noheader = _sig("sprintz_mi355x_decompress_noheader", _i64, _i, _i, _vp, _vp, _u16, _u32, _u16)
+# the layer below sprintz.h: payload layout chosen by the caller (sprintz_delta.h:49-91, sprintz_xff.h:43-85)
+LAYOUT_AUTO, LAYOUT_GENERAL, LAYOUT_LOWDIM = 0, 1, 2
+compress_layout = _sig("sprintz_mi355x_compress_layout", _i64, _i, _i, _vp, _u32, _vp, _u16, _i, _i)
+decompress_layout = _sig("sprintz_mi355x_decompress_layout", _i64, _i, _i, _vp, _vp, _i)
 
 # (2) batched device API
 compress_bound = _sig("sprintz_mi355x_compress_bound", _sz, _i, _u32, _u16)
@@ -120,12 +126,12 @@ compress_chunked_host = _sig("sprintz_mi355x_compress_chunked_host", _i64, _i, _
 decompress_chunked_host = _sig("sprintz_mi355x_decompress_chunked_host", _i64, _i, _i, _vp, _vp, _u64, _u32, _u16, _vp)
 
 EXPORTED_SYMBOLS = [
-    "sprintz_mi355x_abi_version", "sprintz_mi355x_last_error",
+    "sprintz_mi355x_abi_version", "sprintz_mi355x_last_error", "sprintz_mi355x_set_option",
     "sprintz_mi355x_compress_delta_8b", "sprintz_mi355x_compress_xff_8b",
     "sprintz_mi355x_compress_delta_16b", "sprintz_mi355x_compress_xff_16b",
     "sprintz_mi355x_decompress_delta_8b", "sprintz_mi355x_decompress_xff_8b",
     "sprintz_mi355x_decompress_delta_16b", "sprintz_mi355x_decompress_xff_16b",
-    "sprintz_mi355x_decompress_noheader",
+    "sprintz_mi355x_decompress_noheader", "sprintz_mi355x_compress_layout", "sprintz_mi355x_decompress_layout",
     "sprintz_mi355x_compress_bound", "sprintz_mi355x_num_chunks",
     "sprintz_mi355x_compress_batch", "sprintz_mi355x_compact_tmp_bytes", "sprintz_mi355x_compact",
     "sprintz_mi355x_decompress_batch",
@@ -143,12 +149,17 @@ EXPORTED_SYMBOLS = [
 ]
 
 
+_CODE_NAMES = {E_INVALID: "invalid argument", E_NO_DEVICE: "no usable HIP device (there is no CPU fallback)",
+               E_HIP: "a HIP call failed", E_UNSUPPORTED: "unsupported argument", E_CORRUPT: "corrupt stream"}
+
+
 def last_error():
-    return _last_error().decode("utf-8", "replace") or _transform_last_error().decode("utf-8", "replace")
+    """message of this thread's last failing call (every failing return of the library sets it)"""
+    return _last_error().decode("utf-8", "replace")
 
 
 def check(rc):
     """raise on negative return codes of the batched API"""
     if rc < 0:
-        raise SprintzError(rc, last_error())
+        raise SprintzError(rc, last_error() or _CODE_NAMES.get(rc, "error"))
     return rc

@@ -125,13 +125,21 @@ class ChunkedCodec:
             raise _lib.SprintzError(_lib.E_NO_DEVICE, "no HIP device visible to torch; there is no CPU fallback")
         self.torch = torch
         self.codec, self.esz, self.ndims, self.chunk_len, self.align = codec, elem_bytes, int(ndims), int(chunk_len), align
-        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        dev = torch.device(device if device is not None else "cuda")
+        if dev.type != "cuda":
+            raise ValueError("device must be a cuda (HIP) device")
+        # always an indexed device: "cuda" alone would never compare equal to a tensor's device
+        self.device = torch.device("cuda", torch.cuda.current_device() if dev.index is None else dev.index)
         self.dtype = torch.uint8 if elem_bytes == 1 else torch.uint16
         self.slot_stride = int(_lib.compress_bound(elem_bytes, self.chunk_len, self.ndims))
         self._ws = {}
 
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _on(self):
+        """the C library launches on the CURRENT HIP device: make it this codec's for the call"""
+        return self.torch.cuda.device(self.device)
 
     def workspace(self, nchunks):
         """slot buffer / sizes / scan scratch, cached per nchunks"""
@@ -159,9 +167,10 @@ class ChunkedCodec:
         """encode kernel only: src (uint8 view, padded) -> slot-strided streams + sizes"""
         nchunks = int(_lib.num_chunks(total_len, self.chunk_len))
         ws = ws or self.workspace(nchunks)
-        _lib.check(_lib.compress_batch(_CODEC_ID[self.codec], self.esz, src_padded_u8.data_ptr(), total_len,
-                                       self.chunk_len, self.ndims, ws["slots"].data_ptr(), self.slot_stride,
-                                       ws["sizes"].data_ptr(), ws["rets"].data_ptr(), self._stream()))
+        with self._on():
+            _lib.check(_lib.compress_batch(_CODEC_ID[self.codec], self.esz, src_padded_u8.data_ptr(), total_len,
+                                           self.chunk_len, self.ndims, ws["slots"].data_ptr(), self.slot_stride,
+                                           ws["sizes"].data_ptr(), ws["rets"].data_ptr(), self._stream()))
         return ws
 
     def compact(self, ws, nchunks, dense=None, offsets=None):
@@ -170,8 +179,9 @@ class ChunkedCodec:
             dense = t.empty(nchunks * self.slot_stride + _lib.READ_SLACK, dtype=t.uint8, device=self.device)
         if offsets is None:
             offsets = t.empty(nchunks + 1, dtype=t.int64, device=self.device)
-        _lib.check(_lib.compact(ws["slots"].data_ptr(), self.slot_stride, ws["sizes"].data_ptr(), nchunks, self.align,
-                                dense.data_ptr(), offsets.data_ptr(), ws["tmp"].data_ptr(), self._stream()))
+        with self._on():
+            _lib.check(_lib.compact(ws["slots"].data_ptr(), self.slot_stride, ws["sizes"].data_ptr(), nchunks, self.align,
+                                    dense.data_ptr(), offsets.data_ptr(), ws["tmp"].data_ptr(), self._stream()))
         return dense, offsets
 
     def compress(self, src):
@@ -197,9 +207,10 @@ class ChunkedCodec:
 
     def decompress_into(self, data, offsets, nchunks, out, rets=None):
         """decode kernel only (what the bench times)"""
-        _lib.check(_lib.decompress_batch(_CODEC_ID[self.codec], self.esz, data.data_ptr(), offsets.data_ptr(), nchunks,
-                                         self.chunk_len, self.ndims, out.data_ptr(),
-                                         rets.data_ptr() if rets is not None else None, self._stream()))
+        with self._on():
+            _lib.check(_lib.decompress_batch(_CODEC_ID[self.codec], self.esz, data.data_ptr(), offsets.data_ptr(), nchunks,
+                                             self.chunk_len, self.ndims, out.data_ptr(),
+                                             rets.data_ptr() if rets is not None else None, self._stream()))
 
 
     # ---- column-major matrices (BASELINE config 5): cols is a [ndims, col_stride] tensor, variable d in row d
@@ -216,9 +227,10 @@ class ChunkedCodec:
         rows_per_chunk = self.chunk_len // self.ndims
         nchunks = (nrows + rows_per_chunk - 1) // rows_per_chunk
         ws = self.workspace(nchunks)
-        _lib.check(_lib.compress_batch_colmajor(_CODEC_ID[self.codec], self.esz, cols.data_ptr(), nrows, col_stride, rows_per_chunk,
-                                                self.ndims, ws["slots"].data_ptr(), self.slot_stride, ws["sizes"].data_ptr(),
-                                                ws["rets"].data_ptr(), self._stream()))
+        with self._on():
+            _lib.check(_lib.compress_batch_colmajor(_CODEC_ID[self.codec], self.esz, cols.data_ptr(), nrows, col_stride, rows_per_chunk,
+                                                    self.ndims, ws["slots"].data_ptr(), self.slot_stride, ws["sizes"].data_ptr(),
+                                                    ws["rets"].data_ptr(), self._stream()))
         dense, offsets = self.compact(ws, nchunks)
         total = int(offsets[-1].item())
         return CompressedBatch(dense[: total + _lib.READ_SLACK].clone(), offsets, ws["sizes"].clone(), nchunks,
@@ -231,9 +243,10 @@ class ChunkedCodec:
         nrows = batch.total_len // self.ndims
         if out is None:
             out = t.empty((self.ndims, batch.nchunks * rows_per_chunk), dtype=self.dtype, device=self.device)
-        _lib.check(_lib.decompress_batch_colmajor(_CODEC_ID[self.codec], self.esz, batch.data.data_ptr(), batch.offsets.data_ptr(),
-                                                  batch.nchunks, rows_per_chunk, self.ndims, int(out.shape[1]), out.data_ptr(),
-                                                  None, self._stream()))
+        with self._on():
+            _lib.check(_lib.decompress_batch_colmajor(_CODEC_ID[self.codec], self.esz, batch.data.data_ptr(), batch.offsets.data_ptr(),
+                                                      batch.nchunks, rows_per_chunk, self.ndims, int(out.shape[1]), out.data_ptr(),
+                                                      None, self._stream()))
         return out[:, :nrows]
 
     def query(self, batch, op, materialize=False, out=None, reduce=True):
@@ -246,14 +259,16 @@ class ChunkedCodec:
         if materialize and out is None:
             out = torch.empty(n * self.chunk_len, dtype=self.dtype, device=self.device)
         partials = torch.empty((n, self.ndims), dtype=torch.int64, device=self.device) if opid else None
-        _lib.check(_lib.query_batch(_CODEC_ID[self.codec], self.esz, batch.data.data_ptr(), batch.offsets.data_ptr(), n,
-                                    self.chunk_len, self.ndims, opid, int(bool(materialize)), 0,
-                                    out.data_ptr() if materialize else None,
-                                    partials.data_ptr() if opid else None, None, self._stream()))
+        with self._on():
+            _lib.check(_lib.query_batch(_CODEC_ID[self.codec], self.esz, batch.data.data_ptr(), batch.offsets.data_ptr(), n,
+                                        self.chunk_len, self.ndims, opid, int(bool(materialize)), 0,
+                                        out.data_ptr() if materialize else None,
+                                        partials.data_ptr() if opid else None, None, self._stream()))
         res = partials
         if opid and reduce:
             res = torch.empty(self.ndims, dtype=torch.int64, device=self.device)
-            _lib.check(_lib.query_reduce(opid, partials.data_ptr(), n, self.ndims, res.data_ptr(), self._stream()))
+            with self._on():
+                _lib.check(_lib.query_reduce(opid, partials.data_ptr(), n, self.ndims, res.data_ptr(), self._stream()))
         return res, (out[: batch.total_len] if materialize else None)
 
 
@@ -422,10 +437,12 @@ def transform_device(kind, x, ndims, inverse=False, out=None):
         out = torch.empty_like(x)
     stream = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
     if not inverse:
-        _lib.check(_lib.transform_encode_device(k, esz, x.data_ptr(), x.numel(), ndims, out.data_ptr(), stream))
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.transform_encode_device(k, esz, x.data_ptr(), x.numel(), ndims, out.data_ptr(), stream))
     else:
         tmp = torch.empty(int(_lib.transform_tmp_bytes(k, esz, x.numel(), ndims)), dtype=torch.uint8, device=x.device)
-        _lib.check(_lib.transform_decode_device(k, esz, x.data_ptr(), x.numel(), ndims, out.data_ptr(), tmp.data_ptr(), stream))
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.transform_decode_device(k, esz, x.data_ptr(), x.numel(), ndims, out.data_ptr(), tmp.data_ptr(), stream))
     return out
 
 
@@ -457,8 +474,9 @@ def huf_compress(batch):
     hoffs = torch.empty(n + 1, dtype=torch.int64, device=dev)
     tables = torch.empty(((n + 63) // 64) * 128, dtype=torch.uint8, device=dev)
     tmp = torch.empty(int(_lib.huf_tmp_bytes(n)), dtype=torch.uint8, device=dev)
-    _lib.check(_lib.huf_compress_batch(batch.data.data_ptr(), batch.offsets.data_ptr(), batch.sizes.data_ptr(), n,
-                                       huf.data_ptr(), hoffs.data_ptr(), tables.data_ptr(), tmp.data_ptr(), stream))
+    with torch.cuda.device(dev):
+        _lib.check(_lib.huf_compress_batch(batch.data.data_ptr(), batch.offsets.data_ptr(), batch.sizes.data_ptr(), n,
+                                           huf.data_ptr(), hoffs.data_ptr(), tables.data_ptr(), tmp.data_ptr(), stream))
     end = int(hoffs[-1].item())
     return HufBatch(huf[: end + _lib.READ_SLACK].clone(), hoffs, tables, n, batch.total_len, batch.chunk_len, batch.ndims)
 
@@ -475,9 +493,10 @@ def huf_decompress(hb, dense_capacity, align=16, rets=None):
     offs = torch.empty(n + 1, dtype=torch.int64, device=dev)
     sizes = torch.empty(n, dtype=torch.int32, device=dev)
     tmp = torch.empty(int(_lib.compact_tmp_bytes(n)) + 64, dtype=torch.uint8, device=dev)
-    _lib.check(_lib.huf_decompress_batch(hb.data.data_ptr(), hb.offsets.data_ptr(), hb.tables.data_ptr(), n, align,
-                                         dense.data_ptr(), cap, offs.data_ptr(), sizes.data_ptr(),
-                                         rets.data_ptr() if rets is not None else None, tmp.data_ptr(), stream))
+    with torch.cuda.device(dev):
+        _lib.check(_lib.huf_decompress_batch(hb.data.data_ptr(), hb.offsets.data_ptr(), hb.tables.data_ptr(), n, align,
+                                             dense.data_ptr(), cap, offs.data_ptr(), sizes.data_ptr(),
+                                             rets.data_ptr() if rets is not None else None, tmp.data_ptr(), stream))
     return CompressedBatch(dense, offs, sizes, n, hb.total_len, hb.chunk_len, hb.ndims)
 
 
@@ -492,8 +511,9 @@ def huf0_compress(batch):
     blocks = torch.zeros(int(_lib.huf0_bound(total, n)), dtype=torch.uint8, device=dev)
     boffs = torch.empty(n + 1, dtype=torch.int64, device=dev)
     tmp = torch.empty(int(_lib.huf0_tmp_bytes(n)), dtype=torch.uint8, device=dev)
-    _lib.check(_lib.huf0_compress_batch(batch.data.data_ptr(), batch.offsets.data_ptr(), batch.sizes.data_ptr(), n,
-                                        blocks.data_ptr(), boffs.data_ptr(), tmp.data_ptr(), stream))
+    with torch.cuda.device(dev):
+        _lib.check(_lib.huf0_compress_batch(batch.data.data_ptr(), batch.offsets.data_ptr(), batch.sizes.data_ptr(), n,
+                                            blocks.data_ptr(), boffs.data_ptr(), tmp.data_ptr(), stream))
     return blocks, boffs
 
 
@@ -508,8 +528,9 @@ def huf0_decompress(blocks, block_offsets, out_offsets, rets=None, out=None):
     if out is None:
         out = torch.zeros(int(out_offsets[-1].item()) + _lib.READ_SLACK, dtype=torch.uint8, device=dev)
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    _lib.check(_lib.huf0_decompress_batch(blocks.data_ptr(), block_offsets.data_ptr(), n, out.data_ptr(), out_offsets.data_ptr(),
-                                          rets.data_ptr() if rets is not None else None, stream))
+    with torch.cuda.device(dev):
+        _lib.check(_lib.huf0_decompress_batch(blocks.data_ptr(), block_offsets.data_ptr(), n, out.data_ptr(), out_offsets.data_ptr(),
+                                              rets.data_ptr() if rets is not None else None, stream))
     return out
 
 

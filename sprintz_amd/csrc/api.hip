@@ -8,9 +8,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -38,28 +40,34 @@ int fail(int code, const char* what, hipError_t e = hipSuccess)
         if (e_ != hipSuccess) return fail(SPRINTZ_E_HIP, #expr, e_); \
     } while (0)
 
-int ensure_device()
+// Process-wide facts, established exactly once (the header promises re-entrancy from any thread):
+// whether a HIP device exists at all, and the tuning knobs of the environment.
+// (the knobs start from the environment, read once, and change only through sprintz_mi355x_set_option)
+struct Process {
+    bool have_device = false;
+    std::atomic<int> no_fast{0};            // SPRINTZ_MI355X_NO_FAST: generic kernels only (A/B runs, tests)
+    std::atomic<int> chunks_per_group{1};   // SPRINTZ_MI355X_CHUNKS_PER_GROUP (decode_fast read-ahead across chunks)
+};
+Process& process()
 {
-    static int state = 0;   // 0 unknown, 1 ok, -1 none
-    if (state == 0) {
+    static Process p;
+    static std::once_flag once;
+    std::call_once(once, [] {
         int n = 0;
-        hipError_t e = hipGetDeviceCount(&n);
-        state = (e == hipSuccess && n > 0) ? 1 : -1;
-    }
-    if (state < 0) return fail(SPRINTZ_E_NO_DEVICE, "no usable HIP device (libsprintz_mi355x has no CPU fallback)");
-    return 0;
+        p.have_device = hipGetDeviceCount(&n) == hipSuccess && n > 0;
+        p.no_fast = getenv("SPRINTZ_MI355X_NO_FAST") != nullptr ? 1 : 0;
+        if (const char* e = getenv("SPRINTZ_MI355X_CHUNKS_PER_GROUP")) {
+            const int k = atoi(e);
+            p.chunks_per_group = k < 1 ? 1 : k > 64 ? 64 : k;
+        }
+    });
+    return p;
 }
 
-int num_cus()
+int ensure_device()
 {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
-        else n = 256;
-    }
-    return n;
+    if (!process().have_device) return fail(SPRINTZ_E_NO_DEVICE, "no usable HIP device (libsprintz_mi355x has no CPU fallback)");
+    return 0;
 }
 
 bool is_lowdim(int esz, int D) { return esz == 1 ? D <= 4 : D <= 2; }   // sprintz.cpp:34-50
@@ -180,6 +188,7 @@ __global__ void __launch_bounds__(kThreads) compact_copy_kernel(const uint8_t* s
 }  // namespace
 
 namespace sprintz {
+int set_error(int code, const char* what) { return fail(code, what); }
 // exclusive scan of (aligned) u32 sizes into u64 offsets[n+1]; tmp = sprintz_mi355x_compact_tmp_bytes(n)
 hipError_t launch_size_scan(const uint32_t* d_sizes, uint64_t n, uint32_t align, uint64_t* d_offsets, void* d_tmp, hipStream_t st)
 {
@@ -274,7 +283,7 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
     // and chunks not much shorter than the read-ahead ring (it is filled before the first header is parsed)
     const size_t fring = decode_fast_lds_bytes(8 * esz, fdp, fcpl, D, cs != 0 && fcpl == 1);
     const bool fast_common = !lowdim && !a.raw && !noheader && D <= 256 && 2 * D > fdp * fcpl && (uint64_t)chunk_len * esz * 2 >= fring &&
-                             !getenv("SPRINTZ_MI355X_NO_FAST");
+                             !process().no_fast.load(std::memory_order_relaxed);
     // column-major: a lane's 8 samples per block are one aligned 16-byte (8-byte) piece of its column
     const bool fast = cs ? fast_common && qs.q == kQueryOff && cs % 8 == 0 && (chunk_len / (uint32_t)D) % 8 == 0 &&
                                ((uintptr_t)d_out % 16) == 0 && (uint64_t)D * cs * esz < 0xf0000000ull
@@ -287,23 +296,10 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
         // (padding the stride by 16 / 32 / 48 bytes to move the groups' staging rows onto other banks: no change, 0.4225 ms each)
         const size_t fstride = decode_fast_lds_bytes(8 * esz, fdp, fcpl, D, cs != 0 && fcpl == 1);
         a.lds_group_stride = (uint32_t)fstride;
-        // consecutive chunks per lane group: aim at ONE resident generation of workgroups
-        // (no second cold start of the read-ahead ring, no partial last round)
-        {
-            size_t blocks_per_cu = (160 * 1024) / (fstride * fgroups);
-            if (blocks_per_cu > 5) blocks_per_cu = 5;          // VGPR budget of decode_fast_kernel
-            if (blocks_per_cu < 1) blocks_per_cu = 1;
-            const uint64_t resident_groups = (uint64_t)num_cus() * blocks_per_cu * fgroups;
-            // Measured on MI355X (cfg2, 131072 chunks): k = 1 / 2 / 4 / 8 -> 0.498 / 0.496 / 0.510 /
-            // 0.560 ms.  One generation of lock-stepped groups is no faster than four staggered
-            // ones, so the default stays at one chunk per group; the knob remains for tuning.
-            (void)resident_groups;
-            uint64_t k = 1;
-            if (const char* e = getenv("SPRINTZ_MI355X_CHUNKS_PER_GROUP")) k = (uint64_t)atoi(e);
-            if (k < 1) k = 1;
-            if (k > 64) k = 64;
-            a.chunks_per_group = (uint32_t)k;
-        }
+        // consecutive chunks per lane group.  Measured on MI355X (cfg2, 131072 chunks): k = 1 / 2 / 4 /
+        // 8 -> 0.498 / 0.496 / 0.510 / 0.560 ms: one generation of lock-stepped groups is no faster
+        // than four staggered ones, so the default stays at one chunk per group (env knob for tuning).
+        a.chunks_per_group = (uint32_t)process().chunks_per_group.load(std::memory_order_relaxed);
         const uint64_t ngroups_launch = (nchunks + a.chunks_per_group - 1) / a.chunks_per_group;
         const uint64_t fthreads = ngroups_launch * (uint64_t)fdp;
         const uint64_t fgrid = (fthreads + kThreads - 1) / kThreads;
@@ -315,7 +311,7 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
     }
     // univariate streams: one lane per chunk, LDS ring in, quad-transposed 64-byte bursts out (decode_uni.h)
     // (and the other low-dim shapes: 2 columns, 3 and 4 at 8 bits)
-    if (lowdim && (D <= 2 || esz == 1) && !noheader && !cs && !getenv("SPRINTZ_MI355X_NO_FAST")) {
+    if (lowdim && (D <= 2 || esz == 1) && !noheader && !cs && !process().no_fast.load(std::memory_order_relaxed)) {
         const uint64_t ugrid = (nchunks + 255) / 256;
         if (ugrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
         e = esz == 1 ? launch_decode_uni_w8(codec == SPRINTZ_CODEC_XFF, D, qs.q, (unsigned)ugrid, st, a)
@@ -334,13 +330,13 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
 
 int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uint32_t chunk_len, uint16_t ndims,
                   void* d_slots, size_t slot_stride, uint32_t* d_sizes, int64_t* d_rets, hipStream_t st, int write_size,
-                  uint64_t col_stride = 0)
+                  uint64_t col_stride = 0, int general = 0)
 {
     const uint64_t nchunks = sprintz_mi355x_num_chunks(total_len, chunk_len);
     if (nchunks == 0) return 0;
     const int D = ndims;
     const bool norle = codec >= SPRINTZ_CODEC_DELTA_NORLE;
-    const bool lowdim = norle ? false : is_lowdim(esz, D);
+    const bool lowdim = (norle || general) ? false : is_lowdim(esz, D);
     const Mapping m = choose_mapping(D, lowdim);
     const int DP = 1 << m.log2DP;
 
@@ -368,7 +364,7 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     int fdp = 4;
     while (fdp < D) fdp <<= 1;
     const size_t blk_bytes = (size_t)8 * D * esz;
-    const bool fast_common = !lowdim && !a.raw && D <= 64 && 2 * D > fdp && ((uintptr_t)d_src % 16) == 0 && !getenv("SPRINTZ_MI355X_NO_FAST");
+    const bool fast_common = !lowdim && !a.raw && D <= 64 && 2 * D > fdp && ((uintptr_t)d_src % 16) == 0 && !process().no_fast.load(std::memory_order_relaxed);
     const bool fast = col_stride ? fast_common && col_stride % 8 == 0 && (chunk_len / (uint32_t)D) % 8 == 0
                                  : fast_common && blk_bytes % 16 == 0 && ((uint64_t)chunk_len * esz) % 16 == 0;
     hipError_t e;
@@ -388,7 +384,7 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     }
     // streams of 65 .. 128 columns (BASELINE config 3): two columns per lane (encode_wide.h)
     if (!lowdim && !a.raw && !col_stride && D > 64 && D <= 128 && blk_bytes % 16 == 0 && ((uint64_t)chunk_len * esz) % 16 == 0 &&
-        (uint64_t)chunk_len * esz >= 2 * blk_bytes && ((uintptr_t)d_src % 16) == 0 && !getenv("SPRINTZ_MI355X_NO_FAST")) {
+        (uint64_t)chunk_len * esz >= 2 * blk_bytes && ((uintptr_t)d_src % 16) == 0 && !process().no_fast.load(std::memory_order_relaxed)) {
         const size_t wgroups = kThreads / 64;
         a.lds_group_stride = (uint32_t)(a.cap + ((blk_bytes + 15) & ~(size_t)15) + 16);
         const uint64_t wgrid = (nchunks * 64ull + kThreads - 1) / kThreads;
@@ -401,7 +397,7 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     }
     // univariate streams: one lane per chunk, quad-loaded 64-byte input windows, 64-byte output units (encode_uni.h)
     // (and the other low-dim shapes: 2 columns, 3 and 4 at 8 bits)
-    if (lowdim && (D <= 2 || esz == 1) && !col_stride && !getenv("SPRINTZ_MI355X_NO_FAST")) {
+    if (lowdim && (D <= 2 || esz == 1) && !col_stride && !process().no_fast.load(std::memory_order_relaxed)) {
         const uint64_t ugrid = (nchunks + 255) / 256;
         if (ugrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
         e = esz == 1 ? launch_encode_uni_w8(codec == SPRINTZ_CODEC_XFF, D, (unsigned)ugrid, st, a)
@@ -429,7 +425,14 @@ struct DevBuf {
 // elements does it decode to?  Needed because the reference's decompress()
 // signature carries no length (sprintz.h:20) but an H2D copy must be sized.
 // Touches headers and run lengths only -- no sample is decoded here.
-void walk_stream(const uint8_t* s, int esz, int D, uint32_t ngroups, uint32_t remaining, bool lowdim,
+//
+// The walk trusts nothing it reads: it stops with `false` as soon as the framing claims more than
+// one call may carry -- kMaxCallElems decoded elements or kMaxCallBytes of stream -- so a garbage
+// group count or run length cannot send it (or the H2D copy sized from it) across the address
+// space.  (The reference has no such limit: it reads wherever its header points.)
+constexpr uint64_t kMaxCallElems = 1ull << 31;
+constexpr uint64_t kMaxCallBytes = 1ull << 32;
+bool walk_stream(const uint8_t* s, int esz, int D, uint32_t ngroups, uint32_t remaining, bool lowdim,
                  uint64_t* nbytes, uint64_t* nelems, bool norle = false)
 {
     const int W = 8 * esz, HB = esz == 1 ? 3 : 4;
@@ -442,6 +445,7 @@ void walk_stream(const uint8_t* s, int esz, int D, uint32_t ngroups, uint32_t re
         return (x >> (bit & 7)) & ((1u << HB) - 1);
     };
     for (uint32_t g = 0; g < ngroups; g++) {
+        if (pos > kMaxCallBytes || blocks * 8ull * D > kMaxCallElems) return false;
         const uint8_t* h = s + pos;
         pos += hdr_bytes;
         for (int slot = 0; slot < 2; slot++) {
@@ -464,25 +468,105 @@ void walk_stream(const uint8_t* s, int esz, int D, uint32_t ngroups, uint32_t re
     }
     *nbytes = pos + (uint64_t)remaining * esz;
     *nelems = blocks * 8ull * D + remaining;
+    return *nbytes <= kMaxCallBytes && *nelems <= kMaxCallElems;
 }
 
-int64_t compress_host(int codec, int esz, const void* src, uint32_t len, void* dest, uint16_t ndims, int write_size)
+// ---- per-thread scratch of the host-pointer entry points -------------------------------------
+// lzbench drives the single-call symbols once per 10 KB block, so they must not pay for
+// hipMalloc/hipFree and pageable copies on every call: each thread keeps ONE device buffer and
+// ONE pinned staging buffer that only grow, and a private non-blocking stream.  A call is then
+// memcpy -> one H2D -> kernel -> one D2H -> memcpy, one stream synchronisation.  A thread that
+// ends hands its scratch to a process-wide free list (no HIP call runs in a thread_local
+// destructor; nothing is freed before the process ends).
+struct Scratch {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    uint8_t* dev = nullptr;
+    size_t dev_cap = 0;
+    uint8_t* pin = nullptr;
+    size_t pin_cap = 0;
+};
+constexpr size_t kPinMax = 4u << 20;     // larger transfers go straight from/to the caller's memory
+
+std::mutex g_scratch_mu;
+std::vector<Scratch*> g_scratch_free;
+
+struct ScratchHolder {
+    Scratch* s = nullptr;
+    ~ScratchHolder()
+    {
+        if (!s) return;
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        g_scratch_free.push_back(s);
+    }
+};
+thread_local ScratchHolder t_scratch;
+
+size_t round_up(size_t x, size_t a) { return (x + a - 1) & ~(a - 1); }
+
+// this thread's scratch on the current device, with at least dev_bytes / pin_bytes of room
+int acquire_scratch(size_t dev_bytes, size_t pin_bytes, Scratch** out)
+{
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    Scratch* sc = t_scratch.s;
+    if (sc && sc->device != dev) {                       // the thread moved to another device
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        g_scratch_free.push_back(sc);
+        sc = t_scratch.s = nullptr;
+    }
+    if (!sc) {
+        {
+            std::lock_guard<std::mutex> lk(g_scratch_mu);
+            for (size_t i = 0; i < g_scratch_free.size(); i++)
+                if (g_scratch_free[i]->device == dev) {
+                    sc = g_scratch_free[i];
+                    g_scratch_free.erase(g_scratch_free.begin() + (long)i);
+                    break;
+                }
+        }
+        if (!sc) {
+            sc = new Scratch();
+            sc->device = dev;
+            hipError_t e = hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking);
+            if (e != hipSuccess) { delete sc; return fail(SPRINTZ_E_HIP, "hipStreamCreateWithFlags", e); }
+        }
+        t_scratch.s = sc;
+    }
+    if (sc->dev_cap < dev_bytes) {
+        HIP_TRY(hipStreamSynchronize(sc->stream));
+        if (sc->dev) (void)hipFree(sc->dev);
+        sc->dev = nullptr; sc->dev_cap = 0;
+        const size_t want = round_up(dev_bytes + dev_bytes / 2, 1u << 16);
+        HIP_TRY(hipMalloc((void**)&sc->dev, want));
+        sc->dev_cap = want;
+    }
+    if (sc->pin_cap < pin_bytes) {
+        HIP_TRY(hipStreamSynchronize(sc->stream));
+        if (sc->pin) (void)hipHostFree(sc->pin);
+        sc->pin = nullptr; sc->pin_cap = 0;
+        const size_t want = round_up(pin_bytes + pin_bytes / 2, 1u << 16);
+        HIP_TRY(hipHostMalloc((void**)&sc->pin, want, hipHostMallocDefault));
+        sc->pin_cap = want;
+    }
+    *out = sc;
+    return 0;
+}
+
+int64_t compress_host(int codec, int esz, const void* src, uint32_t len, void* dest, uint16_t ndims, int write_size,
+                      int layout = SPRINTZ_LAYOUT_AUTO)
 {
     if (ndims == 0) { fail(SPRINTZ_E_INVALID, "ndims == 0"); return -1; }          // sprintz.cpp:36
     int rc = check_common(codec, esz, ndims);
     if (rc) return rc;
+    if (layout < SPRINTZ_LAYOUT_AUTO || layout > SPRINTZ_LAYOUT_LOWDIM || (layout && codec > SPRINTZ_CODEC_XFF))
+        return fail(SPRINTZ_E_INVALID, "layout must be 0 (by ndims), 1 (general) or 2 (low-dim), RLE codecs only");
+    if (layout == SPRINTZ_LAYOUT_LOWDIM && !is_lowdim(esz, ndims)) {               // sprintz_delta_lowdim.cpp:64-70
+        fail(SPRINTZ_E_INVALID, "the low-dim layout takes ndims <= 4 at 8 bits, <= 2 at 16 bits");
+        return -1;
+    }
     if (len > (1u << 30)) return fail(SPRINTZ_E_UNSUPPORTED, "single call limited to 2^30 elements");
     if ((rc = ensure_device())) return rc;
-    const size_t bound = sprintz_mi355x_compress_bound(esz, len, ndims);
-    DevBuf d_src, d_slot, d_meta;
-    HIP_TRY(d_src.alloc((size_t)len * esz + SPRINTZ_MI355X_READ_SLACK));
-    HIP_TRY(d_slot.alloc(bound));
-    HIP_TRY(d_meta.alloc(16));
-    HIP_TRY(hipMemcpy(d_src.p, src, (size_t)len * esz, hipMemcpyHostToDevice));
-    uint32_t* d_size = (uint32_t*)d_meta.p;
-    int64_t* d_ret = (int64_t*)((uint8_t*)d_meta.p + 8);
-    rc = encode_launch(codec, esz, d_src.p, len, len ? len : 1, ndims, d_slot.p, bound, d_size, d_ret, nullptr, write_size);
-    if (rc) return rc;
     if (len == 0 && codec == SPRINTZ_CODEC_XFF_NORLE) {     // u64 0 with ndims in bytes 6..7 (sprintz_xff.cpp:58-63)
         uint8_t h[8] = {0, 0, 0, 0, 0, 0, (uint8_t)(ndims & 0xff), (uint8_t)(ndims >> 8)};
         memcpy(dest, h, 8);
@@ -499,18 +583,112 @@ int64_t compress_host(int codec, int esz, const void* src, uint32_t len, void* d
         if (write_size) memcpy(dest, h, 8);
         return write_size ? 8 / esz : 0;
     }
-    HIP_TRY(hipDeviceSynchronize());
+    // device scratch: [source + read slack | size, ret (16 B) | slot]
+    const size_t bound = sprintz_mi355x_compress_bound(esz, len, ndims);
+    const size_t src_bytes = (size_t)len * esz;
+    const size_t o_meta = round_up(src_bytes + SPRINTZ_MI355X_READ_SLACK, 256), o_slot = o_meta + 16;
+    const bool pin_in = src_bytes <= kPinMax, pin_out = 16 + bound <= kPinMax;
+    Scratch* sc = nullptr;
+    if ((rc = acquire_scratch(o_slot + bound, std::max(pin_in ? src_bytes : 0, pin_out ? 16 + bound : 0), &sc))) return rc;
+    if (pin_in) {
+        memcpy(sc->pin, src, src_bytes);
+        HIP_TRY(hipMemcpyAsync(sc->dev, sc->pin, src_bytes, hipMemcpyHostToDevice, sc->stream));
+    } else {
+        HIP_TRY(hipMemcpyAsync(sc->dev, src, src_bytes, hipMemcpyHostToDevice, sc->stream));
+    }
+    uint32_t* d_size = (uint32_t*)(sc->dev + o_meta);
+    int64_t* d_ret = (int64_t*)(sc->dev + o_meta + 8);
+    rc = encode_launch(codec, esz, sc->dev, len, len, ndims, sc->dev + o_slot, bound, d_size, d_ret, sc->stream, write_size, 0,
+                       layout == SPRINTZ_LAYOUT_GENERAL);
+    if (rc) return rc;
     uint32_t size = 0;
     int64_t ret = 0;
-    HIP_TRY(hipMemcpy(&size, d_size, 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&ret, d_ret, 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(dest, d_slot.p, size, hipMemcpyDeviceToHost));
+    if (pin_out) {                                            // size, ret and the whole slot in one copy
+        HIP_TRY(hipMemcpyAsync(sc->pin, sc->dev + o_meta, 16 + bound, hipMemcpyDeviceToHost, sc->stream));
+        HIP_TRY(hipStreamSynchronize(sc->stream));
+        memcpy(&size, sc->pin, 4);
+        memcpy(&ret, sc->pin + 8, 8);
+        if (size > bound) return fail(SPRINTZ_E_HIP, "encoder reported a size above its bound");
+        memcpy(dest, sc->pin + 16, size);
+    } else {
+        uint8_t meta[16];
+        HIP_TRY(hipMemcpyAsync(meta, sc->dev + o_meta, 16, hipMemcpyDeviceToHost, sc->stream));
+        HIP_TRY(hipStreamSynchronize(sc->stream));
+        memcpy(&size, meta, 4);
+        memcpy(&ret, meta + 8, 8);
+        if (size > bound) return fail(SPRINTZ_E_HIP, "encoder reported a size above its bound");
+        HIP_TRY(hipMemcpyAsync(dest, sc->dev + o_slot, size, hipMemcpyDeviceToHost, sc->stream));
+        HIP_TRY(hipStreamSynchronize(sc->stream));
+    }
+    return ret;
+}
+
+// shared tail of the single-call decoders: stream [s, s + nbytes) (host) -> nelems elements.
+// device scratch: [offsets[2] (16 B) | stream + read slack | ret (16 B) | out]
+int64_t decode_host_common(int codec, int esz, const uint8_t* s, uint64_t nbytes, uint64_t nelems, uint16_t ndims, void* dest,
+                           int noheader, uint32_t ngroups, uint32_t remaining, const QuerySpec* qspec, uint64_t* result)
+{
+    const size_t o_out_meta = round_up(16 + nbytes + SPRINTZ_MI355X_READ_SLACK, 256), o_out = o_out_meta + 16;
+    const size_t out_bytes = (size_t)nelems * esz;
+    const bool want_out = !qspec || qspec->q != kQueryReduceOnly;
+    const size_t o_res = round_up(o_out + (want_out ? out_bytes : 0), 256);
+    const size_t res_bytes = qspec && qspec->qop ? (size_t)ndims * 8 : 0;
+    const bool pin_in = 16 + nbytes <= kPinMax, pin_out = 16 + out_bytes <= kPinMax;
+    Scratch* sc = nullptr;
+    int rc = acquire_scratch(o_res + res_bytes, std::max<size_t>(std::max<size_t>(pin_in ? 16 + nbytes : 16, pin_out ? 16 + out_bytes : 16), res_bytes), &sc);
+    if (rc) return rc;
+    const uint64_t meta[2] = {16, 16 + nbytes};              // offsets[0], offsets[1] (= stream end) relative to the scratch
+    if (pin_in) {
+        memcpy(sc->pin, meta, 16);
+        memcpy(sc->pin + 16, s, nbytes);
+        HIP_TRY(hipMemcpyAsync(sc->dev, sc->pin, 16 + nbytes, hipMemcpyHostToDevice, sc->stream));
+    } else {
+        memcpy(sc->pin, meta, 16);
+        HIP_TRY(hipMemcpyAsync(sc->dev, sc->pin, 16, hipMemcpyHostToDevice, sc->stream));
+        HIP_TRY(hipMemcpyAsync(sc->dev + 16, s, nbytes, hipMemcpyHostToDevice, sc->stream));
+    }
+    int64_t* d_ret = (int64_t*)(sc->dev + o_out_meta);
+    HIP_TRY(hipMemsetAsync(d_ret, 0xff, 8, sc->stream));      // a kernel that never reports reads as an error
+    QuerySpec qs = qspec ? *qspec : QuerySpec{};
+    if (res_bytes) {
+        qs.qres = (uint64_t*)(sc->dev + o_res);
+        HIP_TRY(hipMemsetAsync(qs.qres, 0, res_bytes, sc->stream));
+    }
+    rc = decode_launch(codec, esz, sc->dev, (const uint64_t*)sc->dev, 1, (uint32_t)nelems, ndims, want_out ? sc->dev + o_out : nullptr,
+                       d_ret, sc->stream, noheader, ngroups, remaining, qs);
+    if (rc) return rc;
+    int64_t ret = 0;
+    if (want_out && pin_out) {                                // ret and the samples in one copy
+        HIP_TRY(hipMemcpyAsync(sc->pin, sc->dev + o_out_meta, 16 + out_bytes, hipMemcpyDeviceToHost, sc->stream));
+        HIP_TRY(hipStreamSynchronize(sc->stream));
+        memcpy(&ret, sc->pin, 8);
+        if (ret < 0) return fail((int)ret, "decoder rejected the stream");
+        if ((uint64_t)ret > nelems) return fail(SPRINTZ_E_CORRUPT, "decoder rejected the stream");
+        memcpy(dest, sc->pin + 16, (size_t)ret * esz);
+    } else {
+        HIP_TRY(hipMemcpyAsync(sc->pin, d_ret, 8, hipMemcpyDeviceToHost, sc->stream));
+        HIP_TRY(hipStreamSynchronize(sc->stream));
+        memcpy(&ret, sc->pin, 8);
+        if (ret < 0) return fail((int)ret, "decoder rejected the stream");
+        if ((uint64_t)ret > nelems) return fail(SPRINTZ_E_CORRUPT, "decoder rejected the stream");
+        if (want_out) {
+            HIP_TRY(hipMemcpyAsync(dest, sc->dev + o_out, (size_t)ret * esz, hipMemcpyDeviceToHost, sc->stream));
+            HIP_TRY(hipStreamSynchronize(sc->stream));
+        }
+    }
+    if (result && res_bytes) {
+        HIP_TRY(hipMemcpyAsync(sc->pin, sc->dev + o_res, res_bytes, hipMemcpyDeviceToHost, sc->stream));
+        HIP_TRY(hipStreamSynchronize(sc->stream));
+        memcpy(result, sc->pin, res_bytes);
+    }
     return ret;
 }
 
 int64_t decompress_host(int codec, int esz, const void* src, void* dest, int noheader, uint16_t nh_ndims,
-                        uint32_t nh_ngroups, uint16_t nh_remaining)
+                        uint32_t nh_ngroups, uint16_t nh_remaining, int layout = SPRINTZ_LAYOUT_AUTO)
 {
+    if (layout < SPRINTZ_LAYOUT_AUTO || layout > SPRINTZ_LAYOUT_LOWDIM || (layout && codec > SPRINTZ_CODEC_XFF))
+        return fail(SPRINTZ_E_INVALID, "layout must be 0 (by ndims), 1 (general) or 2 (low-dim), RLE codecs only");
     const uint8_t* s = (const uint8_t*)src;
     uint32_t ngroups, remaining;
     uint16_t ndims;
@@ -535,30 +713,20 @@ int64_t decompress_host(int codec, int esz, const void* src, void* dest, int noh
     int rc = check_common(codec, esz, ndims);
     if (rc) return rc;
     if ((rc = ensure_device())) return rc;
+    if (layout == SPRINTZ_LAYOUT_LOWDIM && !is_lowdim(esz, ndims)) {               // sprintz_delta_lowdim.cpp:423-429
+        fail(SPRINTZ_E_INVALID, "the low-dim layout takes ndims <= 4 at 8 bits, <= 2 at 16 bits");
+        return -1;
+    }
+    const bool general = layout == SPRINTZ_LAYOUT_GENERAL;
     const uint32_t hlen = norle ? (codec == SPRINTZ_CODEC_XFF_NORLE ? 8 : 6) : (noheader ? 0 : 8);
     uint64_t nbytes = 0, nelems = 0;
-    walk_stream(s + hlen, esz, ndims, ngroups, remaining, norle ? false : is_lowdim(esz, ndims), &nbytes, &nelems, norle);
+    if (!walk_stream(s + hlen, esz, ndims, ngroups, remaining, (norle || general) ? false : is_lowdim(esz, ndims), &nbytes, &nelems, norle))
+        return fail(SPRINTZ_E_UNSUPPORTED, "stream framing exceeds the single-call limits (2^31 elements / 4 GiB): damaged header?");
     nbytes += hlen;
     if (nelems == 0) return 0;
-    if (nelems > (1ull << 31)) return fail(SPRINTZ_E_UNSUPPORTED, "single call limited to 2^31 elements");
-    DevBuf d_comp, d_out, d_meta;
-    HIP_TRY(d_comp.alloc(nbytes + SPRINTZ_MI355X_READ_SLACK));
-    HIP_TRY(d_out.alloc(nelems * esz));
-    HIP_TRY(d_meta.alloc(24));
-    HIP_TRY(hipMemcpy(d_comp.p, src, nbytes, hipMemcpyHostToDevice));
-    const uint64_t meta[3] = {0, nbytes, 0};               // offsets[0], offsets[1] (= stream end), ret
-    HIP_TRY(hipMemcpy(d_meta.p, meta, 24, hipMemcpyHostToDevice));
-    uint64_t* d_off = (uint64_t*)d_meta.p;
-    int64_t* d_ret = (int64_t*)((uint8_t*)d_meta.p + 16);
-    rc = decode_launch(codec, esz, d_comp.p, d_off, 1, (uint32_t)nelems, ndims, d_out.p, d_ret, nullptr,
-                       noheader, ngroups, remaining);
-    if (rc) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    int64_t ret = 0;
-    HIP_TRY(hipMemcpy(&ret, d_ret, 8, hipMemcpyDeviceToHost));
-    if (ret < 0) return fail((int)ret, "decoder rejected the stream");
-    HIP_TRY(hipMemcpy(dest, d_out.p, (size_t)ret * esz, hipMemcpyDeviceToHost));
-    return ret;
+    QuerySpec qs;
+    qs.general = general ? 1 : 0;
+    return decode_host_common(codec, esz, s, nbytes, nelems, ndims, dest, noheader, ngroups, remaining, general ? &qs : nullptr, nullptr);
 }
 
 // per-column reduction of the per-chunk partials.  A workgroup covers RB rows x D columns per
@@ -617,35 +785,16 @@ int64_t query_host(int codec, int esz, const void* src, void* dest, int op, int 
     if (rc) return rc;
     if ((rc = ensure_device())) return rc;
     uint64_t nbytes = 0, nelems = 0;
-    walk_stream(s + 8, esz, ndims, ngroups, remaining, general ? false : is_lowdim(esz, ndims), &nbytes, &nelems);
+    if (!walk_stream(s + 8, esz, ndims, ngroups, remaining, general ? false : is_lowdim(esz, ndims), &nbytes, &nelems))
+        return fail(SPRINTZ_E_UNSUPPORTED, "stream framing exceeds the single-call limits (2^31 elements / 4 GiB): damaged header?");
     nbytes += 8;
     if (result) memset(result, 0, (size_t)ndims * 8);
     if (nelems == 0) return 0;
-    if (nelems > (1ull << 31)) return fail(SPRINTZ_E_UNSUPPORTED, "single call limited to 2^31 elements");
-    DevBuf d_comp, d_out, d_meta, d_res;
-    HIP_TRY(d_comp.alloc(nbytes + SPRINTZ_MI355X_READ_SLACK));
-    if (materialize) HIP_TRY(d_out.alloc(nelems * esz));
-    HIP_TRY(d_meta.alloc(24));
-    HIP_TRY(d_res.alloc((size_t)ndims * 8));
-    HIP_TRY(hipMemset(d_res.p, 0, (size_t)ndims * 8));
-    HIP_TRY(hipMemcpy(d_comp.p, src, nbytes, hipMemcpyHostToDevice));
-    const uint64_t meta[3] = {0, nbytes, 0};
-    HIP_TRY(hipMemcpy(d_meta.p, meta, 24, hipMemcpyHostToDevice));
     QuerySpec qs;
     qs.q = materialize ? (op ? kQueryMaterialize : kQueryOff) : kQueryReduceOnly;
     qs.qop = op;
-    qs.qres = (uint64_t*)d_res.p;
     qs.general = general;
-    int64_t* d_ret = (int64_t*)((uint8_t*)d_meta.p + 16);
-    rc = decode_launch(codec, esz, d_comp.p, (uint64_t*)d_meta.p, 1, (uint32_t)nelems, ndims, d_out.p, d_ret, nullptr, 0, 0, 0, qs);
-    if (rc) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    int64_t ret = 0;
-    HIP_TRY(hipMemcpy(&ret, d_ret, 8, hipMemcpyDeviceToHost));
-    if (ret < 0) return fail((int)ret, "decoder rejected the stream");
-    if (materialize) HIP_TRY(hipMemcpy(dest, d_out.p, (size_t)ret * esz, hipMemcpyDeviceToHost));
-    if (result && op) HIP_TRY(hipMemcpy(result, d_res.p, (size_t)ndims * 8, hipMemcpyDeviceToHost));
-    return ret;
+    return decode_host_common(codec, esz, s, nbytes, nelems, ndims, dest, 0, 0, 0, &qs, result);
 }
 
 }  // namespace
@@ -654,6 +803,17 @@ int64_t query_host(int codec, int esz, const void* src, void* dest, int op, int 
 extern "C" {
 
 int sprintz_mi355x_abi_version(void) { return SPRINTZ_MI355X_ABI_VERSION; }
+
+int sprintz_mi355x_set_option(int option, int value)
+{
+    if (option == SPRINTZ_OPT_NO_FAST) { process().no_fast = value ? 1 : 0; return 0; }
+    if (option == SPRINTZ_OPT_CHUNKS_PER_GROUP) {
+        if (value < 1 || value > 64) return fail(SPRINTZ_E_INVALID, "chunks per group must be in 1..64");
+        process().chunks_per_group = value;
+        return 0;
+    }
+    return fail(SPRINTZ_E_INVALID, "unknown option");
+}
 const char* sprintz_mi355x_last_error(void) { return g_last_error.c_str(); }
 
 size_t sprintz_mi355x_compress_bound(int elem_bytes, uint32_t chunk_len, uint16_t ndims)
@@ -743,6 +903,17 @@ int64_t sprintz_mi355x_decompress_noheader(int codec, int elem_bytes, const void
     return decompress_host(codec, elem_bytes, src, dest, 1, ndims, ngroups, remaining_len);
 }
 
+int64_t sprintz_mi355x_compress_layout(int codec, int elem_bytes, const void* src, uint32_t len, void* dest, uint16_t ndims,
+                                       int write_size, int layout)
+{
+    return compress_host(codec, elem_bytes, src, len, dest, ndims, write_size, layout);
+}
+
+int64_t sprintz_mi355x_decompress_layout(int codec, int elem_bytes, const void* src, void* dest, int layout)
+{
+    return decompress_host(codec, elem_bytes, src, dest, 0, 0, 0, 0, layout);
+}
+
 // ---- host convenience: chunked codec over host buffers
 int64_t sprintz_mi355x_compress_chunked_host(int codec, int elem_bytes, const void* src, uint64_t total_len, uint32_t chunk_len,
                                              uint16_t ndims, void* comp, size_t comp_capacity, uint64_t* offsets)
@@ -801,6 +972,9 @@ int64_t sprintz_mi355x_decompress_chunked_host(int codec, int elem_bytes, const 
     int64_t sum = 0;
     for (uint64_t c = 0; c < nchunks; c++) {
         if (rets[c] < 0) return fail((int)rets[c], "decoder rejected a chunk stream");
+        // the copy below takes `sum` CONTIGUOUS elements: every chunk but the last must be full
+        if (c + 1 < nchunks && rets[c] != (int64_t)chunk_len)
+            return fail(SPRINTZ_E_CORRUPT, "a chunk other than the last decoded to fewer than chunk_len elements");
         sum += rets[c];
     }
     // chunks are full except possibly the last: decoded data is contiguous

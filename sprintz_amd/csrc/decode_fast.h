@@ -53,6 +53,14 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p)
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
 }
 
+// a 64-bit value that is the same in every lane of the wavefront, moved to SGPRs
+// (the builtin returns int: go through uint32_t, or a low word >= 2^31 sign-extends into the high one)
+__device__ __forceinline__ uint64_t wave_uniform64(uint64_t x)
+{
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) << 32) |
+           (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+}
+
 // 24-bit multiply-add / multiply, pinned to the full-rate opcodes (hipcc turns
 // __mul24 of values it cannot range-prove into quarter-rate v_mul_lo_u32)
 __device__ __forceinline__ int mad24(int a, int b, int c)
@@ -137,9 +145,7 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     // instead of faulting -- the read-ahead needs no bounds test.
     const uint64_t wave_first = (((uint64_t)blockIdx.x * kThreads + (threadIdx.x & ~63u)) >> LOG2DP) * (uint64_t)a.chunks_per_group;
     uint64_t wave_base = a.offsets[wave_first < a.nchunks ? wave_first : 0] & ~(uint64_t)15;
-    // (the builtin returns int: go through uint32_t, or a low word >= 2^31 sign-extends into the high one)
-    wave_base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(wave_base >> 32)) << 32) |
-                (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)wave_base);
+    wave_base = wave_uniform64(wave_base);
     // rounded up to whole 16-byte pieces (gfx950 zeroes a dwordx4 whose END is out of range);
     // the <= 15 extra bytes are inside the SPRINTZ_MI355X_READ_SLACK the API asks for
     const uint64_t wave_span = ((a.offsets[a.nchunks] - wave_base) + 15) & ~(uint64_t)15;
@@ -155,8 +161,11 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
                                  : (wave_first < a.nchunks ? wave_first : 0) * (uint64_t)a.chunk_len * ESZ;
     const uint64_t out_span = CM ? (uint64_t)(EXACT ? DCAP : a.D) * a.col_stride * ESZ - out_base
                                  : a.nchunks * (uint64_t)a.chunk_len * ESZ - out_base;
+    // (both are wave-uniform by construction; saying so keeps hipcc from wrapping every store in a
+    //  readfirstlane waterfall loop -- 8 VALU per store it cannot prove away)
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((uint8_t*)a.out + out_base), 0, (uint32_t)(out_span < 0xfffffff0ull ? out_span : 0xfffffff0ull), 0x00020000);
+        (void*)((uint8_t*)a.out + wave_uniform64(out_base)), 0,
+        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(out_span < 0xfffffff0ull ? out_span : 0xfffffff0ull)), 0x00020000);
     constexpr uint32_t kDropStore = 0xfffffff0u;          // out of range of every descriptor
     const uint32_t lane16 = (uint32_t)lane_d * 16u;
     uint64_t gabs = 0;                                     // container offset the cursors below are relative to

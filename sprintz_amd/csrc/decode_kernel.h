@@ -66,7 +66,12 @@ __global__ void __launch_bounds__(kThreads) decode_kernel(DecodeArgs a)
     const int lane_d = (int)(threadIdx.x & (uint32_t)(DP - 1));
     if (chunk >= a.nchunks) return;                 // whole groups leave together
 
-    const uint8_t* s = a.comp + a.offsets[chunk];
+    const uint64_t off_c = a.offsets[chunk];
+    const uint8_t* s = a.comp + off_c;
+    // the stream ends where the next one starts (offsets has nchunks + 1 entries): a damaged header,
+    // field or run length must never walk the input cursor past it (the output side is guarded below)
+    const uint64_t slen64 = a.offsets[chunk + 1] - off_c;
+    const uint32_t stream_len = slen64 < 0xffffffffull ? (uint32_t)slen64 : 0xffffffffu;
     U* const o = (U*)a.out + chunk * (uint64_t)a.chunk_len;
     const uint64_t cs = a.col_stride;
     U* const cm0 = (U*)a.out + (cs ? chunk * (uint64_t)(a.chunk_len / (uint32_t)a.D) : 0);   // column 0 at this chunk's first row
@@ -105,7 +110,7 @@ __global__ void __launch_bounds__(kThreads) decode_kernel(DecodeArgs a)
     const uint32_t blk_elems = 8u * (uint32_t)D;
     // a damaged header must not make the loop spin: every group of a valid stream holds at
     // least one non-empty slot, except the one that closes the stream
-    bool corrupt = groups_left > a.chunk_len / blk_elems + 2u;
+    bool corrupt = groups_left > a.chunk_len / blk_elems + 2u || pos > stream_len;
     if (corrupt) groups_left = 0;
 
     // per-column predictor state (all start at 0: sprintz_xff_rle.cpp:149-152)
@@ -139,6 +144,7 @@ __global__ void __launch_bounds__(kThreads) decode_kernel(DecodeArgs a)
             for (;;) {
                 if (slot == 2) {
                     if (groups_left == 0) break;
+                    if (hdr_bytes > stream_len - pos) { corrupt = true; break; }
                     groups_left--;
                     // group header: 2*D fields of HB bits, LSB-first (sprintz_xff_rle.cpp:713-735)
                     uint32_t s0 = 0, s1 = 0;
@@ -168,6 +174,9 @@ __global__ void __launch_bounds__(kThreads) decode_kernel(DecodeArgs a)
                     have = true;
                     break;
                 } else if (total == 0) {         // RUN slot: varint length in blocks (:829-833)
+                    if (stream_len - pos < 2u) {     // room for the longest run length, or the stream is damaged
+                        if (stream_len == pos || (load_u8(s + pos) & 0x80u)) { corrupt = true; break; }
+                    }
                     const uint32_t b0 = load_u8(s + pos);
                     uint32_t len = b0 & 0x7fu;
                     if (b0 & 0x80u) { len |= load_u8(s + pos + 1) << 7; pos += 2; }
@@ -181,6 +190,7 @@ __global__ void __launch_bounds__(kThreads) decode_kernel(DecodeArgs a)
                     for (int k = 0; k < CPL; k++) { cur[k] = slot ? nb1[k] : nb0[k]; lane_bits += cur[k]; }
                     uint32_t tot_unused;
                     uint32_t off = group_excl_scan(lane_bits, lane_d, DP, tot_unused);
+                    if ((LOWDIM ? total : ((total + 7u) >> 3) << 3) > stream_len - pos) { corrupt = true; break; }
                     if constexpr (!LOWDIM) {
                         // row r: LSB-first bit stream of the D fields, padded to a byte (:961-990)
                         const uint32_t row_bits = ((total + 7u) >> 3) << 3;
@@ -209,7 +219,7 @@ __global__ void __launch_bounds__(kThreads) decode_kernel(DecodeArgs a)
                 }
             }
         }
-        if (!have) break;
+        if (!have || corrupt) break;
         if (out_elems + blk_elems > a.chunk_len) { corrupt = true; break; }   // never write outside the chunk slot
 
         // ---- zigzag^-1 + forecast recurrence, lane-local down each column (:993-1150)
@@ -309,7 +319,7 @@ __global__ void __launch_bounds__(kThreads) decode_kernel(DecodeArgs a)
     }
 
     // ---- verbatim tail (:1171)
-    if (!corrupt && out_elems + remaining > a.chunk_len) corrupt = true;
+    if (!corrupt && (out_elems + remaining > a.chunk_len || (uint64_t)remaining * ESZ > (uint64_t)(stream_len - pos))) corrupt = true;
     if constexpr (Q != 0) {
         // the verbatim tail continues the row-major order: element e sits in column e % D
         // (out_elems is a multiple of 8*D)

@@ -815,9 +815,9 @@ size_t sprintz_mi355x_huf_bound(uint64_t total_stream_bytes, uint64_t nchunks)
 int sprintz_mi355x_huf_compress_batch(const void* d_dense, const uint64_t* d_offsets, const uint32_t* d_sizes, uint64_t nchunks,
                                       void* d_huf, uint64_t* d_huf_offsets, void* d_tables, void* d_tmp, void* hip_stream)
 {
-    if (!d_dense || !d_offsets || !d_sizes || !d_huf || !d_huf_offsets || !d_tables || !d_tmp) return SPRINTZ_E_INVALID;
+    if (!d_dense || !d_offsets || !d_sizes || !d_huf || !d_huf_offsets || !d_tables || !d_tmp) return sprintz::set_error(SPRINTZ_E_INVALID, "Huffman stage: invalid argument (null pointer, alignment or size)");
     hipStream_t st = (hipStream_t)hip_stream;
-    if (nchunks == 0) return hipMemsetAsync(d_huf_offsets, 0, 8, st) == hipSuccess ? 0 : SPRINTZ_E_HIP;
+    if (nchunks == 0) return hipMemsetAsync(d_huf_offsets, 0, 8, st) == hipSuccess ? 0 : sprintz::set_error(SPRINTZ_E_HIP, "Huffman stage: a HIP call or kernel launch failed");
     const uint64_t nseg = (nchunks + SEG - 1) / SEG;
     uint8_t* tmp = (uint8_t*)d_tmp;
     uint32_t* enc_tables = (uint32_t*)tmp;
@@ -828,10 +828,10 @@ int sprintz_mi355x_huf_compress_batch(const void* d_dense, const uint64_t* d_off
                        enc_tables, (uint8_t*)d_tables);
     hipLaunchKernelGGL(huf_size_kernel, dim3((unsigned)nseg), dim3(256), 0, st, (const uint8_t*)d_dense, d_offsets, d_sizes, nchunks,
                        (const uint32_t*)enc_tables, rec_sizes, meta);
-    if (launch_size_scan(rec_sizes, nchunks, 4, d_huf_offsets, scan_tmp, st) != hipSuccess) return SPRINTZ_E_HIP;
+    if (launch_size_scan(rec_sizes, nchunks, 4, d_huf_offsets, scan_tmp, st) != hipSuccess) return sprintz::set_error(SPRINTZ_E_HIP, "Huffman stage: a HIP call or kernel launch failed");
     hipLaunchKernelGGL(huf_encode_kernel, dim3((unsigned)nseg), dim3(256), 0, st, (const uint8_t*)d_dense, d_offsets, d_sizes, nchunks,
                        (const uint32_t*)enc_tables, (const uint64_t*)meta, (uint8_t*)d_huf, (const uint64_t*)d_huf_offsets);
-    return hipGetLastError() == hipSuccess ? 0 : SPRINTZ_E_HIP;
+    return hipGetLastError() == hipSuccess ? 0 : sprintz::set_error(SPRINTZ_E_HIP, "Huffman stage: a HIP call or kernel launch failed");
 }
 
 // ---- Huff0-format writer (huf0_write.h).  tmp: K1's code tables | nibble tables | segment records | block sizes | meta | scan scratch
@@ -851,11 +851,11 @@ size_t sprintz_mi355x_huf0_bound(uint64_t total_stream_bytes, uint64_t nchunks)
 int sprintz_mi355x_huf0_compress_batch(const void* d_dense, const uint64_t* d_offsets, const uint32_t* d_sizes, uint64_t nchunks,
                                        void* d_blocks, uint64_t* d_block_offsets, void* d_tmp, void* hip_stream)
 {
-    if (!d_dense || !d_offsets || !d_sizes || !d_blocks || !d_block_offsets || !d_tmp) return SPRINTZ_E_INVALID;
+    if (!d_dense || !d_offsets || !d_sizes || !d_blocks || !d_block_offsets || !d_tmp) return sprintz::set_error(SPRINTZ_E_INVALID, "Huffman stage: invalid argument (null pointer, alignment or size)");
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return SPRINTZ_E_NO_DEVICE;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return sprintz::set_error(SPRINTZ_E_NO_DEVICE, "Huffman stage: no usable HIP device (there is no CPU fallback)");
     hipStream_t st = (hipStream_t)hip_stream;
-    if (nchunks == 0) return hipMemsetAsync(d_block_offsets, 0, 8, st) == hipSuccess ? 0 : SPRINTZ_E_HIP;
+    if (nchunks == 0) return hipMemsetAsync(d_block_offsets, 0, 8, st) == hipSuccess ? 0 : sprintz::set_error(SPRINTZ_E_HIP, "Huffman stage: a HIP call or kernel launch failed");
     const uint64_t nseg = (nchunks + SEG - 1) / SEG;
     uint8_t* tmp = (uint8_t*)d_tmp;
     uint32_t* enc_tables = (uint32_t*)tmp;
@@ -869,27 +869,27 @@ int sprintz_mi355x_huf0_compress_batch(const void* d_dense, const uint64_t* d_of
     hipLaunchKernelGGL(huf0_table_kernel, dim3((unsigned)nseg), dim3(64), 0, st, (const uint8_t*)nib, recs);
     hipLaunchKernelGGL(huf0_size_kernel, dim3((unsigned)nseg), dim3(256), 0, st, (const uint8_t*)d_dense, d_offsets, d_sizes, nchunks,
                        (const uint8_t*)recs, bsizes, meta);
-    if (launch_size_scan(bsizes, nchunks, 1, d_block_offsets, scan_tmp, st) != hipSuccess) return SPRINTZ_E_HIP;
+    if (launch_size_scan(bsizes, nchunks, 1, d_block_offsets, scan_tmp, st) != hipSuccess) return sprintz::set_error(SPRINTZ_E_HIP, "Huffman stage: a HIP call or kernel launch failed");
     hipLaunchKernelGGL(huf0_encode_kernel, dim3((unsigned)nseg), dim3(256), 0, st, (const uint8_t*)d_dense, d_offsets, d_sizes, nchunks,
                        (const uint8_t*)recs, (const uint64_t*)meta, (uint8_t*)d_blocks, (const uint64_t*)d_block_offsets);
-    return hipGetLastError() == hipSuccess ? 0 : SPRINTZ_E_HIP;
+    return hipGetLastError() == hipSuccess ? 0 : sprintz::set_error(SPRINTZ_E_HIP, "Huffman stage: a HIP call or kernel launch failed");
 }
 
 int sprintz_mi355x_huf_decompress_batch(const void* d_huf, const uint64_t* d_huf_offsets, const void* d_tables, uint64_t nchunks,
                                         uint32_t align, void* d_dense, uint64_t dense_capacity, uint64_t* d_offsets,
                                         uint32_t* d_sizes, int64_t* d_rets, void* d_tmp, void* hip_stream)
 {
-    if (!d_huf || !d_huf_offsets || !d_tables || !d_dense || !d_offsets || !d_sizes || !d_tmp) return SPRINTZ_E_INVALID;
-    if (align == 0 || align > 16 || (align & (align - 1))) return SPRINTZ_E_INVALID;
+    if (!d_huf || !d_huf_offsets || !d_tables || !d_dense || !d_offsets || !d_sizes || !d_tmp) return sprintz::set_error(SPRINTZ_E_INVALID, "Huffman stage: invalid argument (null pointer, alignment or size)");
+    if (align == 0 || align > 16 || (align & (align - 1))) return sprintz::set_error(SPRINTZ_E_INVALID, "Huffman stage: invalid argument (null pointer, alignment or size)");
     hipStream_t st = (hipStream_t)hip_stream;
-    if (nchunks == 0) return hipMemsetAsync(d_offsets, 0, 8, st) == hipSuccess ? 0 : SPRINTZ_E_HIP;
+    if (nchunks == 0) return hipMemsetAsync(d_offsets, 0, 8, st) == hipSuccess ? 0 : sprintz::set_error(SPRINTZ_E_HIP, "Huffman stage: a HIP call or kernel launch failed");
     const uint64_t nseg = (nchunks + SEG - 1) / SEG;
     hipLaunchKernelGGL(huf_rawsize_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, st, (const uint8_t*)d_huf, d_huf_offsets,
                        nchunks, d_sizes);
-    if (launch_size_scan(d_sizes, nchunks, align, d_offsets, d_tmp, st) != hipSuccess) return SPRINTZ_E_HIP;
+    if (launch_size_scan(d_sizes, nchunks, align, d_offsets, d_tmp, st) != hipSuccess) return sprintz::set_error(SPRINTZ_E_HIP, "Huffman stage: a HIP call or kernel launch failed");
     hipLaunchKernelGGL(huf_decode_kernel, dim3((unsigned)nseg), dim3(256), 0, st, (const uint8_t*)d_huf, d_huf_offsets,
                        (const uint8_t*)d_tables, nchunks, (uint8_t*)d_dense, (const uint64_t*)d_offsets, dense_capacity, d_rets);
-    return hipGetLastError() == hipSuccess ? 0 : SPRINTZ_E_HIP;
+    return hipGetLastError() == hipSuccess ? 0 : sprintz::set_error(SPRINTZ_E_HIP, "Huffman stage: a HIP call or kernel launch failed");
 }
 
 }  // extern "C"

@@ -27,6 +27,8 @@
 
 #include <string>
 
+namespace sprintz { int set_error(int code, const char* what); }   // api.hip: the library's one error sink
+
 namespace {
 
 constexpr int kWStride = 256 + 4;                // weights per chunk, padded off the bank stride
@@ -477,15 +479,15 @@ extern "C" {
 int sprintz_mi355x_huf0_decompress_batch(const void* d_blocks, const uint64_t* d_block_offsets, uint64_t nchunks, void* d_out,
                                          const uint64_t* d_out_offsets, int64_t* d_rets, void* hip_stream)
 {
-    if (!d_blocks || !d_block_offsets || !d_out || !d_out_offsets || ((uintptr_t)d_blocks & 15)) return SPRINTZ_E_INVALID;
+    if (!d_blocks || !d_block_offsets || !d_out || !d_out_offsets || ((uintptr_t)d_blocks & 15)) return sprintz::set_error(SPRINTZ_E_INVALID, "Huff0 stage: invalid argument (null pointer, alignment or size)");
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return SPRINTZ_E_NO_DEVICE;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return sprintz::set_error(SPRINTZ_E_NO_DEVICE, "Huff0 stage: no usable HIP device (there is no CPU fallback)");
     if (nchunks == 0) return 0;
     const uint64_t grid = (nchunks + 15) / 16;
-    if (grid > 0x7fffffffull) return SPRINTZ_E_INVALID;
+    if (grid > 0x7fffffffull) return sprintz::set_error(SPRINTZ_E_INVALID, "Huff0 stage: invalid argument (null pointer, alignment or size)");
     hipLaunchKernelGGL(huf0_decode_kernel, dim3((unsigned)grid), dim3(64), 0, (hipStream_t)hip_stream, (const uint8_t*)d_blocks,
                        d_block_offsets, nchunks, (uint8_t*)d_out, d_out_offsets, d_rets);
-    return hipGetLastError() == hipSuccess ? 0 : SPRINTZ_E_HIP;
+    return hipGetLastError() == hipSuccess ? 0 : sprintz::set_error(SPRINTZ_E_HIP, "Huff0 stage: a HIP call or kernel launch failed");
 }
 
 }  // extern "C"

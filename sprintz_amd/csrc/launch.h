@@ -36,6 +36,10 @@ hipError_t launch_encode_fast_w16(bool fire, int dp, bool exact, unsigned grid, 
 hipError_t launch_encode_w8(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
 hipError_t launch_encode_w16(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
 
+// records `what` as this thread's last error (sprintz_mi355x_last_error) and returns `code`: every
+// failing return of every translation unit goes through it, so the message is never stale
+int set_error(int code, const char* what);
+
 hipError_t launch_size_scan(const uint32_t* d_sizes, uint64_t n, uint32_t align, uint64_t* d_offsets, void* d_tmp, hipStream_t st);
 
 template <typename K, typename A>

@@ -362,12 +362,10 @@ __global__ void __launch_bounds__(kTB) wave_scan_kernel(const typename E::T* y, 
     }
 }
 
-thread_local std::string g_err;
-int fail(int code, const char* what)
-{
-    g_err = what;
-    return code;
-}
+}  // namespace
+namespace sprintz { int set_error(int code, const char* what); }   // api.hip: the library's one error sink
+namespace {
+int fail(int code, const char* what) { return sprintz::set_error(code, what); }
 
 struct Plan {
     std::vector<uint64_t> rows;      // rows[k] = runs at level k (rows[0] = input rows)
@@ -637,7 +635,7 @@ bool have_device()
 
 extern "C" {
 
-const char* sprintz_mi355x_transform_last_error(void) { return g_err.c_str(); }
+const char* sprintz_mi355x_transform_last_error(void) { return sprintz_mi355x_last_error(); }   // kept for ABI 1 callers
 
 size_t sprintz_mi355x_transform_tmp_bytes(int kind, int elem_bytes, uint64_t len, uint16_t ndims)
 {
@@ -703,9 +701,9 @@ int64_t sprintz_mi355x_transform_encode(int kind, int elem_bytes, const void* sr
     void *dx = nullptr, *dy = nullptr;
     const size_t nb = (size_t)len * elem_bytes;
     if (hipMalloc(&dx, nb) != hipSuccess || hipMalloc(&dy, nb) != hipSuccess) { (void)hipFree(dx); return fail(SPRINTZ_E_HIP, "hipMalloc"); }
-    int rc = hipMemcpy(dx, src, nb, hipMemcpyHostToDevice) == hipSuccess ? 0 : SPRINTZ_E_HIP;
+    int rc = hipMemcpy(dx, src, nb, hipMemcpyHostToDevice) == hipSuccess ? 0 : fail(SPRINTZ_E_HIP, "hipMemcpy (host to device)");
     if (!rc) rc = sprintz_mi355x_transform_encode_device(kind, elem_bytes, dx, len, ndims, dy, nullptr);
-    if (!rc && hipMemcpy(d, dy, nb, hipMemcpyDeviceToHost) != hipSuccess) rc = SPRINTZ_E_HIP;
+    if (!rc && hipMemcpy(d, dy, nb, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SPRINTZ_E_HIP, "hipMemcpy (device to host)");
     (void)hipFree(dx);
     (void)hipFree(dy);
     return rc ? rc : (int64_t)len + hdr;
@@ -735,9 +733,9 @@ int64_t sprintz_mi355x_transform_decode(int kind, int elem_bytes, const void* sr
         (void)hipFree(dy); (void)hipFree(dx);
         return fail(SPRINTZ_E_HIP, "hipMalloc");
     }
-    int rc = hipMemcpy(dy, s, nb, hipMemcpyHostToDevice) == hipSuccess ? 0 : SPRINTZ_E_HIP;
+    int rc = hipMemcpy(dy, s, nb, hipMemcpyHostToDevice) == hipSuccess ? 0 : fail(SPRINTZ_E_HIP, "hipMemcpy (host to device)");
     if (!rc) rc = sprintz_mi355x_transform_decode_device(kind, elem_bytes, dy, len, ndims, dx, dt, nullptr);
-    if (!rc && hipMemcpy(dest, dx, nb, hipMemcpyDeviceToHost) != hipSuccess) rc = SPRINTZ_E_HIP;
+    if (!rc && hipMemcpy(dest, dx, nb, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(SPRINTZ_E_HIP, "hipMemcpy (device to host)");
     (void)hipFree(dy);
     (void)hipFree(dx);
     (void)hipFree(dt);

@@ -190,11 +190,13 @@ def test_batched_decodes_byte_dense_reference_streams(sz, oracle):
 
 
 @pytest.mark.parametrize("k", [2, 3, 7])
-def test_consecutive_chunks_per_group(sz, oracle, monkeypatch, k):
+def test_consecutive_chunks_per_group(sz, oracle, request, k):
     """decode_fast with several consecutive chunks per lane group (ring read-ahead running
     across chunk boundaries): 16-byte aligned container, byte-dense container, ragged tails"""
     import torch
-    monkeypatch.setenv("SPRINTZ_MI355X_CHUNKS_PER_GROUP", str(k))
+    from sprintz_amd import _lib
+    _lib.check(_lib.set_option(_lib.OPT_CHUNKS_PER_GROUP, k))
+    request.addfinalizer(lambda: _lib.set_option(_lib.OPT_CHUNKS_PER_GROUP, 1))
     rng = np.random.default_rng(100 + k)
     for codec, esz, ndims, chunk_len, nchunks in [("xff", 2, 8, 5120, 101), ("delta", 1, 16, 4096, 37),
                                                   ("xff", 2, 8, 5000, 50)]:
@@ -418,20 +420,22 @@ def test_huffman_decoder_survives_damaged_containers(sz):
 
 
 @pytest.mark.parametrize("name,codec,esz,ndims,chunk_len", [c for c in CONFIGS if c[0] in ("cfg2", "cfg3_10k", "cfg5", "xff8", "cfg1", "uni16_xff", "uni16_delta_ragged", "low8_d2", "low8_d4", "lowdim16", "low16_d2_delta_ragged", "lowdim8", "low8_d3_delta", "wide8_d128_xff", "wide8_d100_delta", "wide8_d66_xff", "wide16_d80_xff", "wide16_d128_delta", "wide16_d72_xff")])
-def test_generic_kernels_agree_with_the_fast_ones(sz, monkeypatch, name, codec, esz, ndims, chunk_len):
-    """SPRINTZ_MI355X_NO_FAST routes the same calls to decode_kernel.h / encode_kernel.h: same bytes, same samples"""
+def test_generic_kernels_agree_with_the_fast_ones(sz, request, name, codec, esz, ndims, chunk_len):
+    """SPRINTZ_OPT_NO_FAST routes the same calls to decode_kernel.h / encode_kernel.h: same bytes, same samples"""
     import torch
+    from sprintz_amd import _lib
+    request.addfinalizer(lambda: _lib.set_option(_lib.OPT_NO_FAST, 0))
     rng = np.random.default_rng(zlib.crc32(name.encode()) + 1)
     data = np.concatenate([gen_walk(rng, 40 * chunk_len, ndims, esz, 5, flat_every=3), gen_fuzz(rng, 9 * chunk_len + 17 * ndims, esz, 2)])
     cd = sz.ChunkedCodec(codec, esz, ndims, chunk_len, device="cuda:0")
     x = torch.from_numpy(data).cuda()
     fast = cd.compress(x)
-    monkeypatch.setenv("SPRINTZ_MI355X_NO_FAST", "1")
+    _lib.check(_lib.set_option(_lib.OPT_NO_FAST, 1))
     slow = cd.compress(x)
     assert torch.equal(fast.sizes, slow.sizes) and torch.equal(fast.offsets, slow.offsets)
     assert torch.equal(fast.data[: fast.total_bytes()], slow.data[: slow.total_bytes()])
     out_slow = cd.decompress(fast)
-    monkeypatch.delenv("SPRINTZ_MI355X_NO_FAST")
+    _lib.check(_lib.set_option(_lib.OPT_NO_FAST, 0))
     out_fast = cd.decompress(slow)
     assert torch.equal(out_slow, out_fast) and np.array_equal(out_fast.cpu().numpy(), data)
 
