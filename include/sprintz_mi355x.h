@@ -352,6 +352,28 @@ int64_t sprintz_mi355x_transform_decode(int kind, int elem_bytes, const void* sr
 const char* sprintz_mi355x_transform_last_error(void);
 
 /* ------------------------------------------------------------------------
+ * Multi-GPU: one process per GPU, rank r owns a contiguous chunk range, the data
+ * path has NO collective.  The only exchange is one all-gather of 8 bytes per rank -- each rank's
+ * compressed byte count -- from which every rank derives where its container starts in the
+ * job-wide one.  It runs over RCCL (xGMI), in-stream behind sprintz_mi355x_compact:
+ *   rank 0:      sprintz_mi355x_comm_unique_id(id)   -> ship the 128 bytes to the other ranks
+ *                                                        (any bootstrap: torchrun's store, MPI, a file)
+ *   every rank:  sprintz_mi355x_comm_init(id, rank, world, &comm)          (on its own HIP device)
+ *   per batch:   sprintz_mi355x_compact(..., d_offsets, ...)               d_offsets[nchunks] = local bytes
+ *                sprintz_mi355x_gather_layout(comm, &d_offsets[nchunks], d_all, stream)   ncclAllGather
+ *                sprintz_mi355x_layout_bases(d_all, world, bases, stream)  host: bases[r] = global byte offset
+ *                                                                           of rank r's container, bases[world] = total
+ * RCCL is loaded at run time (dlopen by SONAME; inside a torch process that is the copy
+ * torch.distributed's "nccl" backend uses); without it comm_* return SPRINTZ_E_UNSUPPORTED.
+ * ---------------------------------------------------------------------- */
+#define SPRINTZ_MI355X_COMM_ID_BYTES 128
+int sprintz_mi355x_comm_unique_id(void* id_out);
+int sprintz_mi355x_comm_init(const void* id, int rank, int world, void** comm_out);
+int sprintz_mi355x_gather_layout(void* comm, const uint64_t* d_local_total, uint64_t* d_all, void* hip_stream);
+int sprintz_mi355x_layout_bases(const uint64_t* d_all, int world, uint64_t* bases_out /* world + 1 */, void* hip_stream);
+int sprintz_mi355x_comm_destroy(void* comm);
+
+/* ------------------------------------------------------------------------
  * Host convenience: chunked codec over host buffers (what lzbench does per
  * block).  Stages through device memory; PCIe-inclusive by construction.
  * comp layout: chunk streams concatenated byte-dense; offsets[nchunks+1].

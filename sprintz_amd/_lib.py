@@ -121,6 +121,14 @@ _transform_last_error = _sig("sprintz_mi355x_transform_last_error", C.c_char_p)
 compress_norle = _sig("sprintz_mi355x_compress_norle", _i64, _i, _i, _vp, _u32, _vp, _u16)
 decompress_norle = _sig("sprintz_mi355x_decompress_norle", _i64, _i, _i, _vp, _vp)
 
+# multi-GPU: the all-gather of per-rank byte counts over RCCL
+COMM_ID_BYTES = 128
+comm_unique_id = _sig("sprintz_mi355x_comm_unique_id", _i, _vp)
+comm_init = _sig("sprintz_mi355x_comm_init", _i, _vp, _i, _i, C.POINTER(C.c_void_p))
+gather_layout = _sig("sprintz_mi355x_gather_layout", _i, _vp, _vp, _vp, _vp)
+layout_bases = _sig("sprintz_mi355x_layout_bases", _i, _vp, _i, _vp, _vp)
+comm_destroy = _sig("sprintz_mi355x_comm_destroy", _i, _vp)
+
 # host convenience
 compress_chunked_host = _sig("sprintz_mi355x_compress_chunked_host", _i64, _i, _i, _vp, _u64, _u32, _u16, _vp, _sz, _vp)
 decompress_chunked_host = _sig("sprintz_mi355x_decompress_chunked_host", _i64, _i, _i, _vp, _vp, _u64, _u32, _u16, _vp)
@@ -136,6 +144,8 @@ EXPORTED_SYMBOLS = [
     "sprintz_mi355x_compress_batch", "sprintz_mi355x_compact_tmp_bytes", "sprintz_mi355x_compact",
     "sprintz_mi355x_decompress_batch",
     "sprintz_mi355x_compress_chunked_host", "sprintz_mi355x_decompress_chunked_host",
+    "sprintz_mi355x_comm_unique_id", "sprintz_mi355x_comm_init", "sprintz_mi355x_gather_layout",
+    "sprintz_mi355x_layout_bases", "sprintz_mi355x_comm_destroy",
     "sprintz_mi355x_huf_tmp_bytes", "sprintz_mi355x_huf_bound",
     "sprintz_mi355x_huf_compress_batch", "sprintz_mi355x_huf_decompress_batch", "sprintz_mi355x_huf0_decompress_batch",
     "sprintz_mi355x_huf0_tmp_bytes", "sprintz_mi355x_huf0_bound", "sprintz_mi355x_huf0_compress_batch",

@@ -48,6 +48,101 @@ def gather_layout(local_bytes: int, device=None) -> GlobalLayout:
     return GlobalLayout(sizes, base, acc)
 
 
+class LayoutGather:
+    """The write path's one exchange, kept ready across batches: every rank contributes its container's byte
+    count (a device word -- `offsets[nchunks:]` as sprintz_mi355x_compact leaves it) and receives everybody's.
+
+    backend "rccl-c-abi": sprintz_mi355x_gather_layout = ncclAllGather over xGMI, enqueued on the compute stream
+    right behind the compaction pass (the communicator is bootstrapped by shipping RCCL's 128-byte unique id
+    through the process group that torchrun set up -- bootstrap only).  If RCCL cannot be brought up that way
+    the same gather goes through torch.distributed (backend "torch.distributed/nccl" = RCCL as well, or gloo
+    on CPU tensors in the tests); with one rank there is nothing to exchange ("single-rank")."""
+
+    def __init__(self, device=None, prefer_c_abi=True):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size() if self.on else 1
+        self.rank = dist.get_rank() if self.on else 0
+        cuda = device is not None and torch.device(device).type == "cuda"
+        self.device = torch.device(device) if device is not None else torch.device("cpu")
+        self.all = torch.zeros(self.world, dtype=torch.int64, device=self.device)
+        self.comm = None
+        self.backend = "single-rank" if self.world == 1 else f"torch.distributed/{dist.get_backend()}"
+        self.ranks_seen = 1
+        self.c_abi_error = None
+        if cuda and prefer_c_abi and (self.world == 1 or dist.get_backend() == "nccl"):
+            self._init_c_abi()
+
+    def _init_c_abi(self):
+        import ctypes as C
+        from . import _lib
+        torch, dist = self.torch, self.dist
+        idbuf = (C.c_uint8 * _lib.COMM_ID_BYTES)()
+        ok = 1
+        if self.rank == 0:
+            ok = 1 if _lib.comm_unique_id(idbuf) == 0 else 0
+        t = torch.zeros(_lib.COMM_ID_BYTES + 1, dtype=torch.uint8, device=self.device)
+        if self.rank == 0:
+            t[:-1] = torch.frombuffer(bytearray(idbuf), dtype=torch.uint8).to(self.device)
+            t[-1] = ok
+        if self.world > 1:
+            dist.broadcast(t, src=0)
+        host = t.cpu()
+        if int(host[-1]) != 1:
+            self.c_abi_error = _lib.last_error() or "rank 0 could not create an RCCL unique id"
+            return
+        idb = (C.c_uint8 * _lib.COMM_ID_BYTES)(*host[:-1].tolist())
+        comm = C.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = _lib.comm_init(idb, self.rank, self.world, C.byref(comm))
+        good = torch.tensor([1 if rc == 0 else 0], dtype=torch.int64, device=self.device)
+        if self.world > 1:
+            dist.all_reduce(good, op=dist.ReduceOp.MIN)            # all ranks take the same path
+        if int(good.item()) == 1:
+            self.comm = comm
+            self.backend = "rccl-c-abi (sprintz_mi355x_gather_layout: ncclAllGather, in-stream)"
+        else:
+            self.c_abi_error = _lib.last_error()
+            if rc == 0:
+                _lib.comm_destroy(comm)
+
+    def gather_async(self, d_total):
+        """d_total: 1-element int64 tensor holding this rank's byte count (a view is fine).  Enqueues the
+        all-gather on the current stream (device tensors) / runs it (CPU tensors)."""
+        import ctypes as C
+        if self.comm is not None:
+            from . import _lib
+            st = C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+            _lib.check(_lib.gather_layout(self.comm, d_total.data_ptr(), self.all.data_ptr(), st))
+        elif self.world > 1:
+            self.dist.all_gather_into_tensor(self.all, d_total.reshape(1).contiguous())
+        else:
+            self.all[:1] = d_total.reshape(1)
+
+    def layout(self, local_bytes=None) -> GlobalLayout:
+        """the gathered counts as a GlobalLayout (synchronises).  With local_bytes given and no gather issued yet,
+        performs one."""
+        if local_bytes is not None:
+            self.gather_async(self.torch.tensor([int(local_bytes)], dtype=self.torch.int64, device=self.device))
+        sizes = [int(v) for v in self.all.cpu().tolist()]
+        self.ranks_seen = len(sizes)
+        base, acc = [], 0
+        for s in sizes:
+            base.append(acc)
+            acc += s
+        lay = GlobalLayout(sizes, base, acc)
+        lay.bases = base
+        return lay
+
+    def close(self):
+        if self.comm is not None:
+            from . import _lib
+            _lib.comm_destroy(self.comm)
+            self.comm = None
+
+
 def max_over_ranks(x: float, device=None) -> float:
     import torch
     import torch.distributed as dist

@@ -40,7 +40,7 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from sprintz_amd.dist import gather_layout, max_over_ranks, shard_range, sum_over_ranks
+        from sprintz_amd.dist import LayoutGather, gather_layout, max_over_ranks, shard_range, sum_over_ranks
         codec, esz, ndims, chunk_len, nchunks = "xff", 2, 8, 5120, 40
         data = gen_walk(np.random.default_rng(42), nchunks * chunk_len, ndims, esz, 8, flat_every=4)   # same on every rank
         lo, hi = shard_range(nchunks, rank, world)
@@ -49,6 +49,12 @@ def _worker(rank, world, port, q):
         local_sizes = np.array([s.size for s in mine], np.int64)
         local_offsets = np.concatenate([[0], np.cumsum(local_sizes)])[:-1]
         layout = gather_layout(int(local_sizes.sum()))
+        # the object bench.py keeps across batches gives the same answer (CPU tensors: torch.distributed path)
+        lg = LayoutGather(None)
+        lay2 = lg.layout(int(local_sizes.sum()))
+        assert lg.backend == "torch.distributed/gloo" and lg.ranks_seen == world
+        assert (lay2.rank_bytes, lay2.rank_base, lay2.total_bytes) == (layout.rank_bytes, layout.rank_base, layout.total_bytes)
+        lg.close()
         goffs = layout.global_offsets(rank, local_offsets)
         assert max_over_ranks(float(rank)) == world - 1
         assert sum_over_ranks(1.0) == world
@@ -58,9 +64,10 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(180)
-def test_gather_layout_world2_gloo():
-    world, port = 2, _free_port()
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("world", [2, 4])
+def test_gather_layout_gloo(world):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
@@ -69,16 +76,16 @@ def test_gather_layout_world2_gloo():
     [p.join(30) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     # every rank derived the same layout
-    assert res[0][1:4] == res[1][1:4]
+    assert all(r[1:4] == res[0][1:4] for r in res)
     rank_bytes, rank_base, total = res[0][1:4]
-    assert rank_base == [0, rank_bytes[0]] and total == sum(rank_bytes)
+    assert rank_base == [sum(rank_bytes[:r]) for r in range(world)] and total == sum(rank_bytes)
     # the global container assembled from per-rank pieces == one-process compression of everything
     codec, esz, ndims, chunk_len, nchunks = "xff", 2, 8, 5120, 40
     data = gen_walk(np.random.default_rng(42), nchunks * chunk_len, ndims, esz, 8, flat_every=4)
     orc = Oracle()
     whole = orc.compress_chunks(codec, data, chunk_len, ndims)
     assert b"".join(r[5] for r in res) == b"".join(s.tobytes() for s in whole)
-    goffs = res[0][4] + res[1][4]
+    goffs = [g for r in res for g in r[4]]
     want = np.concatenate([[0], np.cumsum([s.size for s in whole])])[:-1]
     assert goffs == want.tolist()
     # and decodes back, chunk by chunk, from the global offsets
