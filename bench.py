@@ -292,9 +292,11 @@ def bench_rowmajor(cx, name, workload, codec, esz, ndims, chunk_len, nchunks_tot
             _lib.check(_lib.huf0_compress_batch(comp.data_ptr(), offs.data_ptr(), ws["sizes"].data_ptr(), n, z_buf.data_ptr(),
                                                 z_offs.data_ptr(), z_tmp.data_ptr(), st))
 
+        zd_tmp = torch.empty(int(_lib.huf0_decode_tmp_bytes(n)), dtype=torch.uint8, device=dev)
+
         def h_dec():
-            _lib.check(_lib.huf0_decompress_batch(z_buf.data_ptr(), z_offs.data_ptr(), n, s_buf.data_ptr(), s_offs.data_ptr(),
-                                                  z_rets.data_ptr(), st))
+            _lib.check(_lib.huf0_decompress_batch_ws(z_buf.data_ptr(), z_offs.data_ptr(), n, s_buf.data_ptr(), s_offs.data_ptr(),
+                                                     z_rets.data_ptr(), zd_tmp.data_ptr(), st))
 
         def chain():
             h_dec()
@@ -313,7 +315,7 @@ def bench_rowmajor(cx, name, workload, codec, esz, ndims, chunk_len, nchunks_tot
                     "huff0_decode_ms": round(h_dec_ms, 4), "sprintz_decode_ms": round(dec_ms, 4),
                     "compress_ms": round(enc_ms + h_enc_ms, 4), "compress_MBps": round(raw / (enc_ms + h_enc_ms) / 1e3, 1),
                     "huff0_encode_ms": round(h_enc_ms, 4),
-                    "roofline": roofline(algo_chain, chain_ms, "huf0_decode_kernel + sprintz decode (two launches)",
+                    "roofline": roofline(algo_chain, chain_ms, "huf0_tree_kernel + huf0_stream_kernel + sprintz decode (three launches)",
                                          {"huff0_decode_frac": round((hbytes + stream_bytes + 16 * n) / (h_dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})})
         if cx.rank == 0 and not args.no_cpu_baseline:
             ns = min(n, max(64, (48 << 20) // (chunk_len * esz)))

@@ -90,6 +90,8 @@ huf0_tmp_bytes = _sig("sprintz_mi355x_huf0_tmp_bytes", _sz, _u64)
 huf0_bound = _sig("sprintz_mi355x_huf0_bound", _sz, _u64, _u64)
 huf0_compress_batch = _sig("sprintz_mi355x_huf0_compress_batch", _i, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _vp)
 huf0_decompress_batch = _sig("sprintz_mi355x_huf0_decompress_batch", _i, _vp, _vp, _u64, _vp, _vp, _vp, _vp)
+huf0_decode_tmp_bytes = _sig("sprintz_mi355x_huf0_decode_tmp_bytes", _sz, _u64)
+huf0_decompress_batch_ws = _sig("sprintz_mi355x_huf0_decompress_batch_ws", _i, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp)
 huf_decompress_batch = _sig("sprintz_mi355x_huf_decompress_batch", _i, _vp, _vp, _vp, _u64, _u32, _vp, _u64, _vp, _vp, _vp, _vp, _vp)
 
 # (4) query on compressed data (query.hpp:23-29; sprintz_delta.h:95-98; sprintz_xff.h:90-93)
@@ -148,6 +150,7 @@ EXPORTED_SYMBOLS = [
     "sprintz_mi355x_layout_bases", "sprintz_mi355x_comm_destroy",
     "sprintz_mi355x_huf_tmp_bytes", "sprintz_mi355x_huf_bound",
     "sprintz_mi355x_huf_compress_batch", "sprintz_mi355x_huf_decompress_batch", "sprintz_mi355x_huf0_decompress_batch",
+    "sprintz_mi355x_huf0_decode_tmp_bytes", "sprintz_mi355x_huf0_decompress_batch_ws",
     "sprintz_mi355x_huf0_tmp_bytes", "sprintz_mi355x_huf0_bound", "sprintz_mi355x_huf0_compress_batch",
     "sprintz_mi355x_query_batch", "sprintz_mi355x_query_reduce",
     "sprintz_mi355x_query_delta_8b", "sprintz_mi355x_query_xff_8b",

@@ -32,7 +32,7 @@ namespace sprintz { int set_error(int code, const char* what); }   // api.hip: t
 namespace {
 
 constexpr int kWStride = 256 + 4;                // weights per chunk, padded off the bank stride
-constexpr int kRStride = 336 + 4;                // per chunk: header copy 144 | norm 32 | next 32 | fse 128; later the sorted symbols (256)
+constexpr int kRStride = 344 + 4;                // per chunk: 8 zero bytes + header copy 144 | norm 32 | next 32 | fse 128; later the sorted symbols (256)
 constexpr int64_t kCorrupt = SPRINTZ_E_CORRUPT;
 
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
@@ -213,6 +213,179 @@ __device__ uint32_t read_stats(const uint8_t* h, uint32_t n, uint8_t* weights, u
     return isize + 1;
 }
 
+// ---- the same function as the tree kernel runs it: one lane per chunk, every lane of the wave busy, so what counts
+// is the length of the DEPENDENT chain of LDS round trips.  Differences in form, none in result (every rejection of
+// read_stats is kept): the header copy `hb` carries 8 zero bytes in front and zero padding behind, so bit fields are
+// two aligned dwords + v_alignbit instead of five byte reads; the two FSE states' table reads are issued together;
+// the weights are read back four at a time; the per-weight counts are LDS adds with no return (cnt[13], zeroed by
+// the caller; on return cnt[w] = number of symbols of weight w, the implied last one included).
+__device__ __forceinline__ uint32_t hb32(const uint8_t* hb, uint32_t bitpos)                       // 32 bits at bit `bitpos` of hb, LSB first
+{
+    const uint32_t* const q = (const uint32_t*)hb + (bitpos >> 5);
+    return __builtin_amdgcn_alignbit(q[1], q[0], bitpos & 31u);
+}
+__device__ uint32_t read_stats2(const uint8_t* hb, uint32_t n, uint8_t* weights, uint8_t* s, uint32_t* cnt, uint32_t& nsym, uint32_t& tl_out)
+{
+    const uint8_t* const h = hb + 8;
+    if (n < 1) return 0;
+    uint32_t isize = h[0], osize;
+    if (isize >= 128) {                                           // 4-bit weights
+        osize = isize - 127;
+        isize = (osize + 1) / 2;
+        if (isize + 1 > n) return 0;
+        for (uint32_t k = 0; k < osize; k += 2) {
+            const uint32_t v = h[1 + k / 2];
+            weights[k] = (uint8_t)(v >> 4);
+            weights[k + 1] = (uint8_t)(v & 15u);
+        }
+    } else {                                                      // FSE_decompress_wksp, table log <= 6
+        if (isize + 1 > n) return 0;
+        int16_t* const norm = (int16_t*)s;
+        uint16_t* const next = (uint16_t*)(s + 32);
+        uint16_t* const fse = (uint16_t*)(s + 64);                // symbol | nbits << 4 | new_state << 8
+        for (int k = 0; k < 8; k++) ((uint32_t*)norm)[k] = 0;
+        // FSE_readNCount: bit 0 of the description is bit 72 of hb (8 lead bytes + the size byte)
+        constexpr uint32_t F0 = 72;
+        uint32_t bp = 0;
+        int nb = (int)(hb32(hb, F0 + bp) & 0xf) + 5;
+        if (nb > 6) return 0;                                     // tableLog > maxLog (6)
+        bp += 4;
+        const uint32_t tl = (uint32_t)nb;
+        int remaining = (1 << nb) + 1, threshold = 1 << nb;
+        nb++;
+        uint32_t charnum = 0;
+        bool previous0 = false;
+        const uint32_t bit_end = 8u * isize;
+        while (remaining > 1 && charnum <= 255u) {
+            if (previous0) {
+                uint32_t n0 = charnum;
+                while ((hb32(hb, F0 + bp) & 0xffffu) == 0xffffu) { n0 += 24; bp += 16; if (bp > bit_end) return 0; }
+                while ((hb32(hb, F0 + bp) & 3u) == 3u) { n0 += 3; bp += 2; if (bp > bit_end) return 0; }
+                n0 += hb32(hb, F0 + bp) & 3u;
+                bp += 2;
+                if (n0 > 255u) return 0;
+                charnum = n0;                                     // norm is zero there already
+            }
+            const uint32_t bits = hb32(hb, F0 + bp);
+            const int max = (2 * threshold - 1) - remaining;
+            int count;
+            if ((int)(bits & (uint32_t)(threshold - 1)) < max) {
+                count = (int)(bits & (uint32_t)(threshold - 1));
+                bp += (uint32_t)(nb - 1);
+            } else {
+                count = (int)(bits & (uint32_t)(2 * threshold - 1));
+                if (count >= threshold) count -= max;
+                bp += (uint32_t)nb;
+            }
+            count--;
+            remaining -= count < 0 ? -count : count;
+            if (charnum > 255u || bp > bit_end) return 0;
+            if (charnum >= 16u) { if (count != 0) return 0; charnum++; }
+            else norm[charnum++] = (int16_t)count;
+            previous0 = count == 0;
+            while (remaining < threshold) { nb--; threshold >>= 1; }
+        }
+        if (remaining != 1 || bp > bit_end || charnum == 0) return 0;
+        const uint32_t max_sv = (charnum < 16u ? charnum : 16u) - 1, hl = (bp + 7) >> 3;
+        if (hl >= isize) return 0;
+        // FSE_buildDTable
+        const uint32_t size = 1u << tl;
+        uint32_t high = size - 1;
+        for (uint32_t sy = 0; sy <= max_sv; sy++) {
+            if (norm[sy] == -1) { fse[high--] = (uint16_t)sy; next[sy] = 1; }
+            else next[sy] = (uint16_t)norm[sy];
+        }
+        {
+            const uint32_t mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+            uint32_t pos = 0, placed = 0;
+            for (uint32_t sy = 0; sy <= max_sv; sy++)
+                for (int i = 0; i < norm[sy]; i++) {
+                    if (++placed > size) return 0;
+                    fse[pos] = (uint16_t)sy;
+                    pos = (pos + step) & mask;
+                    while (pos > high) pos = (pos + step) & mask;
+                }
+            if (pos != 0) return 0;
+        }
+        for (uint32_t u = 0; u < size; u++) {
+            const uint32_t sy = fse[u] & 0xfu, ns = next[sy]++;
+            if (ns == 0 || ns >= 2 * size) return 0;
+            const uint32_t nbits = tl - (uint32_t)highbit(ns);
+            fse[u] = (uint16_t)(sy | (nbits << 4) | (((ns << nbits) - size) << 8));
+        }
+        // FSE_decompress_usingDTable: two interleaved states; the stream ends by running dry
+        const uint8_t* const b = h + 1 + hl;
+        const uint32_t bn = isize - hl;
+        if (b[bn - 1] == 0) return 0;
+        int P = 8 * (int)(bn - 1) + highbit(b[bn - 1]);
+        uint32_t s1 = back_look(b, P, (int)tl); P -= (int)tl;
+        uint32_t s2 = back_look(b, P, (int)tl); P -= (int)tl;
+        osize = 0;
+        const uint32_t B0 = 8u + 1u + hl;                         // byte offset of the bit stream in hb
+        // the stream's next 64 bits ride in a register, refilled every 8 weights (8 x 6 bits <= the 57 a refill guarantees)
+        bool done = false;
+        while (!done) {
+            uint64_t win = 0;
+            if (P > 0) {
+                const uint32_t a = B0 + ((uint32_t)(P - 1) >> 3) - 7u;            // first of the 8 bytes that end at the cursor's byte (>= 2)
+                const uint32_t* const q = (const uint32_t*)hb + (a >> 2);
+                const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+                const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, a & 3u), hi = __builtin_amdgcn_alignbyte(d2, d1, a & 3u);
+                win = (((uint64_t)hi << 32) | lo) << (7 - ((P - 1) & 7));
+                if (P < 64) win &= ~0ull << (64 - P);             // nothing before the stream's first bit
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t e1 = fse[s1], e2 = fse[s2];       // both table reads in flight together
+                if (osize + 2 > 255u) return 0;
+                weights[osize++] = (uint8_t)(e1 & 0xfu);
+                uint32_t nbt = (e1 >> 4) & 0xfu;
+                s1 = (e1 >> 8) + ((((uint32_t)(win >> 32)) >> 1) >> (31u - nbt));
+                win <<= nbt;
+                P -= (int)nbt;
+                if (P < 0) { weights[osize++] = (uint8_t)(e2 & 0xfu); done = true; break; }
+                if (osize + 2 > 255u) return 0;
+                weights[osize++] = (uint8_t)(e2 & 0xfu);
+                nbt = (e2 >> 4) & 0xfu;
+                s2 = (e2 >> 8) + ((((uint32_t)(win >> 32)) >> 1) >> (31u - nbt));
+                win <<= nbt;
+                P -= (int)nbt;
+                if (P < 0) { weights[osize++] = (uint8_t)(fse[s1] & 0xfu); done = true; break; }
+            }
+        }
+    }
+    // weight statistics, four weights a read; the last symbol's weight is implied
+    uint32_t total = 0, rank1 = 0;
+    bool heavy = false;
+    for (uint32_t k = 0; k < osize; k += 4) {
+        const uint32_t four = *(const uint32_t*)(weights + k);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t w = (four >> (8 * i)) & 0xffu;
+            if (k + i < osize) {
+                heavy |= w >= 12u;
+                rank1 += w == 1u;
+                total += (1u << (w & 31u)) >> 1;
+                __hip_atomic_fetch_add(&cnt[w < 12u ? w : 0u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+        }
+    }
+    if (heavy) return 0;
+    if (total == 0) return 0;
+    const uint32_t tl = (uint32_t)highbit(total) + 1u;
+    if (tl > 12u) return 0;
+    const uint32_t rest = (1u << tl) - total;
+    if ((1u << highbit(rest)) != rest) return 0;
+    const uint32_t lw = (uint32_t)highbit(rest) + 1u;
+    weights[osize] = (uint8_t)lw;
+    __hip_atomic_fetch_add(&cnt[lw], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    rank1 += lw == 1u;
+    if (rank1 < 2 || (rank1 & 1u)) return 0;
+    nsym = osize + 1;
+    tl_out = tl;
+    return isize + 1;
+}
+
 __device__ __forceinline__ int quad_bcast0(int v) { return __builtin_amdgcn_mov_dpp(v, 0x00, 0xf, 0xf, true); }
 __device__ __forceinline__ void wave_sync()
 {
@@ -221,25 +394,147 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ void __launch_bounds__(64) huf0_decode_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restrict__ boffs,
-                                                         uint64_t nchunks, uint8_t* __restrict__ out,
-                                                         const uint64_t* __restrict__ ooffs, int64_t* __restrict__ rets)
+// ---------------------------------------------------------------------------------------------
+// Two launches.  (1) huf0_tree_kernel: ONE LANE PER CHUNK (64 chunks a wave) turns every coded
+// block's tree description into a 320-byte descriptor in global memory: the symbols sorted by
+// (weight, symbol), start[w] | symoff[w] << 16 for w = 1..12, and the header length / table log.
+// Phases A and B used to run on the first lane of each quad of the stream decoder -- a quarter of
+// the lanes for a third of its instructions (0.5 of 1.4 ms on the headline shape).
+// (2) huf0_stream_kernel: lane = (chunk, stream), 16 chunks a wave, as before -- but a symbol is no
+// longer an 11-step weight search.  The top 8 bits of the look-ahead index a per-chunk 256-entry
+// table in LDS that resolves every code of <= 8 bits (symbol | length << 8); longer codes can only
+// have the weights 1 .. tableLog - 8 <= 4, so THEIR weight is three compares against start[2..4],
+// and their symbol one more LDS read from the sorted list.  Both reads are issued together; the
+// dependent chain of a symbol is one LDS round trip.
+constexpr int kDescStride = 320;                 // sorted[256] | u32 tab[16]: [0] = hl | tl << 16, [w] = start[w] | symoff[w] << 16
+constexpr int kCStride = 256 + 64 + 512 + 4;     // stream kernel, per chunk in LDS: sorted | tab | table8; odd in dwords
+constexpr int kRingStride = 32 + 8;              // stream kernel, per lane: two 16-byte pieces of its stream (8-byte aligned)
+
+__global__ void __launch_bounds__(64) huf0_tree_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restrict__ boffs,
+                                                       const uint64_t* __restrict__ ooffs, uint64_t nchunks, uint8_t* __restrict__ desc)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_w[16 * kWStride];
-    __shared__ __attribute__((aligned(16))) uint8_t s_r[16 * kRStride];
-    __shared__ uint32_t s_tab[16][17];                            // [w]: start[w] | symoff[w] << 16; [16]: running offsets are in s_run
-    __shared__ uint16_t s_run[16][16];
+    __shared__ __attribute__((aligned(16))) uint8_t s_w[64 * kWStride];
+    __shared__ __attribute__((aligned(16))) uint8_t s_r[64 * kRStride];
+    __shared__ uint32_t s_tab[64][17];
+    __shared__ uint32_t s_run[64][13];
+    __shared__ uint64_t s_src[64];
+    __shared__ uint32_t s_hc[64];
+    const int t = threadIdx.x;
+    const uint64_t chunk0 = (uint64_t)blockIdx.x * 64;
+    const uint64_t chunk = chunk0 + (uint64_t)t;
+    const bool exists = chunk < nchunks;
+    const uint64_t b0 = exists ? boffs[chunk] : 0, b1 = exists ? boffs[chunk + 1] : 0;
+    const uint64_t o0 = exists ? ooffs[chunk] : 0, o1 = exists ? ooffs[chunk + 1] : 0;
+    const uint64_t csize = b1 - b0, dsize = o1 - o0;
+    const bool coded = exists && b1 >= b0 && o1 >= o0 && csize > 1 && csize < dsize;      // HUF_decompress's third case
+    const uint32_t hcopy = coded ? (uint32_t)(csize < 129 ? csize : 129) : 0u;
+    s_src[t] = (uint64_t)(uintptr_t)(blocks + b0);
+    s_hc[t] = hcopy;
+    wave_sync();
+    // the wave copies one chunk's header per trip: 38 lanes, one (unaligned) dword each -- 8 zero bytes, the 129 header bytes
+    // (one request), zero padding up to byte 152
+    for (int c0 = 0; c0 < 64; c0 += 8) {                          // eight chunks a trip, their loads in flight together
+        uint32_t v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t hc = s_hc[c0 + i];
+            const uint8_t* const src = (const uint8_t*)(uintptr_t)s_src[c0 + i];
+            v[i] = 0;
+            if (t >= 2 && t < 38) {
+                const uint32_t k = 4u * (uint32_t)(t - 2);
+                if (k + 4 <= hc) v[i] = *(const u32_a1*)(src + k);
+                else for (uint32_t bb = 0; bb < 4 && k + bb < hc; bb++) v[i] |= (uint32_t)src[k + bb] << (8 * bb);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            if (t < 38) *(uint32_t*)(s_r + (c0 + i) * kRStride + 4u * (uint32_t)t) = v[i];
+    }
+#pragma unroll
+    for (int w = 0; w < 13; w++) s_tab[t][w] = 0;                 // the per-weight counts
+    wave_sync();
+    uint8_t* const wts = s_w + t * kWStride;
+    uint8_t* const scratch = s_r + t * kRStride;
+    uint8_t* const sorted = scratch;
+    uint32_t hl = 0, nsym = 0, tl = 0;
+    if (coded) {
+        hl = read_stats2(scratch, hcopy, wts, scratch + 152, &s_tab[t][0], nsym, tl);
+        if (hl >= csize) hl = 0;
+    }
+    if (hl) {
+        // start[w] (first table index of weight w), symoff[w], and the symbols sorted by (weight, symbol)
+        uint32_t cnt[13];
+#pragma unroll
+        for (int w = 1; w < 13; w++) cnt[w] = s_tab[t][w];
+        uint32_t at = 0, so = 0;
+#pragma unroll
+        for (int w = 1; w < 13; w++) {
+            s_tab[t][w] = at | (so << 16);
+            s_run[t][w] = so;
+            at += cnt[w] << (w - 1);
+            so += cnt[w];
+        }
+        // counting sort, four symbols a trip: their slots come back from four LDS adds issued together
+        // (DS operations of a wave execute in issue order, so equal weights keep their symbol order)
+        for (uint32_t sy = 0; sy < nsym; sy += 4) {
+            const uint32_t four = *(const uint32_t*)(wts + sy);
+            uint32_t pos[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t w = (four >> (8 * i)) & 0xffu;
+                pos[i] = 0xffffffffu;
+                if (sy + i < nsym && w) pos[i] = __hip_atomic_fetch_add(&s_run[t][w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                if (pos[i] != 0xffffffffu) sorted[pos[i] & 0xffu] = (uint8_t)(sy + i);
+        }
+    }
+    s_tab[t][0] = hl | (tl << 16);
+    wave_sync();
+    // descriptors out: 64 dwords of sorted symbols + 13 words of table per chunk, one chunk per trip
+    for (int c = 0; c < 64; c++) {
+        if (chunk0 + (uint64_t)c >= nchunks) break;
+        uint8_t* const d = desc + (chunk0 + (uint64_t)c) * kDescStride;
+        const uint32_t v = *(const uint32_t*)(s_r + c * kRStride + 4 * t);
+        *(uint32_t*)(d + 4 * t) = v;
+        if (t < 13) *(uint32_t*)(d + 256 + 4 * t) = s_tab[c][t];
+    }
+}
+
+__global__ void __launch_bounds__(64) huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restrict__ boffs,
+                                                         uint64_t nchunks, uint8_t* __restrict__ out,
+                                                         const uint64_t* __restrict__ ooffs, int64_t* __restrict__ rets,
+                                                         const uint8_t* __restrict__ desc)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_c[16 * kCStride];
+    __shared__ __attribute__((aligned(16))) uint8_t s_ring[64 * kRingStride];
     const int t = threadIdx.x, q = t >> 2, j = t & 3;
-    const uint64_t chunk = (uint64_t)blockIdx.x * 16 + (uint64_t)q;
+    const uint64_t chunk0 = (uint64_t)blockIdx.x * 16;
+    const uint64_t chunk = chunk0 + (uint64_t)q;
     const bool exists = chunk < nchunks;
     const uint64_t b0 = exists ? boffs[chunk] : 0, b1 = exists ? boffs[chunk + 1] : 0;
     const uint64_t o0 = exists ? ooffs[chunk] : 0, o1 = exists ? ooffs[chunk + 1] : 0;
     const uint8_t* const src = blocks + b0;
     uint8_t* const dst = out + o0;
     const uint64_t csize = b1 - b0, dsize = o1 - o0;
-    uint8_t* const wts = s_w + q * kWStride;
-    uint8_t* const scratch = s_r + q * kRStride;
-    uint8_t* const sorted = scratch;                              // phase B on: the symbols by (weight, symbol)
+    uint8_t* const cbase = s_c + q * kCStride;
+    const uint8_t* const sorted = cbase;
+    const uint32_t* const tab = (const uint32_t*)(cbase + 256);
+    uint16_t* const table8 = (uint16_t*)(cbase + 320);
+
+    // ---- descriptors of this wave's 16 chunks -> LDS: 320 pieces of 16 bytes, five per lane
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    typedef v4u __attribute__((aligned(1), may_alias)) v4u_a1;
+    typedef v4u __attribute__((aligned(16), may_alias)) v4u_a16;
+#pragma unroll
+    for (int r = 0; r < 5; r++) {
+        const uint32_t piece = (uint32_t)r * 64 + (uint32_t)t, c = piece / 20u, part = piece % 20u;
+        v4u v = {0, 0, 0, 0};
+        if (chunk0 + c < nchunks) v = *(const v4u_a16*)(desc + (chunk0 + c) * kDescStride + 16u * part);
+        uint32_t* const d = (uint32_t*)(s_c + c * kCStride + 16u * part);
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
 
     // ---- HUF_decompress's conventions (huf_decompress.c): stored, one repeated byte, or a coded block
     int mode = 0;                                                 // 0 nothing / damaged, 1 stored, 2 repeated byte, 3 coded
@@ -253,60 +548,38 @@ __global__ void __launch_bounds__(64) huf0_decode_kernel(const uint8_t* __restri
     }
     if (mode == 1) for (uint64_t k = (uint64_t)j; k < dsize; k += 4) dst[k] = src[k];
     if (mode == 2) { const uint8_t v = src[0]; for (uint64_t k = (uint64_t)j; k < dsize; k += 4) dst[k] = v; }
-
-    // ---- phase A: tree description -> weights (first lane of the quad)
-    const uint32_t hcopy = mode == 3 ? (uint32_t)(csize < 129 ? csize : 129) : 0u;
-    for (uint32_t k = 4u * (uint32_t)j; k < 144u; k += 16) {     // a dword per lane per trip (byte loads cost the address path as much)
-        uint32_t v = 0;
-        if (k + 4 <= hcopy) v = *(const u32_a1*)(src + k);
-        else for (uint32_t b = 0; b < 4 && k + b < hcopy; b++) v |= (uint32_t)src[k + b] << (8 * b);
-        *(uint32_t*)(scratch + k) = v;
-    }
     wave_sync();
-    uint32_t hl = 0, nsym = 0, tl = 0;
-    if (mode == 3 && j == 0) {
-        hl = read_stats(scratch, hcopy, wts, scratch + 144, nsym, tl);
-        if (hl == 0 || hl >= csize) { hl = 0; ret = kCorrupt; }
-        if (hl) {
-            // ---- phase B: start[w] (first table index of weight w), symoff[w], and the symbols sorted by (weight, symbol)
-            uint32_t cnt[13];
-#pragma unroll
-            for (int w = 0; w < 13; w++) cnt[w] = 0;
-            for (uint32_t sy = 0; sy < nsym; sy++) {
-                const uint32_t w = wts[sy];
-#pragma unroll
-                for (int ww = 1; ww < 13; ww++) cnt[ww] += (uint32_t)(w == (uint32_t)ww);
-            }
-            uint32_t at = 0, so = 0;
-#pragma unroll
-            for (int w = 1; w < 13; w++) {
-                s_tab[q][w] = at | (so << 16);
-                s_run[q][w] = (uint16_t)so;
-                at += cnt[w] << (w - 1);
-                so += cnt[w];
-            }
-            for (uint32_t sy = 0; sy < nsym; sy++) {
-                const uint32_t w = wts[sy];
-                if (w) { const uint32_t pos = s_run[q][w]; s_run[q][w] = (uint16_t)(pos + 1); sorted[pos] = (uint8_t)sy; }
-            }
-        }
-    }
-    hl = (uint32_t)quad_bcast0((int)hl);
-    tl = (uint32_t)quad_bcast0((int)tl);
-    wave_sync();
+    const uint32_t hl = mode == 3 ? (tab[0] & 0xffffu) : 0u, tl = mode == 3 ? (tab[0] >> 16) : 0u;
+    if (mode == 3 && hl == 0) ret = kCorrupt;
     const bool coded = mode == 3 && hl != 0;
 
-    // ---- phase C: lane j decodes stream j (HUF_decompress4X1_usingDTable_internal).  Set-up per lane, then ONE
+    // ---- table8: entry b = the code that starts with the 8 bits b, if it is at most 8 bits long.  Lane j of the
+    // quad fills entries 64 j .. 64 j + 63; the weight only ever grows along them.
+    if (coded) {
+        const uint32_t start_short = tl > 8u ? (tab[tl - 7u] & 0xffffu) : 0u;      // first index of the codes of <= 8 bits
+        uint32_t w = 1, e = tab[1], nxt = tab[2] & 0xffffu;
+        for (uint32_t k = 0; k < 64; k++) {
+            const uint32_t b = 64u * (uint32_t)j + k;
+            const uint32_t idx0 = tl >= 8u ? b << (tl - 8u) : b >> (8u - tl);
+            uint32_t entry = 0;
+            if (idx0 >= start_short) {
+                while (w < 12u && idx0 >= nxt) { w++; e = tab[w]; nxt = w < 12u ? (tab[w + 1] & 0xffffu) : 0xffffffffu; }
+                const uint32_t sym = sorted[(e >> 16) + ((idx0 - (e & 0xffffu)) >> (w - 1u))];
+                entry = sym | ((tl + 1u - w) << 8);
+            }
+            table8[b] = (uint16_t)entry;
+        }
+    }
+    wave_sync();
+
+    // ---- lane j decodes stream j (HUF_decompress4X1_usingDTable_internal).  Set-up per lane, then ONE
     // wave-uniform loop: the quad exchanges of the output path need every lane, streamless ones included.
-    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-    typedef v4u __attribute__((aligned(1), may_alias)) v4u_a1;
-    typedef v4u __attribute__((aligned(16), may_alias)) v4u_a16;
     bool bad = false;
-    uint32_t T[13];                                               // T[k] = start[k]: thresholds of the weight search (k > tableLog: never reached)
-#pragma unroll
-    for (int k = 2; k < 13; k++) T[k] = (coded && (uint32_t)k <= tl) ? (s_tab[q][k] & 0xffffu) : 0xffffu;
+    // long codes (> 8 bits) have weight <= tableLog - 8 <= 4: their weight is 1 + #{k in 2..4 : start[k] <= idx}
+    const uint32_t E2 = coded ? tab[2] : 0xffffu, E3 = coded ? tab[3] : 0xffffu, E4 = coded ? tab[4] : 0xffffu;
+    const uint32_t T2 = E2 & 0xffffu, T3 = E3 & 0xffffu, T4 = E4 & 0xffffu;
     const uint8_t* sp = blocks;                                   // this lane's stream
-    int64_t P = 0;
+    int32_t P = 0;
     uint8_t* op = dst;
     uint64_t left = 0;
     if (coded) {
@@ -320,6 +593,7 @@ __global__ void __launch_bounds__(64) huf0_decode_kernel(const uint8_t* __restri
             l[2] = (uint64_t)ip[4] | ((uint64_t)ip[5] << 8);
             if (6 + l[0] + l[1] + l[2] > n) bad = true;
             else l[3] = n - 6 - l[0] - l[1] - l[2];
+            if (l[3] >= (1ull << 27)) bad = true;                 // the bit cursor is 32 bits: streams below 128 MiB (a Huff0 block is at most 128 KB)
         }
         if (!bad) {
             const uint64_t seg = (dsize + 3) / 4;
@@ -333,7 +607,7 @@ __global__ void __launch_bounds__(64) huf0_decode_kernel(const uint8_t* __restri
             if (slen < 1 || ip[so + slen - 1] == 0) bad = true;
             if (!bad) {
                 sp = ip + so;
-                P = 8 * (int64_t)(slen - 1) + highbit(sp[slen - 1]);
+                P = 8 * (int32_t)(slen - 1) + highbit(sp[slen - 1]);
                 op = dst + w0;
                 left = w1 - w0;
             }
@@ -341,58 +615,77 @@ __global__ void __launch_bounds__(64) huf0_decode_kernel(const uint8_t* __restri
     }
     const bool streaming = left > 0 || (coded && !bad);           // has a stream whose end must be checked
     const uint32_t look_shift = 32u - (tl ? tl : 1u);
-    // The stream reaches the lane as 16-byte ALIGNED pieces, three of them in registers: the one that holds the
-    // cursor's byte (pc0), the one below (pc1) and the one below that, in flight (pn).  A step takes at most 6
-    // bytes, so the cursor leaves a piece every ~3 steps: only then is a new piece requested -- a third of the
-    // requests of "16 unaligned bytes every step", which kept the address path 66 % busy -- and a piece has two
-    // crossings (>= 5 steps) to arrive.  Piece k covers bytes [16 k - s_al, 16 k - s_al + 16) of the stream.
+    const uint32_t t8 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)table8;
+    const uint32_t so8 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)sorted;
+    // The stream is read from its last byte down.  It reaches the lane as 16-byte aligned PIECES parked in a per-lane
+    // LDS ring of two pieces (the 8-byte window never spans more); the piece below the ring is in flight in a register
+    // and is only touched -- written into the ring slot the cursor just left -- when the cursor crosses into the next
+    // piece, ~3 steps after it was requested.  (The first version rotated three pieces through registers: the
+    // compiler's copies for the rotation made every step wait for the piece requested one step earlier.  A ring of
+    // two 64-byte blocks hid the latency better but cost 8.7 KB of LDS a wave: 7 waves a CU instead of 10.)
+    // Byte i of the stream sits at ring offset (s_al + i) & 31; piece k covers stream bytes [16 k - s_al, 16 k - s_al + 16).
     const uint32_t s_al = (uint32_t)((uintptr_t)sp & 15u);
     const uint8_t* const sp_al = sp - s_al;                       // >= blocks: the API asks for a 16-byte aligned buffer
-    auto load_piece = [&](int32_t k) -> v4u {
-        if (!streaming || k < 0) return v4u{0, 0, 0, 0};
+    const int32_t last_piece = streaming ? (int32_t)((((P > 0 ? (uint32_t)(P - 1) >> 3 : 0u)) + s_al) >> 4) : -1;
+    auto load_piece = [&](int32_t k) -> v4u {                     // pieces outside the stream read as zero, never touched
+        if (k < 0 || k > last_piece) return v4u{0, 0, 0, 0};
         return *(const v4u_a16*)(sp_al + 16 * (int64_t)k);
     };
-    int32_t cur_k = (int32_t)(((P > 0 ? (P - 1) >> 3 : 0) + (int64_t)s_al) >> 4);
-    v4u pc0 = load_piece(cur_k), pc1 = load_piece(cur_k - 1), pn = load_piece(cur_k - 2);
-    // one step = 4 symbols = one dword of output
+    const uint32_t ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)s_ring + (uint32_t)t * kRingStride;
+    auto park = [&](int32_t pk, const v4u& f) {                   // piece pk -> its ring slot
+        const uint32_t at = ring + (((uint32_t)pk & 1u) << 4);
+        typedef __attribute__((address_space(3))) uint64_t lds_u64;
+        *(lds_u64*)(uintptr_t)at = (uint64_t)f.x | ((uint64_t)f.y << 32);
+        *(lds_u64*)(uintptr_t)(at + 8u) = (uint64_t)f.z | ((uint64_t)f.w << 32);
+    };
+    int32_t cur_b = last_piece;                                   // piece of the cursor's byte
+    v4u fl;
+    {
+        const v4u f0 = load_piece(cur_b), f1 = load_piece(cur_b - 1);
+        fl = load_piece(cur_b - 2);
+        park(cur_b, f0);
+        park(cur_b - 1, f1);
+    }
+    wave_sync();
+    typedef __attribute__((address_space(3))) const uint16_t lds_u16;
+    typedef __attribute__((address_space(3))) const uint8_t lds_u8c;
+    typedef __attribute__((address_space(3))) const uint32_t lds_u32c;
+    // one step = up to 4 symbols = one dword of output; branch-free except for the block crossing
     auto step = [&](uint32_t m) -> uint32_t {
-        uint64_t win = 0;
-        const int64_t Pc = P;
-        if (Pc > 0) {
-            const uint32_t r = (uint32_t)((Pc - 1) >> 3) + s_al;  // the cursor's byte, counted from piece 0
-            if ((int32_t)(r >> 4) < cur_k) {                      // left pc0: shift the pieces up, request the next one down
-                pc0 = pc1;
-                pc1 = pn;
-                cur_k--;
-                pn = load_piece(cur_k - 2);
-            }
-            // the 8 bytes ending at byte r, out of the 32 of (pc1 | pc0): first byte at o = 9 .. 24
-            const uint32_t o = r - 7u - 16u * (uint32_t)(cur_k - 1);
-            const uint32_t t3 = (o >> 2) - 2u;                    // 0 .. 4: which dword the window starts in, minus 2
-            const bool b0 = (t3 & 1u) != 0, b1 = (t3 & 2u) != 0, b2 = (t3 & 4u) != 0;
-            const uint32_t D2 = pc1.z, D3 = pc1.w, D4 = pc0.x, D5 = pc0.y, D6 = pc0.z, D7 = pc0.w;
-            const uint32_t wa = b2 ? D6 : (b1 ? (b0 ? D5 : D4) : (b0 ? D3 : D2));
-            const uint32_t wb = b2 ? D7 : (b1 ? (b0 ? D6 : D5) : (b0 ? D4 : D3));
-            const uint32_t wc = b2 ? 0u : (b1 ? (b0 ? D7 : D6) : (b0 ? D5 : D4));
-            const uint32_t lo = __builtin_amdgcn_alignbyte(wb, wa, o & 3u), hi = __builtin_amdgcn_alignbyte(wc, wb, o & 3u);
-            win = (((uint64_t)hi << 32) | lo) << (7 - (int)((Pc - 1) & 7));
-            if (Pc < 64) win &= ~0ull << (64 - (int)Pc);         // nothing before the stream's first bit
+        const int32_t Pc = P;
+        const uint32_t x = ((uint32_t)(Pc > 0 ? Pc - 1 : 0) >> 3) + s_al;      // the cursor's byte, counted from piece 0
+        if ((int32_t)(x >> 4) < cur_b) {                          // crossed into the piece below: the one in flight takes the freed slot
+            park(cur_b - 2, fl);
+            cur_b--;
+            fl = load_piece(cur_b - 2);
         }
+        // the 8 bytes ending at byte x: three aligned dwords of the ring, two v_alignbyte
+        const uint32_t o = x - 7u;                                // may be "negative": bytes before the stream read as what the ring holds, masked below
+        const uint32_t d0 = *(lds_u32c*)(uintptr_t)(ring + (o & 28u));
+        const uint32_t d1 = *(lds_u32c*)(uintptr_t)(ring + ((o + 4u) & 28u));
+        const uint32_t d2 = *(lds_u32c*)(uintptr_t)(ring + ((o + 8u) & 28u));
+        const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, o & 3u), hi0 = __builtin_amdgcn_alignbyte(d2, d1, o & 3u);
+        uint64_t win = (((uint64_t)hi0 << 32) | lo) << (7 - (int)((uint32_t)(Pc - 1) & 7u));
+        const uint64_t keep = Pc >= 64 ? ~0ull : (Pc > 0 ? ~0ull << (64 - Pc) : 0ull);   // nothing before the stream's first bit
+        win &= keep;
         uint32_t word = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            if ((uint32_t)k < m) {
-                const uint32_t idx = (uint32_t)(win >> 32) >> look_shift;
-                uint32_t w = 1;
-#pragma unroll
-                for (int kk = 2; kk < 13; kk++) w += (uint32_t)(idx >= T[kk]);
-                const uint32_t e = s_tab[q][w];
-                const uint32_t sym = sorted[(e >> 16) + ((idx - (e & 0xffffu)) >> (w - 1u))];
-                const uint32_t nb = tl + 1u - w;
-                word |= sym << (8 * k);
-                win <<= nb;
-                P -= (int64_t)nb;
-            }
+            const uint32_t hi = (uint32_t)(win >> 32);
+            const uint32_t e8 = *(lds_u16*)(uintptr_t)(t8 + ((hi >> 24) << 1));
+            const uint32_t idx = hi >> look_shift;
+            const bool g2 = idx >= T2, g3 = idx >= T3, g4 = idx >= T4;
+            const uint32_t el = g4 ? E4 : (g3 ? E3 : (g2 ? E2 : 0u));       // start[w] | symoff[w] << 16 of the long code's weight
+            const uint32_t wm1 = (uint32_t)g2 + (uint32_t)g3 + (uint32_t)g4;   // w - 1
+            const uint32_t pos = ((el >> 16) + ((idx - (el & 0xffffu)) >> wm1)) & 0xffu;
+            const uint32_t syl = *(lds_u8c*)(uintptr_t)(so8 + pos);
+            const bool is_short = e8 != 0;
+            const bool on = (uint32_t)k < m;
+            const uint32_t sym = is_short ? (e8 & 0xffu) : syl;
+            const uint32_t nb = on ? (is_short ? (e8 >> 8) : (tl - wm1)) : 0u;
+            word |= (on ? sym : 0u) << (8 * k);
+            win <<= nb;
+            P -= (int32_t)nb;
         }
         return word;
     };
@@ -410,7 +703,7 @@ __global__ void __launch_bounds__(64) huf0_decode_kernel(const uint8_t* __restri
         for (int sN = 0; sN < 16; sN++) {
             const uint32_t done = 4u * sN;
             const uint32_t m = (left > done && P >= -64) ? (left - done < 4 ? (uint32_t)(left - done) : 4u) : 0u;
-            wb[sN] = m ? step(m) : 0u;
+            wb[sN] = step(m);
         }
         const uint32_t cnt = left < 64 ? (uint32_t)left : 64u;
         uint32_t v[4][4];
@@ -476,18 +769,41 @@ std::string g_err0;
 
 extern "C" {
 
-int sprintz_mi355x_huf0_decompress_batch(const void* d_blocks, const uint64_t* d_block_offsets, uint64_t nchunks, void* d_out,
-                                         const uint64_t* d_out_offsets, int64_t* d_rets, void* hip_stream)
+size_t sprintz_mi355x_huf0_decode_tmp_bytes(uint64_t nchunks) { return (size_t)nchunks * kDescStride + 256; }
+
+int sprintz_mi355x_huf0_decompress_batch_ws(const void* d_blocks, const uint64_t* d_block_offsets, uint64_t nchunks, void* d_out,
+                                            const uint64_t* d_out_offsets, int64_t* d_rets, void* d_tmp, void* hip_stream)
 {
-    if (!d_blocks || !d_block_offsets || !d_out || !d_out_offsets || ((uintptr_t)d_blocks & 15)) return sprintz::set_error(SPRINTZ_E_INVALID, "Huff0 stage: invalid argument (null pointer, alignment or size)");
+    if (!d_blocks || !d_block_offsets || !d_out || !d_out_offsets || ((uintptr_t)d_blocks & 15) || (nchunks && (!d_tmp || ((uintptr_t)d_tmp & 15))))
+        return sprintz::set_error(SPRINTZ_E_INVALID, "Huff0 stage: invalid argument (null pointer, alignment or size)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return sprintz::set_error(SPRINTZ_E_NO_DEVICE, "Huff0 stage: no usable HIP device (there is no CPU fallback)");
     if (nchunks == 0) return 0;
-    const uint64_t grid = (nchunks + 15) / 16;
-    if (grid > 0x7fffffffull) return sprintz::set_error(SPRINTZ_E_INVALID, "Huff0 stage: invalid argument (null pointer, alignment or size)");
-    hipLaunchKernelGGL(huf0_decode_kernel, dim3((unsigned)grid), dim3(64), 0, (hipStream_t)hip_stream, (const uint8_t*)d_blocks,
-                       d_block_offsets, nchunks, (uint8_t*)d_out, d_out_offsets, d_rets);
+    const uint64_t grid1 = (nchunks + 63) / 64, grid2 = (nchunks + 15) / 16;
+    if (grid2 > 0x7fffffffull) return sprintz::set_error(SPRINTZ_E_INVALID, "Huff0 stage: invalid argument (null pointer, alignment or size)");
+    hipStream_t st = (hipStream_t)hip_stream;
+    hipLaunchKernelGGL(huf0_tree_kernel, dim3((unsigned)grid1), dim3(64), 0, st, (const uint8_t*)d_blocks, d_block_offsets, d_out_offsets,
+                       nchunks, (uint8_t*)d_tmp);
+    hipLaunchKernelGGL(huf0_stream_kernel, dim3((unsigned)grid2), dim3(64), 0, st, (const uint8_t*)d_blocks, d_block_offsets, nchunks,
+                       (uint8_t*)d_out, d_out_offsets, d_rets, (const uint8_t*)d_tmp);
     return hipGetLastError() == hipSuccess ? 0 : sprintz::set_error(SPRINTZ_E_HIP, "Huff0 stage: a HIP call or kernel launch failed");
+}
+
+// the ABI-1 form without a workspace argument: stream-ordered allocation of the descriptors
+int sprintz_mi355x_huf0_decompress_batch(const void* d_blocks, const uint64_t* d_block_offsets, uint64_t nchunks, void* d_out,
+                                         const uint64_t* d_out_offsets, int64_t* d_rets, void* hip_stream)
+{
+    if (!d_blocks || !d_block_offsets || !d_out || !d_out_offsets || ((uintptr_t)d_blocks & 15))
+        return sprintz::set_error(SPRINTZ_E_INVALID, "Huff0 stage: invalid argument (null pointer, alignment or size)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return sprintz::set_error(SPRINTZ_E_NO_DEVICE, "Huff0 stage: no usable HIP device (there is no CPU fallback)");
+    if (nchunks == 0) return 0;
+    void* tmp = nullptr;
+    if (hipMallocAsync(&tmp, sprintz_mi355x_huf0_decode_tmp_bytes(nchunks), (hipStream_t)hip_stream) != hipSuccess)
+        return sprintz::set_error(SPRINTZ_E_HIP, "Huff0 stage: hipMallocAsync of the descriptor workspace failed");
+    const int rc = sprintz_mi355x_huf0_decompress_batch_ws(d_blocks, d_block_offsets, nchunks, d_out, d_out_offsets, d_rets, tmp, hip_stream);
+    (void)hipFreeAsync(tmp, (hipStream_t)hip_stream);
+    return rc;
 }
 
 }  // extern "C"
