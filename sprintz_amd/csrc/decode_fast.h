@@ -167,6 +167,13 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         (void*)((uint8_t*)a.out + wave_uniform64(out_base)), 0,
         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(out_span < 0xfffffff0ull ? out_span : 0xfffffff0ull)), 0x00020000);
     constexpr uint32_t kDropStore = 0xfffffff0u;          // out of range of every descriptor
+    // the decoded samples are written once and not read again by this kernel: non-temporal stores (aux bit 1 = nt)
+    // keep them from displacing the compressed streams in L2 and let whole lines go out -- measured with the
+    // univariate decoder first (0.402 -> 0.336 ms on BASELINE config 1)
+#ifndef SPRINTZ_STORE_AUX
+#define SPRINTZ_STORE_AUX 2
+#endif
+    constexpr int kStoreAux = SPRINTZ_STORE_AUX;
     const uint32_t lane16 = (uint32_t)lane_d * 16u;
     uint64_t gabs = 0;                                     // container offset the cursors below are relative to
     uint32_t gvo = 0;                                      // this lane's next 16 bytes to request (offset from wave_base)
@@ -184,6 +191,8 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     auto request = [&](uint4 (&v)[CPL], bool wanted) {
 #pragma unroll
         for (int j = 0; j < CPL; j++) {
+                        // (non-temporal LOADS were tried too: the read-ahead re-reads what neighbouring groups fetched, and with nt
+            //  those re-reads go back to HBM -- 0.413 -> 0.461 ms)
             const auto t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, wanted ? gvo + j * ROW16 : 0u, 0, 0);
             v[j] = make_uint4(t[0], t[1], t[2], t[3]);
         }
@@ -285,11 +294,11 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     }
     auto store_col = [&](const uint4& t, uint32_t vo) {
         if constexpr (W == 16) {
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, t), orsrc, vo, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, t), orsrc, vo, 0, kStoreAux);
         } else {
             typedef __attribute__((__vector_size__(2 * sizeof(uint32_t)))) uint32_t v2u;
             v2u h = {t.x, t.y};
-            __builtin_amdgcn_raw_buffer_store_b64(h, orsrc, vo, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(h, orsrc, vo, 0, kStoreAux);
         }
     };
     // Column-major burst (one column per lane): a lone 16-byte store per lane per block costs
@@ -383,7 +392,7 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
                 held[slot][q] = t;
                 held_vo[slot][q] = in ? ovo + u : kDropStore;
             } else {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, t), orsrc, in ? ovo + u : kDropStore, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, t), orsrc, in ? ovo + u : kDropStore, 0, kStoreAux);
             }
         }
         wave_lds_sync();
@@ -623,7 +632,7 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
             for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
                 for (int q = 0; q < PIECES; q++)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, held[s2][q]), orsrc, held_vo[s2][q], 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, held[s2][q]), orsrc, held_vo[s2][q], 0, kStoreAux);
         }
 #pragma unroll
         for (uint32_t k = 0; k < NPEND; k++)

@@ -19,10 +19,25 @@
 
 namespace sprintz {
 
+// Geometry shared by the kernel and its launcher.  A lane refills its ring once every R blocks (a 64-byte piece per
+// refill, so R * STEPMAX <= 64); the ring holds RP pieces so that two refill periods fit behind the cursor's piece.
+// 8-bit univariate streams (BASELINE config 1) take R = 4: one round of loads per 32 samples instead of per 8.
+constexpr int decode_uni_stepmax(int W, int ND) { return (2 * ND * (W == 8 ? 3 : 4) + 7) / 8 + 2 + ND * W; }
+constexpr int decode_uni_refill_every(int W, int ND) { return 1 + 0 * (W + ND); }
+constexpr int decode_uni_ring_pieces(int W, int ND)
+{
+    const int r = decode_uni_refill_every(W, ND), sm = decode_uni_stepmax(W, ND), hb = (2 * ND * (W == 8 ? 3 : 4) + 7) / 8;
+    if (r == 1) return (2 * sm + hb + 6 <= 64) ? 2 : 4;
+    return 4;                                              // (2 r sm + 63) / 64 + 1 = 4 for r = 4, sm = 11
+}
+constexpr int decode_uni_threads(int W, int ND) { return (decode_uni_ring_pieces(W, ND) == 4 && decode_uni_refill_every(W, ND) > 1) ? 128 : 256; }
+
 // Q: query-on-compressed (decode_kernel.h): per-column max and sum ride along; reduce-only never stores samples
 template <int W, bool FIRE, int ND = 1, int Q = 0>
-__global__ void __launch_bounds__(256) decode_uni_kernel(DecodeArgs a)
+__global__ void __launch_bounds__(decode_uni_threads(W, ND)) decode_uni_kernel(DecodeArgs a)
 {
+    constexpr int TPB = decode_uni_threads(W, ND);
+    constexpr int RFE = decode_uni_refill_every(W, ND);
     constexpr int HB = Elem<W>::HB;
     constexpr int ESZ = W / 8;
     constexpr uint32_t MASK = Elem<W>::MASK;
@@ -33,7 +48,8 @@ __global__ void __launch_bounds__(256) decode_uni_kernel(DecodeArgs a)
     constexpr uint32_t STEPMAX = HBYTES + 2 + ND * W;      // most bytes one step takes: header + run length / payload
     // ring pieces of 64 bytes: a piece requested in one step is usable in the next, and a step that starts
     // up to STEPMAX - 1 bytes into a piece must not need the piece after the next resident one
-    constexpr int RP = (2 * STEPMAX + HBYTES + 6 <= 64) ? 2 : 4;   // pieces in the ring (128 or 256 bytes per lane)
+    constexpr int RP = decode_uni_ring_pieces(W, ND);      // pieces in the ring (128 or 256 bytes per lane)
+    static_assert(STEPMAX == (uint32_t)decode_uni_stepmax(W, ND) && RFE * STEPMAX <= 64, "refill period");
     constexpr uint32_t RDW = RP * 16;                      // ring dwords
     static_assert(BW * BD == 16 * WINS && BW >= 1, "whole blocks per span of windows");
     typedef uint32_t v4 __attribute__((ext_vector_type(4)));
@@ -41,9 +57,9 @@ __global__ void __launch_bounds__(256) decode_uni_kernel(DecodeArgs a)
     typedef uint32_t v2 __attribute__((ext_vector_type(2)));
     typedef v2 __attribute__((aligned(1), may_alias)) v2a1;
 
-    __shared__ uint32_t ring[RDW * 256];                   // 128 / 256 bytes per lane
+    __shared__ uint32_t ring[RDW * TPB];                   // 128 / 256 bytes per lane
     const int t = threadIdx.x;
-    const uint64_t chunk = (uint64_t)blockIdx.x * 256 + t;
+    const uint64_t chunk = (uint64_t)blockIdx.x * TPB + t;
     const bool exists = chunk < a.nchunks;
     uint32_t* const my = ring + t;
 
@@ -66,13 +82,13 @@ __global__ void __launch_bounds__(256) decode_uni_kernel(DecodeArgs a)
         return pc;
     };
     auto park = [&](uint32_t k, const Piece& pc) {
-        uint32_t* q = my + ((k & (uint32_t)(RP - 1)) << 12);
+        uint32_t* q = my + (k & (uint32_t)(RP - 1)) * (16u * TPB);
 #pragma unroll
         for (int m = 0; m < 4; m++) {
-            q[(4 * m + 0) * 256] = pc.v[m].x;
-            q[(4 * m + 1) * 256] = pc.v[m].y;
-            q[(4 * m + 2) * 256] = pc.v[m].z;
-            q[(4 * m + 3) * 256] = pc.v[m].w;
+            q[(4 * m + 0) * TPB] = pc.v[m].x;
+            q[(4 * m + 1) * TPB] = pc.v[m].y;
+            q[(4 * m + 2) * TPB] = pc.v[m].z;
+            q[(4 * m + 3) * TPB] = pc.v[m].w;
         }
     };
 #pragma unroll
@@ -90,9 +106,10 @@ __global__ void __launch_bounds__(256) decode_uni_kernel(DecodeArgs a)
             fpiece++;
         }
         have_pend = exists && fpiece - (c >> 6) < (uint32_t)RP;
-        pend = load_piece(fpiece, have_pend);
+        if (have_pend) pend = load_piece(fpiece, true);    // (issued unconditionally -- an idle lane re-reading one hot line -- this cost four
+                                                           //  wave-wide loads per block where one block in ~19 needs them: 0.426 -> see DESIGN.md)
     };
-    auto rd_dw = [&](uint32_t dw) -> uint32_t { return my[(dw & (RDW - 1u)) << 8]; };
+    auto rd_dw = [&](uint32_t dw) -> uint32_t { return my[(dw & (RDW - 1u)) * TPB]; };
     auto rd8 = [&](uint32_t at) -> uint32_t { return (rd_dw(at >> 2) >> ((at & 3u) * 8u)) & 0xffu; };
     auto rd32 = [&](uint32_t at) -> uint32_t { return __builtin_amdgcn_alignbyte(rd_dw((at >> 2) + 1u), rd_dw(at >> 2), at); };
 
@@ -132,13 +149,49 @@ __global__ void __launch_bounds__(256) decode_uni_kernel(DecodeArgs a)
         for (int b = 0; b < BW; b++) {
 #pragma unroll
             for (int d = 0; d < BD; d++) win[b][d] = 0;
-            refill();
+            if (b % RFE == 0) refill();
             // ---- this lane's next block: inside a run, or the next slot of the stream
             bool have = false;
             uint32_t nb[ND], cfield = 0, nbsum = 0;
 #pragma unroll
             for (int k = 0; k < ND; k++) nb[k] = 0;
-            if (alive) {
+            // ---- univariate streams: the common step (inside a run, or a payload block, with or without a new group
+            // header in front of it) is taken by the whole wave at once with selects instead of divergent branches --
+            // the general state machine below costs ~130 scalar instructions of exec-mask bookkeeping per block.
+            // It still takes every step in which some lane meets a run length, a padding slot or the stream's end.
+            bool fast_step = false;
+            if constexpr (ND == 1) {
+                const bool in_run = alive && run_left > 0;
+                const bool need_hdr = alive && !in_run && slot == 2;
+                uint32_t hpeek = 0;
+                if (__ballot(need_hdr) != 0) hpeek = rd8(c);
+                const uint32_t f0 = hpeek & ((1u << HB) - 1u), f1 = (hpeek >> HB) & ((1u << HB) - 1u);
+                const uint32_t n0 = need_hdr ? (f0 == (uint32_t)(W - 1) ? (uint32_t)W : f0) : nb0[0];
+                const uint32_t n1 = need_hdr ? (f1 == (uint32_t)(W - 1) ? (uint32_t)W : f1) : nb1[0];
+                const uint32_t s_eff = need_hdr ? 0u : (uint32_t)slot;
+                const uint32_t nbn = s_eff ? n1 : n0;                       // width of the slot this step would take
+                const bool simple = !alive || in_run || (s_eff < 2u && nbn != 0u && (!need_hdr || groups_left > 0u));
+                if (__ballot(!simple) == 0) {
+                    fast_step = true;
+                    const bool take = alive && !in_run;
+                    groups_left -= need_hdr ? 1u : 0u;
+                    c += need_hdr ? (uint32_t)HBYTES : 0u;
+                    nb0[0] = n0;
+                    nb1[0] = n1;
+                    run_left -= in_run ? 1u : 0u;
+                    nb[0] = take ? nbn : 0u;
+                    nbsum = nb[0];
+                    cfield = c;
+                    c += nb[0];
+                    slot = take ? (int)s_eff + 1 : slot;
+                    have = alive;
+                    const bool over = alive && ((uint64_t)(c - c_begin) > stream_len + 2 || out_elems + 8 > a.chunk_len);
+                    corrupt = corrupt || over;
+                    alive = alive && !over;
+                    have = have && !over;
+                }
+            }
+            if (alive && !fast_step) {
                 if (run_left > 0) {
                     run_left--;
                     have = true;
@@ -190,10 +243,25 @@ __global__ void __launch_bounds__(256) decode_uni_kernel(DecodeArgs a)
                     const int coef = FIRE ? fire_coef<W, true>(ctr[k]) : 0;
                     const uint32_t nbk = nbsum ? nb[k] : 0u;                 // inside a run every field is empty
                     int grad = 0;
+                    // W == 8: a column's 8 fields are nbk <= 8 contiguous bytes -- ONE 64-bit window per column (three aligned
+                    // ring dwords, two v_alignbyte), its fields taken four at a time (4 nbk <= 32 bits: v_alignbit + v_bfe each)
+                    uint32_t plo = 0, phi = 0;
+                    if constexpr (W == 8) {
+                        const uint32_t d0 = rd_dw(cf >> 2), d1 = rd_dw((cf >> 2) + 1u), d2 = rd_dw((cf >> 2) + 2u);
+                        plo = __builtin_amdgcn_alignbyte(d1, d0, cf);
+                        phi = __builtin_amdgcn_alignbyte(d2, d1, cf);
+                    }
 #pragma unroll
                     for (int i = 0; i < 8; i++) {
                         uint32_t z = 0;
-                        if (nbk != 0) {
+                        if constexpr (W == 8) {
+                            if (i == 4) {                         // the upper four fields start at bit 4 nbk
+                                const uint64_t both = (((uint64_t)phi << 32) | plo) >> ((4u * nbk) & 63u);
+                                plo = nbk == 8u ? phi : (uint32_t)both;
+                                phi = (uint32_t)(both >> 32);
+                            }
+                            z = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(phi, plo, (uint32_t)(i & 3) * nbk), 0, nbk);
+                        } else if (nbk != 0) {
                             const uint32_t bit = (cf & 3u) * 8u + (uint32_t)i * nbk;
                             const uint32_t dw = (cf >> 2) + (bit >> 5);
                             z = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(rd_dw(dw + 1u), rd_dw(dw), bit & 31u), 0, nbk);
@@ -211,8 +279,15 @@ __global__ void __launch_bounds__(256) decode_uni_kernel(DecodeArgs a)
                     cf += nbk;
                 }
                 // row-major block: element e = row * ND + column at byte e * ESZ
+                if constexpr (W == 8 && ND == 1) {             // four low bytes -> one dword: three v_perm_b32, no masks
+                    const uint32_t p01 = __builtin_amdgcn_perm(x[0][1], x[0][0], 0x0c0c0400u), p23 = __builtin_amdgcn_perm(x[0][3], x[0][2], 0x0c0c0400u);
+                    const uint32_t p45 = __builtin_amdgcn_perm(x[0][5], x[0][4], 0x0c0c0400u), p67 = __builtin_amdgcn_perm(x[0][7], x[0][6], 0x0c0c0400u);
+                    win[b][0] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+                    win[b][1] = __builtin_amdgcn_perm(p67, p45, 0x05040100u);
+                } else {
 #pragma unroll
                 for (int e = 0; e < 8 * ND; e++) win[b][(e * ESZ) / 4] |= x[e % ND][e / ND] << (((e * ESZ) % 4) * 8);
+                }
                 valid |= 1u << b;
                 out_elems += 8 * ND;
             }
@@ -257,7 +332,7 @@ __global__ void __launch_bounds__(256) decode_uni_kernel(DecodeArgs a)
             const uint64_t dst = ((uint64_t)dhi << 32) | dlo;
             if (dst) {
                 v4 piece = {v[q][0], v[q][1], v[q][2], v[q][3]};
-                *(v4a1*)(uintptr_t)(dst + 16u * part) = piece;
+                __builtin_nontemporal_store(piece, (v4a1*)(uintptr_t)(dst + 16u * part));   // written once, never re-read here: 0.402 -> 0.336 ms on config 1
             }
         }
         }

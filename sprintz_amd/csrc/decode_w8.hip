@@ -11,8 +11,10 @@ hipError_t launch_decode_fast_w8(bool fire, int dp, int cpl, bool exact, int q, 
 }
 #define SPRINTZ_UNI_CASE(NDV, QV)                                                                          \
     if (nd == NDV && q == QV) {                                                                             \
-        if (fire) hipLaunchKernelGGL((decode_uni_kernel<8, true, NDV, QV>), dim3(grid), dim3(256), 0, st, a);   \
-        else hipLaunchKernelGGL((decode_uni_kernel<8, false, NDV, QV>), dim3(grid), dim3(256), 0, st, a);       \
+        constexpr int tpb = decode_uni_threads(8, NDV);                                                   \
+        const unsigned g = (unsigned)((a.nchunks + tpb - 1) / tpb);                                          \
+        if (fire) hipLaunchKernelGGL((decode_uni_kernel<8, true, NDV, QV>), dim3(g), dim3(tpb), 0, st, a);   \
+        else hipLaunchKernelGGL((decode_uni_kernel<8, false, NDV, QV>), dim3(g), dim3(tpb), 0, st, a);       \
         return hipGetLastError();                                                                           \
     }
 hipError_t launch_decode_uni_w8(bool fire, int nd, int q, unsigned grid, hipStream_t st, const DecodeArgs& a)

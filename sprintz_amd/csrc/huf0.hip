@@ -739,7 +739,7 @@ __global__ void __launch_bounds__(64) huf0_stream_kernel(const uint8_t* __restri
             const uint64_t da = ((uint64_t)dhi << 32) | dlo;
             if (da) {
                 v4u piece = {v[qq][0], v[qq][1], v[qq][2], v[qq][3]};
-                *(v4u_a1*)(uintptr_t)(da + 16u * part) = piece;
+                __builtin_nontemporal_store(piece, (v4u_a1*)(uintptr_t)(da + 16u * part));   // streamed out once
             }
         }
         if (!full && cnt) {

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--cfg", default="headline")
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--no-verify", action="store_true", help="ablated builds that decode garbage on purpose")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     res = {}
@@ -37,6 +38,8 @@ def main():
                 cmd = [sys.executable, "bench.py", "--configs", "none", "--no-extras", "--no-cpu-baseline", "--steps", str(a.reps)]
             else:
                 cmd = [sys.executable, "bench.py", "--only", a.cfg, "--no-cpu-baseline", "--config-reps", str(a.reps)]
+            if a.no_verify:
+                cmd.append("--no-verify")
             p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
             try:
                 d = json.loads(p.stdout.strip().splitlines()[-1])
