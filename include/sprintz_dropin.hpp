@@ -14,6 +14,7 @@
 #ifndef SPRINTZ_DROPIN_HPP
 #define SPRINTZ_DROPIN_HPP
 
+#include <stddef.h>
 #include <stdint.h>
 
 #include "sprintz_mi355x.h"
@@ -100,5 +101,17 @@ SPRINTZ_DROPIN_TRANSFORM(doubledelta, 16)
 SPRINTZ_DROPIN_TRANSFORM(xff, 8)
 SPRINTZ_DROPIN_TRANSFORM(xff, 16)
 #undef SPRINTZ_DROPIN_TRANSFORM
+
+// ================================================================ online.hpp:395-445 (1-D uint16 streams)
+typedef uint32_t len_t;                                    // online.hpp:15
+len_t dynamic_delta_pack_u16(const uint16_t* data_in, size_t length, int16_t* data_out);
+len_t dynamic_delta_pack_u16_altloss(const uint16_t* data_in, size_t length, int16_t* data_out);
+len_t dynamic_delta_unpack_u16(const int16_t* data_in, uint16_t* data_out);
+len_t zigzag_pack_u16(const uint16_t* data_in, size_t length, int16_t* data_out);
+len_t zigzag_unpack_u16(const int16_t* data_in, uint16_t* data_out);
+len_t sprintzpack_pack_u16(const uint16_t* data_in, size_t length, int16_t* data_out);
+len_t sprintzpack_pack_u16_zigzag(const uint16_t* data_in, size_t length, int16_t* data_out);
+len_t sprintzpack_unpack_u16(const int16_t* data_in, uint16_t* data_out);
+len_t sprintzpack_unpack_u16_zigzag(const int16_t* data_in, uint16_t* data_out);
 
 #endif  // SPRINTZ_DROPIN_HPP

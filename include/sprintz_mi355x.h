@@ -359,6 +359,29 @@ int64_t sprintz_mi355x_transform_decode(int kind, int elem_bytes, const void* sr
 const char* sprintz_mi355x_transform_last_error(void);
 
 /* ------------------------------------------------------------------------
+ * The reference's 2020 "online" coders for 1-D uint16 streams.  Replace
+ *   dynamic_delta_pack_u16 / dynamic_delta_pack_u16_altloss / dynamic_delta_unpack_u16   cpp/Compress/online.hpp:412-424
+ *   zigzag_pack_u16 / zigzag_unpack_u16                                                  cpp/Compress/online.hpp:431-438
+ *   sprintzpack_pack_u16 / _zigzag / sprintzpack_unpack_u16 / _zigzag                    cpp/Compress/online.hpp:450-462
+ * One call codes ONE stream; the containers ({u32 len} + payload, restated in oracle/online_oracle.c) are byte-exact
+ * with the reference on every byte it writes (it leaves header padding unwritten; here those bytes are 0).
+ * Return values are ELEMENTS like the reference's.  Device forms: d_src / d_dest 16-byte aligned,
+ * d_dest of sprintz_mi355x_online_bound() bytes, d_tmp of sprintz_mi355x_online_tmp_bytes(); *d_ret (device) receives the
+ * return value -- for unpack, SPRINTZ_E_CORRUPT if the container's length field differs from `len`.
+ * ---------------------------------------------------------------------- */
+#define SPRINTZ_ONLINE_DYNDELTA 0        /* dynamic delta / double delta, loss SumLogAbs */
+#define SPRINTZ_ONLINE_DYNDELTA_ALT 1    /* ... loss MaxAbs (encoder only differs) */
+#define SPRINTZ_ONLINE_ZIGZAG 2
+#define SPRINTZ_ONLINE_PACK 3            /* sprintzpack: per-block width + bit-packing, no zigzag */
+#define SPRINTZ_ONLINE_PACK_ZIGZAG 4
+size_t sprintz_mi355x_online_bound(int kind, uint32_t len);
+size_t sprintz_mi355x_online_tmp_bytes(int kind, uint32_t len);
+int sprintz_mi355x_online_pack_device(int kind, const uint16_t* d_src, uint32_t len, void* d_dest, int64_t* d_ret, void* d_tmp, void* hip_stream);
+int sprintz_mi355x_online_unpack_device(int kind, const void* d_src, uint32_t len, uint16_t* d_dest, int64_t* d_ret, void* d_tmp, void* hip_stream);
+int64_t sprintz_mi355x_online_pack(int kind, const uint16_t* src, uint32_t len, int16_t* dest);     /* host buffers */
+int64_t sprintz_mi355x_online_unpack(int kind, const int16_t* src, uint16_t* dest);                 /* host buffers; len from the header */
+
+/* ------------------------------------------------------------------------
  * Multi-GPU: one process per GPU, rank r owns a contiguous chunk range, the data
  * path has NO collective.  The only exchange is one all-gather of 8 bytes per rank -- each rank's
  * compressed byte count -- from which every rank derives where its container starts in the

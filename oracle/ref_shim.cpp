@@ -16,6 +16,7 @@
 #include "sprintz_xff.h"     /* compress_rowmajor_xff_rle_*: :45-55; query_rowmajor_xff_rle_*: :90-93 */
 #include "delta.h"           /* encode/decode_{delta,doubledelta}_rowmajor_{8b,16b}: :17-68 */
 #include "predict.h"         /* encode/decode_xff_rowmajor_{8b,16b}: :15-30 */
+#include "online.hpp"        /* dynamic_delta_pack_u16 / zigzag_pack_u16 / sprintzpack_pack_u16 ...: :395-445 */
 
 extern "C" {
 
@@ -162,4 +163,27 @@ int64_t ref_decompress_norle(int raw, int elem_bytes, const void* src, void* des
                : decompress_rowmajor_delta_16b((const int16_t*)src, (uint16_t*)dest);
 }
 
-}  // extern "C"
+
+/* online.hpp's u16 coders; kind: 0 dynamic delta, 1 dynamic delta (alt loss), 2 zigzag, 3 sprintzpack, 4 sprintzpack + zigzag */
+int64_t ref_online_pack(int kind, const uint16_t* src, uint32_t len, int16_t* dest)
+{
+    switch (kind) {
+    case 0: return dynamic_delta_pack_u16(src, len, dest);
+    case 1: return dynamic_delta_pack_u16_altloss(src, len, dest);
+    case 2: return zigzag_pack_u16(src, len, dest);
+    case 3: return sprintzpack_pack_u16(src, len, dest);
+    case 4: return sprintzpack_pack_u16_zigzag(src, len, dest);
+    }
+    return -1;
+}
+int64_t ref_online_unpack(int kind, const int16_t* src, uint16_t* dest)
+{
+    switch (kind) {
+    case 0: case 1: return dynamic_delta_unpack_u16(src, dest);
+    case 2: return zigzag_unpack_u16(src, dest);
+    case 3: return sprintzpack_unpack_u16(src, dest);
+    case 4: return sprintzpack_unpack_u16_zigzag(src, dest);
+    }
+    return -1;
+}
+}

@@ -123,6 +123,15 @@ _transform_last_error = _sig("sprintz_mi355x_transform_last_error", C.c_char_p)
 compress_norle = _sig("sprintz_mi355x_compress_norle", _i64, _i, _i, _vp, _u32, _vp, _u16)
 decompress_norle = _sig("sprintz_mi355x_decompress_norle", _i64, _i, _i, _vp, _vp)
 
+# (8) the reference's 2020 "online" u16 coders (online.hpp:395-445)
+ONLINE_DYNDELTA, ONLINE_DYNDELTA_ALT, ONLINE_ZIGZAG, ONLINE_PACK, ONLINE_PACK_ZIGZAG = 0, 1, 2, 3, 4
+online_bound = _sig("sprintz_mi355x_online_bound", _sz, _i, _u32)
+online_tmp_bytes = _sig("sprintz_mi355x_online_tmp_bytes", _sz, _i, _u32)
+online_pack_device = _sig("sprintz_mi355x_online_pack_device", _i, _i, _vp, _u32, _vp, _vp, _vp, _vp)
+online_unpack_device = _sig("sprintz_mi355x_online_unpack_device", _i, _i, _vp, _u32, _vp, _vp, _vp, _vp)
+online_pack = _sig("sprintz_mi355x_online_pack", _i64, _i, _vp, _u32, _vp)
+online_unpack = _sig("sprintz_mi355x_online_unpack", _i64, _i, _vp, _vp)
+
 # multi-GPU: the all-gather of per-rank byte counts over RCCL
 COMM_ID_BYTES = 128
 comm_unique_id = _sig("sprintz_mi355x_comm_unique_id", _i, _vp)
@@ -146,6 +155,8 @@ EXPORTED_SYMBOLS = [
     "sprintz_mi355x_compress_batch", "sprintz_mi355x_compact_tmp_bytes", "sprintz_mi355x_compact",
     "sprintz_mi355x_decompress_batch",
     "sprintz_mi355x_compress_chunked_host", "sprintz_mi355x_decompress_chunked_host",
+    "sprintz_mi355x_online_bound", "sprintz_mi355x_online_tmp_bytes", "sprintz_mi355x_online_pack_device",
+    "sprintz_mi355x_online_unpack_device", "sprintz_mi355x_online_pack", "sprintz_mi355x_online_unpack",
     "sprintz_mi355x_comm_unique_id", "sprintz_mi355x_comm_init", "sprintz_mi355x_gather_layout",
     "sprintz_mi355x_layout_bases", "sprintz_mi355x_comm_destroy",
     "sprintz_mi355x_huf_tmp_bytes", "sprintz_mi355x_huf_bound",

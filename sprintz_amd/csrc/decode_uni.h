@@ -246,31 +246,43 @@ __global__ void __launch_bounds__(decode_uni_threads(W, ND)) decode_uni_kernel(D
                     // W == 8: a column's 8 fields are nbk <= 8 contiguous bytes -- ONE 64-bit window per column (three aligned
                     // ring dwords, two v_alignbyte), its fields taken four at a time (4 nbk <= 32 bits: v_alignbit + v_bfe each)
                     uint32_t plo = 0, phi = 0;
+                    uint32_t w1 = 0, wm = 0, s1 = 0, s2 = 0, s3 = 0;
                     if constexpr (W == 8) {
                         const uint32_t d0 = rd_dw(cf >> 2), d1 = rd_dw((cf >> 2) + 1u), d2 = rd_dw((cf >> 2) + 2u);
                         plo = __builtin_amdgcn_alignbyte(d1, d0, cf);
                         phi = __builtin_amdgcn_alignbyte(d2, d1, cf);
+                        // zigzag^-1 fused with the field fetch, as in decode_fast.h: err = bfe_u(w, s + 1, nb - 1) ^ bfe_i(w, s, 1)
+                        w1 = nbk != 0u ? 1u : 0u;                 // width of the sign field
+                        wm = nbk - w1;                            // width of the magnitude field
+                        s1 = nbk; s2 = 2u * nbk; s3 = 3u * nbk;   // four fields are 4 nbk <= 32 bits: all inside one dword
                     }
 #pragma unroll
                     for (int i = 0; i < 8; i++) {
-                        uint32_t z = 0;
+                        int err;
                         if constexpr (W == 8) {
                             if (i == 4) {                         // the upper four fields start at bit 4 nbk
                                 const uint64_t both = (((uint64_t)phi << 32) | plo) >> ((4u * nbk) & 63u);
-                                plo = nbk == 8u ? phi : (uint32_t)both;
-                                phi = (uint32_t)(both >> 32);
+                                plo = (uint32_t)both;
                             }
-                            z = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(phi, plo, (uint32_t)(i & 3) * nbk), 0, nbk);
-                        } else if (nbk != 0) {
-                            const uint32_t bit = (cf & 3u) * 8u + (uint32_t)i * nbk;
-                            const uint32_t dw = (cf >> 2) + (bit >> 5);
-                            z = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(rd_dw(dw + 1u), rd_dw(dw), bit & 31u), 0, nbk);
+                            const uint32_t sh = (i & 3) == 0 ? 0u : (i & 3) == 1 ? s1 : (i & 3) == 2 ? s2 : s3;
+                            err = (int)(__builtin_amdgcn_ubfe(plo, sh + 1u, wm) ^ (uint32_t)__builtin_amdgcn_sbfe((int)plo, sh, w1));
+                        } else {
+                            uint32_t z = 0;
+                            if (nbk != 0) {
+                                const uint32_t bit = (cf & 3u) * 8u + (uint32_t)i * nbk;
+                                const uint32_t dw = (cf >> 2) + (bit >> 5);
+                                z = __builtin_amdgcn_ubfe(__builtin_amdgcn_alignbit(rd_dw(dw + 1u), rd_dw(dw), bit & 31u), 0, nbk);
+                            }
+                            err = unzigzag(z);
                         }
-                        const int err = unzigzag(z);
                         const int pred = FIRE ? fire_predict<W, true>(pd[k], coef) : 0;
                         const int delta = sext<W>(err + pred);
                         if (FIRE && (i & 1)) grad += sign_times(err, pd[k]);
-                        pv[k] = (pv[k] + (uint32_t)delta) & MASK;
+                        if constexpr (W == 8 && ND == 1 && !FIRE && Q == 0) {
+                            pv[k] += (uint32_t)err;               // only the low byte is ever used (v_perm packing below): no mask, no sign extension
+                        } else {
+                            pv[k] = (pv[k] + (uint32_t)delta) & MASK;
+                        }
                         pd[k] = delta;
                         x[k][i] = pv[k];
                         if constexpr (Q != 0) { qmax[k] = pv[k] > qmax[k] ? pv[k] : qmax[k]; qsum[k] += pv[k]; }

@@ -96,3 +96,15 @@ DROPIN_TRANSFORM(doubledelta, SPRINTZ_TRANSFORM_DOUBLEDELTA, 16)
 DROPIN_TRANSFORM(xff, SPRINTZ_TRANSFORM_XFF, 8)
 DROPIN_TRANSFORM(xff, SPRINTZ_TRANSFORM_XFF, 16)
 #undef DROPIN_TRANSFORM
+
+// ---------------------------------------------------------------- online.hpp:395-445
+// (len_t returns: a failure reads as 0 elements)
+VIS len_t dynamic_delta_pack_u16(const uint16_t* s, size_t n, int16_t* d) { return n >> 32 ? 0u : count_or_zero(sprintz_mi355x_online_pack(SPRINTZ_ONLINE_DYNDELTA, s, (uint32_t)n, d)); }
+VIS len_t dynamic_delta_pack_u16_altloss(const uint16_t* s, size_t n, int16_t* d) { return n >> 32 ? 0u : count_or_zero(sprintz_mi355x_online_pack(SPRINTZ_ONLINE_DYNDELTA_ALT, s, (uint32_t)n, d)); }
+VIS len_t dynamic_delta_unpack_u16(const int16_t* s, uint16_t* d) { return count_or_zero(sprintz_mi355x_online_unpack(SPRINTZ_ONLINE_DYNDELTA, s, d)); }
+VIS len_t zigzag_pack_u16(const uint16_t* s, size_t n, int16_t* d) { return n >> 32 ? 0u : count_or_zero(sprintz_mi355x_online_pack(SPRINTZ_ONLINE_ZIGZAG, s, (uint32_t)n, d)); }
+VIS len_t zigzag_unpack_u16(const int16_t* s, uint16_t* d) { return count_or_zero(sprintz_mi355x_online_unpack(SPRINTZ_ONLINE_ZIGZAG, s, d)); }
+VIS len_t sprintzpack_pack_u16(const uint16_t* s, size_t n, int16_t* d) { return n >> 32 ? 0u : count_or_zero(sprintz_mi355x_online_pack(SPRINTZ_ONLINE_PACK, s, (uint32_t)n, d)); }
+VIS len_t sprintzpack_pack_u16_zigzag(const uint16_t* s, size_t n, int16_t* d) { return n >> 32 ? 0u : count_or_zero(sprintz_mi355x_online_pack(SPRINTZ_ONLINE_PACK_ZIGZAG, s, (uint32_t)n, d)); }
+VIS len_t sprintzpack_unpack_u16(const int16_t* s, uint16_t* d) { return count_or_zero(sprintz_mi355x_online_unpack(SPRINTZ_ONLINE_PACK, s, d)); }
+VIS len_t sprintzpack_unpack_u16_zigzag(const int16_t* s, uint16_t* d) { return count_or_zero(sprintz_mi355x_online_unpack(SPRINTZ_ONLINE_PACK_ZIGZAG, s, d)); }

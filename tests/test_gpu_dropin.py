@@ -49,6 +49,13 @@ int64_t query_rowmajor_xff_rle_16b(const int16_t* src, uint16_t* dest, const Que
 uint32_t encode_delta_rowmajor_16b(const uint16_t* src, uint32_t len, int16_t* dest, uint16_t ndims, bool write_size=true);
 uint32_t decode_delta_rowmajor_16b(const int16_t* src, uint16_t* dest);
 
+// ---- cpp/Compress/online.hpp:15,412-462
+typedef uint32_t len_t;
+len_t dynamic_delta_pack_u16(const uint16_t* data_in, size_t length, int16_t* data_out);
+len_t dynamic_delta_unpack_u16(const int16_t* data_in, uint16_t* data_out);
+len_t sprintzpack_pack_u16_zigzag(const uint16_t* data_in, size_t length, int16_t* data_out);
+len_t sprintzpack_unpack_u16_zigzag(const int16_t* data_in, uint16_t* data_out);
+
 struct Job { uint8_t kind, esz; uint16_t ndims; uint32_t len; };   // kind: 0 delta, 1 xff (sprintz.h); 2.. see below
 
 int main(int argc, char** argv)
@@ -80,6 +87,8 @@ int main(int argc, char** argv)
             dret = query_rowmajor_xff_rle_16b(c16, o16, qp); break; }
         case 6: cret = encode_delta_rowmajor_16b(s16, j.len, c16, j.ndims); dret = decode_delta_rowmajor_16b(c16, o16); break;
         case 7: cret = sprintz_compress_xff_16b(s16, j.len, c16, j.ndims, false); dret = 0; break;   // headerless
+        case 8: cret = dynamic_delta_pack_u16(s16, j.len, c16); dret = dynamic_delta_unpack_u16(c16, o16); break;
+        case 9: cret = sprintzpack_pack_u16_zigzag(s16, j.len, c16); dret = sprintzpack_unpack_u16_zigzag(c16, o16); break;
         default: return 5;
         }
         // stream bytes: the return value is in elements (floor'ed), so report the exact byte count by
@@ -197,6 +206,8 @@ def test_layer_below_sprintz_h(caller, oracle):
     jobs.append((4, 1, 5, gen_fuzz(rng, 1000, 1, 2)))                          # invalid for the low-dim codec: -1
     jobs.append((6, 2, 4, gen_fuzz(rng, 4 * 300, 2, 2)))
     jobs.append((7, 2, 8, gen_fuzz(rng, 8 * 64, 2, 3)))
+    jobs.append((8, 2, 1, gen_fuzz(rng, 5003, 2, 7)))                          # online.hpp names
+    jobs.append((9, 2, 1, gen_fuzz(rng, 4099, 2, 9)))
     res = run_jobs(caller, jobs)
     for (kind, esz, nd, data), (cret, dret, stream, dec) in zip(jobs, res):
         if kind == 4 and nd == 5:
@@ -212,4 +223,15 @@ def test_layer_below_sprintz_h(caller, oracle):
             want, wret = oracle.compress("xff", data, nd, write_size=False)
             assert cret == wret and np.array_equal(stream, trimmed(want))
             continue
+        if kind in (8, 9):
+            from test_online_cpu import oracle_pack
+            import ctypes as C
+            from harness import ORACLE_SO
+            lib = C.CDLL(ORACLE_SO)
+            lib.online_oracle_pack.restype = C.c_int64
+            lib.online_oracle_pack.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_size_t)]
+            lib.online_oracle_bound.restype = C.c_size_t
+            lib.online_oracle_bound.argtypes = [C.c_int, C.c_uint32]
+            want, wret, _ = oracle_pack(lib, 0 if kind == 8 else 4, data)
+            assert cret == wret and np.array_equal(stream, trimmed(want)), kind
         assert dret == data.size and np.array_equal(dec, data), (kind, nd)
