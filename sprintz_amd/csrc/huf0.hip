@@ -561,12 +561,12 @@ __global__ void __launch_bounds__(64) huf0_stream_kernel(const uint8_t* __restri
         for (uint32_t k = 0; k < 64; k++) {
             const uint32_t b = 64u * (uint32_t)j + k;
             const uint32_t idx0 = tl >= 8u ? b << (tl - 8u) : b >> (8u - tl);
-            uint32_t entry = 0;
-            if (idx0 >= start_short) {
-                while (w < 12u && idx0 >= nxt) { w++; e = tab[w]; nxt = w < 12u ? (tab[w + 1] & 0xffffu) : 0xffffffffu; }
-                const uint32_t sym = sorted[(e >> 16) + ((idx0 - (e & 0xffffu)) >> (w - 1u))];
-                entry = sym | ((tl + 1u - w) << 8);
-            }
+            while (w < 12u && idx0 >= nxt) { w++; e = tab[w]; nxt = w < 12u ? (tab[w + 1] & 0xffffu) : 0xffffffffu; }
+            const uint32_t pos = (e >> 16) + ((idx0 - (e & 0xffffu)) >> (w - 1u));
+            uint32_t entry;
+            if (idx0 >= start_short) entry = sorted[pos & 0xffu] | ((tl + 1u - w) << 8);                    // the code is <= 8 bits: symbol | length << 8
+            else if (idx0 + (1u << (tl - 8u)) <= nxt) entry = 0x8000u | ((w - 1u) << 8) | (pos & 0xffu);   // longer codes, all of weight w: where they start in `sorted`
+            else entry = 0xffffu;                                                                         // codes of several weights share these 8 bits: the general search
             table8[b] = (uint16_t)entry;
         }
     }
@@ -615,6 +615,7 @@ __global__ void __launch_bounds__(64) huf0_stream_kernel(const uint8_t* __restri
     }
     const bool streaming = left > 0 || (coded && !bad);           // has a stream whose end must be checked
     const uint32_t look_shift = 32u - (tl ? tl : 1u);
+    const uint32_t bmask = tl > 8u ? (1u << (tl - 8u)) - 1u : 0u;     // the index bits below the 8-bit prefix
     const uint32_t t8 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)table8;
     const uint32_t so8 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)sorted;
     // The stream is read from its last byte down.  It reaches the lane as 16-byte aligned PIECES parked in a per-lane
@@ -666,20 +667,29 @@ __global__ void __launch_bounds__(64) huf0_stream_kernel(const uint8_t* __restri
         const uint32_t d2 = *(lds_u32c*)(uintptr_t)(ring + ((o + 8u) & 28u));
         const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, o & 3u), hi0 = __builtin_amdgcn_alignbyte(d2, d1, o & 3u);
         uint64_t win = (((uint64_t)hi0 << 32) | lo) << (7 - (int)((uint32_t)(Pc - 1) & 7u));
-        const uint64_t keep = Pc >= 64 ? ~0ull : (Pc > 0 ? ~0ull << (64 - Pc) : 0ull);   // nothing before the stream's first bit
-        win &= keep;
+        if (__ballot(Pc < 64) != 0) {                             // only the last steps of a stream: nothing before its first bit
+            const uint64_t keep = Pc >= 64 ? ~0ull : (Pc > 0 ? ~0ull << (64 - Pc) : 0ull);
+            win &= keep;
+        }
         uint32_t word = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint32_t hi = (uint32_t)(win >> 32);
             const uint32_t e8 = *(lds_u16*)(uintptr_t)(t8 + ((hi >> 24) << 1));
             const uint32_t idx = hi >> look_shift;
-            const bool g2 = idx >= T2, g3 = idx >= T3, g4 = idx >= T4;
-            const uint32_t el = g4 ? E4 : (g3 ? E3 : (g2 ? E2 : 0u));       // start[w] | symoff[w] << 16 of the long code's weight
-            const uint32_t wm1 = (uint32_t)g2 + (uint32_t)g3 + (uint32_t)g4;   // w - 1
-            const uint32_t pos = ((el >> 16) + ((idx - (el & 0xffffu)) >> wm1)) & 0xffu;
-            const uint32_t syl = *(lds_u8c*)(uintptr_t)(so8 + pos);
-            const bool is_short = e8 != 0;
+            // a longer code whose 8-bit prefix holds one weight only: its symbol sits at base + (low index bits >> (w - 1))
+            uint32_t wm1 = (e8 >> 8) & 3u;
+            uint32_t pos = (e8 & 0xffu) + ((idx & bmask) >> wm1);
+            if (__ballot(e8 == 0xffffu) != 0) {                   // rare: prefixes shared by several weights -- weight = 1 + #{k in 2..4 : start[k] <= idx}
+                const bool g2 = idx >= T2, g3 = idx >= T3, g4 = idx >= T4;
+                const uint32_t el = g4 ? E4 : (g3 ? E3 : (g2 ? E2 : 0u));
+                const uint32_t wg = (uint32_t)g2 + (uint32_t)g3 + (uint32_t)g4;
+                const bool mixed = e8 == 0xffffu;
+                pos = mixed ? (el >> 16) + ((idx - (el & 0xffffu)) >> wg) : pos;
+                wm1 = mixed ? wg : wm1;
+            }
+            const uint32_t syl = *(lds_u8c*)(uintptr_t)(so8 + (pos & 0xffu));
+            const bool is_short = (e8 & 0x8000u) == 0;
             const bool on = (uint32_t)k < m;
             const uint32_t sym = is_short ? (e8 & 0xffu) : syl;
             const uint32_t nb = on ? (is_short ? (e8 >> 8) : (tl - wm1)) : 0u;
