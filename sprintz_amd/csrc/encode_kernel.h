@@ -82,6 +82,9 @@ __global__ void __launch_bounds__(kThreads) encode_kernel(EncodeArgs a)
             done = nbytes & ~7u;
         }
         for (uint32_t j = done + (uint32_t)lane_d; j < nbytes; j += (uint32_t)DP) dst[j] = src[j];
+        // slots are zero padded to 16 bytes (sprintz_mi355x_compact copies whole 16-byte units: the container's
+        // alignment padding must not carry stale workspace bytes)
+        for (uint32_t j = hdr + nbytes + (uint32_t)lane_d; j < ((hdr + nbytes + 15u) & ~15u); j += (uint32_t)DP) gdst[j] = 0;
         if (lane_d == 0) {
             if (a.write_size) {
                 ((uint32_t*)gdst)[0] = 0;

@@ -302,6 +302,61 @@ def test_corrupt_streams_do_not_hang_or_overrun(sz, oracle, codec, esz, ndims, c
         assert (out[nchunks * chunk_len:].cpu().numpy() == 0x5A).all(), trial
 
 
+@pytest.mark.parametrize("codec,esz,ndims,chunk_len,nchunks", [("xff", 2, 8, 5120, 64), ("delta", 1, 80, 10240, 32), ("xff", 1, 1, 1024, 128),
+                                                               ("delta", 2, 300, 9600, 16), ("xff", 2, 8, 5001, 32), ("bitpack", 1, 5, 4000, 32)])
+def test_generic_decoder_never_reads_past_a_stream(sz, request, codec, esz, ndims, chunk_len, nchunks):
+    """decode_kernel.h (D > 256, odd chunk sizes, the bit-packing codec, and every shape under SPRINTZ_OPT_NO_FAST) checks its
+    input cursor against the stream's end: truncated streams are SPRINTZ_E_CORRUPT, bit-flipped ones terminate inside
+    their own ranges, and the slot padding of short verbatim chunks is zero"""
+    import torch
+    from sprintz_amd import _lib
+    _lib.check(_lib.set_option(_lib.OPT_NO_FAST, 1))
+    request.addfinalizer(lambda: _lib.set_option(_lib.OPT_NO_FAST, 0))
+    rng = np.random.default_rng(91)
+    data = gen_walk(rng, nchunks * chunk_len, ndims, esz, 6, flat_every=5)
+    cd = sz.ChunkedCodec(codec, esz, ndims, chunk_len, device="cuda:0")
+    batch = cd.compress(torch.from_numpy(data).cuda())
+    comp0, offs, sizes = batch.data.cpu().numpy().copy(), batch.offsets.cpu().numpy(), batch.sizes.cpu().numpy()
+    assert np.array_equal(cd.decompress(batch).cpu().numpy(), data)
+    # every stream cut short by 1 .. 9 bytes and packed densely again: each must be reported, none decoded past its end
+    cut = [comp0[offs[c]:offs[c] + sizes[c] - 1 - (c % 9)] for c in range(nchunks)]
+    toffs = np.zeros(nchunks + 1, np.int64)
+    toffs[1:] = np.cumsum([s.size for s in cut])
+    tcomp = np.concatenate(cut + [np.zeros(16, np.uint8)])
+    guard = 4096
+    out = torch.full((nchunks * chunk_len + guard,), 0x5A, dtype=torch.int16 if esz == 2 else torch.int8, device="cuda:0")
+    rets = torch.zeros(nchunks, dtype=torch.int64, device="cuda:0")
+    cd.decompress_into(torch.from_numpy(tcomp).cuda(), torch.from_numpy(toffs).cuda(), nchunks, out, rets)
+    torch.cuda.synchronize()
+    assert (rets.cpu().numpy() == _lib.E_CORRUPT).all(), rets.cpu().numpy()[:8]
+    assert (out[nchunks * chunk_len:].cpu().numpy() == 0x5A).all()
+    for trial in range(3):                               # random bit flips: terminate, stay inside the slots
+        comp = comp0.copy()
+        idx = rng.integers(0, comp.size, comp.size // 40)
+        comp[idx] ^= rng.integers(1, 256, idx.size).astype(np.uint8)
+        cd.decompress_into(torch.from_numpy(comp).cuda(), batch.offsets, nchunks, out, rets)
+        torch.cuda.synchronize()
+        r = rets.cpu().numpy()
+        assert ((r == _lib.E_CORRUPT) | ((r >= 0) & (r <= chunk_len))).all(), (trial, r[:8])
+        assert (out[nchunks * chunk_len:].cpu().numpy() == 0x5A).all(), trial
+
+
+def test_short_verbatim_chunks_leave_zero_padding(sz):
+    """chunks too short for one group are stored verbatim (sprintz_xff_rle.cpp:116-124): the 16-byte alignment padding of the
+    container must be zeros, not stale workspace bytes"""
+    import torch
+    rng = np.random.default_rng(5)
+    nchunks, chunk_len, ndims = 200, 1021, 80                     # 1021 < 16 * 80: verbatim; 8 + 1021 = 1029 bytes -> 11 bytes of padding
+    data = gen_fuzz(rng, nchunks * chunk_len, 1, 0)
+    cd = sz.ChunkedCodec("delta", 1, ndims, chunk_len, device="cuda:0")
+    cd.workspace(nchunks)["slots"].fill_(0xEE)                    # stale bytes in the slot buffer
+    batch = cd.compress(torch.from_numpy(data).cuda())
+    comp, offs, sizes = batch.data.cpu().numpy(), batch.offsets.cpu().numpy(), batch.sizes.cpu().numpy()
+    for c in range(nchunks):
+        assert sizes[c] == 8 + chunk_len
+        assert not comp[offs[c] + sizes[c]:offs[c + 1]].any(), c
+
+
 # ------------------------------------------------ optional Huffman stage (format: oracle/huf_oracle.c)
 
 @pytest.mark.parametrize("step", [2, 8, 300])
