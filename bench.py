@@ -452,10 +452,18 @@ def main():
         except Exception:
             pass
         os.write(json_fd, (json.dumps(obj) + "\n").encode())
+    # (test aid: BENCH_ONE_DEVICE=1 BENCH_BACKEND=gloo runs N ranks on ONE GPU to exercise the sharding / strong-scaling /
+    #  merge logic on a single-GPU box; RCCL itself refuses two ranks on one device)
+    if os.environ.get("BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import sprintz_amd

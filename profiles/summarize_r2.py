@@ -36,11 +36,12 @@ def main():
     ap.add_argument("run_dir")
     ap.add_argument("out_prefix")
     ap.add_argument("--build", default="unlabelled")
+    ap.add_argument("--traffic-json", default=None, help="where to write hbm_traffic.json (default: next to out_prefix)")
     a = ap.parse_args()
     entries = {}
     for wdir in sorted(glob.glob(os.path.join(a.run_dir, "*"))):
         w = os.path.basename(wdir)
-        if not os.path.isdir(wdir):
+        if not os.path.isdir(wdir) or w == "summary":
             continue
         db = one_db(os.path.join(wdir, "trace"))
         if db:
@@ -84,7 +85,7 @@ def main():
                                     bytes_per_launch=int(fetch + write), source=os.path.basename(a.out_prefix) + f"_{w}_pmc.csv", build=a.build,
                                     method="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950), KiB->B")
     if entries:
-        with open(os.path.join(os.path.dirname(a.out_prefix) or ".", "hbm_traffic.json"), "w") as f:
+        with open(a.traffic_json or os.path.join(os.path.dirname(a.out_prefix) or ".", "hbm_traffic.json"), "w") as f:
             json.dump({"entries": entries}, f, indent=1)
     print(json.dumps(entries, indent=1))
 

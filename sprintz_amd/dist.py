@@ -117,7 +117,8 @@ class LayoutGather:
             st = C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
             _lib.check(_lib.gather_layout(self.comm, d_total.data_ptr(), self.all.data_ptr(), st))
         elif self.world > 1:
-            self.dist.all_gather_into_tensor(self.all, d_total.reshape(1).contiguous())
+            parts = [self.all[r:r + 1] for r in range(self.world)]          # views: the gather lands in self.all
+            self.dist.all_gather(parts, d_total.reshape(1).contiguous())
         else:
             self.all[:1] = d_total.reshape(1)
 

@@ -20,5 +20,8 @@ for w in $WL; do
   (cd /tmp && timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/$w/pmc_write -o r -- python $ROOT/bench.py $PARGS > /dev/null 2> $OUT/$w/pmc_write.err)
   echo "$w done $(date +%T)"
 done
-# keep what travels back small: only the databases
-find $OUT -name "*.db" | wc -l
+# the databases are tens of MB each: summarise here, carry only the text back (gpurun merges <= 64 MiB)
+mkdir -p $OUT/summary
+python profiles/summarize_r2.py $OUT $OUT/summary/r2 --build "${BUILD_ID:-unlabelled}" --traffic-json $OUT/summary/hbm_traffic.json > $OUT/summary/summarize.log 2>&1
+for w in $WL; do cp $OUT/$w/bench_under_trace.json $OUT/summary/${w}_bench_under_trace.json 2>/dev/null; rm -rf $OUT/$w; done
+ls $OUT/summary | head -40
