@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <type_traits>
 
 namespace sprintz { int set_error(int code, const char* what); }   // api.hip: the library's one error sink
 
@@ -408,10 +409,72 @@ __device__ __forceinline__ void wave_sync()
 // dependent chain of a symbol is one LDS round trip.
 constexpr int kDescStride = 320;                 // sorted[256] | u32 tab[16]: [0] = hl | tl << 16, [w] = start[w] | symoff[w] << 16
 constexpr int kCStride = 256 + 64 + 512 + 4;     // stream kernel, per chunk in LDS: sorted | tab | table8; odd in dwords
-constexpr int kRingStride = 32 + 8;              // stream kernel, per lane: two 16-byte pieces of its stream (8-byte aligned)
+// stream kernel, per lane: a ring of two PIECES of its stream (+ the first 8 bytes again).  A piece is 16 bytes for the
+// general kernel and 64 for the one-table kernel, which has the LDS to spare (see the note on memory traffic there).
+// (Measured at 800 000 chunks, one-table kernel: 64-byte pieces +13 %, a workgroup of 4 waves around one table +3 %,
+// both together +3 % against 16-byte pieces and a table per wave: what they save in requests they lose in resident waves.)
+#ifndef HUF0_SO_PLOG
+#define HUF0_SO_PLOG 4
+#endif
+#ifndef HUF0_SO_WG
+#define HUF0_SO_WG 1
+#endif
+constexpr int piece_log(bool so) { return so ? HUF0_SO_PLOG : 4; }
+constexpr int ring_stride(bool so) { return 2 * (1 << piece_log(so)) + 8; }
 
+// Blocks written with one code per SEGMENT of 64 chunks (our writer; any writer that repeats a tree description) need
+// the tree only once per segment.  follow[c] = 1 iff chunk c is not the first of its 64-aligned segment and its tree
+// description is byte-for-byte the one of the segment's first chunk: such a chunk takes a copy of that chunk's
+// descriptor (huf0_copy_kernel) instead of parsing.  The tree kernel then runs twice: over the segment leaders (a lane
+// per leader: 4096 chunks a wave), and over whatever is left (libzstd's blocks: everything), waves with nothing left
+// exiting at once.  Per wave the tree is ~115 us of serial work; this takes it from ceil(chunks / 64 / 768) rounds to one.
+__device__ __forceinline__ uint32_t tree_desc_bytes(uint32_t b0) { return b0 < 128u ? 1u + b0 : 1u + (b0 - 127u + 1u) / 2u; }   // HUF_readStats: iSize + 1
+
+__global__ void __launch_bounds__(256) huf0_follow_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restrict__ boffs,
+                                                          const uint64_t* __restrict__ ooffs, uint64_t nchunks, uint8_t* __restrict__ follow)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= nchunks) return;
+    const uint64_t L = c & ~(uint64_t)63;
+    uint8_t f = 0;
+    if (c != L) {
+        const uint64_t b0 = boffs[c], b1 = boffs[c + 1], l0 = boffs[L], l1 = boffs[L + 1];
+        const uint64_t cs = b1 - b0, ls = l1 - l0, cd = ooffs[c + 1] - ooffs[c], ld = ooffs[L + 1] - ooffs[L];
+        if (b1 >= b0 && l1 >= l0 && cs > 1 && ls > 1 && cs < cd && ls < ld) {      // both are coded blocks
+            const uint8_t* const p = blocks + b0;
+            const uint8_t* const q = blocks + l0;
+            const uint32_t hl = tree_desc_bytes(p[0]);
+            if (hl < cs && hl < ls) {
+                typedef uint64_t __attribute__((aligned(1))) u64_a1;
+                uint64_t diff = 0;                                // no early exit: the loads of one lane are all in flight together
+                if (hl >= 8) {
+                    for (uint32_t k = 0; k + 8 <= hl; k += 8) diff |= *(const u64_a1*)(p + k) ^ *(const u64_a1*)(q + k);
+                    diff |= *(const u64_a1*)(p + hl - 8) ^ *(const u64_a1*)(q + hl - 8);       // the tail, overlapping
+                } else {
+                    for (uint32_t k = 0; k < hl; k++) diff |= (uint64_t)(p[k] ^ q[k]);
+                }
+                f = diff == 0 ? 1 : 0;
+            }
+        }
+    }
+    follow[c] = f;
+}
+
+// thread = one 16-byte piece of one follower's descriptor
+__global__ void __launch_bounds__(256) huf0_copy_kernel(uint8_t* __restrict__ desc, const uint8_t* __restrict__ follow, uint64_t nchunks)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x, c = i / 20, part = i % 20;
+    if (c >= nchunks || !follow[c]) return;
+    const uint64_t L = c & ~(uint64_t)63;
+    *(uint4*)(desc + c * kDescStride + 16 * part) = *(const uint4*)(desc + L * kDescStride + 16 * part);
+}
+
+// MODE 1: lane t of workgroup g parses the segment leader 64 (64 g + t).  MODE 2: lane t parses chunk 64 g + t unless it is a
+// leader or a follower.
+template <int MODE>
 __global__ void __launch_bounds__(64) huf0_tree_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restrict__ boffs,
-                                                       const uint64_t* __restrict__ ooffs, uint64_t nchunks, uint8_t* __restrict__ desc)
+                                                       const uint64_t* __restrict__ ooffs, uint64_t nchunks, uint8_t* __restrict__ desc,
+                                                       const uint8_t* __restrict__ follow)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_w[64 * kWStride];
     __shared__ __attribute__((aligned(16))) uint8_t s_r[64 * kRStride];
@@ -419,10 +482,14 @@ __global__ void __launch_bounds__(64) huf0_tree_kernel(const uint8_t* __restrict
     __shared__ uint32_t s_run[64][13];
     __shared__ uint64_t s_src[64];
     __shared__ uint32_t s_hc[64];
+    __shared__ uint64_t s_chunk[64];                              // the chunk a lane works on, or ~0: nothing to write back
     const int t = threadIdx.x;
-    const uint64_t chunk0 = (uint64_t)blockIdx.x * 64;
-    const uint64_t chunk = chunk0 + (uint64_t)t;
-    const bool exists = chunk < nchunks;
+    const uint64_t lane_item = (uint64_t)blockIdx.x * 64 + (uint64_t)t;
+    const uint64_t chunk = MODE == 1 ? lane_item * 64 : lane_item;
+    bool exists = chunk < nchunks;
+    if (MODE == 2 && exists) exists = (chunk & 63) != 0 && follow[chunk] == 0;
+    if (__ballot(exists) == 0) return;                            // a wave of followers: nothing to parse
+    s_chunk[t] = exists ? chunk : ~0ull;
     const uint64_t b0 = exists ? boffs[chunk] : 0, b1 = exists ? boffs[chunk + 1] : 0;
     const uint64_t o0 = exists ? ooffs[chunk] : 0, o1 = exists ? ooffs[chunk + 1] : 0;
     const uint64_t csize = b1 - b0, dsize = o1 - o0;
@@ -474,6 +541,9 @@ __global__ void __launch_bounds__(64) huf0_tree_kernel(const uint8_t* __restrict
             at += cnt[w] << (w - 1);
             so += cnt[w];
         }
+        // (zeroed first: blocks with the same tree description must give byte-identical descriptors -- the stream kernel
+        //  shares one decode table among the chunks of a wave when they do)
+        for (int k = 0; k < 64; k++) ((uint32_t*)sorted)[k] = 0;
         // counting sort, four symbols a trip: their slots come back from four LDS adds issued together
         // (DS operations of a wave execute in issue order, so equal weights keep their symbol order)
         for (uint32_t sy = 0; sy < nsym; sy += 4) {
@@ -494,23 +564,69 @@ __global__ void __launch_bounds__(64) huf0_tree_kernel(const uint8_t* __restrict
     wave_sync();
     // descriptors out: 64 dwords of sorted symbols + 13 words of table per chunk, one chunk per trip
     for (int c = 0; c < 64; c++) {
-        if (chunk0 + (uint64_t)c >= nchunks) break;
-        uint8_t* const d = desc + (chunk0 + (uint64_t)c) * kDescStride;
+        const uint64_t ch = s_chunk[c];
+        if (ch == ~0ull) continue;
+        uint8_t* const d = desc + ch * kDescStride;
         const uint32_t v = *(const uint32_t*)(s_r + c * kRStride + 4 * t);
         *(uint32_t*)(d + 4 * t) = v;
-        if (t < 13) *(uint32_t*)(d + 256 + 4 * t) = s_tab[c][t];
+        if (t < 16) *(uint32_t*)(d + 256 + 4 * t) = t < 13 ? s_tab[c][t] : 0u;      // the whole descriptor is defined: equal trees give equal bytes
     }
 }
 
-__global__ void __launch_bounds__(64) huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restrict__ boffs,
+// share[s] = 1 iff the chunks of segment s (64, fewer in the last one) all follow the segment's leader (one tree, so one descriptor)
+// and its table log is at most kSharedMaxLog: the segment is the one-table kernel's.  thread = segment.
+constexpr uint32_t kSharedMaxLog = 11;
+__global__ void __launch_bounds__(256) huf0_share_kernel(const uint8_t* __restrict__ desc, const uint8_t* __restrict__ follow, uint64_t nchunks,
+                                                         uint8_t* __restrict__ share)
+{
+    const uint64_t sg = (uint64_t)blockIdx.x * 256 + threadIdx.x, c0 = sg * 64;
+    if (c0 >= nchunks) return;
+    bool ok = true;
+    if (c0 + 64 > nchunks) {                                      // the last, short segment: the chunks that exist
+        for (uint64_t c = c0 + 1; c < nchunks; c++) ok = ok && follow[c] == 1;
+        const uint32_t tab0 = *(const uint32_t*)(desc + c0 * kDescStride + 256);
+        ok = ok && nchunks - c0 > 1 && (tab0 & 0xffffu) != 0u && (tab0 >> 16) <= kSharedMaxLog && (tab0 >> 16) != 0u;
+    } else {
+        const uint4* const f = (const uint4*)(follow + c0);       // 64-byte aligned
+        uint32_t all = 0x01010101u, first = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint4 v = f[k];
+            if (k == 0) { first = v.x; all &= v.x | 1u; } else all &= v.x;
+            all &= v.y & v.z & v.w;
+        }
+        const uint32_t tab0 = *(const uint32_t*)(desc + c0 * kDescStride + 256);
+        ok = all == 0x01010101u && (first & 0xffu) == 0 && (tab0 & 0xffffu) != 0u && (tab0 >> 16) <= kSharedMaxLog && (tab0 >> 16) != 0u;
+    }
+    share[sg] = ok ? 1 : 0;
+}
+
+// Two instantiations, launched back to back; every chunk is taken by exactly one of them:
+//   SO = true   workgroup = a 64-chunk segment that share[] marks: 4 waves around ONE full decode table of 2^tableLog entries
+//               (4.4 KB) -- a symbol is one LDS read -- and 64-byte stream pieces;
+//   SO = false  wave = 16 chunks of every other segment: sixteen 8-bit prefix tables (13 KB); a wave whose chunks do share a
+//               tree (table log 12, or a short last segment) still builds the one table, over the prefix tables' space.
+#ifndef HUF0_SO_WAVES
+#define HUF0_SO_WAVES 5
+#endif
+#ifndef HUF0_G_WAVES
+#define HUF0_G_WAVES 2
+#endif
+template <bool SO>
+__global__ void __launch_bounds__(SO ? 64 * HUF0_SO_WG : 64) __attribute__((amdgpu_waves_per_eu(SO ? HUF0_SO_WAVES : HUF0_G_WAVES)))
+huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restrict__ boffs,
                                                          uint64_t nchunks, uint8_t* __restrict__ out,
                                                          const uint64_t* __restrict__ ooffs, int64_t* __restrict__ rets,
-                                                         const uint8_t* __restrict__ desc)
+                                                         const uint8_t* __restrict__ desc, const uint8_t* __restrict__ share)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_c[16 * kCStride];
-    __shared__ __attribute__((aligned(16))) uint8_t s_ring[64 * kRingStride];
+    constexpr int kThreads = SO ? 64 * HUF0_SO_WG : 64, kChunks = kThreads / 4;
+    if ((share[(uint64_t)blockIdx.x * kChunks >> 6] != 0) != SO) return;      // the other instantiation's
+    auto sync = [] { if constexpr (SO) __syncthreads(); else wave_sync(); };
+    __shared__ __attribute__((aligned(16))) uint8_t s_c[SO ? 336 + (2u << kSharedMaxLog) : 16 * kCStride];
+    constexpr int kPLog = piece_log(SO), kPB = 1 << kPLog, kPL = kPB / 16, kRingStride = ring_stride(SO);
+    __shared__ __attribute__((aligned(16))) uint8_t s_ring[kThreads * kRingStride];
     const int t = threadIdx.x, q = t >> 2, j = t & 3;
-    const uint64_t chunk0 = (uint64_t)blockIdx.x * 16;
+    const uint64_t chunk0 = (uint64_t)blockIdx.x * kChunks;
     const uint64_t chunk = chunk0 + (uint64_t)q;
     const bool exists = chunk < nchunks;
     const uint64_t b0 = exists ? boffs[chunk] : 0, b1 = exists ? boffs[chunk + 1] : 0;
@@ -518,15 +634,22 @@ __global__ void __launch_bounds__(64) huf0_stream_kernel(const uint8_t* __restri
     const uint8_t* const src = blocks + b0;
     uint8_t* const dst = out + o0;
     const uint64_t csize = b1 - b0, dsize = o1 - o0;
-    uint8_t* const cbase = s_c + q * kCStride;
+    uint8_t* const cbase = SO ? s_c : s_c + q * kCStride;       // (one tree for the wave: everybody reads the first chunk's copy)
     const uint8_t* const sorted = cbase;
     const uint32_t* const tab = (const uint32_t*)(cbase + 256);
     uint16_t* const table8 = (uint16_t*)(cbase + 320);
 
-    // ---- descriptors of this wave's 16 chunks -> LDS: 320 pieces of 16 bytes, five per lane
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     typedef v4u __attribute__((aligned(1), may_alias)) v4u_a1;
     typedef v4u __attribute__((aligned(16), may_alias)) v4u_a16;
+    if constexpr (SO) {                                           // the leader's descriptor stands for all 64
+        if (t < 20) {
+            const v4u v = *(const v4u_a16*)(desc + chunk0 * kDescStride + 16u * (uint32_t)t);
+            uint32_t* const d = (uint32_t*)(s_c + 16u * (uint32_t)t);
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    } else {
+    // ---- descriptors of this wave's 16 chunks -> LDS: 320 pieces of 16 bytes, five per lane
 #pragma unroll
     for (int r = 0; r < 5; r++) {
         const uint32_t piece = (uint32_t)r * 64 + (uint32_t)t, c = piece / 20u, part = piece % 20u;
@@ -534,6 +657,7 @@ __global__ void __launch_bounds__(64) huf0_stream_kernel(const uint8_t* __restri
         if (chunk0 + c < nchunks) v = *(const v4u_a16*)(desc + (chunk0 + c) * kDescStride + 16u * part);
         uint32_t* const d = (uint32_t*)(s_c + c * kCStride + 16u * part);
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
     }
 
     // ---- HUF_decompress's conventions (huf_decompress.c): stored, one repeated byte, or a coded block
@@ -548,14 +672,25 @@ __global__ void __launch_bounds__(64) huf0_stream_kernel(const uint8_t* __restri
     }
     if (mode == 1) for (uint64_t k = (uint64_t)j; k < dsize; k += 4) dst[k] = src[k];
     if (mode == 2) { const uint8_t v = src[0]; for (uint64_t k = (uint64_t)j; k < dsize; k += 4) dst[k] = v; }
-    wave_sync();
+    sync();
     const uint32_t hl = mode == 3 ? (tab[0] & 0xffffu) : 0u, tl = mode == 3 ? (tab[0] >> 16) : 0u;
     if (mode == 3 && hl == 0) ret = kCorrupt;
     const bool coded = mode == 3 && hl != 0;
 
     // ---- table8: entry b = the code that starts with the 8 bits b, if it is at most 8 bits long.  Lane j of the
     // quad fills entries 64 j .. 64 j + 63; the weight only ever grows along them.
-    if (coded) {
+    // (SO = false: is this wave the other instantiation's?  Same test, on the LDS copies.)
+    bool same_lane = !exists;
+    if (exists && coded) {
+        same_lane = true;
+        const uint32_t* const mine = (const uint32_t*)cbase + 20 * j;
+        const uint32_t* const first = (const uint32_t*)s_c + 20 * j;
+#pragma unroll
+        for (int k = 0; k < 20; k++) same_lane = same_lane && mine[k] == first[k];
+    }
+    const uint32_t tab00 = *(const uint32_t*)(s_c + 256);
+    const bool shared = SO || (__ballot(!same_lane) == 0 && chunk0 < nchunks && (tab00 & 0xffffu) != 0u && __builtin_amdgcn_readfirstlane((int)coded) != 0);
+    if (coded && !shared) {
         const uint32_t start_short = tl > 8u ? (tab[tl - 7u] & 0xffffu) : 0u;      // first index of the codes of <= 8 bits
         uint32_t w = 1, e = tab[1], nxt = tab[2] & 0xffffu;
         for (uint32_t k = 0; k < 64; k++) {
@@ -570,7 +705,25 @@ __global__ void __launch_bounds__(64) huf0_stream_kernel(const uint8_t* __restri
             table8[b] = (uint16_t)entry;
         }
     }
-    wave_sync();
+    sync();
+
+    // ---- One code for the whole wave: ONE full decode table (2^tableLog entries of symbol | length << 8) instead of sixteen
+    // 8-bit prefix tables -- a symbol is then one LDS read and no weight logic at all.
+    uint16_t* const full_table = (uint16_t*)(s_c + (SO ? 336 : kCStride + 12));      // 16-byte aligned; SO = false: over the other chunks' space
+    sync();
+    if (shared) {
+        const uint32_t* const tab0 = (const uint32_t*)(s_c + 256);
+        const uint32_t tl0 = tab0[0] >> 16, size = 1u << tl0, per = size >= (uint32_t)kThreads ? size / (uint32_t)kThreads : 1u;
+        uint32_t w = 1, e = tab0[1], nxt = tab0[2] & 0xffffu;
+        for (uint32_t k = 0; k < per; k++) {
+            const uint32_t idx0 = (uint32_t)t * per + k;
+            if (idx0 >= size) break;
+            while (w < 12u && idx0 >= nxt) { w++; e = tab0[w]; nxt = w < 12u ? (tab0[w + 1] & 0xffffu) : 0xffffffffu; }
+            const uint32_t pos = (e >> 16) + ((idx0 - (e & 0xffffu)) >> (w - 1u));
+            full_table[idx0] = (uint16_t)(s_c[pos & 0xffu] | ((tl0 + 1u - w) << 8));
+        }
+    }
+    sync();
 
     // ---- lane j decodes stream j (HUF_decompress4X1_usingDTable_internal).  Set-up per lane, then ONE
     // wave-uniform loop: the quad exchanges of the output path need every lane, streamless ones included.
@@ -625,46 +778,69 @@ __global__ void __launch_bounds__(64) huf0_stream_kernel(const uint8_t* __restri
     // compiler's copies for the rotation made every step wait for the piece requested one step earlier.  A ring of
     // two 64-byte blocks hid the latency better but cost 8.7 KB of LDS a wave: 7 waves a CU instead of 10.)
     // Byte i of the stream sits at ring offset (s_al + i) & 31; piece k covers stream bytes [16 k - s_al, 16 k - s_al + 16).
-    const uint32_t s_al = (uint32_t)((uintptr_t)sp & 15u);
-    const uint8_t* const sp_al = sp - s_al;                       // >= blocks: the API asks for a 16-byte aligned buffer
-    const int32_t last_piece = streaming ? (int32_t)((((P > 0 ? (uint32_t)(P - 1) >> 3 : 0u)) + s_al) >> 4) : -1;
-    auto load_piece = [&](int32_t k) -> v4u {                     // pieces outside the stream read as zero, never touched
-        if (k < 0 || k > last_piece) return v4u{0, 0, 0, 0};
-        return *(const v4u_a16*)(sp_al + 16 * (int64_t)k);
+    const uint32_t s_al = (uint32_t)((uintptr_t)sp & (uint32_t)(kPB - 1));
+    // An aligned piece may start before `blocks` or end behind the last block by less than its size: it never leaves
+    // the page of a byte that IS in the buffer, and those bytes are never looked at.
+    const uint8_t* const sp_al = sp - s_al;
+    const int32_t last_piece = streaming ? (int32_t)((((P > 0 ? (uint32_t)(P - 1) >> 3 : 0u)) + s_al) >> kPLog) : -1;
+    struct Piece { v4u q[kPL]; };
+    auto load_piece = [&](int32_t k) -> Piece {                   // pieces outside the stream read as zero, never touched
+        Piece f;
+#pragma unroll
+        for (int i = 0; i < kPL; i++) f.q[i] = v4u{0, 0, 0, 0};
+#ifdef ABL_NO_LOAD
+        if (k < 0 || k > last_piece || k < last_piece - 2) return f;
+#else
+        if (k < 0 || k > last_piece) return f;
+#endif
+#pragma unroll
+        for (int i = 0; i < kPL; i++) f.q[i] = *(const v4u_a16*)(sp_al + kPB * (int64_t)k + 16 * i);
+        return f;
     };
     const uint32_t ring = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)s_ring + (uint32_t)t * kRingStride;
-    auto park = [&](int32_t pk, const v4u& f) {                   // piece pk -> its ring slot
-        const uint32_t at = ring + (((uint32_t)pk & 1u) << 4);
+    auto park = [&](int32_t pk, const Piece& f) {                 // piece pk -> its ring slot
+        const bool s0 = ((uint32_t)pk & 1u) == 0;
+        const uint32_t at = ring + (s0 ? 0u : (uint32_t)kPB);
         typedef __attribute__((address_space(3))) uint64_t lds_u64;
-        *(lds_u64*)(uintptr_t)at = (uint64_t)f.x | ((uint64_t)f.y << 32);
-        *(lds_u64*)(uintptr_t)(at + 8u) = (uint64_t)f.z | ((uint64_t)f.w << 32);
+#pragma unroll
+        for (int i = 0; i < kPL; i++) {
+            *(lds_u64*)(uintptr_t)(at + 16u * i) = (uint64_t)f.q[i].x | ((uint64_t)f.q[i].y << 32);
+            *(lds_u64*)(uintptr_t)(at + 16u * i + 8u) = (uint64_t)f.q[i].z | ((uint64_t)f.q[i].w << 32);
+        }
+        // the first 8 bytes of slot 0 again behind slot 1: a window that wraps reads straight on (fast_step).  Slot 1
+        // rewrites its own last 8 bytes instead -- no branch.
+        *(lds_u64*)(uintptr_t)(ring + 2u * kPB - (s0 ? 0u : 8u)) =
+            s0 ? ((uint64_t)f.q[0].x | ((uint64_t)f.q[0].y << 32)) : ((uint64_t)f.q[kPL - 1].z | ((uint64_t)f.q[kPL - 1].w << 32));
     };
     int32_t cur_b = last_piece;                                   // piece of the cursor's byte
-    v4u fl;
+    Piece fl;
     {
-        const v4u f0 = load_piece(cur_b), f1 = load_piece(cur_b - 1);
+        const Piece f0 = load_piece(cur_b), f1 = load_piece(cur_b - 1);
         fl = load_piece(cur_b - 2);
         park(cur_b, f0);
         park(cur_b - 1, f1);
     }
-    wave_sync();
+    sync();
     typedef __attribute__((address_space(3))) const uint16_t lds_u16;
     typedef __attribute__((address_space(3))) const uint8_t lds_u8c;
     typedef __attribute__((address_space(3))) const uint32_t lds_u32c;
     // one step = up to 4 symbols = one dword of output; branch-free except for the block crossing
-    auto step = [&](uint32_t m) -> uint32_t {
+    const uint32_t ft = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)full_table;
+    auto step = [&](uint32_t m, auto SH) -> uint32_t {
+        constexpr bool kShared = decltype(SH)::value;
         const int32_t Pc = P;
         const uint32_t x = ((uint32_t)(Pc > 0 ? Pc - 1 : 0) >> 3) + s_al;      // the cursor's byte, counted from piece 0
-        if ((int32_t)(x >> 4) < cur_b) {                          // crossed into the piece below: the one in flight takes the freed slot
+        if ((int32_t)(x >> kPLog) < cur_b) {                      // crossed into the piece below: the one in flight takes the freed slot
             park(cur_b - 2, fl);
             cur_b--;
             fl = load_piece(cur_b - 2);
         }
         // the 8 bytes ending at byte x: three aligned dwords of the ring, two v_alignbyte
         const uint32_t o = x - 7u;                                // may be "negative": bytes before the stream read as what the ring holds, masked below
-        const uint32_t d0 = *(lds_u32c*)(uintptr_t)(ring + (o & 28u));
-        const uint32_t d1 = *(lds_u32c*)(uintptr_t)(ring + ((o + 4u) & 28u));
-        const uint32_t d2 = *(lds_u32c*)(uintptr_t)(ring + ((o + 8u) & 28u));
+        constexpr uint32_t kRM = 2u * kPB - 4u;
+        const uint32_t d0 = *(lds_u32c*)(uintptr_t)(ring + (o & kRM));
+        const uint32_t d1 = *(lds_u32c*)(uintptr_t)(ring + ((o + 4u) & kRM));
+        const uint32_t d2 = *(lds_u32c*)(uintptr_t)(ring + ((o + 8u) & kRM));
         const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, o & 3u), hi0 = __builtin_amdgcn_alignbyte(d2, d1, o & 3u);
         uint64_t win = (((uint64_t)hi0 << 32) | lo) << (7 - (int)((uint32_t)(Pc - 1) & 7u));
         if (__ballot(Pc < 64) != 0) {                             // only the last steps of a stream: nothing before its first bit
@@ -675,6 +851,15 @@ __global__ void __launch_bounds__(64) huf0_stream_kernel(const uint8_t* __restri
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const uint32_t hi = (uint32_t)(win >> 32);
+            if constexpr (kShared) {
+                const uint32_t e = *(lds_u16*)(uintptr_t)(ft + ((hi >> look_shift) << 1));
+                const bool on = (uint32_t)k < m;
+                const uint32_t nb = on ? (e >> 8) : 0u;
+                word |= (on ? (e & 0xffu) : 0u) << (8 * k);
+                win <<= nb;
+                P -= (int32_t)nb;
+                continue;
+            }
             const uint32_t e8 = *(lds_u16*)(uintptr_t)(t8 + ((hi >> 24) << 1));
             const uint32_t idx = hi >> look_shift;
             // a longer code whose 8-bit prefix holds one weight only: its symbol sits at base + (low index bits >> (w - 1))
@@ -699,23 +884,76 @@ __global__ void __launch_bounds__(64) huf0_stream_kernel(const uint8_t* __restri
         }
         return word;
     };
+    // The bulk of a stream: every lane of the wave has >= 64 symbols to go and its cursor far enough from the stream's
+    // first bit that 16 steps (<= 16 * 4 * 12 bits) need no masking, no symbol count and no bounds on the piece index.
+    // 4 symbols are then ~45 instructions instead of ~130 (the per-symbol `on` masks alone took 40 SGPRs a step).
+    constexpr int32_t kFastBits = 64 + 3 * 48;                    // four steps at a time
+    auto fast_step = [&]() -> uint32_t {
+        const uint32_t pm1 = (uint32_t)P - 1u;
+        const uint32_t x = (pm1 >> 3) + s_al;
+        if ((int32_t)(x >> kPLog) < cur_b) {
+            park(cur_b - 2, fl);
+            cur_b--;
+            fl = load_piece(cur_b - 2);
+        }
+        const uint32_t o = x - 7u, a = ring + (o & (2u * kPB - 4u));
+        const uint32_t d0 = *(lds_u32c*)(uintptr_t)a, d1 = *(lds_u32c*)(uintptr_t)(a + 4u), d2 = *(lds_u32c*)(uintptr_t)(a + 8u);
+        const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, o & 3u), hi0 = __builtin_amdgcn_alignbyte(d2, d1, o & 3u);
+        uint64_t win = (((uint64_t)hi0 << 32) | lo) << (7u - (pm1 & 7u));
+        const uint32_t e0 = *(lds_u16*)(uintptr_t)(ft + (((uint32_t)(win >> 32) >> look_shift) << 1));
+        win <<= e0 >> 8;
+        const uint32_t e1 = *(lds_u16*)(uintptr_t)(ft + (((uint32_t)(win >> 32) >> look_shift) << 1));
+        win <<= e1 >> 8;
+        const uint32_t e2 = *(lds_u16*)(uintptr_t)(ft + (((uint32_t)(win >> 32) >> look_shift) << 1));
+        win <<= e2 >> 8;
+        const uint32_t e3 = *(lds_u16*)(uintptr_t)(ft + (((uint32_t)(win >> 32) >> look_shift) << 1));
+        P -= (int32_t)((e0 >> 8) + (e1 >> 8) + (e2 >> 8) + (e3 >> 8));
+        const uint32_t w01 = __builtin_amdgcn_perm(e1, e0, 0x0c0c0400u), w23 = __builtin_amdgcn_perm(e3, e2, 0x0c0c0400u);
+        return __builtin_amdgcn_perm(w23, w01, 0x05040100u);
+    };
     // The output leaves 64 bytes at a time: a lane collects 16 steps in registers, the quad transposes
     // its 16-byte pieces (two DPP butterfly stages) and every store writes ONE stream's 64 contiguous
     // bytes (4-byte stores per lane per step -- 524 288 open lines at the headline shape -- made this
     // phase 3.2 ms of a 3.7 ms launch).  A stream's final partial burst goes out narrow.
     const bool odd1 = (t & 1) != 0, odd2 = (t & 2) != 0;
     const uint32_t part = (uint32_t)t & 3u;
+    uint32_t head = streaming ? (uint32_t)(0u - (uint32_t)(uintptr_t)op) & 63u : 0u;
+    auto run = [&](auto SH) {
     for (;;) {
         if (__ballot(left > 0) == 0) break;
-        const bool full = left >= 64;
+        // a stream's first burst only goes up to the next 64-byte line of the output: every later one stores whole lines
+        const uint64_t lim = head != 0 && head < left ? (uint64_t)head : left;
+        const bool full = lim >= 64;
         uint32_t wb[16];
+        if constexpr (decltype(SH)::value) {
+            const bool all_full = __ballot(streaming && lim < 64) == 0;      // (lanes without a stream just go through the motions)
 #pragma unroll
-        for (int sN = 0; sN < 16; sN++) {
-            const uint32_t done = 4u * sN;
-            const uint32_t m = (left > done && P >= -64) ? (left - done < 4 ? (uint32_t)(left - done) : 4u) : 0u;
-            wb[sN] = step(m);
+            for (int g = 0; g < 4; g++) {
+                if (all_full && __ballot(streaming && P < kFastBits) == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) wb[4 * g + i] = fast_step();
+                } else {                                          // the ends of the streams: rolled, so that the bulk's registers set the occupancy
+                    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+#pragma unroll 1
+                    for (int i = 0; i < 4; i++) {
+                        const uint32_t done = 16u * g + 4u * i;
+                        const uint32_t m = (lim > done && P >= -64) ? (lim - done < 4 ? (uint32_t)(lim - done) : 4u) : 0u;
+                        const uint32_t w = step(m, SH);
+                        w0 = i == 0 ? w : w0; w1 = i == 1 ? w : w1; w2 = i == 2 ? w : w2; w3 = i == 3 ? w : w3;
+                    }
+                    wb[4 * g] = w0; wb[4 * g + 1] = w1; wb[4 * g + 2] = w2; wb[4 * g + 3] = w3;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int sN = 0; sN < 16; sN++) {
+                const uint32_t done = 4u * sN;
+                const uint32_t m = (lim > done && P >= -64) ? (lim - done < 4 ? (uint32_t)(lim - done) : 4u) : 0u;
+                wb[sN] = step(m, SH);
+            }
         }
-        const uint32_t cnt = left < 64 ? (uint32_t)left : 64u;
+        const uint32_t cnt = lim < 64 ? (uint32_t)lim : 64u;
+        head = 0;
         uint32_t v[4][4];
 #pragma unroll
         for (int k = 0; k < 4; k++)
@@ -747,7 +985,11 @@ __global__ void __launch_bounds__(64) huf0_stream_kernel(const uint8_t* __restri
             else if (qq == 2) { dlo = (uint32_t)__builtin_amdgcn_mov_dpp(mlo, 0xAA, 0xf, 0xf, true); dhi = (uint32_t)__builtin_amdgcn_mov_dpp(mhi, 0xAA, 0xf, 0xf, true); }
             else { dlo = (uint32_t)__builtin_amdgcn_mov_dpp(mlo, 0xFF, 0xf, 0xf, true); dhi = (uint32_t)__builtin_amdgcn_mov_dpp(mhi, 0xFF, 0xf, 0xf, true); }
             const uint64_t da = ((uint64_t)dhi << 32) | dlo;
+#ifdef ABL_NO_STORE
+            if (da == 1) {
+#else
             if (da) {
+#endif
                 v4u piece = {v[qq][0], v[qq][1], v[qq][2], v[qq][3]};
                 __builtin_nontemporal_store(piece, (v4u_a1*)(uintptr_t)(da + 16u * part));   // streamed out once
             }
@@ -763,6 +1005,8 @@ __global__ void __launch_bounds__(64) huf0_stream_kernel(const uint8_t* __restri
         op += cnt;
         left -= cnt;
     }
+    };
+    if (shared) run(std::true_type{}); else run(std::false_type{});
     if (streaming && P != 0) bad = true;                          // every stream ends exactly (BIT_endOfDStream)
     const bool any_bad = __builtin_amdgcn_mov_dpp((int)bad, 0x00, 0xf, 0xf, true) | __builtin_amdgcn_mov_dpp((int)bad, 0x55, 0xf, 0xf, true) |
                          __builtin_amdgcn_mov_dpp((int)bad, 0xAA, 0xf, 0xf, true) | __builtin_amdgcn_mov_dpp((int)bad, 0xFF, 0xf, 0xf, true);
@@ -779,7 +1023,11 @@ std::string g_err0;
 
 extern "C" {
 
-size_t sprintz_mi355x_huf0_decode_tmp_bytes(uint64_t nchunks) { return (size_t)nchunks * kDescStride + 256; }
+// descriptors | follow flags (a multiple of 64) | share flags (one per segment)
+size_t sprintz_mi355x_huf0_decode_tmp_bytes(uint64_t nchunks)
+{
+    return (size_t)nchunks * kDescStride + 256 + (((size_t)nchunks + 63) & ~(size_t)63) + (size_t)((nchunks + 63) / 64) + 64;
+}
 
 int sprintz_mi355x_huf0_decompress_batch_ws(const void* d_blocks, const uint64_t* d_block_offsets, uint64_t nchunks, void* d_out,
                                             const uint64_t* d_out_offsets, int64_t* d_rets, void* d_tmp, void* hip_stream)
@@ -789,13 +1037,24 @@ int sprintz_mi355x_huf0_decompress_batch_ws(const void* d_blocks, const uint64_t
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return sprintz::set_error(SPRINTZ_E_NO_DEVICE, "Huff0 stage: no usable HIP device (there is no CPU fallback)");
     if (nchunks == 0) return 0;
-    const uint64_t grid1 = (nchunks + 63) / 64, grid2 = (nchunks + 15) / 16;
+    const uint64_t grid1 = (nchunks + 63) / 64, grid2 = (nchunks + 15) / 16, nleaders = grid1;
     if (grid2 > 0x7fffffffull) return sprintz::set_error(SPRINTZ_E_INVALID, "Huff0 stage: invalid argument (null pointer, alignment or size)");
     hipStream_t st = (hipStream_t)hip_stream;
-    hipLaunchKernelGGL(huf0_tree_kernel, dim3((unsigned)grid1), dim3(64), 0, st, (const uint8_t*)d_blocks, d_block_offsets, d_out_offsets,
-                       nchunks, (uint8_t*)d_tmp);
-    hipLaunchKernelGGL(huf0_stream_kernel, dim3((unsigned)grid2), dim3(64), 0, st, (const uint8_t*)d_blocks, d_block_offsets, nchunks,
-                       (uint8_t*)d_out, d_out_offsets, d_rets, (const uint8_t*)d_tmp);
+    uint8_t* const desc = (uint8_t*)d_tmp;
+    uint8_t* const follow = desc + (((size_t)nchunks * kDescStride + 255) & ~(size_t)255);
+    uint8_t* const share = follow + ((nchunks + 63) & ~(uint64_t)63);
+    const uint8_t* const blk = (const uint8_t*)d_blocks;
+    hipLaunchKernelGGL(huf0_follow_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, st, blk, d_block_offsets, d_out_offsets, nchunks, follow);
+    hipLaunchKernelGGL(huf0_tree_kernel<1>, dim3((unsigned)((nleaders + 63) / 64)), dim3(64), 0, st, blk, d_block_offsets, d_out_offsets, nchunks, desc,
+                       (const uint8_t*)follow);
+    hipLaunchKernelGGL(huf0_copy_kernel, dim3((unsigned)((nchunks * 20 + 255) / 256)), dim3(256), 0, st, desc, (const uint8_t*)follow, nchunks);
+    hipLaunchKernelGGL(huf0_tree_kernel<2>, dim3((unsigned)grid1), dim3(64), 0, st, blk, d_block_offsets, d_out_offsets, nchunks, desc,
+                       (const uint8_t*)follow);
+    hipLaunchKernelGGL(huf0_share_kernel, dim3((unsigned)((nleaders + 255) / 256)), dim3(256), 0, st, (const uint8_t*)desc, (const uint8_t*)follow, nchunks, share);
+    hipLaunchKernelGGL(huf0_stream_kernel<true>, dim3((unsigned)(HUF0_SO_WG == 4 ? grid1 : grid2)), dim3(64 * HUF0_SO_WG), 0, st, blk, d_block_offsets, nchunks,
+                       (uint8_t*)d_out, d_out_offsets, d_rets, (const uint8_t*)desc, (const uint8_t*)share);
+    hipLaunchKernelGGL(huf0_stream_kernel<false>, dim3((unsigned)grid2), dim3(64), 0, st, blk, d_block_offsets, nchunks,
+                       (uint8_t*)d_out, d_out_offsets, d_rets, (const uint8_t*)desc, (const uint8_t*)share);
     return hipGetLastError() == hipSuccess ? 0 : sprintz::set_error(SPRINTZ_E_HIP, "Huff0 stage: a HIP call or kernel launch failed");
 }
 
