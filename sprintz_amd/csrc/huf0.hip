@@ -888,7 +888,8 @@ huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restric
     // first bit that 16 steps (<= 16 * 4 * 12 bits) need no masking, no symbol count and no bounds on the piece index.
     // 4 symbols are then ~45 instructions instead of ~130 (the per-symbol `on` masks alone took 40 SGPRs a step).
     constexpr int32_t kFastBits = 64 + 3 * 48;                    // four steps at a time
-    auto fast_step = [&]() -> uint32_t {
+    auto fast_step = [&](auto SH) -> uint32_t {
+        constexpr bool kShared = decltype(SH)::value;
         const uint32_t pm1 = (uint32_t)P - 1u;
         const uint32_t x = (pm1 >> 3) + s_al;
         if ((int32_t)(x >> kPLog) < cur_b) {
@@ -900,6 +901,34 @@ huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restric
         const uint32_t d0 = *(lds_u32c*)(uintptr_t)a, d1 = *(lds_u32c*)(uintptr_t)(a + 4u), d2 = *(lds_u32c*)(uintptr_t)(a + 8u);
         const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, o & 3u), hi0 = __builtin_amdgcn_alignbyte(d2, d1, o & 3u);
         uint64_t win = (((uint64_t)hi0 << 32) | lo) << (7u - (pm1 & 7u));
+        if constexpr (!kShared) {                                 // the chunk's own 8-bit prefix table, then `sorted` for the longer codes
+            uint32_t sy[4], nbs = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t hi = (uint32_t)(win >> 32);
+                const uint32_t e8 = *(lds_u16*)(uintptr_t)(t8 + ((hi >> 24) << 1));
+                const uint32_t idx = hi >> look_shift;
+                uint32_t wm1 = (e8 >> 8) & 3u;
+                uint32_t pos = (e8 & 0xffu) + ((idx & bmask) >> wm1);
+                if (__ballot(e8 == 0xffffu) != 0) {
+                    const bool g2 = idx >= T2, g3 = idx >= T3, g4 = idx >= T4;
+                    const uint32_t el = g4 ? E4 : (g3 ? E3 : (g2 ? E2 : 0u));
+                    const uint32_t wg = (uint32_t)g2 + (uint32_t)g3 + (uint32_t)g4;
+                    const bool mixed = e8 == 0xffffu;
+                    pos = mixed ? (el >> 16) + ((idx - (el & 0xffffu)) >> wg) : pos;
+                    wm1 = mixed ? wg : wm1;
+                }
+                const uint32_t syl = *(lds_u8c*)(uintptr_t)(so8 + (pos & 0xffu));
+                const bool is_short = (e8 & 0x8000u) == 0;
+                sy[k] = is_short ? e8 : syl;
+                const uint32_t nb = is_short ? (e8 >> 8) : (tl - wm1);
+                win <<= nb;
+                nbs += nb;
+            }
+            P -= (int32_t)nbs;
+            const uint32_t w01 = __builtin_amdgcn_perm(sy[1], sy[0], 0x0c0c0400u), w23 = __builtin_amdgcn_perm(sy[3], sy[2], 0x0c0c0400u);
+            return __builtin_amdgcn_perm(w23, w01, 0x05040100u);
+        }
         const uint32_t e0 = *(lds_u16*)(uintptr_t)(ft + (((uint32_t)(win >> 32) >> look_shift) << 1));
         win <<= e0 >> 8;
         const uint32_t e1 = *(lds_u16*)(uintptr_t)(ft + (((uint32_t)(win >> 32) >> look_shift) << 1));
@@ -925,13 +954,13 @@ huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restric
         const uint64_t lim = head != 0 && head < left ? (uint64_t)head : left;
         const bool full = lim >= 64;
         uint32_t wb[16];
-        if constexpr (decltype(SH)::value) {
+        {
             const bool all_full = __ballot(streaming && lim < 64) == 0;      // (lanes without a stream just go through the motions)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
                 if (all_full && __ballot(streaming && P < kFastBits) == 0) {
 #pragma unroll
-                    for (int i = 0; i < 4; i++) wb[4 * g + i] = fast_step();
+                    for (int i = 0; i < 4; i++) wb[4 * g + i] = fast_step(SH);
                 } else {                                          // the ends of the streams: rolled, so that the bulk's registers set the occupancy
                     uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
 #pragma unroll 1
@@ -943,13 +972,6 @@ huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restric
                     }
                     wb[4 * g] = w0; wb[4 * g + 1] = w1; wb[4 * g + 2] = w2; wb[4 * g + 3] = w3;
                 }
-            }
-        } else {
-#pragma unroll
-            for (int sN = 0; sN < 16; sN++) {
-                const uint32_t done = 4u * sN;
-                const uint32_t m = (lim > done && P >= -64) ? (lim - done < 4 ? (uint32_t)(lim - done) : 4u) : 0u;
-                wb[sN] = step(m, SH);
             }
         }
         const uint32_t cnt = lim < 64 ? (uint32_t)lim : 64u;
