@@ -32,8 +32,10 @@ namespace sprintz { int set_error(int code, const char* what); }   // api.hip: t
 
 namespace {
 
-constexpr int kWStride = 256 + 4;                // weights per chunk, padded off the bank stride
-constexpr int kRStride = 344 + 4;                // per chunk: 8 zero bytes + header copy 144 | norm 32 | next 32 | fse 128; later the sorted symbols (256)
+constexpr int kWStride = 128 + 4;                // weights per chunk, a nibble each (symbol 2b = high nibble of byte b), padded off the bank stride
+constexpr int kRStride = 344 + 4;                // per chunk: 8 zero bytes + header copy 144 | norm 32 (later the weight counts) | next 32 | fse 128;
+                                                 // after read_stats2: the sorted symbols (256) | the table words (68)
+constexpr int kCntOff = 152, kTabOff = 256;
 constexpr int64_t kCorrupt = SPRINTZ_E_CORRUPT;
 
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
@@ -47,8 +49,6 @@ __device__ __forceinline__ uint64_t rd40(const uint8_t* h, uint32_t b)
 {
     return (uint64_t)h[b] | ((uint64_t)h[b + 1] << 8) | ((uint64_t)h[b + 2] << 16) | ((uint64_t)h[b + 3] << 24) | ((uint64_t)h[b + 4] << 32);
 }
-// forward LSB-first reader (FSE_readNCount): 32 bits at bit position bp
-__device__ __forceinline__ uint32_t fwd32(const uint8_t* h, uint32_t bp) { return (uint32_t)(rd40(h, bp >> 3) >> (bp & 7u)); }
 // backward reader (BIT_DStream_t as a cursor P = unread bits): the nb (<= 16) bits below P, MSB first, 0 before the start
 __device__ __forceinline__ uint32_t back_look(const uint8_t* h, int P, int nb)
 {
@@ -58,174 +58,22 @@ __device__ __forceinline__ uint32_t back_look(const uint8_t* h, int P, int nb)
     return ((uint32_t)rd40(h, 0) & ((1u << P) - 1u)) << (-lo);
 }
 
-// HUF_readStats (entropy_common.c) over the header bytes h[0..n) (zero padded); weights[0..nsym).
-// Scratch s: int16 norm[16] | u16 next[16] | u16 fse[64]: weights are < 12, so a description that
-// gives probability to a symbol >= 16 is damaged.  Returns header bytes, 0 if damaged.
-__device__ uint32_t read_stats(const uint8_t* h, uint32_t n, uint8_t* weights, uint8_t* s, uint32_t& nsym, uint32_t& tl_out)
-{
-    if (n < 1) return 0;
-    uint32_t isize = h[0], osize;
-    if (isize >= 128) {                                           // 4-bit weights
-        osize = isize - 127;
-        isize = (osize + 1) / 2;
-        if (isize + 1 > n) return 0;
-        for (uint32_t k = 0; k < osize; k += 2) {
-            weights[k] = h[1 + k / 2] >> 4;
-            weights[k + 1] = h[1 + k / 2] & 15;
-        }
-    } else {                                                      // FSE_decompress_wksp, table log <= 6
-        if (isize + 1 > n) return 0;
-        const uint8_t* const f = h + 1;
-        int16_t* const norm = (int16_t*)s;
-        uint16_t* const next = (uint16_t*)(s + 32);
-        uint16_t* const fse = (uint16_t*)(s + 64);                // symbol | nbits << 4 | new_state << 8
-        for (int k = 0; k < 16; k++) norm[k] = 0;
-        // FSE_readNCount
-        uint32_t bp = 0;
-        int nb = (int)(fwd32(f, bp) & 0xf) + 5;
-        if (nb > 6) return 0;                                     // tableLog > maxLog (6)
-        bp += 4;
-        const uint32_t tl = (uint32_t)nb;
-        int remaining = (1 << nb) + 1, threshold = 1 << nb;
-        nb++;
-        uint32_t charnum = 0;
-        bool previous0 = false;
-        const uint32_t bit_end = 8u * isize;
-        while (remaining > 1 && charnum <= 255u) {
-            if (previous0) {
-                uint32_t n0 = charnum;
-                while ((fwd32(f, bp) & 0xffffu) == 0xffffu) { n0 += 24; bp += 16; if (bp > bit_end) return 0; }
-                while ((fwd32(f, bp) & 3u) == 3u) { n0 += 3; bp += 2; if (bp > bit_end) return 0; }
-                n0 += fwd32(f, bp) & 3u;
-                bp += 2;
-                if (n0 > 255u) return 0;
-                charnum = n0;                                     // norm is zero there already
-            }
-            const uint32_t bits = fwd32(f, bp);
-            const int max = (2 * threshold - 1) - remaining;
-            int count;
-            if ((int)(bits & (uint32_t)(threshold - 1)) < max) {
-                count = (int)(bits & (uint32_t)(threshold - 1));
-                bp += (uint32_t)(nb - 1);
-            } else {
-                count = (int)(bits & (uint32_t)(2 * threshold - 1));
-                if (count >= threshold) count -= max;
-                bp += (uint32_t)nb;
-            }
-            count--;
-            remaining -= count < 0 ? -count : count;
-            if (charnum > 255u || bp > bit_end) return 0;
-            if (charnum >= 16u) { if (count != 0) return 0; charnum++; }
-            else norm[charnum++] = (int16_t)count;
-            previous0 = count == 0;
-            while (remaining < threshold) { nb--; threshold >>= 1; }
-        }
-        if (remaining != 1 || bp > bit_end || charnum == 0) return 0;
-        const uint32_t max_sv = (charnum < 16u ? charnum : 16u) - 1, hl = (bp + 7) >> 3;
-        if (hl >= isize) return 0;
-        // FSE_buildDTable
-        const uint32_t size = 1u << tl;
-        uint32_t high = size - 1;
-        for (uint32_t sy = 0; sy <= max_sv; sy++) {
-            if (norm[sy] == -1) { fse[high--] = (uint16_t)sy; next[sy] = 1; }
-            else next[sy] = (uint16_t)norm[sy];
-        }
-        {
-            const uint32_t mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
-            uint32_t pos = 0, placed = 0;
-            for (uint32_t sy = 0; sy <= max_sv; sy++)
-                for (int i = 0; i < norm[sy]; i++) {
-                    if (++placed > size) return 0;
-                    fse[pos] = (uint16_t)sy;
-                    pos = (pos + step) & mask;
-                    while (pos > high) pos = (pos + step) & mask;
-                }
-            if (pos != 0) return 0;
-        }
-        for (uint32_t u = 0; u < size; u++) {
-            const uint32_t sy = fse[u] & 0xfu, ns = next[sy]++;
-            if (ns == 0 || ns >= 2 * size) return 0;
-            const uint32_t nbits = tl - (uint32_t)highbit(ns);
-            fse[u] = (uint16_t)(sy | (nbits << 4) | (((ns << nbits) - size) << 8));
-        }
-        // FSE_decompress_usingDTable: two interleaved states; the stream ends by running dry
-        const uint8_t* const b = f + hl;
-        const uint32_t bn = isize - hl;
-        if (b[bn - 1] == 0) return 0;
-        int P = 8 * (int)(bn - 1) + highbit(b[bn - 1]);
-        uint32_t s1 = back_look(b, P, (int)tl); P -= (int)tl;
-        uint32_t s2 = back_look(b, P, (int)tl); P -= (int)tl;
-        osize = 0;
-        // the stream's next 64 bits ride in a register, refilled every 8 weights (8 x 6 bits <= the 57 a refill guarantees)
-        for (;;) {
-            uint64_t win = 0;
-            if (P > 0) {
-                const int tb = (P - 1) >> 3;
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const int at = tb - 7 + k;
-                    win |= (uint64_t)(at >= 0 ? b[at] : (uint8_t)0) << (8 * k);
-                }
-                win <<= 7 - ((P - 1) & 7);
-                if (P < 64) win &= ~0ull << (64 - P);
-            }
-            bool done = false;
-#pragma unroll
-            for (int r = 0; r < 4 && !done; r++) {
-                if (osize + 2 > 255u) return 0;
-                uint32_t e = fse[s1];
-                weights[osize++] = (uint8_t)(e & 0xfu);
-                uint32_t nbt = (e >> 4) & 0xfu;
-                s1 = (e >> 8) + (nbt ? (uint32_t)(win >> (64u - nbt)) : 0u);
-                win <<= nbt;
-                P -= (int)nbt;
-                if (P < 0) { weights[osize++] = (uint8_t)(fse[s2] & 0xfu); done = true; break; }
-                if (osize + 2 > 255u) return 0;
-                e = fse[s2];
-                weights[osize++] = (uint8_t)(e & 0xfu);
-                nbt = (e >> 4) & 0xfu;
-                s2 = (e >> 8) + (nbt ? (uint32_t)(win >> (64u - nbt)) : 0u);
-                win <<= nbt;
-                P -= (int)nbt;
-                if (P < 0) { weights[osize++] = (uint8_t)(fse[s1] & 0xfu); done = true; break; }
-            }
-            if (done) break;
-        }
-    }
-    // weight statistics; the last symbol's weight is implied
-    uint32_t total = 0, rank1 = 0;
-    for (uint32_t k = 0; k < osize; k++) {
-        const uint32_t w = weights[k];
-        if (w >= 12u) return 0;
-        rank1 += w == 1u;
-        total += (1u << w) >> 1;
-    }
-    if (total == 0) return 0;
-    const uint32_t tl = (uint32_t)highbit(total) + 1u;
-    if (tl > 12u) return 0;
-    const uint32_t rest = (1u << tl) - total;
-    if ((1u << highbit(rest)) != rest) return 0;
-    const uint32_t lw = (uint32_t)highbit(rest) + 1u;
-    weights[osize] = (uint8_t)lw;
-    rank1 += lw == 1u;
-    if (rank1 < 2 || (rank1 & 1u)) return 0;
-    nsym = osize + 1;
-    tl_out = tl;
-    return isize + 1;
-}
-
-// ---- the same function as the tree kernel runs it: one lane per chunk, every lane of the wave busy, so what counts
-// is the length of the DEPENDENT chain of LDS round trips.  Differences in form, none in result (every rejection of
-// read_stats is kept): the header copy `hb` carries 8 zero bytes in front and zero padding behind, so bit fields are
-// two aligned dwords + v_alignbit instead of five byte reads; the two FSE states' table reads are issued together;
-// the weights are read back four at a time; the per-weight counts are LDS adds with no return (cnt[13], zeroed by
-// the caller; on return cnt[w] = number of symbols of weight w, the implied last one included).
+// ---- HUF_readStats (entropy_common.c) as the tree kernel runs it: one lane per chunk, every lane of the wave busy, so
+// what counts is the length of the DEPENDENT chain of LDS round trips and the LDS a lane holds (it sets the waves a CU
+// keeps).  Every rejection of the CPU function is kept.  The header copy `hb` carries 8 zero bytes in front and zero
+// padding behind, so bit fields are two aligned dwords + v_alignbit instead of five byte reads; the two FSE states' table
+// reads are issued together; the weights are kept a nibble each (wq: symbol 2b = high nibble of byte b -- the order of
+// the 4-bit description, which is then just copied), written and read back eight at a time; the per-weight counts are
+// LDS adds with no return (cnt[13], over the dead norm[]; on return cnt[w] = number of symbols of weight w, the implied
+// last one included).  s: int16 norm[16] | u16 next[16] | u16 fse[64]: weights are < 12, so a description that gives
+// probability to a symbol >= 16 is damaged.  Returns header bytes, 0 if damaged.
 __device__ __forceinline__ uint32_t hb32(const uint8_t* hb, uint32_t bitpos)                       // 32 bits at bit `bitpos` of hb, LSB first
 {
     const uint32_t* const q = (const uint32_t*)hb + (bitpos >> 5);
     return __builtin_amdgcn_alignbit(q[1], q[0], bitpos & 31u);
 }
-__device__ uint32_t read_stats2(const uint8_t* hb, uint32_t n, uint8_t* weights, uint8_t* s, uint32_t* cnt, uint32_t& nsym, uint32_t& tl_out)
+__device__ __forceinline__ uint32_t nib_shift(uint32_t i) { return 8u * ((i & 7u) >> 1) + ((i & 1u) ? 0u : 4u); }   // weight i in its dword
+__device__ uint32_t read_stats2(const uint8_t* hb, uint32_t n, uint32_t* wq, uint8_t* s, uint32_t* cnt, uint32_t& nsym, uint32_t& tl_out)
 {
     const uint8_t* const h = hb + 8;
     if (n < 1) return 0;
@@ -234,11 +82,7 @@ __device__ uint32_t read_stats2(const uint8_t* hb, uint32_t n, uint8_t* weights,
         osize = isize - 127;
         isize = (osize + 1) / 2;
         if (isize + 1 > n) return 0;
-        for (uint32_t k = 0; k < osize; k += 2) {
-            const uint32_t v = h[1 + k / 2];
-            weights[k] = (uint8_t)(v >> 4);
-            weights[k + 1] = (uint8_t)(v & 15u);
-        }
+        for (uint32_t k = 0; 8 * k < osize; k++) wq[k] = hb32(hb, 72u + 32u * k);      // the description IS the nibbles, in this order
     } else {                                                      // FSE_decompress_wksp, table log <= 6
         if (isize + 1 > n) return 0;
         int16_t* const norm = (int16_t*)s;
@@ -325,7 +169,7 @@ __device__ uint32_t read_stats2(const uint8_t* hb, uint32_t n, uint8_t* weights,
         const uint32_t B0 = 8u + 1u + hl;                         // byte offset of the bit stream in hb
         // the stream's next 64 bits ride in a register, refilled every 8 weights (8 x 6 bits <= the 57 a refill guarantees)
         bool done = false;
-        while (!done) {
+        while (!done) {                                           // eight weights a trip: one dword of nibbles
             uint64_t win = 0;
             if (P > 0) {
                 const uint32_t a = B0 + ((uint32_t)(P - 1) >> 3) - 7u;            // first of the 8 bytes that end at the cursor's byte (>= 2)
@@ -335,38 +179,52 @@ __device__ uint32_t read_stats2(const uint8_t* hb, uint32_t n, uint8_t* weights,
                 win = (((uint64_t)hi << 32) | lo) << (7 - ((P - 1) & 7));
                 if (P < 64) win &= ~0ull << (64 - P);             // nothing before the stream's first bit
             }
+            uint32_t pack = 0, spill = 0;
+            const uint32_t q0 = osize >> 3;                       // osize is a multiple of 8 here
+            bool over = false;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const uint32_t e1 = fse[s1], e2 = fse[s2];       // both table reads in flight together
                 if (osize + 2 > 255u) return 0;
-                weights[osize++] = (uint8_t)(e1 & 0xfu);
+                pack |= (e1 & 0xfu) << (8 * r + 4);
+                osize++;
                 uint32_t nbt = (e1 >> 4) & 0xfu;
                 s1 = (e1 >> 8) + ((((uint32_t)(win >> 32)) >> 1) >> (31u - nbt));
                 win <<= nbt;
                 P -= (int)nbt;
-                if (P < 0) { weights[osize++] = (uint8_t)(e2 & 0xfu); done = true; break; }
+                if (P < 0) { pack |= (e2 & 0xfu) << (8 * r); osize++; done = true; break; }
                 if (osize + 2 > 255u) return 0;
-                weights[osize++] = (uint8_t)(e2 & 0xfu);
+                pack |= (e2 & 0xfu) << (8 * r);
+                osize++;
                 nbt = (e2 >> 4) & 0xfu;
                 s2 = (e2 >> 8) + ((((uint32_t)(win >> 32)) >> 1) >> (31u - nbt));
                 win <<= nbt;
                 P -= (int)nbt;
-                if (P < 0) { weights[osize++] = (uint8_t)(fse[s1] & 0xfu); done = true; break; }
+                if (P < 0) {
+                    const uint32_t w = fse[s1] & 0xfu;
+                    if (r < 3) pack |= w << (8 * (r + 1) + 4); else { spill = w << 4; over = true; }
+                    osize++;
+                    done = true;
+                    break;
+                }
             }
+            wq[q0] = pack;
+            if (over) wq[q0 + 1] = spill;
         }
     }
-    // weight statistics, four weights a read; the last symbol's weight is implied
+    // weight statistics, eight weights a read; the last symbol's weight is implied.  The counts take the place of norm.
+    for (int k = 0; k < 13; k++) cnt[k] = 0;
     uint32_t total = 0, rank1 = 0;
     bool heavy = false;
-    for (uint32_t k = 0; k < osize; k += 4) {
-        const uint32_t four = *(const uint32_t*)(weights + k);
+    for (uint32_t k = 0; k < osize; k += 8) {
+        const uint32_t eight = wq[k >> 3];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t w = (four >> (8 * i)) & 0xffu;
+        for (int i = 0; i < 8; i++) {
+            const uint32_t w = (eight >> (8 * (i >> 1) + ((i & 1) ? 0 : 4))) & 0xfu;
             if (k + i < osize) {
                 heavy |= w >= 12u;
                 rank1 += w == 1u;
-                total += (1u << (w & 31u)) >> 1;
+                total += (1u << w) >> 1;
                 __hip_atomic_fetch_add(&cnt[w < 12u ? w : 0u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
         }
@@ -378,7 +236,10 @@ __device__ uint32_t read_stats2(const uint8_t* hb, uint32_t n, uint8_t* weights,
     const uint32_t rest = (1u << tl) - total;
     if ((1u << highbit(rest)) != rest) return 0;
     const uint32_t lw = (uint32_t)highbit(rest) + 1u;
-    weights[osize] = (uint8_t)lw;
+    {
+        const uint32_t sh = nib_shift(osize), old = (osize & 7u) ? wq[osize >> 3] : 0u;     // (a fresh dword if osize is a multiple of 8)
+        wq[osize >> 3] = (old & ~(0xfu << sh)) | (lw << sh);
+    }
     __hip_atomic_fetch_add(&cnt[lw], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     rank1 += lw == 1u;
     if (rank1 < 2 || (rank1 & 1u)) return 0;
@@ -478,8 +339,6 @@ __global__ void __launch_bounds__(64) huf0_tree_kernel(const uint8_t* __restrict
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_w[64 * kWStride];
     __shared__ __attribute__((aligned(16))) uint8_t s_r[64 * kRStride];
-    __shared__ uint32_t s_tab[64][17];
-    __shared__ uint32_t s_run[64][13];
     __shared__ uint64_t s_src[64];
     __shared__ uint32_t s_hc[64];
     __shared__ uint64_t s_chunk[64];                              // the chunk a lane works on, or ~0: nothing to write back
@@ -517,50 +376,64 @@ __global__ void __launch_bounds__(64) huf0_tree_kernel(const uint8_t* __restrict
         for (int i = 0; i < 8; i++)
             if (t < 38) *(uint32_t*)(s_r + (c0 + i) * kRStride + 4u * (uint32_t)t) = v[i];
     }
-#pragma unroll
-    for (int w = 0; w < 13; w++) s_tab[t][w] = 0;                 // the per-weight counts
     wave_sync();
-    uint8_t* const wts = s_w + t * kWStride;
+    uint32_t* const wq = (uint32_t*)(s_w + t * kWStride);
     uint8_t* const scratch = s_r + t * kRStride;
     uint8_t* const sorted = scratch;
+    uint32_t* const tab = (uint32_t*)(scratch + kTabOff);         // over the FSE table, dead by then
     uint32_t hl = 0, nsym = 0, tl = 0;
-    if (coded) {
-        hl = read_stats2(scratch, hcopy, wts, scratch + 152, &s_tab[t][0], nsym, tl);
-        if (hl >= csize) hl = 0;
-    }
-    if (hl) {
-        // start[w] (first table index of weight w), symoff[w], and the symbols sorted by (weight, symbol)
-        uint32_t cnt[13];
+    uint32_t cnt[13];
 #pragma unroll
-        for (int w = 1; w < 13; w++) cnt[w] = s_tab[t][w];
+    for (int w = 0; w < 13; w++) cnt[w] = 0;
+    if (coded) {
+        uint32_t* const c = (uint32_t*)(scratch + kCntOff);
+        hl = read_stats2(scratch, hcopy, wq, scratch + 152, c, nsym, tl);
+        if (hl >= csize) hl = 0;
+        if (hl) {
+#pragma unroll
+            for (int w = 1; w < 13; w++) cnt[w] = c[w];
+        }
+    }
+    // start[w] (first table index of weight w) | symoff[w] << 16; the symbols sorted by (weight, symbol)
+    {
         uint32_t at = 0, so = 0;
 #pragma unroll
         for (int w = 1; w < 13; w++) {
-            s_tab[t][w] = at | (so << 16);
-            s_run[t][w] = so;
+            tab[w] = at | (so << 16);
             at += cnt[w] << (w - 1);
             so += cnt[w];
         }
+        tab[0] = hl | (tl << 16);
+        tab[13] = tab[14] = tab[15] = tab[16] = 0;
+    }
+    if (hl) {
         // (zeroed first: blocks with the same tree description must give byte-identical descriptors -- the stream kernel
         //  shares one decode table among the chunks of a wave when they do)
         for (int k = 0; k < 64; k++) ((uint32_t*)sorted)[k] = 0;
-        // counting sort, four symbols a trip: their slots come back from four LDS adds issued together
-        // (DS operations of a wave execute in issue order, so equal weights keep their symbol order)
-        for (uint32_t sy = 0; sy < nsym; sy += 4) {
-            const uint32_t four = *(const uint32_t*)(wts + sy);
-            uint32_t pos[4];
+        // counting sort, eight symbols a trip: their slots come back from eight LDS adds issued together (DS operations
+        // of a wave execute in issue order, so equal weights keep their symbol order).  The running slot of weight w is
+        // the upper half of tab[w]; the table words are written again afterwards.
+        for (uint32_t sy = 0; sy < nsym; sy += 8) {
+            const uint32_t eight = wq[sy >> 3];
+            uint32_t pos[8];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const uint32_t w = (four >> (8 * i)) & 0xffu;
+            for (int i = 0; i < 8; i++) {
+                const uint32_t w = (eight >> (8 * (i >> 1) + ((i & 1) ? 0 : 4))) & 0xfu;
                 pos[i] = 0xffffffffu;
-                if (sy + i < nsym && w) pos[i] = __hip_atomic_fetch_add(&s_run[t][w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if (sy + i < nsym && w) pos[i] = __hip_atomic_fetch_add(&tab[w], 0x10000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) >> 16;
             }
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < 8; i++)
                 if (pos[i] != 0xffffffffu) sorted[pos[i] & 0xffu] = (uint8_t)(sy + i);
         }
+        uint32_t at = 0, so = 0;
+#pragma unroll
+        for (int w = 1; w < 13; w++) {
+            tab[w] = at | (so << 16);
+            at += cnt[w] << (w - 1);
+            so += cnt[w];
+        }
     }
-    s_tab[t][0] = hl | (tl << 16);
     wave_sync();
     // descriptors out: 64 dwords of sorted symbols + 13 words of table per chunk, one chunk per trip
     for (int c = 0; c < 64; c++) {
@@ -569,7 +442,7 @@ __global__ void __launch_bounds__(64) huf0_tree_kernel(const uint8_t* __restrict
         uint8_t* const d = desc + ch * kDescStride;
         const uint32_t v = *(const uint32_t*)(s_r + c * kRStride + 4 * t);
         *(uint32_t*)(d + 4 * t) = v;
-        if (t < 16) *(uint32_t*)(d + 256 + 4 * t) = t < 13 ? s_tab[c][t] : 0u;      // the whole descriptor is defined: equal trees give equal bytes
+        if (t < 16) *(uint32_t*)(d + 256 + 4 * t) = t < 13 ? *(const uint32_t*)(s_r + c * kRStride + kTabOff + 4 * t) : 0u;   // all of it defined: equal trees, equal bytes
     }
 }
 
