@@ -432,7 +432,7 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     // straight from the dword (3 VALU per sample instead of bfe + 3); for an empty column
     // (nb == 0) both widths are 0 and the field reads as 0.  The XOR lands in the UPPER
     // half of the register (SDWA dst_sel:WORD_1), i.e. it yields E = err << 16 directly,
-    // which is what the FIRE step and the sign test want (W == 16); for W == 8 a shift follows.
+    // which is what the FIRE step and the sign test want (W == 16); for W == 8 one shift follows (FIRE) or none (delta).
     auto fetch_rows = [&](int (&e)[CPL][8], uint32_t at, const uint32_t (&off)[CPL], const uint32_t (&nb)[CPL], uint32_t row_bytes) {
 #pragma unroll
         for (int k = 0; k < CPL; k++) {
@@ -450,14 +450,16 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
                     asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0"
                         : "=v"(x) : "v"(mag), "v"(sgn));
                     e[k][i] = x;                           // err << 16
+                } else if constexpr (FIRE) {
+                    e[k][i] = (int)(mag ^ (uint32_t)sgn) << 8;            // err << 8 (mag ^ sgn is err, sign and all)
                 } else {
-                    e[k][i] = (int)((mag ^ (uint32_t)sgn) << 24) >> 16;   // err << 8, sign-extended
+                    e[k][i] = (int)(mag ^ (uint32_t)sgn);                 // the delta itself: nothing to scale it for
                 }
                 p += row_bytes;
             }
         }
     };
-    // zigzag^-1 is done; e[][] holds E = err << W (sign-extended to 32 bits)
+    // zigzag^-1 is done; e[][] holds E = err << W (sign-extended to 32 bits); 8-bit delta coding: err itself
     auto packed_block = [&](const int (&e)[CPL][8], int slot) {   // forecast recurrence (:993-1150)
         if (out_left < blk_elems) { corrupt = true; return; }
         out_left -= blk_elems;
@@ -480,7 +482,7 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
                         if (i & 1) grad = mad24(sign_of(e[k][i]), pd[k], grad);
                         delta = __builtin_amdgcn_sbfe(mad24(pd[k], coef, e[k][i]), W, W);
                     } else {
-                        delta = e[k][i] >> W;
+                        delta = e[k][i];
                     }
                     pv[k] += (uint32_t)delta;
                     pd[k] = delta;
