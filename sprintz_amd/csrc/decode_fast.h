@@ -234,7 +234,16 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     const uint32_t blk_bytes = blk_elems * ESZ;
     const uint32_t row_stride = (uint32_t)D * ESZ;
     const int col0 = lane_d * CPL;                         // first column of this lane
-    uint8_t* const stage_col = stage + col0 * ESZ;
+    // A lane column past the last one (ndims is not DP*CPL) stands in for column D-1: it reads the same header fields and
+    // bit fields, runs the same recurrence and stages the same bytes at the same place as the genuine one -- so the per-sample
+    // code needs no predicate (54 exec-mask regions a group step at 80 columns on 64 x 2); only the scan must not count it.
+    int colk[CPL];
+    uint8_t* stage_k[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; k++) {
+        colk[k] = EXACT ? col0 + k : (col0 + k < D ? col0 + k : D - 1);
+        stage_k[k] = stage + colk[k] * ESZ;
+    }
 
     uint32_t pv[CPL];
     int pd[CPL], ctr[CPL];
@@ -420,7 +429,7 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
                     q_row(k);
                     pack_row(k, i);
                     if constexpr (Q != kQueryReduceOnly && !CM)
-                        if (col_ok[k]) *(U*)(stage_col + k * ESZ + i * row_stride) = (U)pv[k];
+                        *(U*)(stage_k[k] + i * row_stride) = (U)pv[k];
                 }
                 q_block(k);
             }
@@ -490,7 +499,7 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
                 q_row(k);
                 pack_row(k, i);
                 if constexpr (Q != kQueryReduceOnly && !CM)
-                    if (col_ok[k]) *(U*)(stage_col + k * ESZ + i * row_stride) = (U)pv[k];
+                    *(U*)(stage_k[k] + i * row_stride) = (U)pv[k];
             }
             q_block(k);
             if constexpr (FIRE) ctr[k] = wrap_counter<W>(ctr[k] + __builtin_amdgcn_sbfe(grad, 2, W - 2));   // sext_W(grad) >> 2
@@ -573,16 +582,13 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         uint32_t nb_both[CPL], lane_both = 0;
 #pragma unroll
         for (int k = 0; k < CPL; k++) {
-            const uint32_t hbit0 = (uint32_t)(col0 + k) * HB, hbit1 = (uint32_t)(D + col0 + k) * HB;
-            uint32_t f0 = 0, f1 = 0;
-            if (col_ok[k]) {
-                f0 = __builtin_amdgcn_ubfe(lds_rd32(r + (hbit0 >> 3)), hbit0 & 7u, HB);
-                f1 = __builtin_amdgcn_ubfe(lds_rd32(r + (hbit1 >> 3)), hbit1 & 7u, HB);
-            }
+            const uint32_t hbit0 = (uint32_t)colk[k] * HB, hbit1 = (uint32_t)(D + colk[k]) * HB;
+            uint32_t f0 = __builtin_amdgcn_ubfe(lds_rd32(r + (hbit0 >> 3)), hbit0 & 7u, HB);
+            uint32_t f1 = __builtin_amdgcn_ubfe(lds_rd32(r + (hbit1 >> 3)), hbit1 & 7u, HB);
             f0 += (f0 == (uint32_t)(W - 1));               // W-1 means W (:747-749)
             f1 += (f1 == (uint32_t)(W - 1));
             nb_both[k] = f0 | (f1 << 16);
-            lane_both += nb_both[k];
+            lane_both += col_ok[k] ? nb_both[k] : 0u;
         }
         uint32_t tot_both;
         uint32_t excl_both = group_scan<DP>(lane_both, lane_d, tot_both);
@@ -590,8 +596,9 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         uint32_t off0[CPL], off1[CPL], nb0[CPL], nb1[CPL];
 #pragma unroll
         for (int k = 0; k < CPL; k++) {
-            off0[k] = excl_both & 0xffffu;
-            off1[k] = excl_both >> 16;
+            const uint32_t o_both = col_ok[k] ? excl_both : tot_both - nb_both[k];   // (a stand-in: where column D-1 starts)
+            off0[k] = o_both & 0xffffu;
+            off1[k] = o_both >> 16;
             nb0[k] = nb_both[k] & 0xffffu;
             nb1[k] = nb_both[k] >> 16;
             excl_both += nb_both[k];
