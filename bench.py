@@ -315,7 +315,7 @@ def bench_rowmajor(cx, name, workload, codec, esz, ndims, chunk_len, nchunks_tot
                     "huff0_decode_ms": round(h_dec_ms, 4), "sprintz_decode_ms": round(dec_ms, 4),
                     "compress_ms": round(enc_ms + h_enc_ms, 4), "compress_MBps": round(raw / (enc_ms + h_enc_ms) / 1e3, 1),
                     "huff0_encode_ms": round(h_enc_ms, 4),
-                    "roofline": roofline(algo_chain, chain_ms, "huf0_tree_kernel + huf0_stream_kernel + sprintz decode (three launches)",
+                    "roofline": roofline(algo_chain, chain_ms, "Huff0 stage (tree passes + stream kernels, sprintz_mi355x_huf0_decompress_batch_ws) + sprintz decode; the Sprintz streams cross HBM between the two",
                                          {"huff0_decode_frac": round((hbytes + stream_bytes + 16 * n) / (h_dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})})
         if cx.rank == 0 and not args.no_cpu_baseline:
             ns = min(n, max(64, (48 << 20) // (chunk_len * esz)))

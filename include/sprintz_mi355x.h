@@ -302,7 +302,7 @@ int64_t sprintz_mi355x_decompress_norle(int codec, int elem_bytes, const void* s
 int sprintz_mi355x_huf0_decompress_batch(const void* d_blocks, const uint64_t* d_block_offsets, uint64_t nchunks, void* d_out,
                                          const uint64_t* d_out_offsets, int64_t* d_rets, void* hip_stream);
 /* The same with the caller's workspace (d_tmp: sprintz_mi355x_huf0_decode_tmp_bytes(nchunks) bytes, 16-byte aligned;
- * holds one 320-byte code descriptor per chunk between the two launches).  The form above allocates it
+ * holds one 320-byte code descriptor per chunk and two flag arrays between the launches).  The form above allocates it
  * stream-ordered (hipMallocAsync) per call; a caller with a steady batch size passes its own.  A block's
  * streams are limited to 128 MiB each (HUF_compress never writes a block above 128 KB). */
 size_t sprintz_mi355x_huf0_decode_tmp_bytes(uint64_t nchunks);

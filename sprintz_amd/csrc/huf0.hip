@@ -9,18 +9,15 @@
 // takes 16 chunks, lane = (chunk, stream).  The library's decoder looks codes up in a
 // 2^tableLog-entry table; 16 such tables are 64 KB of LDS and leave a CU two waves (measured:
 // 4.6 ms on the headline shape, every phase latency-bound).  The code is canonical -- per code
-// length ascending symbols, the longest codes lowest (HUF_readDTableX1's fill order) -- so the
-// table is not needed: with start[w] = the first table index of weight w, a look-ahead value
-// idx has weight w = 1 + #{k >= 2 : start[k] <= idx} (11 compare-and-adds on per-lane
-// registers), its symbol is sorted[symoff[w] + ((idx - start[w]) >> (w - 1))] and it is
-// tableLog + 1 - w bits long.  Per chunk that is 256 bytes of sorted symbols and 13 words in
-// LDS instead of 4 KB, a dozen waves per CU instead of two, and every table log the format
-// allows (12 included).  Headline shape (131 072 blocks of ~3.4 KB): 1.4 ms, of which phases
-// A + B 0.5 and C 0.9 (its ~200 VALU per 4 symbols bound it at ~0.6).
-// Phase A (first lane of each quad, serial): tree description -> weights; the FSE-compressed form
-// is decoded with a 64-entry table in LDS.  Phase B (same lane): counting sort of the symbols by
-// weight.  Phase C (every lane): its stream, read from the last byte down through a 64-bit
-// window, 4 symbols per refill, refilled from 16-byte aligned pieces held in registers.
+// length ascending symbols, the longest codes lowest (HUF_readDTableX1's fill order) -- so a
+// block's table follows from the symbols sorted by (weight, symbol) and start[w] = the first
+// table index of weight w: a look-ahead value idx of weight w has the symbol
+// sorted[symoff[w] + ((idx - start[w]) >> (w - 1))] and is tableLog + 1 - w bits long.  That
+// 320-byte DESCRIPTOR per chunk is what the tree passes leave in global memory and what the
+// stream kernels build their LDS tables from:
+//   follow -> tree<1> (segment leaders) -> copy (followers) -> tree<2> (everybody else) -> share
+//   -> stream<true> (segments with one tree: one full table a wave) -> stream<false> (the rest:
+//   an 8-bit prefix table per chunk).  DESIGN.md 4.4b has the measurements behind each step.
 #include "../../include/sprintz_mi355x.h"
 
 #include <hip/hip_runtime.h>
@@ -257,17 +254,15 @@ __device__ __forceinline__ void wave_sync()
 }
 
 // ---------------------------------------------------------------------------------------------
-// Two launches.  (1) huf0_tree_kernel: ONE LANE PER CHUNK (64 chunks a wave) turns every coded
-// block's tree description into a 320-byte descriptor in global memory: the symbols sorted by
-// (weight, symbol), start[w] | symoff[w] << 16 for w = 1..12, and the header length / table log.
-// Phases A and B used to run on the first lane of each quad of the stream decoder -- a quarter of
-// the lanes for a third of its instructions (0.5 of 1.4 ms on the headline shape).
-// (2) huf0_stream_kernel: lane = (chunk, stream), 16 chunks a wave, as before -- but a symbol is no
-// longer an 11-step weight search.  The top 8 bits of the look-ahead index a per-chunk 256-entry
-// table in LDS that resolves every code of <= 8 bits (symbol | length << 8); longer codes can only
-// have the weights 1 .. tableLog - 8 <= 4, so THEIR weight is three compares against start[2..4],
-// and their symbol one more LDS read from the sorted list.  Both reads are issued together; the
-// dependent chain of a symbol is one LDS round trip.
+// The tree passes.  huf0_tree_kernel: ONE LANE PER CHUNK (64 chunks a wave) turns a coded block's tree
+// description into the descriptor: the symbols sorted by (weight, symbol), start[w] | symoff[w] << 16 for
+// w = 1..12, and the header length / table log.  (Round 1 ran this on the first lane of each quad of the
+// stream decoder -- a quarter of the lanes for a third of its instructions, 0.5 of 1.4 ms on the headline shape.)
+// The stream kernels: lane = (chunk, stream), 16 chunks a wave.  Per-chunk tables (SO = false): the top 8
+// bits of the look-ahead index a 256-entry table in LDS that resolves every code of <= 8 bits
+// (symbol | length << 8); longer codes can only have the weights 1 .. tableLog - 8 <= 4, so THEIR weight is
+// three compares against start[2..4] -- or sits in the entry when the prefix holds one weight only -- and
+// their symbol one more LDS read from the sorted list.  One table for the wave (SO = true): see below.
 constexpr int kDescStride = 320;                 // sorted[256] | u32 tab[16]: [0] = hl | tl << 16, [w] = start[w] | symoff[w] << 16
 constexpr int kCStride = 256 + 64 + 512 + 4;     // stream kernel, per chunk in LDS: sorted | tab | table8; odd in dwords
 // stream kernel, per lane: a ring of two PIECES of its stream (+ the first 8 bytes again).  A piece is 16 bytes for the
