@@ -684,13 +684,7 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     } else if (!corrupt && remaining > 0 && Q != kQueryReduceOnly) {
         const uint8_t* t = a.comp + gabs + rp;
         uint8_t* d = (uint8_t*)a.out + out_base + ovo;
-        const uint32_t nbytes = remaining * ESZ;
-        uint32_t done = 0;
-        if ((((uintptr_t)t | (uintptr_t)d) & 7u) == 0) {   // 8 bytes per lane when both sides allow
-            for (uint32_t j = (uint32_t)lane_d; j < (nbytes >> 3); j += DP) ((uint2*)d)[j] = ((const uint2*)t)[j];
-            done = nbytes & ~7u;
-        }
-        for (uint32_t j = done + (uint32_t)lane_d; j < nbytes; j += DP) d[j] = t[j];
+        copy_verbatim(t, d, remaining * ESZ, (uint32_t)lane_d, (uint32_t)DP);
     }
     if (corrupt || remaining > 0) need_prime = true;       // cursor no longer at the next stream
     if (lane_d == 0 && a.rets) a.rets[chunk] = corrupt ? kErrCorrupt : (int64_t)out_elems + remaining;

@@ -348,13 +348,7 @@ __global__ void __launch_bounds__(kThreads) decode_kernel(DecodeArgs a)
     } else if (!corrupt && Q != kQueryReduceOnly) {
         const uint8_t* t = s + pos;
         uint8_t* d = (uint8_t*)(o + out_elems);
-        const uint32_t nbytes = remaining * ESZ;
-        uint32_t done = 0;
-        if ((((uintptr_t)t | (uintptr_t)d) & 7u) == 0) {   // 8 bytes per lane when both sides allow
-            for (uint32_t j = (uint32_t)lane_d; j < (nbytes >> 3); j += (uint32_t)DP) ((uint2*)d)[j] = ((const uint2*)t)[j];
-            done = nbytes & ~7u;
-        }
-        for (uint32_t j = done + (uint32_t)lane_d; j < nbytes; j += (uint32_t)DP) d[j] = t[j];
+        copy_verbatim(t, d, remaining * ESZ, (uint32_t)lane_d, (uint32_t)DP);
     }
     if (lane_d == 0 && a.rets) a.rets[chunk] = corrupt ? kErrCorrupt : (int64_t)out_elems + remaining;
 }

@@ -70,18 +70,13 @@ __global__ void __launch_bounds__(kThreads) encode_kernel(EncodeArgs a)
 
     // A chunk too short for one group (n < 128 or n < 16 D: BASELINE config 3 at 1 KB chunks) is
     // stored verbatim behind its header (sprintz_xff_rle.cpp:116-124, :158-160): straight copy,
-    // 8 bytes per lane, instead of the byte-wise trip through the LDS ring below.
+    // 16 bytes per lane, instead of the byte-wise trip through the LDS ring below.
     if (!a.norle && !cs && !(n >= 128u && (int64_t)n - 16 * (int64_t)D >= 0)) {
         const uint32_t hdr = a.write_size ? 8u : 0u;
         const uint8_t* src = (const uint8_t*)sc;
         uint8_t* dst = gdst + hdr;
         const uint32_t nbytes = n * ESZ;
-        uint32_t done = 0;
-        if ((((uintptr_t)src | (uintptr_t)dst) & 7u) == 0) {
-            for (uint32_t j = (uint32_t)lane_d; j < (nbytes >> 3); j += (uint32_t)DP) ((uint2*)dst)[j] = ((const uint2*)src)[j];
-            done = nbytes & ~7u;
-        }
-        for (uint32_t j = done + (uint32_t)lane_d; j < nbytes; j += (uint32_t)DP) dst[j] = src[j];
+        copy_verbatim<false>(src, dst, nbytes, (uint32_t)lane_d, (uint32_t)DP);      // (the compaction pass reads it next: ordinary stores)
         // slots are zero padded to 16 bytes (sprintz_mi355x_compact copies whole 16-byte units: the container's
         // alignment padding must not carry stale workspace bytes)
         for (uint32_t j = hdr + nbytes + (uint32_t)lane_d; j < ((hdr + nbytes + 15u) & ~15u); j += (uint32_t)DP) gdst[j] = 0;

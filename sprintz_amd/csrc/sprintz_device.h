@@ -136,4 +136,34 @@ __device__ __forceinline__ void wave_lds_sync()
 #endif
 constexpr int kThreads = SPRINTZ_THREADS;        // wavefronts per workgroup x 64
 
+// The verbatim tail of a stream (:1171) -- for chunks shorter than one group, the whole chunk (BASELINE config 3 at
+// 1 KB): `nlanes` lanes copy nbytes from t to d.  16 bytes per lane per trip, FOUR trips' loads issued before the first
+// store (t and d may not alias, but the compiler cannot know: written as load-store pairs, every trip waited for a
+// round trip to memory -- 0.352 ms for 512 MiB of 1 KB chunks); NT: written non-temporally (decoded samples); the tail bytewise.
+template <bool NT = true>
+__device__ __forceinline__ void copy_verbatim(const uint8_t* __restrict__ t, uint8_t* __restrict__ d, uint32_t nbytes, uint32_t lane, uint32_t nlanes)
+{
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    typedef v4u __attribute__((aligned(1), may_alias)) v4u_a1;
+    const uint32_t n16 = nbytes >> 4;
+    for (uint32_t j0 = lane; j0 < n16; j0 += 4u * nlanes) {
+        v4u v[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t j = j0 + k * nlanes;
+            if (j < n16) v[k] = *(const v4u_a1*)(t + 16u * j);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t j = j0 + k * nlanes;
+            if (j < n16) {
+                if constexpr (NT) __builtin_nontemporal_store(v[k], (v4u_a1*)(d + 16u * j));
+                else *(v4u_a1*)(d + 16u * j) = v[k];
+            }
+        }
+    }
+    for (uint32_t j = (n16 << 4) + lane; j < nbytes; j += nlanes) d[j] = t[j];
+}
+
+
 }  // namespace sprintz
