@@ -64,20 +64,26 @@ __global__ void __launch_bounds__(decode_uni_threads(W, ND)) decode_uni_kernel(D
     uint32_t* const my = ring + t;
 
     const uint64_t total = a.offsets[a.nchunks];
-    const uint64_t last16 = total ? (total - 1) >> 4 : 0;
     const uint64_t off = exists ? a.offsets[chunk] : 0;
     const uint64_t stream_len = exists ? a.offsets[chunk + 1] - off : 0;
-    const uint64_t piece0 = off >> 6;
-    const uint8_t* const idle = a.comp;                    // what a lane with no free slot reads instead (one hot line)
+    // All stream loads go through ONE wave-uniform buffer descriptor from the 64-byte line of this wave's first stream to
+    // the end of the container (decode_fast.h does the same): a piece is one 32-bit offset + immediates instead of four
+    // clamped 64-bit addresses (~27 VALU a refill, and the refill code runs in nearly every step: some lane of the 64
+    // always needs one), and a load that runs past the container returns 0 instead of faulting.
+    const uint64_t chunk_w0 = (uint64_t)blockIdx.x * TPB + (uint64_t)(t & ~63);
+    const uint64_t wave_base = wave_uniform64(a.offsets[chunk_w0 < a.nchunks ? chunk_w0 : 0] & ~(uint64_t)63);
+    const uint64_t wave_span = ((total - wave_base) + 15) & ~(uint64_t)15;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.comp + wave_base), 0, (uint32_t)(wave_span < 0xffffffffull ? wave_span : 0xffffffffull), 0x00020000);
+    const uint32_t rel0 = (uint32_t)((off & ~(uint64_t)63) - wave_base);      // this lane's piece 0 (meaningless for a lane without a chunk: it never asks)
     struct Piece { v4 v[4]; };
     auto load_piece = [&](uint32_t k, bool wanted) -> Piece {
         Piece pc;
-        const uint64_t q0 = (piece0 + k) << 2;
+        const uint32_t vo = wanted ? rel0 + (k << 6) : 0u;
 #pragma unroll
         for (int m = 0; m < 4; m++) {
-            uint64_t q = q0 + m;
-            q = q < last16 ? q : last16;
-            pc.v[m] = *(const v4a1*)(wanted ? a.comp + (q << 4) : idle);
+            const auto tt = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo + 16u * m, 0, 0);
+            pc.v[m] = v4{tt[0], tt[1], tt[2], tt[3]};
         }
         return pc;
     };
