@@ -23,12 +23,18 @@ namespace sprintz {
 // refill, so R * STEPMAX <= 64); the ring holds RP pieces so that two refill periods fit behind the cursor's piece.
 // 8-bit univariate streams (BASELINE config 1) take R = 4: one round of loads per 32 samples instead of per 8.
 constexpr int decode_uni_stepmax(int W, int ND) { return (2 * ND * (W == 8 ? 3 : 4) + 7) / 8 + 2 + ND * W; }
-constexpr int decode_uni_refill_every(int W, int ND) { return 1 + 0 * (W + ND); }
+// A piece the cursor makes room for is noticed at the next refill (<= R - 1 blocks later), requested there and parked one
+// refill on: it is resident 2 R - 1 blocks after the cursor entered the piece before it, when the cursor is at most
+// (2 R - 1) STEPMAX bytes in and the next block may look STEPMAX + 12 bytes ahead (a 64-bit payload window = three ring
+// dwords).  Two pieces do while 2 R STEPMAX + 12 <= 64: R = 2 for 8-bit univariate streams (STEPMAX 11) -- the refill
+// code runs in nearly every step it is placed in (one of 64 lanes always has room), so half as often is ~10 VALU and 8
+// LDS writes a block less.
+constexpr int decode_uni_refill_every(int W, int ND) { return (W == 8 && ND == 1) ? 2 : 1; }
 constexpr int decode_uni_ring_pieces(int W, int ND)
 {
     const int r = decode_uni_refill_every(W, ND), sm = decode_uni_stepmax(W, ND), hb = (2 * ND * (W == 8 ? 3 : 4) + 7) / 8;
     if (r == 1) return (2 * sm + hb + 6 <= 64) ? 2 : 4;
-    return 4;                                              // (2 r sm + 63) / 64 + 1 = 4 for r = 4, sm = 11
+    return (2 * r * sm + 12 <= 64) ? 2 : 4;
 }
 constexpr int decode_uni_threads(int W, int ND) { return (decode_uni_ring_pieces(W, ND) == 4 && decode_uni_refill_every(W, ND) > 1) ? 128 : 256; }
 

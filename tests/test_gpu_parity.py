@@ -172,6 +172,44 @@ def test_batched_matches_oracle(sz, oracle, name, codec, esz, ndims, chunk_len):
     assert (r[:-1] == chunk_len).all() and r[-1] == total - (nchunks - 1) * chunk_len
 
 
+@pytest.mark.parametrize("codec,esz,ndims", [("delta", 1, 1), ("xff", 1, 1), ("delta", 2, 1), ("xff", 2, 1), ("delta", 1, 2), ("xff", 1, 3)])
+def test_lowdim_worst_case_streams_keep_the_ring_fed(sz, oracle, codec, esz, ndims):
+    """decode_uni.h refills a lane's 128-byte ring on a fixed cadence (every 2nd block for 8-bit univariate streams): the
+    bound it rests on is the LARGEST block (every field full width).  Chunks that switch between incompressible noise,
+    runs and small steps at random points put the lanes of a wave at every phase of that cadence."""
+    import torch
+    rng = np.random.default_rng(2024 + esz * 10 + ndims)
+    chunk_len, nchunks = 1024 * ndims, 700
+    hi = 256 if esz == 1 else 65536
+    data = np.zeros(nchunks * chunk_len, dtype=np.uint8 if esz == 1 else np.uint16)
+    pos = 0
+    while pos < data.size:
+        n = int(rng.integers(8, 400)) * ndims
+        kind = int(rng.integers(0, 4))
+        seg = data[pos:pos + n]
+        if kind <= 1:
+            seg[:] = rng.integers(0, hi, seg.size)                       # full-width fields, block after block
+        elif kind == 2:
+            seg[:] = data[pos - 1] if pos else 0                         # runs
+        else:
+            seg[:] = (np.cumsum(rng.integers(-2, 3, seg.size)) + 100) % hi
+        pos += n
+    cd = sz.ChunkedCodec(codec, esz, ndims, chunk_len, device="cuda:0")
+    batch = cd.compress(torch.from_numpy(data).cuda())
+    want = oracle.compress_chunks(codec, data, chunk_len, ndims)
+    comp, offs, sizes = batch.data.cpu().numpy(), batch.offsets.cpu().numpy(), batch.sizes.cpu().numpy()
+    for c in range(nchunks):
+        assert sizes[c] == want[c].size and np.array_equal(comp[offs[c]:offs[c] + sizes[c]], want[c]), c
+    assert np.array_equal(cd.decompress(batch).cpu().numpy(), data)
+    # the same streams byte-dense (every alignment of a stream's start inside its 64-byte piece)
+    dense = np.concatenate(want + [np.zeros(64, np.uint8)])
+    doffs = np.zeros(nchunks + 1, np.int64)
+    doffs[1:] = np.cumsum([w.size for w in want])
+    out = torch.empty(nchunks * chunk_len, dtype=torch.uint8 if esz == 1 else torch.int16, device="cuda:0")
+    cd.decompress_into(torch.from_numpy(dense).cuda(), torch.from_numpy(doffs).cuda(), nchunks, out)
+    assert np.array_equal(out.cpu().numpy().view(data.dtype), data)
+
+
 def test_batched_decodes_byte_dense_reference_streams(sz, oracle):
     """streams concatenated with no alignment (odd offsets) decode identically"""
     import torch
