@@ -70,7 +70,8 @@ __device__ __forceinline__ uint32_t hb32(const uint8_t* hb, uint32_t bitpos)    
     return __builtin_amdgcn_alignbit(q[1], q[0], bitpos & 31u);
 }
 __device__ __forceinline__ uint32_t nib_shift(uint32_t i) { return 8u * ((i & 7u) >> 1) + ((i & 1u) ? 0u : 4u); }   // weight i in its dword
-__device__ uint32_t read_stats2(const uint8_t* hb, uint32_t n, uint32_t* wq, uint8_t* s, uint32_t* cnt, uint32_t& nsym, uint32_t& tl_out)
+// first half: the weights of all symbols but the last (osize of them) -> wq; returns the header bytes, 0 if damaged
+__device__ uint32_t read_weights(const uint8_t* hb, uint32_t n, uint32_t* wq, uint8_t* s, uint32_t& osize_out)
 {
     const uint8_t* const h = hb + 8;
     if (n < 1) return 0;
@@ -209,7 +210,17 @@ __device__ uint32_t read_stats2(const uint8_t* hb, uint32_t n, uint32_t* wq, uin
             if (over) wq[q0 + 1] = spill;
         }
     }
-    // weight statistics, eight weights a read; the last symbol's weight is implied.  The counts take the place of norm.
+    osize_out = osize;
+    return isize + 1;
+}
+
+// both halves, one lane: the weights, then their statistics (eight weights a read; the last symbol's weight is implied;
+// the counts take the place of norm)
+__device__ uint32_t read_stats2(const uint8_t* hb, uint32_t n, uint32_t* wq, uint8_t* s, uint32_t* cnt, uint32_t& nsym, uint32_t& tl_out)
+{
+    uint32_t osize = 0;
+    const uint32_t hlen = read_weights(hb, n, wq, s, osize);
+    if (hlen == 0) return 0;
     for (int k = 0; k < 13; k++) cnt[k] = 0;
     uint32_t total = 0, rank1 = 0;
     bool heavy = false;
@@ -242,7 +253,7 @@ __device__ uint32_t read_stats2(const uint8_t* hb, uint32_t n, uint32_t* wq, uin
     if (rank1 < 2 || (rank1 & 1u)) return 0;
     nsym = osize + 1;
     tl_out = tl;
-    return isize + 1;
+    return hlen;
 }
 
 __device__ __forceinline__ int quad_bcast0(int v) { return __builtin_amdgcn_mov_dpp(v, 0x00, 0xf, 0xf, true); }
@@ -438,6 +449,132 @@ __global__ void __launch_bounds__(64) huf0_tree_kernel(const uint8_t* __restrict
         const uint32_t v = *(const uint32_t*)(s_r + c * kRStride + 4 * t);
         *(uint32_t*)(d + 4 * t) = v;
         if (t < 16) *(uint32_t*)(d + 256 + 4 * t) = t < 13 ? *(const uint32_t*)(s_r + c * kRStride + kTabOff + 4 * t) : 0u;   // all of it defined: equal trees, equal bytes
+    }
+}
+
+// One WAVE per segment leader.  A lane's tree parse is ~112 us of dependent LDS round trips however few lanes run, and the
+// leaders are few (157 at BASELINE config 4's 10 000 chunks): lane 0 keeps what is serial -- FSE_readNCount, the FSE
+// table, the two-state weight decode (read_weights) -- and the wave does the rest in a handful of ballots: header copy,
+// weight statistics (HUF_readStats' checks, all kept), the per-weight prefix and the counting sort (a symbol's slot =
+// its weight's running offset + the set lanes below it in the ballot of that weight).  Same descriptor, byte for byte.
+__global__ void __launch_bounds__(64) huf0_tree_wave_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restrict__ boffs,
+                                                            const uint64_t* __restrict__ ooffs, uint64_t nchunks, uint8_t* __restrict__ desc)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_hb[152 + 192 + 8];      // header copy (8 zero bytes in front) | norm, next, fse
+    __shared__ __attribute__((aligned(16))) uint32_t s_wq[36];
+    __shared__ __attribute__((aligned(16))) uint8_t s_sorted[256];
+    __shared__ uint32_t s_red;
+    const int t = threadIdx.x;
+    const uint64_t chunk = (uint64_t)blockIdx.x * 64;
+    if (chunk >= nchunks) return;
+    const uint64_t b0 = boffs[chunk], b1 = boffs[chunk + 1], o0 = ooffs[chunk], o1 = ooffs[chunk + 1];
+    const uint64_t csize = b1 - b0, dsize = o1 - o0;
+    const bool coded = b1 >= b0 && o1 >= o0 && csize > 1 && csize < dsize;      // HUF_decompress's third case
+    const uint32_t hcopy = coded ? (uint32_t)(csize < 129 ? csize : 129) : 0u;
+    if (t < 38) {
+        uint32_t v = 0;
+        if (t >= 2) {
+            const uint8_t* const src = blocks + b0;
+            const uint32_t k = 4u * (uint32_t)(t - 2);
+            if (k + 4 <= hcopy) v = *(const u32_a1*)(src + k);
+            else for (uint32_t bb = 0; bb < 4 && k + bb < hcopy; bb++) v |= (uint32_t)src[k + bb] << (8 * bb);
+        }
+        ((uint32_t*)s_hb)[t] = v;
+    }
+    if (t == 0) s_red = 0;
+    wave_sync();
+    uint32_t hl = 0, osize = 0;
+    if (t == 0 && coded) {
+        hl = read_weights(s_hb, hcopy, s_wq, s_hb + 152, osize);
+        if (hl >= csize) hl = 0;
+    }
+    wave_sync();
+    hl = (uint32_t)__builtin_amdgcn_readlane((int)hl, 0);
+    osize = (uint32_t)__builtin_amdgcn_readlane((int)osize, 0);
+    auto weight_of = [&](uint32_t sy) -> uint32_t { return (s_wq[sy >> 3] >> nib_shift(sy)) & 0xfu; };
+    auto below = [&](uint64_t m) -> uint32_t { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
+    uint32_t tl = 0, nsym = 0;
+    uint32_t cnt[13];
+#pragma unroll
+    for (int w = 0; w < 13; w++) cnt[w] = 0;
+    if (hl) {
+        uint32_t mine = 0;
+        bool heavy_l = false;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t sy = 64u * i + (uint32_t)t;
+            const bool valid = sy < osize;
+            const uint32_t w = valid ? weight_of(sy) : 0u;
+            heavy_l |= valid && w >= 12u;
+            mine += valid ? (1u << w) >> 1 : 0u;
+#pragma unroll
+            for (int ww = 0; ww < 12; ww++) cnt[ww] += (uint32_t)__builtin_popcountll(__ballot(valid && w == (uint32_t)ww));
+        }
+        __hip_atomic_fetch_add(&s_red, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        wave_sync();
+        const uint32_t total = s_red;
+        bool ok = __ballot(heavy_l) == 0 && total != 0;
+        uint32_t lw = 0;
+        if (ok) {
+            tl = (uint32_t)highbit(total) + 1u;
+            ok = tl <= 12u;
+            if (ok) {
+                const uint32_t rest = (1u << tl) - total;
+                ok = (1u << highbit(rest)) == rest;
+                lw = (uint32_t)highbit(rest) + 1u;
+            }
+        }
+        if (ok) {
+            if (t == 0) {
+                const uint32_t sh = nib_shift(osize), old = (osize & 7u) ? s_wq[osize >> 3] : 0u;
+                s_wq[osize >> 3] = (old & ~(0xfu << sh)) | (lw << sh);
+            }
+#pragma unroll
+            for (int ww = 1; ww < 13; ww++) cnt[ww] += lw == (uint32_t)ww ? 1u : 0u;
+            ok = cnt[1] >= 2u && (cnt[1] & 1u) == 0u;
+            nsym = osize + 1;
+        }
+        if (!ok) { hl = 0; tl = 0; }
+        wave_sync();
+    }
+    // start[w] (first table index of weight w) | symoff[w] << 16
+    uint32_t tabw[13], run[13];
+    {
+        uint32_t at = 0, so = 0;
+        tabw[0] = hl | (tl << 16);
+        run[0] = 0;
+#pragma unroll
+        for (int w = 1; w < 13; w++) {
+            const uint32_t c = hl ? cnt[w] : 0u;
+            tabw[w] = at | (so << 16);
+            run[w] = so;
+            at += c << (w - 1);
+            so += c;
+        }
+    }
+    ((uint32_t*)s_sorted)[t] = 0;
+    wave_sync();
+    if (hl) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t sy = 64u * i + (uint32_t)t;
+            const uint32_t w = sy < nsym ? weight_of(sy) : 0u;
+#pragma unroll
+            for (int ww = 1; ww < 13; ww++) {
+                const uint64_t m = __ballot(w == (uint32_t)ww);
+                if (w == (uint32_t)ww) s_sorted[(run[ww] + below(m)) & 0xffu] = (uint8_t)sy;
+                run[ww] += (uint32_t)__builtin_popcountll(m);
+            }
+        }
+    }
+    wave_sync();
+    uint8_t* const d = desc + chunk * kDescStride;
+    *(uint32_t*)(d + 4 * t) = ((const uint32_t*)s_sorted)[t];
+    if (t < 16) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int w = 0; w < 13; w++) v = t == w ? tabw[w] : v;
+        *(uint32_t*)(d + 256 + 4 * t) = v;
     }
 }
 
@@ -935,8 +1072,13 @@ int sprintz_mi355x_huf0_decompress_batch_ws(const void* d_blocks, const uint64_t
     uint8_t* const share = follow + ((nchunks + 63) & ~(uint64_t)63);
     const uint8_t* const blk = (const uint8_t*)d_blocks;
     hipLaunchKernelGGL(huf0_follow_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, st, blk, d_block_offsets, d_out_offsets, nchunks, follow);
-    hipLaunchKernelGGL(huf0_tree_kernel<1>, dim3((unsigned)((nleaders + 63) / 64)), dim3(64), 0, st, blk, d_block_offsets, d_out_offsets, nchunks, desc,
-                       (const uint8_t*)follow);
+    // leaders: a wave each while they are few (46 us instead of 112 at 157 .. 1 250 leaders; at 12 500 the lane-per-leader
+    // pass is the faster one: 0.13 against 0.22 ms)
+    if (nleaders <= 4096)
+        hipLaunchKernelGGL(huf0_tree_wave_kernel, dim3((unsigned)nleaders), dim3(64), 0, st, blk, d_block_offsets, d_out_offsets, nchunks, desc);
+    else
+        hipLaunchKernelGGL(huf0_tree_kernel<1>, dim3((unsigned)((nleaders + 63) / 64)), dim3(64), 0, st, blk, d_block_offsets, d_out_offsets, nchunks, desc,
+                           (const uint8_t*)follow);
     hipLaunchKernelGGL(huf0_copy_kernel, dim3((unsigned)((nchunks * 20 + 255) / 256)), dim3(256), 0, st, desc, (const uint8_t*)follow, nchunks);
     hipLaunchKernelGGL(huf0_tree_kernel<2>, dim3((unsigned)grid1), dim3(64), 0, st, blk, d_block_offsets, d_out_offsets, nchunks, desc,
                        (const uint8_t*)follow);

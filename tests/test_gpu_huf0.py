@@ -76,6 +76,47 @@ def test_damaged_blocks_are_contained(sz, oracle, golden_huf0):
     assert rejected > 10
 
 
+def test_every_block_as_a_segment_leader_and_as_a_follower(sz, oracle, golden_huf0):
+    """The reader parses the first block of every 64-block segment with its own kernel (a wave per leader), lets blocks
+    that repeat the leader's tree copy its descriptor and decodes such segments through one shared table.  Here every
+    committed block -- and a damaged twin of every second one -- leads a segment of copies of itself (the follower /
+    one-table path), followed by a segment it leads with strangers behind it (the per-chunk path)."""
+    import torch
+    manifest, arrays = golden_huf0
+    rng = np.random.default_rng(5)
+    coded = [m for m in manifest if m["n"] <= 6000]
+    stranger = [(arrays["b%04d" % m["idx"]], arrays["p%04d" % m["idx"]]) for m in coded[:63]]
+    blocks, plains, want = [], [], []
+    for k, m in enumerate(coded):
+        plain, blk = arrays["p%04d" % m["idx"]], arrays["b%04d" % m["idx"]].copy()
+        if k % 2 and blk.size > 4 and blk.size < plain.size:
+            if k % 4 == 1:
+                blk[rng.integers(0, min(blk.size, 60))] ^= 1 << rng.integers(0, 8)
+            else:
+                blk = blk[: rng.integers(2, blk.size)]
+        got, ret = oracle.huf0_decompress(blk, plain.size)
+        copies = 64 if k % 3 else 17 + k % 40                 # a full segment of copies, or a short run of them ...
+        for _ in range(copies):
+            blocks.append(blk); plains.append(plain); want.append((got, ret))
+        while len(blocks) % 64:                                # ... filled up with strangers (their own trees)
+            b, p = stranger[len(blocks) % 63]
+            blocks.append(b); plains.append(p); want.append((p, p.size))
+    d, bo, oo, oo_h = pack(blocks, plains)
+    rets = torch.full((len(blocks),), -99, dtype=torch.int64, device="cuda")
+    out = sz.huf0_decompress(d, bo, oo, rets=rets).cpu().numpy()
+    r = rets.cpu().numpy()
+    rejected = 0
+    for k in range(len(blocks)):
+        got, ret = want[k]
+        if ret < 0:
+            assert r[k] < 0, (k, r[k])
+            rejected += 1
+        else:
+            assert r[k] == plains[k].size, (k, r[k], plains[k].size)
+            assert np.array_equal(out[oo_h[k]:oo_h[k + 1]], got), k
+    assert rejected > 100
+
+
 def test_huff0_then_sprintz(sz, oracle, golden_huf0):
     """the chain the paper describes: Huff0 blocks of Sprintz streams -> streams -> samples"""
     import torch
