@@ -16,6 +16,7 @@
 // 320-byte DESCRIPTOR per chunk is what the tree passes leave in global memory and what the
 // stream kernels build their LDS tables from:
 //   follow -> tree<1> (segment leaders) -> copy (followers) -> tree<2> (everybody else) -> share
+//   (small batches: one kernel, a wave per segment, for follow + leader + copy + share)
 //   -> stream<true> (segments with one tree: one full table a wave) -> stream<false> (the rest:
 //   an 8-bit prefix table per chunk).  DESIGN.md 4.4b has the measurements behind each step.
 #include "../../include/sprintz_mi355x.h"
@@ -274,6 +275,7 @@ __device__ __forceinline__ void wave_sync()
 // (symbol | length << 8); longer codes can only have the weights 1 .. tableLog - 8 <= 4, so THEIR weight is
 // three compares against start[2..4] -- or sits in the entry when the prefix holds one weight only -- and
 // their symbol one more LDS read from the sorted list.  One table for the wave (SO = true): see below.
+constexpr uint32_t kSharedMaxLog = 11;           // table log up to which a segment of one tree decodes through ONE full table
 constexpr int kDescStride = 320;                 // sorted[256] | u32 tab[16]: [0] = hl | tl << 16, [w] = start[w] | symoff[w] << 16
 constexpr int kCStride = 256 + 64 + 512 + 4;     // stream kernel, per chunk in LDS: sorted | tab | table8; odd in dwords
 // stream kernel, per lane: a ring of two PIECES of its stream (+ the first 8 bytes again).  A piece is 16 bytes for the
@@ -297,11 +299,9 @@ constexpr int ring_stride(bool so) { return 2 * (1 << piece_log(so)) + 8; }
 // exiting at once.  Per wave the tree is ~115 us of serial work; this takes it from ceil(chunks / 64 / 768) rounds to one.
 __device__ __forceinline__ uint32_t tree_desc_bytes(uint32_t b0) { return b0 < 128u ? 1u + b0 : 1u + (b0 - 127u + 1u) / 2u; }   // HUF_readStats: iSize + 1
 
-__global__ void __launch_bounds__(256) huf0_follow_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restrict__ boffs,
-                                                          const uint64_t* __restrict__ ooffs, uint64_t nchunks, uint8_t* __restrict__ follow)
+__device__ __forceinline__ uint8_t follows_leader(const uint8_t* __restrict__ blocks, const uint64_t* __restrict__ boffs,
+                                                  const uint64_t* __restrict__ ooffs, uint64_t c)
 {
-    const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= nchunks) return;
     const uint64_t L = c & ~(uint64_t)63;
     uint8_t f = 0;
     if (c != L) {
@@ -324,7 +324,14 @@ __global__ void __launch_bounds__(256) huf0_follow_kernel(const uint8_t* __restr
             }
         }
     }
-    follow[c] = f;
+    return f;
+}
+
+__global__ void __launch_bounds__(256) huf0_follow_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restrict__ boffs,
+                                                          const uint64_t* __restrict__ ooffs, uint64_t nchunks, uint8_t* __restrict__ follow)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c < nchunks) follow[c] = follows_leader(blocks, boffs, ooffs, c);
 }
 
 // thread = one 16-byte piece of one follower's descriptor
@@ -458,7 +465,8 @@ __global__ void __launch_bounds__(64) huf0_tree_kernel(const uint8_t* __restrict
 // weight statistics (HUF_readStats' checks, all kept), the per-weight prefix and the counting sort (a symbol's slot =
 // its weight's running offset + the set lanes below it in the ballot of that weight).  Same descriptor, byte for byte.
 __global__ void __launch_bounds__(64) huf0_tree_wave_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restrict__ boffs,
-                                                            const uint64_t* __restrict__ ooffs, uint64_t nchunks, uint8_t* __restrict__ desc)
+                                                            const uint64_t* __restrict__ ooffs, uint64_t nchunks, uint8_t* __restrict__ desc,
+                                                            uint8_t* __restrict__ follow, uint8_t* __restrict__ share)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_hb[152 + 192 + 8];      // header copy (8 zero bytes in front) | norm, next, fse
     __shared__ __attribute__((aligned(16))) uint32_t s_wq[36];
@@ -483,11 +491,21 @@ __global__ void __launch_bounds__(64) huf0_tree_wave_kernel(const uint8_t* __res
     }
     if (t == 0) s_red = 0;
     wave_sync();
+    // lane t is also chunk t of the segment: does it follow the leader?  (what huf0_follow_kernel, huf0_copy_kernel and
+    // huf0_share_kernel do for large batches happens here: three launches less where a launch is 2 % of the job)
+    const uint64_t mine_c = chunk + (uint64_t)t;
+    const bool mine_exists = mine_c < nchunks;
+    uint8_t fol = 0;
     uint32_t hl = 0, osize = 0;
-    if (t == 0 && coded) {
-        hl = read_weights(s_hb, hcopy, s_wq, s_hb + 152, osize);
-        if (hl >= csize) hl = 0;
+    if (t == 0) {
+        if (coded) {
+            hl = read_weights(s_hb, hcopy, s_wq, s_hb + 152, osize);
+            if (hl >= csize) hl = 0;
+        }
+    } else if (mine_exists) {
+        fol = follows_leader(blocks, boffs, ooffs, mine_c);
     }
+    if (mine_exists) follow[mine_c] = fol;
     wave_sync();
     hl = (uint32_t)__builtin_amdgcn_readlane((int)hl, 0);
     osize = (uint32_t)__builtin_amdgcn_readlane((int)osize, 0);
@@ -576,11 +594,24 @@ __global__ void __launch_bounds__(64) huf0_tree_wave_kernel(const uint8_t* __res
         for (int w = 0; w < 13; w++) v = t == w ? tabw[w] : v;
         *(uint32_t*)(d + 256 + 4 * t) = v;
     }
+    // the followers' copies, a lane each: 16 pieces of sorted symbols from LDS, 4 of table words from the registers
+    if (fol) {
+        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+        uint8_t* const dm = desc + mine_c * kDescStride;
+#pragma unroll
+        for (int k = 0; k < 16; k++) *(v4u*)(dm + 16 * k) = ((const v4u*)s_sorted)[k];
+        *(v4u*)(dm + 256) = v4u{tabw[0], tabw[1], tabw[2], tabw[3]};
+        *(v4u*)(dm + 272) = v4u{tabw[4], tabw[5], tabw[6], tabw[7]};
+        *(v4u*)(dm + 288) = v4u{tabw[8], tabw[9], tabw[10], tabw[11]};
+        *(v4u*)(dm + 304) = v4u{tabw[12], 0u, 0u, 0u};
+    }
+    // huf0_share_kernel's verdict for this segment
+    const bool all_follow = __ballot(mine_exists && t != 0 && !fol) == 0;
+    if (t == 0) share[blockIdx.x] = (all_follow && nchunks - chunk > 1 && hl != 0 && tl != 0 && tl <= kSharedMaxLog) ? 1 : 0;
 }
 
 // share[s] = 1 iff the chunks of segment s (64, fewer in the last one) all follow the segment's leader (one tree, so one descriptor)
 // and its table log is at most kSharedMaxLog: the segment is the one-table kernel's.  thread = segment.
-constexpr uint32_t kSharedMaxLog = 11;
 __global__ void __launch_bounds__(256) huf0_share_kernel(const uint8_t* __restrict__ desc, const uint8_t* __restrict__ follow, uint64_t nchunks,
                                                          uint8_t* __restrict__ share)
 {
@@ -1071,18 +1102,23 @@ int sprintz_mi355x_huf0_decompress_batch_ws(const void* d_blocks, const uint64_t
     uint8_t* const follow = desc + (((size_t)nchunks * kDescStride + 255) & ~(size_t)255);
     uint8_t* const share = follow + ((nchunks + 63) & ~(uint64_t)63);
     const uint8_t* const blk = (const uint8_t*)d_blocks;
-    hipLaunchKernelGGL(huf0_follow_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, st, blk, d_block_offsets, d_out_offsets, nchunks, follow);
-    // leaders: a wave each while they are few (46 us instead of 112 at 157 .. 1 250 leaders; at 12 500 the lane-per-leader
-    // pass is the faster one: 0.13 against 0.22 ms)
-    if (nleaders <= 4096)
-        hipLaunchKernelGGL(huf0_tree_wave_kernel, dim3((unsigned)nleaders), dim3(64), 0, st, blk, d_block_offsets, d_out_offsets, nchunks, desc);
-    else
+    // Few leaders (<= 4096 segments): ONE kernel, a wave per segment, does the follow test, the leader's tree, the followers'
+    // copies and the share flag (46 us instead of 112 for the leader's tree at 157 .. 1 250 leaders, and three launches less).
+    // Many: the follow pass, a LANE per leader (0.13 ms at 12 500 leaders; the wave kernel takes 0.22), the copy pass, the
+    // share pass.  Either way huf0_tree_kernel<2> then parses every chunk that is neither leader nor follower.
+    if (nleaders <= 4096) {
+        hipLaunchKernelGGL(huf0_tree_wave_kernel, dim3((unsigned)nleaders), dim3(64), 0, st, blk, d_block_offsets, d_out_offsets, nchunks, desc, follow, share);
+        hipLaunchKernelGGL(huf0_tree_kernel<2>, dim3((unsigned)grid1), dim3(64), 0, st, blk, d_block_offsets, d_out_offsets, nchunks, desc,
+                           (const uint8_t*)follow);
+    } else {
+        hipLaunchKernelGGL(huf0_follow_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, st, blk, d_block_offsets, d_out_offsets, nchunks, follow);
         hipLaunchKernelGGL(huf0_tree_kernel<1>, dim3((unsigned)((nleaders + 63) / 64)), dim3(64), 0, st, blk, d_block_offsets, d_out_offsets, nchunks, desc,
                            (const uint8_t*)follow);
-    hipLaunchKernelGGL(huf0_copy_kernel, dim3((unsigned)((nchunks * 20 + 255) / 256)), dim3(256), 0, st, desc, (const uint8_t*)follow, nchunks);
-    hipLaunchKernelGGL(huf0_tree_kernel<2>, dim3((unsigned)grid1), dim3(64), 0, st, blk, d_block_offsets, d_out_offsets, nchunks, desc,
-                       (const uint8_t*)follow);
-    hipLaunchKernelGGL(huf0_share_kernel, dim3((unsigned)((nleaders + 255) / 256)), dim3(256), 0, st, (const uint8_t*)desc, (const uint8_t*)follow, nchunks, share);
+        hipLaunchKernelGGL(huf0_copy_kernel, dim3((unsigned)((nchunks * 20 + 255) / 256)), dim3(256), 0, st, desc, (const uint8_t*)follow, nchunks);
+        hipLaunchKernelGGL(huf0_tree_kernel<2>, dim3((unsigned)grid1), dim3(64), 0, st, blk, d_block_offsets, d_out_offsets, nchunks, desc,
+                           (const uint8_t*)follow);
+        hipLaunchKernelGGL(huf0_share_kernel, dim3((unsigned)((nleaders + 255) / 256)), dim3(256), 0, st, (const uint8_t*)desc, (const uint8_t*)follow, nchunks, share);
+    }
     hipLaunchKernelGGL(huf0_stream_kernel<true>, dim3((unsigned)(HUF0_SO_WG == 4 ? grid1 : grid2)), dim3(64 * HUF0_SO_WG), 0, st, blk, d_block_offsets, nchunks,
                        (uint8_t*)d_out, d_out_offsets, d_rets, (const uint8_t*)desc, (const uint8_t*)share);
     hipLaunchKernelGGL(huf0_stream_kernel<false>, dim3((unsigned)grid2), dim3(64), 0, st, blk, d_block_offsets, nchunks,
