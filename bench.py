@@ -317,6 +317,10 @@ def bench_rowmajor(cx, name, workload, codec, esz, ndims, chunk_len, nchunks_tot
                     "huff0_encode_ms": round(h_enc_ms, 4),
                     "roofline": roofline(algo_chain, chain_ms, "Huff0 stage (tree passes + stream kernels, sprintz_mi355x_huf0_decompress_batch_ws) + sprintz decode; the Sprintz streams cross HBM between the two",
                                          {"huff0_decode_frac": round((hbytes + stream_bytes + 16 * n) / (h_dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})})
+        if cx.rank == 0 and cx.world == 1 and not args.no_cpu_baseline:
+            pt = huf0_private_trees(cx, comp, offs, ws["sizes"], n, timer, reps)
+            if pt:
+                res["huff0_private_trees"] = pt
         if cx.rank == 0 and not args.no_cpu_baseline:
             ns = min(n, max(64, (48 << 20) // (chunk_len * esz)))
             zo = z_offs[: ns + 1].cpu().numpy().astype("uint64")
@@ -410,6 +414,60 @@ def run_config(cx, name):
     if name == "cfg5":
         return bench_cfg5(cx)
     raise ValueError(name)
+
+
+def huf0_private_trees(cx, comp, offs, sizes, n, timer, reps):
+    """cfg4's Huff0 stage on blocks as `HUF_compress` writes them -- a tree of its own in EVERY block (the writer of this
+    library repeats one tree per 64-chunk segment, which its reader exploits): the first <= 4096 chunks' Sprintz streams
+    coded by the host's libzstd, tiled to the batch, decoded on the GPU and compared with the streams.  None without libzstd."""
+    import numpy as np
+    torch, dev = cx.torch, cx.device
+    try:
+        z = C.CDLL("libzstd.so.1")
+        z.HUF_compress.restype = C.c_size_t
+        z.HUF_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        z.HUF_isError.restype = C.c_uint
+        z.HUF_isError.argtypes = [C.c_size_t]
+    except (OSError, AttributeError):
+        return None
+    from sprintz_amd import _lib
+    nd = min(n, 4096)
+    o = offs[: nd + 1].cpu().numpy().astype(np.int64)
+    sz_h = sizes[:nd].cpu().numpy().astype(np.int64)
+    host = comp[: int(o[nd])].cpu().numpy()
+    blocks, tmp = [], np.zeros(1 << 17, np.uint8)
+    for c in range(nd):
+        st = np.ascontiguousarray(host[o[c]:o[c] + sz_h[c]])
+        r = z.HUF_compress(tmp.ctypes.data, tmp.size, st.ctypes.data, st.size)
+        blocks.append(st if (r == 0 or z.HUF_isError(r)) else tmp[:r].copy())
+    k = max(1, n // nd)
+    nt = nd * k
+    bsz = np.array([b.size for b in blocks], np.int64)
+    bo = np.zeros(nt + 1, np.int64)
+    bo[1:] = np.cumsum(np.tile(bsz, k))
+    oo = np.zeros(nt + 1, np.int64)
+    oo[1:] = np.cumsum(np.tile(sz_h, k))
+    one = torch.from_numpy(np.concatenate(blocks)).to(dev)
+    d_blocks = torch.cat([one.repeat(k), torch.zeros(64, dtype=torch.uint8, device=dev)])
+    plain_one = torch.from_numpy(np.concatenate([host[o[c]:o[c] + sz_h[c]] for c in range(nd)])).to(dev)
+    d_bo, d_oo = torch.from_numpy(bo).to(dev), torch.from_numpy(oo).to(dev)
+    d_out = torch.zeros(int(oo[-1]) + 64, dtype=torch.uint8, device=dev)
+    d_rets = torch.empty(nt, dtype=torch.int64, device=dev)
+    d_tmp = torch.empty(int(_lib.huf0_decode_tmp_bytes(nt)), dtype=torch.uint8, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def h_dec():
+        _lib.check(_lib.huf0_decompress_batch_ws(d_blocks.data_ptr(), d_bo.data_ptr(), nt, d_out.data_ptr(), d_oo.data_ptr(),
+                                                 d_rets.data_ptr(), d_tmp.data_ptr(), st))
+    ms = timer(h_dec, reps)
+    if not cx.args.no_verify:
+        assert torch.equal(d_rets, torch.from_numpy(np.tile(sz_h, k)).to(dev)), "Huff0 decode (libzstd blocks): a block was rejected"
+        assert torch.equal(d_out[: int(oo[-1])], plain_one.repeat(k)), "Huff0 decode (libzstd blocks) != the streams"
+    hb, sb = int(bo[-1]), int(oo[-1])
+    return {"blocks": "libzstd HUF_compress, one call per chunk (a tree of its own in every block); the first %d chunks' streams, "
+                      "tiled %d times" % (nd, k),
+            "chunks": nt, "huff0_bytes": hb, "stream_bytes": sb, "huff0_decode_ms": round(ms, 4),
+            "huff0_decode_frac": round((hb + sb + 16 * nt) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
 
 def merge_over_ranks(cx, res):
