@@ -9,7 +9,7 @@ key = sys.argv[2]
 minn = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 m = re.search(r"^(\S*" + re.escape(key) + r"\S*):[^\n]*\n", s, re.M)
 i = m.end()
-body = s[i:s.index('s_endpgm', i)].split('\n')
+body = s[i:s.index(".Lfunc_end", i)].split('\n')
 labels = {}
 for n, l in enumerate(body):
     mm = re.match(r'^(\.LBB\d+_\d+):', l)
