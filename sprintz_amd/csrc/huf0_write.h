@@ -196,15 +196,21 @@ __global__ void __launch_bounds__(256) huf0_size_kernel(const uint8_t* __restric
     uint32_t bits = 0;
     bool same = true;
     uint32_t k = k0;
-    for (; k + 16 <= k1; k += 16) {
-        const u32x4 x = *(const u32x4_a1*)(s + k);
+    auto sixteen = [&](const u32x4& x) {
 #pragma unroll
         for (int d = 0; d < 4; d++) {
             const uint32_t v = d == 0 ? x.x : d == 1 ? x.y : d == 2 ? x.z : x.w;
             bits += lens[v & 255] + lens[(v >> 8) & 255] + lens[(v >> 16) & 255] + lens[v >> 24];
             same = same && v == first * 0x01010101u;
         }
+    };
+    // four pieces in flight: a lane's loads are otherwise one dependent round trip to memory per 16 bytes
+    for (; k + 64 <= k1; k += 64) {
+        const u32x4 x0 = *(const u32x4_a1*)(s + k), x1 = *(const u32x4_a1*)(s + k + 16), x2 = *(const u32x4_a1*)(s + k + 32),
+                    x3 = *(const u32x4_a1*)(s + k + 48);
+        sixteen(x0); sixteen(x1); sixteen(x2); sixteen(x3);
     }
+    for (; k + 16 <= k1; k += 16) { const u32x4 x = *(const u32x4_a1*)(s + k); sixteen(x); }
     for (; k < k1; k++) { bits += lens[s[k]]; same = same && s[k] == first; }
     const uint32_t bytes = (bits + 1 + 7) >> 3;
     const int all_same = __builtin_amdgcn_mov_dpp((int)same, 0x00, 0xf, 0xf, true) & __builtin_amdgcn_mov_dpp((int)same, 0x55, 0xf, 0xf, true) &
@@ -303,6 +309,8 @@ __global__ void __launch_bounds__(256) huf0_encode_kernel(const uint8_t* __restr
             put((v >> 8) & 255u); put(v & 255u); drain();
         }
     }
+    // (64 source bytes per trip, the four loads issued together, was tried for the same reason as in the size kernel: the
+    //  four copies of the 16-symbol body with their conditional ring flushes made the kernel 4x slower)
     acc |= 1ull << nbits;                                 // the closing 1 bit (BIT_closeCStream)
     nbits += 1;
     drain();
