@@ -1,0 +1,65 @@
+"""The one JSON line `bench.py` prints, checked on the line a default run of the committed build printed on an MI355X
+(profiles/r2_bench_full_*.json): the driver's contract fields, BASELINE.json's metric, the two objects the hot-path tier
+asks for (`roofline`, `cpu_baseline`) and a `per_config` entry for every other BASELINE configuration."""
+import glob
+import json
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def latest_line():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r2_bench_full_*.json")), key=os.path.getmtime)
+    assert files, "no committed bench line under profiles/"
+    with open(files[-1]) as f:
+        return json.load(f)
+
+
+def test_contract_fields():
+    d = latest_line()
+    with open(os.path.join(ROOT, "BASELINE.json")) as f:
+        base = json.load(f)
+    assert d["metric"] == base["metric"]
+    for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["unit"] == "MB/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "u16"
+    assert d["vs_baseline"] is None                      # BASELINE.md publishes no number for this metric
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["data"].startswith("synthetic")
+    # value = decompressed bytes of the whole job / wall time of the timed steps
+    raw = 131072 * 5120 * 2 * d["n_gpus"]
+    assert abs(d["value"] - raw / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01
+
+
+def test_roofline_and_cpu_baseline():
+    d = latest_line()
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert 0.3 < r["frac"] <= 1.0
+    # achieved = algorithmic bytes per launch / the HIP-event launch duration
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (d["kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 0.01
+    if r["traffic"] is not None:
+        assert 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.5      # no wasted re-reads
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "reference" and c["cores"] >= 1 and c["value"] > 0
+
+
+def test_every_baseline_configuration_has_an_entry():
+    d = latest_line()
+    names = [v["name"] for v in d["per_config"]]
+    for want in ("cfg1", "cfg3_1k", "cfg3_10k", "cfg4_10000", "cfg4_80000", "cfg4_800000", "cfg5"):
+        assert want in names, want
+    for v in d["per_config"]:
+        if v["name"] == "cfg2":
+            continue
+        assert v["decompress_ms"] > 0 and v["compress_ms"] > 0, v["name"]
+        assert 0 < v["roofline"]["frac"] <= 1.0, v["name"]
+        assert v["cpu_baseline"]["kind"] == "reference", v["name"]
+        if v["name"].startswith("cfg4_"):
+            assert "Huff0" in v["entropy_stage"] and v["huff0_decode_ms"] > 0
