@@ -443,6 +443,28 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     // half of the register (SDWA dst_sel:WORD_1), i.e. it yields E = err << 16 directly,
     // which is what the FIRE step and the sign test want (W == 16); for W == 8 one shift follows (FIRE) or none (delta).
     auto fetch_rows = [&](int (&e)[CPL][8], uint32_t at, const uint32_t (&off)[CPL], const uint32_t (&nb)[CPL], uint32_t row_bytes) {
+        if constexpr (W == 8 && CPL % 2 == 0) {
+            // 8 bits: a lane's two adjacent columns are two adjacent fields of at most 8 bits, at most 7 + 16 bits from the byte
+            // the first one starts in -- ONE 32-bit window per row serves both (an address, a mask and a v_alignbyte less per
+            // second column and row).  (A stand-in column repeats the last genuine one: the same window.)
+#pragma unroll
+            for (int k = 0; k < CPL; k += 2) {
+                uint32_t p = at + (off[k] >> 3);
+                const uint32_t sha = off[k] & 7u, shb = off[k + 1] - (off[k] & ~7u);
+                const uint32_t w1a = nb[k] != 0 ? 1u : 0u, wma = nb[k] - w1a;
+                const uint32_t w1b = nb[k + 1] != 0 ? 1u : 0u, wmb = nb[k + 1] - w1b;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const uint32_t w = lds_rd32(p);
+                    const uint32_t ea = __builtin_amdgcn_ubfe(w, sha + 1u, wma) ^ (uint32_t)__builtin_amdgcn_sbfe((int)w, sha, w1a);
+                    const uint32_t eb = __builtin_amdgcn_ubfe(w, shb + 1u, wmb) ^ (uint32_t)__builtin_amdgcn_sbfe((int)w, shb, w1b);
+                    e[k][i] = FIRE ? (int)ea << 8 : (int)ea;
+                    e[k + 1][i] = FIRE ? (int)eb << 8 : (int)eb;
+                    p += row_bytes;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < CPL; k++) {
             uint32_t p = at + (off[k] >> 3);
