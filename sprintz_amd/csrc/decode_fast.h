@@ -602,11 +602,21 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         // nbits ride in one register (slot 0 in bits 0..15, slot 1 in 16..31)
         const uint32_t r = ring + rofs;                    // LDS address of the parse cursor
         uint32_t nb_both[CPL], lane_both = 0;
+        uint32_t hw0 = 0, hw1 = 0;                         // (two columns of a lane: their header fields sit in one window per slot)
 #pragma unroll
         for (int k = 0; k < CPL; k++) {
             const uint32_t hbit0 = (uint32_t)colk[k] * HB, hbit1 = (uint32_t)(D + colk[k]) * HB;
-            uint32_t f0 = __builtin_amdgcn_ubfe(lds_rd32(r + (hbit0 >> 3)), hbit0 & 7u, HB);
-            uint32_t f1 = __builtin_amdgcn_ubfe(lds_rd32(r + (hbit1 >> 3)), hbit1 & 7u, HB);
+            uint32_t s0 = hbit0 & 7u, s1 = hbit1 & 7u;
+            if (CPL % 2 == 0 && (k & 1)) {                 // the odd column reads its pair's window
+                const uint32_t b0 = (uint32_t)colk[k - 1] * HB, b1 = (uint32_t)(D + colk[k - 1]) * HB;
+                s0 = hbit0 - (b0 & ~7u);
+                s1 = hbit1 - (b1 & ~7u);
+            } else {
+                hw0 = lds_rd32(r + (hbit0 >> 3));
+                hw1 = lds_rd32(r + (hbit1 >> 3));
+            }
+            uint32_t f0 = __builtin_amdgcn_ubfe(hw0, s0, HB);
+            uint32_t f1 = __builtin_amdgcn_ubfe(hw1, s1, HB);
             f0 += (f0 == (uint32_t)(W - 1));               // W-1 means W (:747-749)
             f1 += (f1 == (uint32_t)(W - 1));
             nb_both[k] = f0 | (f1 << 16);
