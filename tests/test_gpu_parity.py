@@ -306,6 +306,43 @@ def test_full_size_cfg2_roundtrip_and_size_checksum(sz, oracle):
     assert 2.0 < x.numel() * 2 / sizes.sum() < 6.0
 
 
+@pytest.mark.parametrize("name,codec,esz,ndims,chunk_len,nchunks,step", [
+    ("cfg1", "delta", 1, 1, 1024, 524288, 2),            # 512 MiB of univariate 8-bit streams in 1 KB chunks
+    ("cfg3_1k", "delta", 1, 80, 1024, 524288, 2),        # 80 columns, 1 KB chunks: shorter than one group, stored verbatim
+    ("cfg3_10k", "delta", 1, 80, 10240, 52429, 2),       # 80 columns, 10 KB chunks
+])
+def test_full_size_8bit_configs_roundtrip_and_sample_parity(sz, oracle, name, codec, esz, ndims, chunk_len, nchunks, step):
+    """BASELINE configs 1 and 3 at the sizes bench.py runs them: encode -> decode round trip on the GPU, and the compressed
+    bytes of a strided sample of chunks against the oracle."""
+    import torch
+    g = torch.Generator(device="cuda:0").manual_seed(321)
+    rows = chunk_len // ndims
+    tail = chunk_len - rows * ndims
+    steps = torch.randint(-step, step + 1, (nchunks, rows, ndims), device="cuda:0", generator=g, dtype=torch.int32)
+    if rows > 64:
+        steps[:, rows // 2:rows // 2 + 24] = 0                # a flat span per chunk: runs
+    body = (torch.cumsum(steps, dim=1) + 100).to(torch.uint8).reshape(nchunks, rows * ndims)
+    del steps
+    if tail:
+        body = torch.cat([body, torch.randint(0, 256, (nchunks, tail), device="cuda:0", generator=g, dtype=torch.int32).to(torch.uint8)], dim=1)
+    x = body.reshape(-1).contiguous()
+    del body
+    cd = sz.ChunkedCodec(codec, esz, ndims, chunk_len, device="cuda:0")
+    batch = cd.compress(x)
+    rets = torch.empty(nchunks, dtype=torch.int64, device="cuda:0")
+    out = cd.decompress(batch, rets=rets)
+    assert torch.equal(out, x), name
+    assert bool((rets == chunk_len).all().item())
+    sizes, offs = batch.sizes.cpu().numpy(), batch.offsets.cpu().numpy()
+    sample = np.arange(0, nchunks, max(1, nchunks // 150))
+    xs = x.reshape(nchunks, chunk_len)[torch.from_numpy(sample).cuda()].cpu().numpy()
+    comp = batch.data.cpu().numpy()
+    for j, c in enumerate(sample):
+        want, _ = oracle.compress(codec, xs[j], ndims)
+        assert sizes[c] == want.size, (name, c)
+        assert np.array_equal(comp[offs[c]:offs[c] + sizes[c]], want), (name, c)
+
+
 @pytest.mark.parametrize("codec,esz,ndims,chunk_len,nchunks", [("xff", 2, 8, 5120, 64), ("xff", 1, 1, 1024, 300), ("delta", 2, 1, 2000, 300),
                                                                ("xff", 1, 3, 3000, 64), ("xff", 1, 4, 2000, 300), ("delta", 2, 2, 2000, 300)])
 def test_corrupt_streams_do_not_hang_or_overrun(sz, oracle, codec, esz, ndims, chunk_len, nchunks):
