@@ -183,6 +183,44 @@ def test_writer_matches_its_specification(sz, oracle, codec, esz, ndims, nchunks
     assert np.array_equal(out.cpu().numpy().view(DTYPES[esz])[: data.size], data)
 
 
+@pytest.mark.parametrize("nchunks", [10000, 80000])
+def test_full_size_cfg4_chain(sz, oracle, nchunks):
+    """BASELINE config 4 at the batch sizes bench.py runs (10 000 chunks as stated, 80 000): samples -> Sprintz streams -> Huff0
+    blocks -> streams -> samples on the GPU; on a strided sample of chunks the blocks are what the writer's specification says
+    and the oracle's Huff0 reader turns them back into the Sprintz streams."""
+    import torch
+    chunk_len, ndims = 5120, 8
+    g = torch.Generator(device="cuda:0").manual_seed(7 + nchunks)
+    steps = torch.randint(-8, 9, (nchunks, chunk_len // ndims, ndims), device="cuda:0", generator=g, dtype=torch.int32)
+    steps[:, 300:340] = 0
+    x = (torch.cumsum(steps, dim=1) + 30000).to(torch.int16).view(torch.uint16).reshape(-1)
+    del steps
+    cd = sz.ChunkedCodec("xff", 2, ndims, chunk_len, device="cuda:0")
+    batch = cd.compress(x)
+    blocks, bo = sz.huf0_compress(batch)
+    sizes = batch.sizes.to(torch.int64)
+    oo = torch.zeros(nchunks + 1, dtype=torch.int64, device="cuda")
+    oo[1:] = torch.cumsum(sizes, 0)
+    rets = torch.empty(nchunks, dtype=torch.int64, device="cuda")
+    streams = sz.huf0_decompress(blocks, bo, oo, rets=rets)
+    assert torch.equal(rets, sizes)
+    out = torch.empty(nchunks * chunk_len, dtype=torch.uint16, device="cuda")
+    cd.decompress_into(streams, oo, nchunks, out)
+    assert torch.equal(out.view(torch.int16), x.view(torch.int16))
+    assert int(bo[-1].item()) < int(oo[-1].item())                    # the entropy stage shrinks this data
+    # a sample of whole segments against the specification of the writer and the oracle's reader
+    comp, offs, sz_h = batch.data.cpu().numpy(), batch.offsets.cpu().numpy().astype(np.uint64), batch.sizes.cpu().numpy()
+    bo_h, blk_h = bo.cpu().numpy(), blocks.cpu().numpy()
+    for seg in range(0, nchunks // 64, max(1, nchunks // 64 // 6)):
+        c0 = 64 * seg
+        want, wo = oracle.huf0_compress(comp, offs[c0:c0 + 65], sz_h[c0:c0 + 64])
+        got = blk_h[bo_h[c0]:bo_h[c0 + 64]]
+        assert np.array_equal(got, want), seg
+        for c in (c0, c0 + 17, c0 + 63):
+            plain, ret = oracle.huf0_decompress(blk_h[bo_h[c]:bo_h[c + 1]], int(sz_h[c]))
+            assert ret == sz_h[c] and np.array_equal(plain, comp[int(offs[c]):int(offs[c]) + int(sz_h[c])]), c
+
+
 def test_writer_edge_chunks(sz, oracle):
     """any byte container goes in: empty, 1-byte, 11/12/13-byte chunks, one repeated byte, incompressible
     noise, streams too long for the 16-bit jump table (stored), a chunk count that is not a multiple of 64"""
