@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(kThreads) compact_copy_kernel(const uint8_t* s
     const uint32_t sz = sizes[c];
     if (align == 16) {
         const uint32_t nunits = (sz + 15u) >> 4;     // slots are zero padded to 16
-        for (uint32_t u = lane; u < nunits; u += 64) ((uint4*)d)[u] = ((const uint4*)s)[u];
+        sprintz::copy_verbatim<false>(s, d, nunits << 4, lane, 64u);      // (four 16-byte loads a lane in flight before its first store)
     } else {
         for (uint32_t j = lane; j < sz; j += 64) d[j] = s[j];
     }
