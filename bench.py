@@ -28,7 +28,6 @@ import json
 import os
 import platform
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -36,6 +35,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+CPU_SAMPLE_BYTES = 1342177280   # raw bytes of the all-core CPU legs' sample (the headline batch of one GPU: 131 072 x 10 KB)
 METRIC = "decompress MB/s (and ratio) uint16 rowmajor 8-col, 1/2/4/8 MI355X vs CPU ref"
 ALL_CONFIGS = ["cfg1", "cfg3_1k", "cfg3_10k", "cfg4_10000", "cfg4_80000", "cfg4_800000", "cfg5"]
 
@@ -57,6 +57,9 @@ def parse():
     p.add_argument("--only", default="", help="profiling aid: run ONLY this per_config entry (no headline), print its JSON")
     p.add_argument("--config-reps", type=int, default=20)
     p.add_argument("--no-extras", action="store_true", help="skip the Huffman / query / latency extras of the headline batch")
+    p.add_argument("--dry-launch", action="store_true",
+                   help="launch check only: bring the N ranks up (self-launching them if need be), all-gather the ranks, print one JSON "
+                        "line; needs no GPU (gloo without one)")
     return p.parse_args()
 
 
@@ -110,56 +113,98 @@ def cpu_libs():
     return None, None, None, None
 
 
-def time_cpu(run, nchunks, target_s, threads=None):
-    """run(lo, hi) decodes chunks [lo, hi) once.  -> (best seconds on 1 thread, best seconds on all threads, threads)"""
-    t0 = time.perf_counter(); run(0, nchunks); t1 = time.perf_counter() - t0
-    reps = max(1, int(target_s / max(t1, 1e-6)))
-    best1 = t1
-    for _ in range(reps):
-        s = time.perf_counter(); run(0, nchunks); best1 = min(best1, time.perf_counter() - s)
-    cores = min(threads or os.cpu_count() or 1, nchunks)
-    bounds = [(nchunks * i // cores, nchunks * (i + 1) // cores) for i in range(cores)]
-    bestm = None
-
-    def many(lo, hi):
-        for _ in range(reps):
-            run(lo, hi)
-    for _ in range(3):
-        ths = [threading.Thread(target=many, args=b) for b in bounds]
-        s = time.perf_counter()
-        [t.start() for t in ths]
-        [t.join() for t in ths]
-        d = (time.perf_counter() - s) / reps
-        bestm = d if bestm is None else min(bestm, d)
-    return best1, bestm, cores, reps
+def host_topology():
+    """-> (logical CPUs this process may run on, one logical CPU per PHYSICAL core among them)"""
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = list(range(os.cpu_count() or 1))
+    seen, firsts = set(), []
+    for c in avail:
+        try:
+            sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+        except OSError:
+            sib = str(c)
+        if sib not in seen:
+            seen.add(sib)
+            firsts.append(c)
+    return avail, firsts
 
 
-def cpu_baseline(comp_np, offs_np, nchunks, codec_id, esz, chunk_len, target_s, what):
+def time_cpu_mt(call, n_one, n_all, raw_per_chunk, target_s):
+    """call(nchunks, nthreads, reps, cpus) -> seconds per pass, all in C (oracle/mt_bench.c: pthreads, one chunk range per
+    thread, pinned, sustained over `reps` passes).  Legs: 1 thread on the first n_one chunks; one thread per PHYSICAL core
+    and one per LOGICAL CPU on the first n_all chunks.  -> dict of MB/s figures and what ran"""
+    avail, firsts = host_topology()
+    t = call(n_one, 1, 1, None)                                  # also faults the output pages in
+    reps1 = max(1, min(50, int(target_s / max(t, 1e-6))))
+    best1 = min(call(n_one, 1, reps1, None) for _ in range(2))
+    r = {"value_1thread": round(n_one * raw_per_chunk / best1 / 1e6, 1), "physical_cores": len(firsts), "logical_cpus": len(avail)}
+    legs = {}
+    for name, cpus in (("physical", firsts), ("logical", avail)):
+        if name == "logical" and len(avail) == len(firsts):
+            continue
+        nt = min(len(cpus), n_all)
+        t = call(n_all, nt, 1, cpus[:nt])
+        reps = max(2, min(200, int(target_s / max(t, 1e-6))))
+        legs[name] = (min(call(n_all, nt, reps, cpus[:nt]) for _ in range(3)), nt, reps)
+    bestp, ntp, repsp = legs["physical"]
+    r.update({"value": round(n_all * raw_per_chunk / bestp / 1e6, 1), "cores": ntp, "threads": ntp, "passes": repsp})
+    if "logical" in legs:
+        bl, ntl, _ = legs["logical"]
+        r["value_all_logical_cpus"] = round(n_all * raw_per_chunk / bl / 1e6, 1)
+        r["threads_all_logical_cpus"] = ntl
+    r["scaling_vs_1thread"] = round(r["value"] / r["value_1thread"], 1)
+    # the same threads on a sample small enough to stay in each core's L2 (~256 KB of samples a thread): what the cores do when
+    # DRAM is out of the picture -- the gap between this and `value` is the host's memory system, not the harness
+    n_small = min(n_all, ntp * max(1, (256 << 10) // raw_per_chunk))
+    t = call(n_small, ntp, 1, firsts[:ntp])
+    reps = max(2, min(2000, int(target_s / max(t, 1e-6))))
+    bc = min(call(n_small, ntp, reps, firsts[:ntp]) for _ in range(3))
+    r["value_cache_resident"] = round(n_small * raw_per_chunk / bc / 1e6, 1)
+    r["scaling_cache_resident_vs_1thread"] = round(r["value_cache_resident"] / r["value_1thread"], 1)
+    return r
+
+
+def cpu_baseline(comp_np, offs_np, nchunks, codec_id, esz, chunk_len, target_s, what, n_one=8192, last_chunk_len=None):
     """The CPU path on a bounded sample of the same compressed chunks, on this host's cores.
     kind 'reference' = the real dblalock/sprintz AVX2/BMI2 code compiled into oracle/_ref (travels with
-    the repo); 'port' = our scalar C restatement (oracle/liboracle.so) if that is absent."""
+    the repo); 'port' = our scalar C restatement (oracle/liboracle.so) if that is absent.  The threads are pthreads
+    inside liboracle.so (oracle/mt_bench.c) calling the decoder's chunk loop through a function pointer."""
     import numpy as np
+    from tests.harness import ORACLE_SO
     lib, fn_name, _, kind = cpu_libs()
-    if lib is None:
+    if lib is None or not os.path.exists(ORACLE_SO):
         return None
-    fn = getattr(lib, fn_name)
-    fn.restype = C.c_uint64
-    fn.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
-    out = np.zeros(nchunks * chunk_len * esz + 8192, np.uint8)
+    orc = C.CDLL(ORACLE_SO)
+    mt = orc.oracle_mt_decompress_chunks
+    mt.restype = C.c_double
+    mt.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_int,
+                   C.c_void_p, C.c_void_p]
+    fn = C.cast(getattr(lib, fn_name), C.c_void_p)
+    gap = 4096
     chunk_bytes = chunk_len * esz
+    out = np.zeros(nchunks * chunk_bytes + ((os.cpu_count() or 1) + 1) * gap + 8192, np.uint8)
+    elems = C.c_uint64(0)
 
-    def run(lo, hi):
-        fn(codec_id, esz, comp_np.ctypes.data, offs_np[lo:].ctypes.data, hi - lo, chunk_len, out.ctypes.data + lo * chunk_bytes)
+    def call(n, nthreads, reps, cpus):
+        arr = (C.c_int * nthreads)(*cpus) if cpus else None
+        t = mt(fn, codec_id, esz, comp_np.ctypes.data, offs_np.ctypes.data, n, chunk_len, out.ctypes.data, gap, nthreads, reps, arr, C.byref(elems))
+        want = n * chunk_len - ((chunk_len - last_chunk_len) if (last_chunk_len is not None and n == nchunks) else 0)
+        assert t > 0 and elems.value == want, (t, elems.value, want)
+        return t
 
-    b1, bm, cores, reps = time_cpu(run, nchunks, target_s)
-    raw = nchunks * chunk_bytes
-    return {"value": round(raw / bm / 1e6, 1), "unit": "MB/s", "cores": cores, "kind": kind,
-            "value_1thread": round(raw / b1 / 1e6, 1),
-            "sample": f"{nchunks} of this configuration's own compressed chunks ({raw / 1e6:.0f} MB raw), best of {reps + 1} passes on 1 "
-                      f"thread and best of 3x{reps} passes on {cores} threads (one chunk range per thread), {what} per chunk, data in RAM"}
+    n_one = min(n_one, nchunks)
+    r = time_cpu_mt(call, n_one, nchunks, chunk_bytes, target_s)
+    r.update({"unit": "MB/s", "kind": kind,
+              "sample": f"{what} per chunk on this configuration's own compressed chunks, data in RAM; all-core legs: {nchunks} chunks "
+                        f"({nchunks * chunk_bytes / 1e6:.0f} MB raw), one contiguous chunk range per pinned pthread (oracle/mt_bench.c), sustained "
+                        f"over {r['passes']} passes, best of 3; `value`/`cores` = one thread per physical core; 1-thread leg: first {n_one} chunks; "
+                        f"value_cache_resident: the same threads on ~256 KB of samples each (L2-resident)"})
+    return r
 
 
-def cpu_baseline_huf0_chain(blocks_np, boffs_np, sizes_np, nchunks, esz, chunk_len, target_s):
+def cpu_baseline_huf0_chain(blocks_np, boffs_np, sizes_np, nchunks, esz, chunk_len, target_s, n_one=4096):
     """cfg4 on the host: Huff0 block -> Sprintz stream -> samples, chunk by chunk.  'reference' = the system
     libzstd's HUF_decompress (the coder the paper names) + the compiled reference decoder."""
     import numpy as np
@@ -176,25 +221,31 @@ def cpu_baseline_huf0_chain(blocks_np, boffs_np, sizes_np, nchunks, esz, chunk_l
         huf, hname = C.cast(z.HUF_decompress, C.c_void_p), "libzstd HUF_decompress"
     except (OSError, AttributeError):
         huf, hname, kind = C.cast(orc.oracle_huf0_decompress, C.c_void_p), "oracle_huf0_decompress", "port"
-    chain = orc.oracle_huf0_chain_chunks
-    chain.restype = C.c_uint64
-    chain.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
-    out = np.zeros(nchunks * chunk_len * esz + 8192, np.uint8)
+    mt = orc.oracle_mt_huf0_chain
+    mt.restype = C.c_double
+    mt.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
+                   C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     ncpu = os.cpu_count() or 1
-    scratch = np.zeros((ncpu + 1, 1 << 15), np.uint8)
+    gap = 4096
     chunk_bytes = chunk_len * esz
-    slot = {}
+    out = np.zeros(nchunks * chunk_bytes + (ncpu + 1) * gap + 8192, np.uint8)
+    scratch = np.zeros((ncpu + 1) * 65536, np.uint8)
+    elems = C.c_uint64(0)
 
-    def run(lo, hi):
-        sc = scratch[slot.setdefault(threading.get_ident(), len(slot) % (ncpu + 1))]
-        chain(huf, dec, 1, esz, blocks_np.ctypes.data, boffs_np[lo:].ctypes.data, sizes_np[lo:].ctypes.data, hi - lo, chunk_len,
-              sc.ctypes.data, out.ctypes.data + lo * chunk_bytes)
+    def call(n, nthreads, reps, cpus):
+        arr = (C.c_int * nthreads)(*cpus) if cpus else None
+        t = mt(huf, dec, 1, esz, blocks_np.ctypes.data, boffs_np.ctypes.data, sizes_np.ctypes.data, n, chunk_len, scratch.ctypes.data,
+               out.ctypes.data, gap, nthreads, reps, arr, C.byref(elems))
+        assert t > 0 and elems.value == n * chunk_len, (t, elems.value)
+        return t
 
-    b1, bm, cores, reps = time_cpu(run, nchunks, target_s)
-    raw = nchunks * chunk_bytes
-    return {"value": round(raw / bm / 1e6, 1), "unit": "MB/s", "cores": cores, "kind": kind, "value_1thread": round(raw / b1 / 1e6, 1),
-            "sample": f"{nchunks} of this configuration's own Huff0 blocks ({raw / 1e6:.0f} MB raw): {hname} then sprintz_decompress_xff_16b "
-                      f"per chunk, best of {reps + 1} passes on 1 thread / 3x{reps} on {cores} threads"}
+    n_one = min(n_one, nchunks)
+    r = time_cpu_mt(call, n_one, nchunks, chunk_bytes, target_s)
+    r.update({"unit": "MB/s", "kind": kind,
+              "sample": f"{hname} then sprintz_decompress_xff_16b per chunk on this configuration's own Huff0 blocks; all-core legs: {nchunks} chunks "
+                        f"({nchunks * chunk_bytes / 1e6:.0f} MB raw), one chunk range per pinned pthread, {r['passes']} passes, best of 3; "
+                        f"`value`/`cores` = one thread per physical core; 1-thread leg: first {n_one} chunks"})
+    return r
 
 
 def roofline(algo_bytes, ms, kernel, extra=None):
@@ -273,7 +324,10 @@ def bench_rowmajor(cx, name, workload, codec, esz, ndims, chunk_len, nchunks_tot
            "decompress_ms": round(dec_ms, 4), "decompress_MBps": round(raw / dec_ms / 1e3, 1),
            "compress_ms": round(enc_ms, 4), "compress_MBps": round(raw / enc_ms / 1e3, 1),
            "roofline": roofline(algo, dec_ms, "sprintz decode kernel of this shape (profiles/: per-config kernel stats)"),
-           "compress_roofline": roofline(raw + stream_bytes + total + 12 * n, enc_ms, "encode kernel + size scan + compaction copy")}
+           "compress_roofline": roofline(raw + total + 12 * n, enc_ms, "encode kernel + size scan + compaction copy",
+                                         {"algorithmic": "raw samples in + dense container out + sizes/offsets (SURVEY 8d)",
+                                          "traffic_ratio_by_design": round((raw + stream_bytes + 2 * total + 12 * n) / (raw + total + 12 * n), 3),
+                                          "traffic_note": "the encoder writes slots, the compaction pass re-reads them and writes the dense container"})}
     if n * chunk_len * esz < (64 << 20):
         res["note"] = ("launch-bound: %d chunks keep %d of the chip's 1024 SIMDs' worth of wavefronts busy; the time is one kernel's "
                        "end-to-end latency, not a bandwidth" % (n, min(1024, max(1, n * ndims // 64))))
@@ -308,7 +362,8 @@ def bench_rowmajor(cx, name, workload, codec, esz, ndims, chunk_len, nchunks_tot
             assert torch.equal(z_rets, ws["sizes"].to(torch.int64)), "Huff0 decode: a block was rejected"
             assert torch.equal(out, x), "Huff0 -> Sprintz decode != input"
         hbytes = int(z_offs[-1].item())
-        algo_chain = hbytes + 8 * n + 2 * stream_bytes + 8 * n + raw        # blocks in, streams out and in again, samples out
+        algo_chain = hbytes + 8 * n + 8 * n + raw                           # Huff0 blocks in + samples out + both offset tables
+        moved_chain = algo_chain + 2 * stream_bytes                         # what the two-stage chain moves: the Sprintz streams out and in again
         res.update({"ratio": round(raw / hbytes, 4), "ratio_sprintz_only": round(raw / stream_bytes, 4),
                     "entropy_stage": "Huff0 wire format (HUF_compress-compatible blocks, one per chunk)",
                     "decompress_ms": round(chain_ms, 4), "decompress_MBps": round(raw / chain_ms / 1e3, 1),
@@ -316,22 +371,24 @@ def bench_rowmajor(cx, name, workload, codec, esz, ndims, chunk_len, nchunks_tot
                     "compress_ms": round(enc_ms + h_enc_ms, 4), "compress_MBps": round(raw / (enc_ms + h_enc_ms) / 1e3, 1),
                     "huff0_encode_ms": round(h_enc_ms, 4),
                     "roofline": roofline(algo_chain, chain_ms, "Huff0 stage (tree passes + stream kernels, sprintz_mi355x_huf0_decompress_batch_ws) + sprintz decode; the Sprintz streams cross HBM between the two",
-                                         {"huff0_decode_frac": round((hbytes + stream_bytes + 16 * n) / (h_dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})})
+                                         {"algorithmic": "Huff0 blocks in + samples out + offset tables (SURVEY 8d); the intermediate Sprintz streams are NOT counted",
+                                          "traffic_ratio_by_design": round(moved_chain / algo_chain, 3),
+                                          "huff0_decode_frac": round((hbytes + stream_bytes + 16 * n) / (h_dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})})
         if cx.rank == 0 and cx.world == 1 and not args.no_cpu_baseline:
             pt = huf0_private_trees(cx, comp, offs, ws["sizes"], n, timer, reps)
             if pt:
                 res["huff0_private_trees"] = pt
         if cx.rank == 0 and not args.no_cpu_baseline:
-            ns = min(n, max(64, (48 << 20) // (chunk_len * esz)))
+            ns = min(n, max(64, CPU_SAMPLE_BYTES // (chunk_len * esz)))
             zo = z_offs[: ns + 1].cpu().numpy().astype("uint64")
             res["cpu_baseline"] = cpu_baseline_huf0_chain(z_buf[: int(zo[ns]) + 64].cpu().numpy(), zo,
                                                            ws["sizes"][:ns].cpu().numpy().astype("uint32"), ns, esz, chunk_len, 1.0)
         del z_buf, s_buf
     elif cx.rank == 0 and not args.no_cpu_baseline:
-        ns = min(n, max(64, (48 << 20) // (chunk_len * esz)))
+        ns = min(n, max(64, CPU_SAMPLE_BYTES // (chunk_len * esz)))
         o = offs[: ns + 1].cpu().numpy().astype("uint64")
         res["cpu_baseline"] = cpu_baseline(comp[: int(o[ns]) + 64].cpu().numpy(), o, ns, 1 if codec == "xff" else 0, esz, chunk_len, 1.0,
-                                           f"sprintz_decompress_{codec}_{8 * esz}b")
+                                           f"sprintz_decompress_{codec}_{8 * esz}b", n_one=max(64, (80 << 20) // (chunk_len * esz)))
     res["_local"] = (raw, stream_bytes if not huff0 else hbytes, res["decompress_ms"], res["compress_ms"])
     del x, comp, out, src
     cd._ws = {}
@@ -382,14 +439,16 @@ def bench_cfg5(cx):
            "decompress_ms": round(dec_ms, 4), "decompress_MBps": round(raw / dec_ms / 1e3, 1),
            "compress_ms": round(enc_ms, 4), "compress_MBps": round(raw / enc_ms / 1e3, 1),
            "roofline": roofline(sb + 8 * n + raw, dec_ms, "decode_fast_kernel<16,FIRE,32,1,EXACT,0,CM=true>"),
-           "compress_roofline": roofline(raw + 2 * sb + 12 * n, enc_ms, "encode_fast<..CM> + size scan + compaction copy"),
+           "compress_roofline": roofline(raw + sb + 12 * n, enc_ms, "encode_fast<..CM> + size scan + compaction copy",
+                                         {"algorithmic": "raw samples in + dense container out + sizes/offsets (SURVEY 8d)"}),
            "note": "64 MiB over %d chunks: one launch is %.0f us end to end, about half of it ramp-up and tail (launch-bound at this size; "
                    "the 8 M-row form of the same shape runs at ~2.2 TB/s, DESIGN.md 4.6)" % (n, dec_ms * 1e3)}
     if cx.rank == 0 and not args.no_cpu_baseline:
-        ns = min(n, 4096)
+        ns = n
         o = batch.offsets[: ns + 1].cpu().numpy().astype("uint64")
         res["cpu_baseline"] = cpu_baseline(batch.data[: int(o[ns]) + 64].cpu().numpy(), o, ns, 1, esz, rpc * D, 1.0,
-                                           "sprintz_decompress_xff_16b (row-major flattening: the reference has no column-major entry)")
+                                           "sprintz_decompress_xff_16b (row-major flattening: the reference has no column-major entry)",
+                                           last_chunk_len=(nrows - (n - 1) * rpc) * D)
     res["_local"] = (raw, sb, res["decompress_ms"], res["compress_ms"])
     del cols, batch, out, dense
     cd._ws = {}
@@ -485,13 +544,61 @@ def merge_over_ranks(cx, res):
 
 
 # ------------------------------------------------------------------------------------------ main
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: become `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N ... bench.py <same arguments>` -- one rank per GPU; rank 0 prints the JSON line."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ["BENCH_SELF_LAUNCHED"] = "1"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
+def dry_launch(args, world, rank):
+    """the launch path without the workload: process group up, ranks all-gathered, one JSON line from rank 0"""
+    import torch
+    import torch.distributed as dist
+    use_gpu = torch.cuda.is_available() and torch.cuda.device_count() >= world and not os.environ.get("BENCH_ONE_DEVICE")
+    backend = os.environ.get("BENCH_BACKEND", "nccl" if use_gpu else "gloo")
+    seen = [rank]
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))))
+            t = torch.tensor([rank], device="cuda")
+        else:
+            dist.init_process_group(backend)
+            t = torch.tensor([rank])
+        got = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(got, t)
+        seen = [int(g.item()) for g in got]
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": args.gpus, "world": world, "ranks": seen, "backend": backend if world > 1 else None,
+                          "self_launched": bool(os.environ.get("BENCH_SELF_LAUNCHED"))}), flush=True)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                        # does not return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    assert world == args.gpus, (f"--gpus {args.gpus} but the launcher set WORLD_SIZE={world}: start it with --nproc-per-node {args.gpus}, "
+                                f"or with no launcher at all (bench.py then launches its own ranks)")
+    if args.dry_launch:
+        return dry_launch(args, world, rank)
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -522,7 +629,6 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import sprintz_amd
     from sprintz_amd import _lib
@@ -625,7 +731,9 @@ def main():
         "ratio": round(total_raw / total_stream, 4),
         "compress_MBps": round(total_raw / (compress_ms * 1e-3) / 1e6, 1),
         "compress": {"ms_per_step_max_rank": round(compress_ms, 4), "what": "encode kernel + size scan + compaction copy" +
-                     (" + all-gather of per-rank byte counts" if world > 1 else ""), "layout_gather": gather.backend},
+                     (" + all-gather of per-rank byte counts" if world > 1 else ""), "layout_gather": gather.backend,
+                     "roofline_frac": round((nchunks * chunk_bytes + total_comp + 12 * nchunks) / (compress_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "roofline_algorithmic": "raw samples in + dense container out + sizes/offsets, this rank"},
         "kernel_ms": round(kernel_ms, 4),
         "roofline": {"bound": "hbm", "achieved": round(algo_bytes / (kernel_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(algo_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -639,7 +747,7 @@ def main():
         result.update(headline_extras(cx, codec, x, comp, offsets, ws, out, nchunks, total_comp, chunk_len, ndims, esz, wall / args.steps * 1e3))
 
     if rank == 0 and not args.no_cpu_baseline:
-        ns = min(nchunks, 8192)
+        ns = min(nchunks, max(64, CPU_SAMPLE_BYTES // chunk_bytes))
         offs_np = offsets[: ns + 1].cpu().numpy().astype("uint64")
         comp_np = comp[: int(offs_np[ns]) + 64].cpu().numpy()
         cb = cpu_baseline(comp_np, offs_np, ns, 1, esz, chunk_len, args.cpu_seconds, "sprintz_decompress_xff_16b")
@@ -660,6 +768,17 @@ def main():
                 raise
             per.append({"name": nm, "error": f"{type(e).__name__}: {e}"})
     result["per_config"] = per
+    # the LAST key: one short entry per configuration, so that a reader who keeps only the tail of this line sees them all --
+    # [decompress ms, fraction of the HBM roofline over algorithmic bytes, compress ms, compress fraction, CPU all-core MB/s, CPU 1-thread MB/s]
+    summ = {"cfg2": [result["kernel_ms"], result["roofline"]["frac"], result["compress"]["ms_per_step_max_rank"], result["compress"]["roofline_frac"],
+                     result.get("cpu_baseline", {}).get("value"), result.get("cpu_baseline", {}).get("value_1thread")]}
+    for e in per[1:]:
+        if "error" in e:
+            summ[e["name"]] = "error"
+            continue
+        cb = e.get("cpu_baseline") or {}
+        summ[e["name"]] = [e["decompress_ms"], e["roofline"]["frac"], e["compress_ms"], e["compress_roofline"]["frac"], cb.get("value"), cb.get("value_1thread")]
+    result["per_config_summary"] = {"fields": "dec_ms, dec_frac, enc_ms, enc_frac, cpu_allcore_MBps, cpu_1thread_MBps", **summ}
     if rank == 0:
         emit(result)
     gather.close()

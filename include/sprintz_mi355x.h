@@ -40,7 +40,12 @@
 extern "C" {
 #endif
 
-#define SPRINTZ_MI355X_ABI_VERSION 1
+/* ABI history (additive: a caller built against version n runs against any library with abi_version() >= n)
+ *   1  round 1: the 8 drop-in entry points, the batched device API, the optional Huffman ("SPZH") and query stages
+ *   2  round 2: set_option, *_layout, the Huff0 wire format (huf0_*), online_*, comm_* / gather_layout / layout_bases,
+ *      the column-major and run-less codec entry points, the reference's mangled C++ names (sprintz_dropin.hpp)
+ *   3  round 3: SPRINTZ_MI355X_RCCL_SONAME, huf0 chain entry points (see below) */
+#define SPRINTZ_MI355X_ABI_VERSION 3
 
 /* codec ids */
 #define SPRINTZ_CODEC_DELTA 0   /* sprintz_*_delta_*  (sprintz_delta_rle.cpp / sprintz_delta_lowdim.cpp) */

@@ -51,6 +51,10 @@ def _sig(name, restype, *argtypes):
 
 
 abi_version = _sig("sprintz_mi355x_abi_version", _i)
+ABI_REQUIRED = 3
+if abi_version() < ABI_REQUIRED:      # a stale build would otherwise die below with an AttributeError on the first new symbol
+    raise ImportError(f"{LIB_PATH} has ABI version {abi_version()}, this binding needs >= {ABI_REQUIRED}: rebuild it "
+                      "(`make -C sprintz_amd/csrc`)")
 _last_error = _sig("sprintz_mi355x_last_error", C.c_char_p)
 OPT_NO_FAST, OPT_CHUNKS_PER_GROUP = 0, 1
 set_option = _sig("sprintz_mi355x_set_option", _i, _i, _i)

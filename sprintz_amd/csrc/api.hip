@@ -598,18 +598,32 @@ int64_t compress_host(int codec, int esz, const void* src, uint32_t len, void* d
     }
     uint32_t* d_size = (uint32_t*)(sc->dev + o_meta);
     int64_t* d_ret = (int64_t*)(sc->dev + o_meta + 8);
+    // the scratch is reused: a kernel that never reports must read as an error (size 0xffffffff > bound), not as the last call's answer
+    HIP_TRY(hipMemsetAsync(d_size, 0xff, 16, sc->stream));
     rc = encode_launch(codec, esz, sc->dev, len, len, ndims, sc->dev + o_slot, bound, d_size, d_ret, sc->stream, write_size, 0,
                        layout == SPRINTZ_LAYOUT_GENERAL);
-    if (rc) return rc;
+    if (rc) { (void)hipStreamSynchronize(sc->stream); return rc; }   // the H2D copy out of sc->pin may still be in flight
     uint32_t size = 0;
     int64_t ret = 0;
-    if (pin_out) {                                            // size, ret and the whole slot in one copy
+    // small slots: size, ret and the whole slot in one copy (one round trip); large ones: the 16 bytes first, then exactly `size`
+    // bytes -- a compressible multi-megabyte call would otherwise move 2-4x the stream over PCIe
+    constexpr size_t kOneCopyMax = 64u << 10;
+    if (pin_out && 16 + bound <= kOneCopyMax) {
         HIP_TRY(hipMemcpyAsync(sc->pin, sc->dev + o_meta, 16 + bound, hipMemcpyDeviceToHost, sc->stream));
         HIP_TRY(hipStreamSynchronize(sc->stream));
         memcpy(&size, sc->pin, 4);
         memcpy(&ret, sc->pin + 8, 8);
         if (size > bound) return fail(SPRINTZ_E_HIP, "encoder reported a size above its bound");
         memcpy(dest, sc->pin + 16, size);
+    } else if (pin_out) {
+        HIP_TRY(hipMemcpyAsync(sc->pin, sc->dev + o_meta, 16, hipMemcpyDeviceToHost, sc->stream));
+        HIP_TRY(hipStreamSynchronize(sc->stream));
+        memcpy(&size, sc->pin, 4);
+        memcpy(&ret, sc->pin + 8, 8);
+        if (size > bound) return fail(SPRINTZ_E_HIP, "encoder reported a size above its bound");
+        HIP_TRY(hipMemcpyAsync(sc->pin, sc->dev + o_slot, size, hipMemcpyDeviceToHost, sc->stream));
+        HIP_TRY(hipStreamSynchronize(sc->stream));
+        memcpy(dest, sc->pin, size);
     } else {
         uint8_t meta[16];
         HIP_TRY(hipMemcpyAsync(meta, sc->dev + o_meta, 16, hipMemcpyDeviceToHost, sc->stream));
@@ -656,7 +670,7 @@ int64_t decode_host_common(int codec, int esz, const uint8_t* s, uint64_t nbytes
     }
     rc = decode_launch(codec, esz, sc->dev, (const uint64_t*)sc->dev, 1, (uint32_t)nelems, ndims, want_out ? sc->dev + o_out : nullptr,
                        d_ret, sc->stream, noheader, ngroups, remaining, qs);
-    if (rc) return rc;
+    if (rc) { (void)hipStreamSynchronize(sc->stream); return rc; }   // the H2D copy out of sc->pin may still be in flight
     int64_t ret = 0;
     if (want_out && pin_out) {                                // ret and the samples in one copy
         HIP_TRY(hipMemcpyAsync(sc->pin, sc->dev + o_out_meta, 16 + out_bytes, hipMemcpyDeviceToHost, sc->stream));
@@ -798,6 +812,22 @@ int64_t query_host(int codec, int esz, const void* src, void* dest, int op, int 
 }
 
 }  // namespace
+
+namespace sprintz {
+// what the other translation units' host-pointer entry points (online.hip) share with this one: the process-wide
+// device probe and the calling thread's pooled scratch (one device buffer, one pinned buffer, one non-blocking stream)
+bool have_device() { return process().have_device; }
+int host_scratch(size_t dev_bytes, size_t pin_bytes, HostScratch* out)
+{
+    Scratch* sc = nullptr;
+    const int rc = acquire_scratch(dev_bytes, pin_bytes, &sc);
+    if (rc) return rc;
+    out->stream = sc->stream;
+    out->dev = sc->dev;
+    out->pin = sc->pin;
+    return 0;
+}
+}  // namespace sprintz
 
 // =============================================================== exported C-ABI
 extern "C" {

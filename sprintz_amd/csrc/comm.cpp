@@ -12,6 +12,7 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -35,11 +36,22 @@ const Rccl& rccl()
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (r.handle) break;
+        // SPRINTZ_MI355X_RCCL_SONAME names the one library to try instead of the default list (a site whose RCCL lives
+        // elsewhere; also how tests/test_abi.py makes the load fail on purpose)
+        const char* forced = getenv("SPRINTZ_MI355X_RCCL_SONAME");
+        std::string last = "?";
+        if (forced && *forced) {
+            r.handle = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+            if (!r.handle) { const char* e = dlerror(); if (e) last = e; }      // dlerror() clears what it returns: ask once
+        } else {
+            for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (r.handle) break;
+                const char* e = dlerror();
+                if (e) last = e;
+            }
         }
-        if (!r.handle) { r.why = std::string("RCCL not loadable: ") + (dlerror() ? dlerror() : "?"); return; }
+        if (!r.handle) { r.why = std::string("RCCL not loadable: ") + last; return; }
         r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.handle, "ncclGetUniqueId");
         r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.handle, "ncclCommInitRank");
         r.AllGather = (decltype(r.AllGather))dlsym(r.handle, "ncclAllGather");

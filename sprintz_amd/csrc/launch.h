@@ -40,6 +40,12 @@ hipError_t launch_encode_w16(bool fire, bool lowdim, int cpl, unsigned grid, siz
 // failing return of every translation unit goes through it, so the message is never stale
 int set_error(int code, const char* what);
 
+// the calling thread's pooled scratch for host-pointer entry points (api.hip: acquire_scratch): buffers only grow, the
+// stream is private and non-blocking; valid until the thread's next host_scratch() call
+struct HostScratch { hipStream_t stream; uint8_t* dev; uint8_t* pin; };
+int host_scratch(size_t dev_bytes, size_t pin_bytes, HostScratch* out);
+bool have_device();                       // probed once per process
+
 hipError_t launch_size_scan(const uint32_t* d_sizes, uint64_t n, uint32_t align, uint64_t* d_offsets, void* d_tmp, hipStream_t st);
 
 template <typename K, typename A>

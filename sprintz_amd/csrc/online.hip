@@ -17,6 +17,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 
 #include "launch.h"
@@ -313,17 +314,48 @@ __global__ void check_len_kernel(const uint8_t* src, uint32_t len, int64_t* ret)
     if (have != len && ret) *ret = SPRINTZ_E_CORRUPT;
 }
 
-bool have_device()
-{
-    int n = 0;
-    return hipGetDeviceCount(&n) == hipSuccess && n > 0;
-}
 int fail(int code, const char* what) { return sprintz::set_error(code, what); }
 unsigned grid_for(uint64_t items) { return (unsigned)((items + kT - 1) / kT); }
 
 uint32_t choice_bytes_of(uint32_t len) { return (((len + 7) / 8) + 7) / 8; }                 // online.cpp:253-258
 uint32_t hdr_bytes_of(uint32_t len) { return (((len + 7) / 8) * 4 + 7) / 8; }                // online.cpp:355-359
 
+}  // namespace
+
+namespace {
+constexpr size_t kOnlinePinMax = 4u << 20;     // larger transfers go straight from/to the caller's memory
+size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// `in_bytes` of `in` -> device, run(d_in, d_out, d_ret, d_tmp, stream), then ret elements of 2 bytes -> `out`
+template <typename F>
+int64_t online_host_call(const void* in, size_t in_bytes, size_t out_cap_bytes, size_t tmpb, void* out, F run)
+{
+    const size_t o_out = up256(in_bytes + 64), o_tmp = o_out + up256(out_cap_bytes + 64), o_ret = o_tmp + up256(tmpb + 64);
+    const bool pin_in = in_bytes <= kOnlinePinMax, pin_out = out_cap_bytes <= kOnlinePinMax;
+    HostScratch sc;
+    int rc = host_scratch(o_ret + 16, std::max<size_t>(16, std::max(pin_in ? in_bytes : 0, pin_out ? out_cap_bytes : 0)), &sc);
+    if (rc) return rc;
+    const void* h_in = in;
+    if (pin_in) { memcpy(sc.pin, in, in_bytes); h_in = sc.pin; }
+    if (hipMemcpyAsync(sc.dev, h_in, in_bytes, hipMemcpyHostToDevice, sc.stream) != hipSuccess) return fail(SPRINTZ_E_HIP, "online: H2D copy");
+    int64_t* d_ret = (int64_t*)(sc.dev + o_ret);
+    rc = run(sc.dev, sc.dev + o_out, d_ret, sc.dev + o_tmp, sc.stream);
+    if (rc) { (void)hipStreamSynchronize(sc.stream); return rc; }
+    int64_t ret = SPRINTZ_E_HIP;
+    // sc.pin is free again once the H2D copy has run; the 8 bytes of ret come back first, then exactly ret elements
+    if (hipMemcpyAsync(sc.pin, d_ret, 8, hipMemcpyDeviceToHost, sc.stream) != hipSuccess || hipStreamSynchronize(sc.stream) != hipSuccess)
+        return fail(SPRINTZ_E_HIP, "online: device call failed");
+    memcpy(&ret, sc.pin, 8);
+    if (ret > 0) {
+        const size_t nb = (size_t)ret * 2;
+        if (nb > out_cap_bytes) return fail(SPRINTZ_E_HIP, "online: the device reported more than the bound");
+        void* h_out = pin_out ? (void*)sc.pin : out;
+        if (hipMemcpyAsync(h_out, sc.dev + o_out, nb, hipMemcpyDeviceToHost, sc.stream) != hipSuccess || hipStreamSynchronize(sc.stream) != hipSuccess)
+            return fail(SPRINTZ_E_HIP, "online: D2H copy");
+        if (pin_out) memcpy(out, sc.pin, nb);
+    }
+    return ret;
+}
 }  // namespace
 
 extern "C" {
@@ -424,6 +456,10 @@ int sprintz_mi355x_online_unpack_device(int kind, const void* d_src, uint32_t le
 }
 
 // ---- single-call forms over host buffers (the reference's signatures are in include/sprintz_dropin.hpp)
+// Like api.hip's single calls: the thread's pooled scratch (one device buffer [source | destination | tmp | ret], one
+// pinned staging buffer, one private non-blocking stream) -- no hipMalloc / hipFree per call, no device-wide
+// synchronisation that would stall other threads' streams.
+
 int64_t sprintz_mi355x_online_pack(int kind, const uint16_t* src, uint32_t len, int16_t* dest)
 {
     if (kind < SPRINTZ_ONLINE_DYNDELTA || kind > SPRINTZ_ONLINE_PACK_ZIGZAG) return fail(SPRINTZ_E_INVALID, "online: kind must be 0..4");
@@ -431,21 +467,9 @@ int64_t sprintz_mi355x_online_pack(int kind, const uint16_t* src, uint32_t len, 
     if (len > (1u << 30)) return fail(SPRINTZ_E_UNSUPPORTED, "online: single call limited to 2^30 elements");
     if (!have_device()) return fail(SPRINTZ_E_NO_DEVICE, "online: no usable HIP device (there is no CPU fallback)");
     const size_t bound = sprintz_mi355x_online_bound(kind, len), tmpb = sprintz_mi355x_online_tmp_bytes(kind, len);
-    uint8_t *dx = nullptr, *dy = nullptr, *dt = nullptr;
-    int64_t ret = SPRINTZ_E_HIP;
-    if (hipMalloc((void**)&dx, (size_t)len * 2 + 64) == hipSuccess && hipMalloc((void**)&dy, bound + 64) == hipSuccess &&
-        hipMalloc((void**)&dt, tmpb + 64) == hipSuccess) {
-        bool ok = hipMemcpy(dx, src, (size_t)len * 2, hipMemcpyHostToDevice) == hipSuccess;
-        int64_t* d_ret = (int64_t*)(dt + ((tmpb + 15) & ~(size_t)15));
-        ok = ok && sprintz_mi355x_online_pack_device(kind, (const uint16_t*)dx, len, dy, d_ret, dt, nullptr) == 0;
-        ok = ok && hipDeviceSynchronize() == hipSuccess && hipMemcpy(&ret, d_ret, 8, hipMemcpyDeviceToHost) == hipSuccess;
-        if (ok && ret > 0) ok = hipMemcpy(dest, dy, (size_t)ret * 2, hipMemcpyDeviceToHost) == hipSuccess;
-        if (!ok) ret = fail(SPRINTZ_E_HIP, "online: device call failed");
-    } else {
-        fail(SPRINTZ_E_HIP, "online: hipMalloc");
-    }
-    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dt);
-    return ret;
+    return online_host_call(src, (size_t)len * 2, bound, tmpb, dest, [&](uint8_t* d_in, uint8_t* d_out, int64_t* d_ret, uint8_t* d_tmp, hipStream_t st) {
+        return sprintz_mi355x_online_pack_device(kind, (const uint16_t*)d_in, len, d_out, d_ret, d_tmp, st);
+    });
 }
 
 int64_t sprintz_mi355x_online_unpack(int kind, const int16_t* src, uint16_t* dest)
@@ -457,37 +481,21 @@ int64_t sprintz_mi355x_online_unpack(int kind, const int16_t* src, uint16_t* des
     if (len > (1u << 30)) return fail(SPRINTZ_E_UNSUPPORTED, "online: single call limited to 2^30 elements (damaged header?)");
     if (len == 0) return 0;
     if (!have_device()) return fail(SPRINTZ_E_NO_DEVICE, "online: no usable HIP device (there is no CPU fallback)");
-    // the container is at most bound() bytes; the exact size is only known after the widths are summed, on the device
-    const size_t bound = sprintz_mi355x_online_bound(kind, len), tmpb = sprintz_mi355x_online_tmp_bytes(kind, len);
-    size_t csize = 4 + (size_t)len * 2;
-    if (kind <= SPRINTZ_ONLINE_DYNDELTA_ALT) csize += (size_t)((choice_bytes_of(len) + 1) / 2) * 2;
-    if (kind >= SPRINTZ_ONLINE_PACK) csize += (size_t)((hdr_bytes_of(len) + 1) / 2) * 2;   // worst case: 16 bits a value
-    (void)bound;
-    uint8_t *dx = nullptr, *dy = nullptr, *dt = nullptr;
-    int64_t ret = SPRINTZ_E_HIP;
-    if (hipMalloc((void**)&dx, csize + 64) == hipSuccess && hipMalloc((void**)&dy, (size_t)len * 2 + 64) == hipSuccess &&
-        hipMalloc((void**)&dt, tmpb + 64) == hipSuccess) {
-        // the caller's buffer holds at least the container; a sprintzpack container may be shorter than csize, so the copy is
-        // sized from the header nibbles (host framing walk, no sample touched)
-        size_t have = csize;
-        if (kind >= SPRINTZ_ONLINE_PACK) {
-            const uint8_t* h = (const uint8_t*)src + 4;
-            const uint32_t nblocks = len / 8, helems = (hdr_bytes_of(len) + 1) / 2;
-            size_t pay = 0;
-            for (uint32_t b = 0; b < nblocks; b++) { uint32_t nb = (h[b / 2] >> (4 * (b & 1u))) & 15u; pay += nb + (nb == 15u); }
-            have = 4 + (size_t)helems * 2 + pay + (size_t)(len - 8 * nblocks) * 2;
-        }
-        bool ok = hipMemcpy(dx, src, have, hipMemcpyHostToDevice) == hipSuccess;
-        int64_t* d_ret = (int64_t*)(dt + ((tmpb + 15) & ~(size_t)15));
-        ok = ok && sprintz_mi355x_online_unpack_device(kind, dx, len, (uint16_t*)dy, d_ret, dt, nullptr) == 0;
-        ok = ok && hipDeviceSynchronize() == hipSuccess && hipMemcpy(&ret, d_ret, 8, hipMemcpyDeviceToHost) == hipSuccess;
-        if (ok && ret > 0) ok = hipMemcpy(dest, dy, (size_t)ret * 2, hipMemcpyDeviceToHost) == hipSuccess;
-        if (!ok) ret = fail(SPRINTZ_E_HIP, "online: device call failed");
-    } else {
-        fail(SPRINTZ_E_HIP, "online: hipMalloc");
+    const size_t tmpb = sprintz_mi355x_online_tmp_bytes(kind, len);
+    // the caller's buffer holds the container and not necessarily a byte more: a dynamic-delta / zigzag container's size follows
+    // from len; a sprintzpack container's from its header nibbles (host framing walk, no sample touched)
+    size_t have = 4 + (size_t)len * 2;
+    if (kind <= SPRINTZ_ONLINE_DYNDELTA_ALT) have += (size_t)((choice_bytes_of(len) + 1) / 2) * 2;
+    if (kind >= SPRINTZ_ONLINE_PACK) {
+        const uint8_t* h = (const uint8_t*)src + 4;
+        const uint32_t nblocks = len / 8, helems = (hdr_bytes_of(len) + 1) / 2;
+        size_t pay = 0;
+        for (uint32_t b = 0; b < nblocks; b++) { uint32_t nb = (h[b / 2] >> (4 * (b & 1u))) & 15u; pay += nb + (nb == 15u); }
+        have = 4 + (size_t)helems * 2 + pay + (size_t)(len - 8 * nblocks) * 2;
     }
-    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dt);
-    return ret;
+    return online_host_call(src, have, (size_t)len * 2, tmpb, dest, [&](uint8_t* d_in, uint8_t* d_out, int64_t* d_ret, uint8_t* d_tmp, hipStream_t st) {
+        return sprintz_mi355x_online_unpack_device(kind, d_in, len, (uint16_t*)d_out, d_ret, d_tmp, st);
+    });
 }
 
 }  // extern "C"

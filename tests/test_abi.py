@@ -44,7 +44,7 @@ def test_library_exports_every_declared_symbol(lib_path):
 def test_python_binding_matches_header(lib_path):
     from sprintz_amd import _lib
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared_symbols()
-    assert _lib.abi_version() == 1
+    assert _lib.abi_version() == 3
 
 
 def test_no_cpu_fallback(lib_path):
@@ -161,3 +161,25 @@ def test_argument_checks_come_before_the_device_check(lib_path):
         assert _lib.compress_batch(0, 2, p16, 100, 50, 8, p16, 1024, p16, None, None) == E.E_NO_DEVICE
         assert _lib.transform_encode_device(0, 2, p16, 10, 8, p16, None) == E.E_NO_DEVICE
         assert _lib.query_batch(1, 2, p16, p16, 1, 50, 8, 1, 0, 0, None, p16, None, None) == E.E_NO_DEVICE
+
+
+def test_unloadable_rccl_is_an_error_code_not_a_crash(lib_path):
+    """comm.cpp resolves RCCL with dlopen; when that fails the entry points must return SPRINTZ_E_UNSUPPORTED with the
+    loader's message (round 2 called dlerror() twice and fed the second call's NULL to std::string: a crash inside call_once)"""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys\n"
+        f"lib = C.CDLL({lib_path!r})\n"
+        "lib.sprintz_mi355x_last_error.restype = C.c_char_p\n"
+        "buf = C.create_string_buffer(128)\n"
+        "rc = lib.sprintz_mi355x_comm_unique_id(buf)\n"
+        "comm = C.c_void_p()\n"
+        "rc2 = lib.sprintz_mi355x_comm_init(buf, 0, 1, C.byref(comm))\n"
+        "print(rc, rc2, lib.sprintz_mi355x_last_error().decode())\n")
+    env = dict(os.environ, SPRINTZ_MI355X_RCCL_SONAME="/nonexistent/librccl-not-here.so")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-1500:]
+    rc, rc2, msg = p.stdout.strip().split(" ", 2)
+    assert int(rc) == -4 and int(rc2) == -4              # SPRINTZ_E_UNSUPPORTED
+    assert "RCCL not loadable" in msg and "librccl-not-here" in msg
