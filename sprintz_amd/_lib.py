@@ -56,7 +56,7 @@ if abi_version() < ABI_REQUIRED:      # a stale build would otherwise die below 
     raise ImportError(f"{LIB_PATH} has ABI version {abi_version()}, this binding needs >= {ABI_REQUIRED}: rebuild it "
                       "(`make -C sprintz_amd/csrc`)")
 _last_error = _sig("sprintz_mi355x_last_error", C.c_char_p)
-OPT_NO_FAST, OPT_CHUNKS_PER_GROUP = 0, 1
+OPT_NO_FAST, OPT_CHUNKS_PER_GROUP, OPT_NO_FUSED_COMPACT = 0, 1, 2
 set_option = _sig("sprintz_mi355x_set_option", _i, _i, _i)
 
 # (1) drop-in single-call API, host pointers
@@ -83,6 +83,8 @@ compress_bound = _sig("sprintz_mi355x_compress_bound", _sz, _i, _u32, _u16)
 num_chunks = _sig("sprintz_mi355x_num_chunks", _u64, _u64, _u32)
 compress_batch = _sig("sprintz_mi355x_compress_batch", _i, _i, _i, _vp, _u64, _u32, _u16, _vp, _sz, _vp, _vp, _vp)
 compact_tmp_bytes = _sig("sprintz_mi355x_compact_tmp_bytes", _sz, _u64)
+compress_dense_tmp_bytes = _sig("sprintz_mi355x_compress_dense_tmp_bytes", _sz, _u64)
+compress_batch_dense = _sig("sprintz_mi355x_compress_batch_dense", _i, _i, _i, _vp, _u64, _u32, _u16, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp)
 compact = _sig("sprintz_mi355x_compact", _i, _vp, _sz, _vp, _u64, _u32, _vp, _vp, _vp, _vp)
 decompress_batch = _sig("sprintz_mi355x_decompress_batch", _i, _i, _i, _vp, _vp, _u64, _u32, _u16, _vp, _vp, _vp)
 
@@ -157,6 +159,7 @@ EXPORTED_SYMBOLS = [
     "sprintz_mi355x_decompress_noheader", "sprintz_mi355x_compress_layout", "sprintz_mi355x_decompress_layout",
     "sprintz_mi355x_compress_bound", "sprintz_mi355x_num_chunks",
     "sprintz_mi355x_compress_batch", "sprintz_mi355x_compact_tmp_bytes", "sprintz_mi355x_compact",
+    "sprintz_mi355x_compress_dense_tmp_bytes", "sprintz_mi355x_compress_batch_dense",
     "sprintz_mi355x_decompress_batch",
     "sprintz_mi355x_compress_chunked_host", "sprintz_mi355x_decompress_chunked_host",
     "sprintz_mi355x_online_bound", "sprintz_mi355x_online_tmp_bytes", "sprintz_mi355x_online_pack_device",

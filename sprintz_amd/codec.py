@@ -150,7 +150,7 @@ class ChunkedCodec:
                 slots=t.empty(nchunks * self.slot_stride, dtype=t.uint8, device=self.device),
                 sizes=t.empty(nchunks, dtype=t.int32, device=self.device),
                 rets=t.empty(nchunks, dtype=t.int64, device=self.device),
-                tmp=t.empty(int(_lib.compact_tmp_bytes(nchunks)), dtype=t.uint8, device=self.device),
+                tmp=t.empty(int(_lib.compress_dense_tmp_bytes(nchunks)), dtype=t.uint8, device=self.device),
             )
             self._ws = {nchunks: ws}
         return ws
@@ -184,6 +184,25 @@ class ChunkedCodec:
                                     dense.data_ptr(), offsets.data_ptr(), ws["tmp"].data_ptr(), self._stream()))
         return dense, offsets
 
+    def compress_dense(self, src_padded_u8, total_len, ws=None, dense=None, offsets=None):
+        """the whole write path in one call (what the bench times): src -> dense container + offsets.  For the shapes
+        the fast encoder takes this is ONE launch (the container is built inside it, csrc/compact_tail.h); align 16 only."""
+        t = self.torch
+        if self.align != 16:
+            raise ValueError("compress_dense builds the 16-byte aligned container; use compress_to_slots + compact for another alignment")
+        nchunks = int(_lib.num_chunks(total_len, self.chunk_len))
+        ws = ws or self.workspace(nchunks)
+        if dense is None:
+            dense = t.empty(nchunks * self.slot_stride + _lib.READ_SLACK, dtype=t.uint8, device=self.device)
+        if offsets is None:
+            offsets = t.empty(nchunks + 1, dtype=t.int64, device=self.device)
+        with self._on():
+            _lib.check(_lib.compress_batch_dense(_CODEC_ID[self.codec], self.esz, src_padded_u8.data_ptr(), total_len,
+                                                 self.chunk_len, self.ndims, ws["slots"].data_ptr(), self.slot_stride,
+                                                 ws["sizes"].data_ptr(), ws["rets"].data_ptr(), dense.data_ptr(),
+                                                 offsets.data_ptr(), ws["tmp"].data_ptr(), self._stream()))
+        return ws, dense, offsets
+
     def compress(self, src):
         """src: device tensor of dtype uint8/uint16, any shape, row-major [.., ndims]."""
         t = self.torch
@@ -191,8 +210,11 @@ class ChunkedCodec:
             raise ValueError(f"src must be a {self.esz}-byte integer tensor on {self.device}")
         total_len = src.numel()
         nchunks = int(_lib.num_chunks(total_len, self.chunk_len))
-        ws = self.compress_to_slots(self._padded_view(src.contiguous()), total_len)
-        dense, offsets = self.compact(ws, nchunks)
+        if self.align == 16:
+            ws, dense, offsets = self.compress_dense(self._padded_view(src.contiguous()), total_len)
+        else:
+            ws = self.compress_to_slots(self._padded_view(src.contiguous()), total_len)
+            dense, offsets = self.compact(ws, nchunks)
         total = int(offsets[-1].item())
         data = dense[: total + _lib.READ_SLACK].clone()
         return CompressedBatch(data, offsets, ws["sizes"].clone(), nchunks, total_len, self.chunk_len, self.ndims)

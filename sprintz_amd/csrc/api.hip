@@ -47,6 +47,7 @@ struct Process {
     bool have_device = false;
     std::atomic<int> no_fast{0};            // SPRINTZ_MI355X_NO_FAST: generic kernels only (A/B runs, tests)
     std::atomic<int> chunks_per_group{1};   // SPRINTZ_MI355X_CHUNKS_PER_GROUP (decode_fast read-ahead across chunks)
+    std::atomic<int> no_fused_compact{0};   // SPRINTZ_MI355X_NO_FUSED_COMPACT: compress_batch_dense always takes the two-launch path (A/B runs, tests)
 };
 Process& process()
 {
@@ -56,6 +57,7 @@ Process& process()
         int n = 0;
         p.have_device = hipGetDeviceCount(&n) == hipSuccess && n > 0;
         p.no_fast = getenv("SPRINTZ_MI355X_NO_FAST") != nullptr ? 1 : 0;
+        p.no_fused_compact = getenv("SPRINTZ_MI355X_NO_FUSED_COMPACT") != nullptr ? 1 : 0;
         if (const char* e = getenv("SPRINTZ_MI355X_CHUNKS_PER_GROUP")) {
             const int k = atoi(e);
             p.chunks_per_group = k < 1 ? 1 : k > 64 ? 64 : k;
@@ -328,9 +330,17 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
     return 0;
 }
 
+// what the encode launch needs to build the dense container itself (compact_tail.h); `fused` reports whether it did
+struct DenseRequest {
+    void* d_dense = nullptr;
+    uint64_t* d_offsets = nullptr;
+    void* d_tmp = nullptr;
+    bool fused = false;
+};
+
 int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uint32_t chunk_len, uint16_t ndims,
                   void* d_slots, size_t slot_stride, uint32_t* d_sizes, int64_t* d_rets, hipStream_t st, int write_size,
-                  uint64_t col_stride = 0, int general = 0)
+                  uint64_t col_stride = 0, int general = 0, DenseRequest* dense = nullptr)
 {
     const uint64_t nchunks = sprintz_mi355x_num_chunks(total_len, chunk_len);
     if (nchunks == 0) return 0;
@@ -377,6 +387,14 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
         const uint64_t fthreads = nchunks * (uint64_t)fdp;
         const uint64_t fgrid = (fthreads + kThreads - 1) / kThreads;
         if (fgrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
+        if (dense && dense->d_dense && fgroups <= 64 && !process().no_fused_compact.load(std::memory_order_relaxed)) {
+            a.dn.dense = (uint8_t*)dense->d_dense;
+            a.dn.offsets = dense->d_offsets;
+            a.dn.wg_state = (uint64_t*)dense->d_tmp;
+            a.dn.grid = (uint32_t)fgrid;
+            HIP_TRY(hipMemsetAsync(dense->d_tmp, 0, ((size_t)fgrid + 1) * sizeof(uint64_t), st));   // look-back words + the ticket counter
+            dense->fused = true;
+        }
         e = esz == 1 ? launch_encode_fast_w8((codec == SPRINTZ_CODEC_XFF || codec == SPRINTZ_CODEC_XFF_NORLE), fdp, D == fdp, (unsigned)fgrid, fshmem, st, a)
                      : launch_encode_fast_w16((codec == SPRINTZ_CODEC_XFF || codec == SPRINTZ_CODEC_XFF_NORLE), fdp, D == fdp, (unsigned)fgrid, fshmem, st, a);
         if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "encode_fast kernel launch", e);
@@ -837,6 +855,7 @@ int sprintz_mi355x_abi_version(void) { return SPRINTZ_MI355X_ABI_VERSION; }
 int sprintz_mi355x_set_option(int option, int value)
 {
     if (option == SPRINTZ_OPT_NO_FAST) { process().no_fast = value ? 1 : 0; return 0; }
+    if (option == SPRINTZ_OPT_NO_FUSED_COMPACT) { process().no_fused_compact = value ? 1 : 0; return 0; }
     if (option == SPRINTZ_OPT_CHUNKS_PER_GROUP) {
         if (value < 1 || value > 64) return fail(SPRINTZ_E_INVALID, "chunks per group must be in 1..64");
         process().chunks_per_group = value;
@@ -877,6 +896,43 @@ int sprintz_mi355x_compress_batch(int codec, int elem_bytes, const void* d_src, 
     if ((rc = ensure_device())) return rc;
     return encode_launch(codec, elem_bytes, d_src, total_len, chunk_len, ndims, d_slots, slot_stride, d_sizes, d_rets,
                          (hipStream_t)hip_stream, 1);
+}
+
+size_t sprintz_mi355x_compress_dense_tmp_bytes(uint64_t nchunks)
+{
+    // the chained scan's word per workgroup (at most nchunks / 4 workgroups: a chunk takes at most 64 of a workgroup's 256
+    // lanes) + the ticket counter -- or the two-launch path's scan scratch, whichever is larger
+    const size_t a = (size_t)(nchunks / 4 + 2) * sizeof(uint64_t), b = sprintz_mi355x_compact_tmp_bytes(nchunks);
+    return a > b ? a : b;
+}
+
+int sprintz_mi355x_compress_batch_dense(int codec, int elem_bytes, const void* d_src, uint64_t total_len, uint32_t chunk_len,
+                                        uint16_t ndims, void* d_slots, size_t slot_stride, uint32_t* d_sizes, int64_t* d_rets,
+                                        void* d_dense, uint64_t* d_offsets, void* d_tmp, void* hip_stream)
+{
+    int rc = check_common(codec, elem_bytes, ndims);
+    if (rc) return rc;
+    if (chunk_len == 0 || chunk_len > (1u << 30)) return fail(SPRINTZ_E_INVALID, "chunk_len must be in 1..2^30");
+    if (!d_src || !d_slots || !d_sizes || !d_dense || !d_offsets || !d_tmp) return fail(SPRINTZ_E_INVALID, "null device pointer");
+    if (slot_stride % 16 || (uintptr_t)d_slots % 16 || (uintptr_t)d_dense % 16 || (uintptr_t)d_tmp % 8)
+        return fail(SPRINTZ_E_INVALID, "slots and the container must be 16-byte aligned/strided");
+    if (slot_stride < sprintz_mi355x_compress_bound(elem_bytes, chunk_len, ndims))
+        return fail(SPRINTZ_E_INVALID, "slot_stride below sprintz_mi355x_compress_bound");
+    if ((rc = ensure_device())) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const uint64_t nchunks = sprintz_mi355x_num_chunks(total_len, chunk_len);
+    if (nchunks == 0) {
+        HIP_TRY(hipMemsetAsync(d_offsets, 0, 8, st));
+        return 0;
+    }
+    DenseRequest dr;
+    dr.d_dense = d_dense;
+    dr.d_offsets = d_offsets;
+    dr.d_tmp = d_tmp;
+    rc = encode_launch(codec, elem_bytes, d_src, total_len, chunk_len, ndims, d_slots, slot_stride, d_sizes, d_rets, st, 1, 0, 0, &dr);
+    if (rc || dr.fused) return rc;
+    // shapes whose encoder has no dense tail (low-dim, more than 64 columns, misaligned blocks): the two-launch path
+    return sprintz_mi355x_compact(d_slots, slot_stride, d_sizes, nchunks, 16, d_dense, d_offsets, d_tmp, hip_stream);
 }
 
 size_t sprintz_mi355x_compact_tmp_bytes(uint64_t nchunks)

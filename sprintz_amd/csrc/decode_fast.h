@@ -175,6 +175,15 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
 #ifndef SPRINTZ_STORE_AUX
 #define SPRINTZ_STORE_AUX 2
 #endif
+#ifndef SPRINTZ_DF_LEAN_REQ
+#define SPRINTZ_DF_LEAN_REQ 0
+#endif
+#ifndef SPRINTZ_DF_ALWAYS_LOAD
+#define SPRINTZ_DF_ALWAYS_LOAD 0
+#endif
+#ifndef SPRINTZ_DF_HDR64
+#define SPRINTZ_DF_HDR64 0
+#endif
     constexpr int kStoreAux = SPRINTZ_STORE_AUX;
     const uint32_t lane16 = (uint32_t)lane_d * 16u;
     uint64_t gabs = 0;                                     // container offset the cursors below are relative to
@@ -588,6 +597,32 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         // ---- request the units that fit now; they are parked at the bottom of this step
         {
             const uint32_t room = RB - ahead;              // ring bytes the parser no longer needs
+#if SPRINTZ_DF_LEAN_REQ
+            // how many whole units fit: one shift and a min instead of a compare and two selects per unit; the k-th load's
+            // k * UNIT rides in the instruction's immediate offset
+            if constexpr ((UNIT & (UNIT - 1)) == 0) {
+                constexpr uint32_t LOG2UNIT = UNIT == 64 ? 6 : UNIT == 128 ? 7 : UNIT == 256 ? 8 : UNIT == 512 ? 9 : UNIT == 1024 ? 10 : UNIT == 2048 ? 11 : 12;
+                static_assert((1u << LOG2UNIT) == UNIT, "unit size");
+                const uint32_t fit = room >> LOG2UNIT;
+                npend = fit < NPEND ? fit : NPEND;
+#pragma unroll
+                for (uint32_t k = 0; k < NPEND; k++) {
+#if SPRINTZ_DF_ALWAYS_LOAD
+                    const uint32_t base = gvo;             // a unit that does not fit yet is fetched anyway and dropped (re-requested later)
+#else
+                    const uint32_t base = k < npend ? gvo : 0u;
+#endif
+#pragma unroll
+                    for (int j = 0; j < CPL; j++) {
+                        const auto t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base, (int)(k * UNIT + j * ROW16), 0);
+                        pend[k][j] = make_uint4(t[0], t[1], t[2], t[3]);
+                    }
+                }
+                gvo += npend << LOG2UNIT;
+                ahead += npend << LOG2UNIT;
+            } else
+#endif
+            {
             npend = 0;
 #pragma unroll
             for (uint32_t k = 0; k < NPEND; k++) {
@@ -596,6 +631,7 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
                 npend += wanted ? 1u : 0u;
             }
             ahead += npend * UNIT;
+            }
         }
 
         // ---- group header: 2*D fields of HB bits (sprintz_xff_rle.cpp:713-735); both slots'
@@ -603,6 +639,23 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         const uint32_t r = ring + rofs;                    // LDS address of the parse cursor
         uint32_t nb_both[CPL], lane_both = 0;
         uint32_t hw0 = 0, hw1 = 0;                         // (two columns of a lane: their header fields sit in one window per slot)
+#if SPRINTZ_DF_HDR64
+        constexpr bool HDR64 = EXACT && CPL == 1 && DCAP * HB == 32;   // slot 0's fields are one dword, slot 1's the next
+#else
+        constexpr bool HDR64 = false;
+#endif
+        if constexpr (HDR64) {
+            // three aligned dwords cover the 8 header bytes wherever they start: one address, two v_alignbyte, and both
+            // slots' fields sit at the same bit of their dword; the W-1 -> W fix-up runs on both halves at once
+            lds_u32* q = (lds_u32*)(uintptr_t)(r & ~3u);
+            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+            const uint32_t h0 = __builtin_amdgcn_alignbyte(d1, d0, r), h1 = __builtin_amdgcn_alignbyte(d2, d1, r);
+            const uint32_t sh = (uint32_t)lane_d * HB;
+            uint32_t both = __builtin_amdgcn_ubfe(h0, sh, HB) | (__builtin_amdgcn_ubfe(h1, sh, HB) << 16);
+            both += ((both + 0x00010001u) >> HB) & 0x00010001u;         // a field of 2^HB - 1 = W - 1 means W (:747-749)
+            nb_both[0] = both;
+            lane_both = both;
+        } else
 #pragma unroll
         for (int k = 0; k < CPL; k++) {
             const uint32_t hbit0 = (uint32_t)colk[k] * HB, hbit1 = (uint32_t)(D + colk[k]) * HB;

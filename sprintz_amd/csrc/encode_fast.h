@@ -13,6 +13,7 @@
 //     per stream group.
 #pragma once
 
+#include "compact_tail.h"
 #include "decode_fast.h"
 #include "encode_kernel.h"
 
@@ -21,11 +22,14 @@ namespace sprintz {
 #ifndef SPRINTZ_ENC_PAIR_MERGE
 #define SPRINTZ_ENC_PAIR_MERGE 1
 #endif
+#ifndef SPRINTZ_ENC_PACKED16
+#define SPRINTZ_ENC_PACKED16 0
+#endif
 
 // CM: column-major source (EncodeArgs::col_stride): a lane's 8 samples of a block are
 // contiguous in ITS column -- one 16-byte (8-byte at W == 8) load per lane, no LDS transpose.
-template <int W, bool FIRE, int DP, bool EXACT, bool CM = false>
-__global__ void __launch_bounds__(kThreads) encode_fast_kernel(EncodeArgs a)
+template <int W, bool FIRE, int DP, bool EXACT, bool CM>
+__device__ __forceinline__ uint32_t encode_fast_body(const EncodeArgs& a, uint32_t wg_number)
 {
     using U = typename Elem<W>::U;
     constexpr int HB = Elem<W>::HB;
@@ -35,10 +39,10 @@ __global__ void __launch_bounds__(kThreads) encode_fast_kernel(EncodeArgs a)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     const int D = EXACT ? DP : a.D;
-    const uint64_t gtid = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+    const uint64_t gtid = (uint64_t)wg_number * kThreads + threadIdx.x;
     const uint64_t chunk = gtid >> LOG2DP;
     const int lane_d = (int)(threadIdx.x & (uint32_t)(DP - 1));
-    if (chunk >= a.nchunks) return;
+    if (chunk >= a.nchunks) return 0;
 
     const uint64_t first = chunk * (uint64_t)a.chunk_len;
     const uint32_t n = (uint32_t)((a.total_len - first < a.chunk_len) ? (a.total_len - first) : a.chunk_len);
@@ -225,6 +229,45 @@ __global__ void __launch_bounds__(kThreads) encode_fast_kernel(EncodeArgs a)
         const int coef = FIRE ? fire_coef<W, false>(ctr) : 0;
         int grad = 0;
         uint32_t mask = 0;
+        if constexpr (W == 16 && SPRINTZ_ENC_PACKED16) {
+            // Unlike the decoder's, the encoder's rows do not wait for each other: delta and prev_delta both come from the
+            // INPUT (:222-225).  So two rows ride in one register through packed 16-bit VALU -- x, delta, err and zigzag as
+            // (row 2k | row 2k+1 << 16); only FIRE's multiply-high stays one v_mad_i32_i16 per sample (there is no packed
+            // mul-hi): ~7 instructions per sample instead of ~13.  pv / pd keep the previous PAIR; their high halves are
+            // the previous sample / delta.
+            typedef short v2s __attribute__((ext_vector_type(2)));
+            auto pk = [](uint32_t v) { return __builtin_bit_cast(v2s, v); };
+            auto un = [](v2s v) { return __builtin_bit_cast(uint32_t, v); };
+            uint32_t Pp = pv, Dp = (uint32_t)pd;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t P = x[2 * k] | (x[2 * k + 1] << 16);
+                const uint32_t Pm1 = __builtin_amdgcn_alignbit(P, Pp, 16);           // (x[2k-1], x[2k])
+                const uint32_t Dk = un(pk(P) - pk(Pm1));                              // (delta[2k], delta[2k+1]), wrapping at 16 bits
+                uint32_t E = Dk;
+                if constexpr (FIRE) {
+                    const uint32_t Dm1 = __builtin_amdgcn_alignbit(Dk, Dp, 16);       // (delta[2k-1], delta[2k]) = the two prev_deltas
+                    int pa, pb;                                                       // prev_delta * coef, 32 bits each (:225)
+                    asm("v_mad_i32_i16 %0, %1, %2, 0" : "=v"(pa) : "v"(Dm1), "v"(coef));
+                    asm("v_mad_i32_i16 %0, %1, %2, 0 op_sel:[1,0,0,0]" : "=v"(pb) : "v"(Dm1), "v"(coef));
+                    const uint32_t pred = __builtin_amdgcn_perm((uint32_t)pb, (uint32_t)pa, 0x07060302u);   // (pa >> 16, pb >> 16)
+                    E = un(pk(Dk) - pk(pred));
+                    // odd rows: grad += sign(err) * prev_delta (:240-241); row 2k+1's prev_delta is delta[2k] = the low half of Dk
+                    const int sg = sign_of((int)E >> 16);
+                    asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(grad) : "v"(sg), "v"(Dk), "v"(grad));
+                }
+                const v2s e = pk(E);
+                const uint32_t Z = un((v2s)(e << (v2s)(1)) ^ (v2s)(e >> (v2s)(15)));       // zigzag on both halves
+                mask |= Z;
+                z[2 * k] = Z & 0xffffu;
+                z[2 * k + 1] = Z >> 16;
+                Pp = P;
+                Dp = Dk;
+            }
+            mask = (mask | (mask >> 16)) & 0xffffu;
+            pv = Pp >> 16 << 16;              // the loop only looks at the high half
+            pd = (int)Dp;
+        } else
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const int delta = sext<W>((int)(x[i] - pv));
@@ -360,6 +403,18 @@ __global__ void __launch_bounds__(kThreads) encode_fast_kernel(EncodeArgs a)
         a.sizes[chunk] = total_bytes;
         if (a.rets) a.rets[chunk] = (int64_t)(total_bytes / ESZ);
     }
+    return total_bytes;
+}
+
+template <int W, bool FIRE, int DP, bool EXACT, bool CM = false>
+__global__ void __launch_bounds__(kThreads) encode_fast_kernel(EncodeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr uint32_t LOG2DP = DP == 4 ? 2 : DP == 8 ? 3 : DP == 16 ? 4 : DP == 32 ? 5 : 6;
+    const uint32_t wg = workgroup_number(a.dn);
+    const uint32_t size = encode_fast_body<W, FIRE, DP, EXACT, CM>(a, wg);
+    // the container, built before the workgroup leaves (compact_tail.h); without it the caller compacts the slots
+    if (a.dn.dense) dense_tail(a.dn, wg, a.nchunks, LOG2DP, size, a.slots, a.slot_stride, smem, a.lds_group_stride);
 }
 
 }  // namespace sprintz

@@ -15,6 +15,7 @@
 #pragma once
 
 #include "sprintz_device.h"
+#include "compact_tail.h"
 
 namespace sprintz {
 
@@ -39,6 +40,8 @@ struct EncodeArgs {
     // non-RLE codecs (generic kernel only), see DecodeArgs
     int norle;
     int raw;
+    // the dense container written by the encode launch itself (compact_tail.h; encode_fast only): dn.dense == null -> slots only
+    DenseArgs dn;
 };
 
 template <int W, bool FIRE, bool LOWDIM, int CPL>

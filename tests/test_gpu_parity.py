@@ -643,3 +643,43 @@ def test_random_shapes(sz, oracle, seed):
         assert np.array_equal(comp[offs[c]:offs[c] + sizes[c]], want[c]), (tag, c)
     out = cd.decompress(batch)
     assert np.array_equal(out.cpu().numpy().view(DTYPES[esz])[:total], data), tag
+
+
+@pytest.mark.parametrize("codec,esz,ndims,chunk_len,nchunks", [
+    ("xff", 2, 8, 5120, 1), ("xff", 2, 8, 5120, 31), ("xff", 2, 8, 5120, 33), ("xff", 2, 8, 5120, 20011),
+    ("delta", 1, 16, 4096, 777), ("xff", 2, 32, 5120, 1000), ("delta", 2, 64, 4096, 130), ("xff", 1, 5, 4000, 300),
+    ("delta", 1, 80, 10240, 97),          # 80 columns: no dense tail in that encoder -- the entry point runs the two launches itself
+    ("delta", 1, 1, 1024, 5000),          # low-dim: idem
+])
+def test_container_built_inside_the_encode_launch(sz, oracle, codec, esz, ndims, chunk_len, nchunks):
+    """sprintz_mi355x_compress_batch_dense (one launch: chained scan over workgroups + in-kernel copy, compact_tail.h) writes
+    the container, offsets and sizes that compress_batch + compact(align 16) write -- and that the oracle specifies"""
+    import torch
+    from sprintz_amd import _lib
+    rng = np.random.default_rng(nchunks * 7 + ndims)
+    total = nchunks * chunk_len - (chunk_len // 3 if nchunks > 1 else 0)          # a short last chunk
+    data = gen_walk(rng, total, ndims, esz, 8, flat_every=4)
+    x = torch.from_numpy(data).cuda()
+    cd = sz.ChunkedCodec(codec, esz, ndims, chunk_len, device="cuda:0")
+    src = cd._padded_view(x)
+    res = {}
+    for mode in (0, 1):
+        assert _lib.set_option(_lib.OPT_NO_FUSED_COMPACT, mode) == 0
+        try:
+            cd._ws = {}
+            dense = torch.full((nchunks * cd.slot_stride + 16,), 0xEE, dtype=torch.uint8, device="cuda")
+            offs = torch.full((nchunks + 1,), -1, dtype=torch.int64, device="cuda")
+            ws, dense, offs = cd.compress_dense(src, total, dense=dense, offsets=offs)
+            torch.cuda.synchronize()
+            res[mode] = (dense.cpu().numpy(), offs.cpu().numpy(), ws["sizes"].cpu().numpy().copy(), ws["rets"].cpu().numpy().copy())
+        finally:
+            _lib.set_option(_lib.OPT_NO_FUSED_COMPACT, 0)
+    (d0, o0, s0, r0), (d1, o1, s1, r1) = res[0], res[1]
+    assert np.array_equal(o0, o1) and np.array_equal(s0, s1) and np.array_equal(r0, r1)
+    end = int(o0[-1])
+    assert np.array_equal(d0[:end], d1[:end])
+    assert (d0[end:] == 0xEE).all()                                               # nothing written past the container
+    want = oracle.compress_chunks(codec, data, chunk_len, ndims)
+    for c in range(0, nchunks, max(1, nchunks // 60)):
+        assert s0[c] == want[c].size and np.array_equal(d0[o0[c]:o0[c] + s0[c]], want[c]), c
+        assert o0[c] % 16 == 0 and (c == 0 or o0[c] == o0[c - 1] + ((s0[c - 1] + 15) & ~15))
