@@ -37,7 +37,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
 CPU_SAMPLE_BYTES = 1342177280   # raw bytes of the all-core CPU legs' sample (the headline batch of one GPU: 131 072 x 10 KB)
 METRIC = "decompress MB/s (and ratio) uint16 rowmajor 8-col, 1/2/4/8 MI355X vs CPU ref"
-ALL_CONFIGS = ["cfg1", "cfg3_1k", "cfg3_10k", "cfg4_10000", "cfg4_80000", "cfg4_800000", "cfg5"]
+ALL_CONFIGS = ["cfg1", "cfg3_1k", "cfg3_10k", "cfg4_10000", "cfg4_80000", "cfg4_800000", "cfg5", "cfg5_8m"]
 
 
 def parse():
@@ -395,14 +395,15 @@ def bench_rowmajor(cx, name, workload, codec, esz, ndims, chunk_len, nchunks_tot
     return res
 
 
-def bench_cfg5(cx):
+def bench_cfg5(cx, nrows_all=1 << 20, name="cfg5"):
     """BASELINE config 5: uint16 column-major, 32 variables, 1 M rows (64 MiB), FIRE, 160-row (10 KB) chunks =
-    6554 chunks; contiguous row ranges per rank (strong scaling), sizes all-gathered."""
+    6554 chunks; contiguous row ranges per rank (strong scaling), sizes all-gathered.  cfg5_8m: the same shape with 8 M
+    rows (512 MiB) -- the 1 M-row form is ONE 35 us launch, i.e. a latency; this one is the kernel's bandwidth."""
     torch, dev, timer, args = cx.torch, cx.device, cx.timer, cx.args
     import sprintz_amd
     from sprintz_amd import _lib
     from synth import synth_torch
-    D, rpc, esz, nrows_all = 32, 160, 2, 1 << 20
+    D, rpc, esz = 32, 160, 2
     nchunks_all = (nrows_all + rpc - 1) // rpc
     c_lo, c_hi = nchunks_all * cx.rank // cx.world, nchunks_all * (cx.rank + 1) // cx.world
     r_lo, r_hi = c_lo * rpc, min(c_hi * rpc, nrows_all)
@@ -432,7 +433,7 @@ def bench_cfg5(cx):
     reps = max(args.config_reps, 50)
     enc_ms, dec_ms = timer(enc, reps), timer(dec, reps)
     raw, sb = nrows * D * esz, batch.stream_bytes()
-    res = {"name": "cfg5", "workload": "uint16 colmajor, 32 variables, FIRE + bitpack + RLE, 1M rows (64 MiB), 160-row chunks",
+    res = {"name": name, "workload": f"uint16 colmajor, 32 variables, FIRE + bitpack + RLE, {nrows_all >> 20}M rows ({nrows_all >> 14} MiB), 160-row chunks",
            "dtype": "u16", "ndims": D, "chunk_bytes": rpc * D * esz, "chunks": n, "chunks_all_ranks": nchunks_all, "scaling": "strong",
            "raw_bytes": raw, "ratio": round(raw / sb, 4),
            "decompress_ms": round(dec_ms, 4), "decompress_MBps": round(raw / dec_ms / 1e3, 1),
@@ -440,14 +441,15 @@ def bench_cfg5(cx):
            "roofline": roofline(sb + 8 * n + raw, dec_ms, "decode_fast_kernel<16,FIRE,32,1,EXACT,0,CM=true>"),
            "compress_roofline": roofline(raw + sb + 12 * n, enc_ms, "encode_fast<..CM> + size scan + compaction copy",
                                          {"algorithmic": "raw samples in + dense container out + sizes/offsets (SURVEY 8d)"}),
-           "note": "64 MiB over %d chunks: one launch is %.0f us end to end, about half of it ramp-up and tail (launch-bound at this size; "
-                   "the 8 M-row form of the same shape runs at ~2.2 TB/s, DESIGN.md 4.6)" % (n, dec_ms * 1e3)}
+           "note": ("64 MiB over %d chunks: one launch is %.0f us end to end, about half of it ramp-up and tail (launch-bound at this size; "
+                    "cfg5_8m is the same shape at 512 MiB)" % (n, dec_ms * 1e3)) if nrows_all <= (1 << 20) else
+                   "the column-major kernels at a size where a launch is bandwidth, not latency (BASELINE config 5 states 1M rows: entry cfg5)"}
     if cx.rank == 0 and not args.no_cpu_baseline:
-        ns = n
+        ns = min(n, max(64, CPU_SAMPLE_BYTES // (rpc * D * esz)))
         o = batch.offsets[: ns + 1].cpu().numpy().astype("uint64")
         res["cpu_baseline"] = cpu_baseline(batch.data[: int(o[ns]) + 64].cpu().numpy(), o, ns, 1, esz, rpc * D, 1.0,
                                            "sprintz_decompress_xff_16b (row-major flattening: the reference has no column-major entry)",
-                                           last_chunk_len=(nrows - (n - 1) * rpc) * D)
+                                           last_chunk_len=(nrows - (n - 1) * rpc) * D if ns == n else None)
     res["_local"] = (raw, sb, res["decompress_ms"], res["compress_ms"])
     del cols, batch, out, dense
     cd._ws = {}
@@ -471,6 +473,8 @@ def run_config(cx, name):
                               f"batch of {n} chunks sharded over the ranks", "xff", 2, 8, 5120, n, "walk", 8, huff0=True, strong=True)
     if name == "cfg5":
         return bench_cfg5(cx)
+    if name == "cfg5_8m":
+        return bench_cfg5(cx, nrows_all=8 << 20, name="cfg5_8m")
     raise ValueError(name)
 
 
@@ -880,6 +884,38 @@ def headline_extras(cx, codec, x, comp, offsets, ws, out, nchunks, total_comp, c
             "compress_us_median": round(lat_c[150] * 1e6, 1), "compress_us_p10": round(lat_c[30] * 1e6, 1),
             "what": "sprintz_decompress_xff_16b / sprintz_compress_xff_16b on host buffers through ctypes: memcpy to pinned staging, one H2D, "
                     "one kernel (one chunk = 8 lanes), one D2H, one stream sync; pooled per-thread device scratch, no hipMalloc per call"}
+        # ---------------- the same drop-in symbols from many host threads at once (each thread has its own pooled scratch and stream
+        # inside the library; ctypes releases the interpreter lock around the call): calls per second of the whole process
+        def many_threads(nthreads, calls):
+            import threading
+            bufs = [(np.zeros(chunk_len + 64, np.uint16), np.zeros(chunk_len * 3 // 2 + 64, np.int16)) for _ in range(nthreads)]
+            go = threading.Barrier(nthreads + 1)
+
+            def work(k):
+                d, c = bufs[k]
+                dfn(one.ctypes.data, d.ctypes.data)                       # first call of the thread: scratch, stream
+                go.wait()
+                for _ in range(calls):
+                    dfn(one.ctypes.data, d.ctypes.data)
+                    cfn(raw1.ctypes.data, chunk_len, c.ctypes.data, ndims, 1)
+            ths = [threading.Thread(target=work, args=(k,)) for k in range(nthreads)]
+            [t.start() for t in ths]
+            go.wait()
+            t0 = time.perf_counter()
+            [t.join() for t in ths]
+            dt = time.perf_counter() - t0
+            ok = all(np.array_equal(b[0][:chunk_len], raw1) for b in bufs)
+            return 2 * nthreads * calls / dt, ok
+        res["single_call_threads"] = {}
+        for nt in (1, 8, 64):
+            rate, ok = many_threads(nt, 200 if nt < 64 else 60)
+            assert ok, "a thread's single-call decode differs from the input"
+            res["single_call_threads"][str(nt)] = {"calls_per_s": round(rate), "MBps_of_samples": round(rate * chunk_bytes / 1e6, 1)}
+        res["single_call_threads"]["what"] = ("N host threads, each alternating sprintz_decompress_xff_16b / sprintz_compress_xff_16b on its own 10 KB "
+                                              "chunk: what a multi-threaded lzbench-style driver gets out of the single-call boundary; the batched "
+                                              "device API is the fast path")
+        # ---------------- online.hpp's u16 coders: ONE stream of 64 Mi samples per call, device buffers
+        res["online_coders"] = online_leg(cx)
         # ---------------- PCIe-inclusive: host buffers in and out through the chunked host entry points
         ns = min(nchunks, 16384)
         oh = offsets[: ns + 1].cpu().numpy().astype(np.uint64)
@@ -896,6 +932,35 @@ def headline_extras(cx, codec, x, comp, offsets, ws, out, nchunks, total_comp, c
                                  "what": "sprintz_mi355x_decompress_chunked_host: pageable host buffers in and out (H2D of the streams, kernel, D2H "
                                          "of the samples, allocations included); bounded by the 63 GB/s PCIe Gen5 link -- never `value`"}
     return res
+
+
+def online_leg(cx):
+    """dynamic delta / zigzag / sprintzpack over one 128 MiB uint16 walk: GB/s of samples, pack and unpack, round trip checked"""
+    torch, dev, timed = cx.torch, cx.device, cx.timer
+    from sprintz_amd import _lib
+    from synth import synth_torch
+    n = 64 << 20
+    x = synth_torch("walk", 2, 1, n, 1, dev, seed=123, step=8)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    out = {"samples": n, "what": "sprintz_mi355x_online_{pack,unpack}_device on one uint16 stream (walk, steps in [-8, 8]); not tuned (DESIGN.md 4.9)"}
+    for name, kind in (("dynamic_delta", 0), ("zigzag", 2), ("sprintzpack_zigzag", 4)):
+        dest = torch.zeros(int(_lib.online_bound(kind, n)) + 64, dtype=torch.uint8, device=dev)
+        tmp = torch.zeros(int(_lib.online_tmp_bytes(kind, n)) + 64, dtype=torch.uint8, device=dev)
+        back = torch.empty(n, dtype=torch.uint16, device=dev)
+        ret = torch.zeros(2, dtype=torch.int64, device=dev)
+
+        def pack():
+            _lib.check(_lib.online_pack_device(kind, x.data_ptr(), n, dest.data_ptr(), ret.data_ptr(), tmp.data_ptr(), st))
+
+        def unpack():
+            _lib.check(_lib.online_unpack_device(kind, dest.data_ptr(), n, back.data_ptr(), ret.data_ptr() + 8, tmp.data_ptr(), st))
+        p_ms = timed(pack, 5, 1)
+        elems = int(ret[0].item())
+        u_ms = timed(unpack, 5, 1)
+        assert int(ret[1].item()) == n and torch.equal(back.view(torch.int16), x.view(torch.int16)), name
+        out[name] = {"ratio": round(n / max(elems, 1), 4), "pack_ms": round(p_ms, 3), "pack_GBps": round(2 * n / p_ms / 1e6, 1),
+                     "unpack_ms": round(u_ms, 3), "unpack_GBps": round(2 * n / u_ms / 1e6, 1)}
+    return out
 
 
 if __name__ == "__main__":

@@ -44,7 +44,7 @@ extern "C" {
  *   1  round 1: the 8 drop-in entry points, the batched device API, the optional Huffman ("SPZH") and query stages
  *   2  round 2: set_option, *_layout, the Huff0 wire format (huf0_*), online_*, comm_* / gather_layout / layout_bases,
  *      the column-major and run-less codec entry points, the reference's mangled C++ names (sprintz_dropin.hpp)
- *   3  round 3: compress_batch_dense / compress_dense_tmp_bytes, SPRINTZ_OPT_NO_FUSED_COMPACT, env SPRINTZ_MI355X_RCCL_SONAME */
+ *   3  round 3: compress_batch_dense / compress_dense_tmp_bytes, SPRINTZ_OPT_DENSE_MODE, env SPRINTZ_MI355X_RCCL_SONAME */
 #define SPRINTZ_MI355X_ABI_VERSION 3
 
 /* codec ids */
@@ -80,12 +80,12 @@ const char* sprintz_mi355x_last_error(void);     /* thread-local, never NULL; de
  *                                 env SPRINTZ_MI355X_NO_FAST
  *   SPRINTZ_OPT_CHUNKS_PER_GROUP  consecutive chunks one lane group of the headline decoder walks,
  *                                 1..64, default 1; env SPRINTZ_MI355X_CHUNKS_PER_GROUP
- *   SPRINTZ_OPT_NO_FUSED_COMPACT  1 = sprintz_mi355x_compress_batch_dense always takes the two-launch path (encode, then
- *                                 scan + copy) instead of building the container inside the encode launch (A/B runs,
- *                                 tests); env SPRINTZ_MI355X_NO_FUSED_COMPACT */
+ *   SPRINTZ_OPT_DENSE_MODE        how sprintz_mi355x_compress_batch_dense builds the container: 1 (default) = inside the
+ *                                 encode launch (csrc/compact_tail.h), 0 = encode, then scan + copy (A/B runs, tests);
+ *                                 env SPRINTZ_MI355X_DENSE_MODE */
 #define SPRINTZ_OPT_NO_FAST 0
 #define SPRINTZ_OPT_CHUNKS_PER_GROUP 1
-#define SPRINTZ_OPT_NO_FUSED_COMPACT 2
+#define SPRINTZ_OPT_DENSE_MODE 2
 int sprintz_mi355x_set_option(int option, int value);
 
 /* ------------------------------------------------------------------------
@@ -173,7 +173,7 @@ int sprintz_mi355x_compact(const void* d_slots, size_t slot_stride, const uint32
  * sprintz_mi355x_compact(align = 16), with the same results in d_sizes / d_rets / d_dense / d_offsets -- but for the
  * shapes the fast encoder takes (general layout, ndims <= 64, 16-byte aligned blocks) in ONE launch: every workgroup
  * finds its place in the container by a chained scan over workgroups and copies its own chunks slot -> container before
- * it exits, while other workgroups are still encoding (csrc/compact_tail.h).  d_slots is still needed (the streams pass
+ * it exits (csrc/compact_tail.h).  d_slots is still needed (the streams pass
  * through it); d_tmp: sprintz_mi355x_compress_dense_tmp_bytes(nchunks) bytes, 8-byte aligned; d_dense: 16-byte aligned,
  * capacity as for sprintz_mi355x_compact.  Other shapes run the two launches internally. */
 size_t sprintz_mi355x_compress_dense_tmp_bytes(uint64_t nchunks);

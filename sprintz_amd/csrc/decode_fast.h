@@ -184,6 +184,12 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
 #ifndef SPRINTZ_DF_HDR64
 #define SPRINTZ_DF_HDR64 0
 #endif
+#ifndef SPRINTZ_DF_MERGE8
+#define SPRINTZ_DF_MERGE8 1
+#endif
+#ifndef SPRINTZ_DF_XPOSE32
+#define SPRINTZ_DF_XPOSE32 0
+#endif
     constexpr int kStoreAux = SPRINTZ_STORE_AUX;
     const uint32_t lane16 = (uint32_t)lane_d * 16u;
     uint64_t gabs = 0;                                     // container offset the cursors below are relative to
@@ -246,11 +252,41 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     // A lane column past the last one (ndims is not DP*CPL) stands in for column D-1: it reads the same header fields and
     // bit fields, runs the same recurrence and stages the same bytes at the same place as the genuine one -- so the per-sample
     // code needs no predicate (54 exec-mask regions a group step at 80 columns on 64 x 2); only the scan must not count it.
+    // (8 bits, an even number of columns per lane, row-major output: a lane's two ADJACENT columns leave as one 16-bit staging
+    //  write per row -- half the ds_write instructions, which is what bounds this shape (4 LDS cycles per ds_write_b8, 2 per
+    //  sample for the field window).  A lane past the last column then stands in for the last PAIR, (D-2, D-1) -- the same two
+    //  bytes at the same address as the genuine lane's; with an odd D the last lane's second byte spills into the next row's
+    //  first, which that row's own write -- DS operations of a wave execute in order -- puts right, and after row 7 into padding.)
+    constexpr bool MERGE8 = SPRINTZ_DF_MERGE8 && W == 8 && CPL % 2 == 0 && !CM && Q == 0;
+    // 16 bits, one column per lane, every lane a genuine column: the 8 x D block reaches the staging area as FOUR 32-bit
+    // writes per lane instead of eight 16-bit ones (a ds_write costs 4 LDS cycles whatever its width up to 32 bits, and the
+    // LDS is what this kernel saturates first -- DESIGN.md 4.1).  A lane packs its column's rows in pairs (row 2k | row 2k+1),
+    // swaps with its neighbour -- one DPP move and one v_perm_b32 per pair: the even lane keeps both columns of row 2k, the odd
+    // lane of row 2k+1 -- and writes one dword of its row per pair.
+    constexpr bool XP32 = SPRINTZ_DF_XPOSE32 && W == 16 && CPL == 1 && EXACT && !CM && Q == 0;
+    const uint32_t xp_sel = (lane_d & 1) ? 0x03020706u : 0x05040100u;
+    uint8_t* const xp_at = stage + (uint32_t)(lane_d & 1) * (uint32_t)(DCAP * ESZ) + (uint32_t)(lane_d >> 1) * 4u;
+    auto xp_store = [&](const uint32_t (&rows)[8]) {       // rows[i] = this lane's column at row i (garbage above bit 16 allowed)
+        if constexpr (XP32) {
+#pragma unroll
+            for (int k2 = 0; k2 < 4; k2++) {
+                const uint32_t mine = __builtin_amdgcn_perm(rows[2 * k2 + 1], rows[2 * k2], 0x05040100u);
+                const uint32_t other = dpp<DPP_QUAD_PERM(1, 0, 3, 2)>(0, mine);
+                *(uint32_t*)(xp_at + (uint32_t)k2 * 2u * (uint32_t)(DCAP * ESZ)) = __builtin_amdgcn_perm(other, mine, xp_sel);
+            }
+        }
+    };
+    const bool merge8 = MERGE8 && (EXACT || (D & 1) == 0);   // rows of an odd number of bytes would make every second 16-bit write misaligned
     int colk[CPL];
     uint8_t* stage_k[CPL];
 #pragma unroll
     for (int k = 0; k < CPL; k++) {
-        colk[k] = EXACT ? col0 + k : (col0 + k < D ? col0 + k : D - 1);
+        if (MERGE8 && merge8) {
+            const int pb = (col0 + (k & ~1)) < D ? col0 + (k & ~1) : ((D - 1) & ~1);      // first column of this lane's pair
+            colk[k] = EXACT ? col0 + k : (pb + (k & 1) < D ? pb + (k & 1) : D - 1);
+        } else {
+            colk[k] = EXACT ? col0 + k : (col0 + k < D ? col0 + k : D - 1);
+        }
         stage_k[k] = stage + colk[k] * ESZ;
     }
 
@@ -422,25 +458,44 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         for (; len > 0; len--) {
             if (out_left < blk_elems) { corrupt = true; break; }
             out_left -= blk_elems;
+            auto run_step = [&](int k, int coef) {
+                if constexpr (W == 16 && FIRE) {            // pd[k] holds X (delta in its high half), see packed_block
+                    pd[k] = mad_i16_hi(pd[k], coef, 0);
+                    pv[k] = add_hi16(pv[k], pd[k]);
+                } else {
+                    const int delta = FIRE ? __builtin_amdgcn_sbfe(mad24(pd[k], coef, 0), W, W) : 0;
+                    pv[k] += (uint32_t)delta;
+                    pd[k] = delta;
+                }
+            };
+            if (MERGE8 && merge8) {
+#pragma unroll
+                for (int k = 0; k < CPL; k += 2) {
+                    const int coef0 = FIRE ? fire_coef<W, false>(ctr[k]) : 0, coef1 = FIRE ? fire_coef<W, false>(ctr[k + 1]) : 0;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        run_step(k, coef0);
+                        run_step(k + 1, coef1);
+                        *(uint16_t*)(stage_k[k] + i * row_stride) = (uint16_t)__builtin_amdgcn_perm(pv[k + 1], pv[k], 0x0c0c0400u);
+                    }
+                }
+            } else {
 #pragma unroll
             for (int k = 0; k < CPL; k++) {
                 const int coef = FIRE ? fire_coef<W, false>(ctr[k]) : 0;
+                uint32_t rows[8];
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
-                    if constexpr (W == 16 && FIRE) {        // pd[k] holds X (delta in its high half), see packed_block
-                        pd[k] = mad_i16_hi(pd[k], coef, 0);
-                        pv[k] = add_hi16(pv[k], pd[k]);
-                    } else {
-                        const int delta = FIRE ? __builtin_amdgcn_sbfe(mad24(pd[k], coef, 0), W, W) : 0;
-                        pv[k] += (uint32_t)delta;
-                        pd[k] = delta;
-                    }
+                    run_step(k, coef);
                     q_row(k);
                     pack_row(k, i);
-                    if constexpr (Q != kQueryReduceOnly && !CM)
+                    rows[i] = pv[k];
+                    if constexpr (Q != kQueryReduceOnly && !CM && !XP32)
                         *(U*)(stage_k[k] + i * row_stride) = (U)pv[k];
                 }
+                xp_store(rows);
                 q_block(k);
+            }
             }
             stage_out(-1);
         }
@@ -503,37 +558,61 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     auto packed_block = [&](const int (&e)[CPL][8], int slot) {   // forecast recurrence (:993-1150)
         if (out_left < blk_elems) { corrupt = true; return; }
         out_left -= blk_elems;
+        auto col_step = [&](int k, int i, int coef, int& grad) {
+            if constexpr (W == 16 && FIRE) {
+                // X = prev_delta*coef + E; delta = hi16(X): pd[k] carries X, never the shifted delta
+                if (i & 1) grad = mad_i16_hi(pd[k], sign_of(e[k][i]), grad);   // sign(E) == sign(err)
+                pd[k] = mad_i16_hi(pd[k], coef, e[k][i]);
+                pv[k] = add_hi16(pv[k], pd[k]);
+            } else if constexpr (W == 16) {
+                pv[k] = add_hi16(pv[k], e[k][i]);                               // delta = E >> 16
+            } else {
+                int delta;
+                if constexpr (FIRE) {
+                    if (i & 1) grad = mad24(sign_of(e[k][i]), pd[k], grad);
+                    delta = __builtin_amdgcn_sbfe(mad24(pd[k], coef, e[k][i]), W, W);
+                } else {
+                    delta = e[k][i];
+                }
+                pv[k] += (uint32_t)delta;
+                pd[k] = delta;
+            }
+        };
+        if (MERGE8 && merge8) {                            // a lane's two adjacent 8-bit columns: one 16-bit staging write per row
+#pragma unroll
+            for (int k = 0; k < CPL; k += 2) {
+                int grad0 = 0, grad1 = 0;
+                const int coef0 = FIRE ? fire_coef<W, false>(ctr[k]) : 0, coef1 = FIRE ? fire_coef<W, false>(ctr[k + 1]) : 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    col_step(k, i, coef0, grad0);
+                    col_step(k + 1, i, coef1, grad1);
+                    *(uint16_t*)(stage_k[k] + i * row_stride) = (uint16_t)__builtin_amdgcn_perm(pv[k + 1], pv[k], 0x0c0c0400u);
+                }
+                if constexpr (FIRE) {
+                    ctr[k] = wrap_counter<W>(ctr[k] + __builtin_amdgcn_sbfe(grad0, 2, W - 2));
+                    ctr[k + 1] = wrap_counter<W>(ctr[k + 1] + __builtin_amdgcn_sbfe(grad1, 2, W - 2));
+                }
+            }
+        } else {
 #pragma unroll
         for (int k = 0; k < CPL; k++) {
             int grad = 0;
             const int coef = FIRE ? fire_coef<W, false>(ctr[k]) : 0;
+            uint32_t rows[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                if constexpr (W == 16 && FIRE) {
-                    // X = prev_delta*coef + E; delta = hi16(X): pd[k] carries X, never the shifted delta
-                    if (i & 1) grad = mad_i16_hi(pd[k], sign_of(e[k][i]), grad);   // sign(E) == sign(err)
-                    pd[k] = mad_i16_hi(pd[k], coef, e[k][i]);
-                    pv[k] = add_hi16(pv[k], pd[k]);
-                } else if constexpr (W == 16) {
-                    pv[k] = add_hi16(pv[k], e[k][i]);                               // delta = E >> 16
-                } else {
-                    int delta;
-                    if constexpr (FIRE) {
-                        if (i & 1) grad = mad24(sign_of(e[k][i]), pd[k], grad);
-                        delta = __builtin_amdgcn_sbfe(mad24(pd[k], coef, e[k][i]), W, W);
-                    } else {
-                        delta = e[k][i];
-                    }
-                    pv[k] += (uint32_t)delta;
-                    pd[k] = delta;
-                }
+                col_step(k, i, coef, grad);
                 q_row(k);
                 pack_row(k, i);
-                if constexpr (Q != kQueryReduceOnly && !CM)
+                rows[i] = pv[k];
+                if constexpr (Q != kQueryReduceOnly && !CM && !XP32)
                     *(U*)(stage_k[k] + i * row_stride) = (U)pv[k];
             }
+            xp_store(rows);
             q_block(k);
             if constexpr (FIRE) ctr[k] = wrap_counter<W>(ctr[k] + __builtin_amdgcn_sbfe(grad, 2, W - 2));   // sext_W(grad) >> 2
+        }
         }
         stage_out(slot);
     };
@@ -681,7 +760,10 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         uint32_t off0[CPL], off1[CPL], nb0[CPL], nb1[CPL];
 #pragma unroll
         for (int k = 0; k < CPL; k++) {
-            const uint32_t o_both = col_ok[k] ? excl_both : tot_both - nb_both[k];   // (a stand-in: where column D-1 starts)
+            uint32_t o_both = col_ok[k] ? excl_both : tot_both - nb_both[k];         // (a stand-in: where column D-1 starts)
+            if constexpr (MERGE8 && !EXACT) {              // (a stand-in for column D-2 -- the first of the last pair -- starts one field earlier)
+                if ((k & 1) == 0 && !col_ok[k] && colk[k] != colk[k + 1]) o_both -= nb_both[k + 1];
+            }
             off0[k] = o_both & 0xffffu;
             off1[k] = o_both >> 16;
             nb0[k] = nb_both[k] & 0xffffu;

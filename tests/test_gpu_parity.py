@@ -646,7 +646,7 @@ def test_random_shapes(sz, oracle, seed):
 
 
 @pytest.mark.parametrize("codec,esz,ndims,chunk_len,nchunks", [
-    ("xff", 2, 8, 5120, 1), ("xff", 2, 8, 5120, 31), ("xff", 2, 8, 5120, 33), ("xff", 2, 8, 5120, 20011),
+    ("xff", 2, 8, 5120, 1), ("xff", 2, 8, 5120, 31), ("xff", 2, 8, 5120, 33), ("xff", 2, 8, 5120, 20011), ("xff", 2, 8, 1280, 70001),
     ("delta", 1, 16, 4096, 777), ("xff", 2, 32, 5120, 1000), ("delta", 2, 64, 4096, 130), ("xff", 1, 5, 4000, 300),
     ("delta", 1, 80, 10240, 97),          # 80 columns: no dense tail in that encoder -- the entry point runs the two launches itself
     ("delta", 1, 1, 1024, 5000),          # low-dim: idem
@@ -664,7 +664,7 @@ def test_container_built_inside_the_encode_launch(sz, oracle, codec, esz, ndims,
     src = cd._padded_view(x)
     res = {}
     for mode in (0, 1):
-        assert _lib.set_option(_lib.OPT_NO_FUSED_COMPACT, mode) == 0
+        assert _lib.set_option(_lib.OPT_DENSE_MODE, mode) == 0
         try:
             cd._ws = {}
             dense = torch.full((nchunks * cd.slot_stride + 16,), 0xEE, dtype=torch.uint8, device="cuda")
@@ -673,12 +673,14 @@ def test_container_built_inside_the_encode_launch(sz, oracle, codec, esz, ndims,
             torch.cuda.synchronize()
             res[mode] = (dense.cpu().numpy(), offs.cpu().numpy(), ws["sizes"].cpu().numpy().copy(), ws["rets"].cpu().numpy().copy())
         finally:
-            _lib.set_option(_lib.OPT_NO_FUSED_COMPACT, 0)
-    (d0, o0, s0, r0), (d1, o1, s1, r1) = res[0], res[1]
-    assert np.array_equal(o0, o1) and np.array_equal(s0, s1) and np.array_equal(r0, r1)
+            _lib.set_option(_lib.OPT_DENSE_MODE, 1)
+    d0, o0, s0, r0 = res[0]                              # mode 0: encode, then scan + copy -- round 2's path
     end = int(o0[-1])
-    assert np.array_equal(d0[:end], d1[:end])
-    assert (d0[end:] == 0xEE).all()                                               # nothing written past the container
+    for mode in (1,):                                    # 1: the container built inside the encode launch
+        d1, o1, s1, r1 = res[mode]
+        assert np.array_equal(o0, o1) and np.array_equal(s0, s1) and np.array_equal(r0, r1), mode
+        assert np.array_equal(d0[:end], d1[:end]), mode
+        assert (d1[end:] == 0xEE).all(), mode                                     # nothing written past the container
     want = oracle.compress_chunks(codec, data, chunk_len, ndims)
     for c in range(0, nchunks, max(1, nchunks // 60)):
         assert s0[c] == want[c].size and np.array_equal(d0[o0[c]:o0[c] + s0[c]], want[c]), c
