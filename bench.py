@@ -77,7 +77,7 @@ def host_description():
     except OSError:
         pass
     fl = set(flags.split())
-    return {"cpu_model": model, "logical_cpus": os.cpu_count(), "machine": platform.machine(),
+    return {"cpu_model": model, "logical_cpus": os.cpu_count(), "machine": platform.machine(), "cgroup_cpu_quota_cores": cgroup_cpu_limit()[0],
             "isa": {k: (k in fl) for k in ("avx2", "bmi2", "bmi1", "abm", "avx512f")},
             "reference_build": "g++ -O3 -mavx2 -mbmi2 -mbmi -mlzcnt (oracle/Makefile ref): the reference REQUIRES AVX2+BMI2 (sprintz_delta.h:21)"}
 
@@ -113,6 +113,32 @@ def cpu_libs():
     return None, None, None, None
 
 
+def cgroup_cpu_limit():
+    """CPU time this container may use, in cores (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited / unreadable;
+    plus the throttle counter, so that a run can show whether the all-core leg hit the limit"""
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = None if q <= 0 else q / per
+        except (OSError, ValueError):
+            pass
+    throttled = None
+    for f in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        try:
+            for line in open(f):
+                if line.startswith("nr_throttled"):
+                    throttled = int(line.split()[1])
+            break
+        except OSError:
+            pass
+    return quota, throttled
+
+
 def host_topology():
     """-> (logical CPUs this process may run on, one logical CPU per PHYSICAL core among them)"""
     try:
@@ -136,6 +162,7 @@ def time_cpu_mt(call, n_one, n_all, raw_per_chunk, target_s):
     thread, pinned, sustained over `reps` passes).  Legs: 1 thread on the first n_one chunks; one thread per PHYSICAL core
     and one per LOGICAL CPU on the first n_all chunks.  -> dict of MB/s figures and what ran"""
     avail, firsts = host_topology()
+    quota, thr0 = cgroup_cpu_limit()
     t = call(n_one, 1, 1, None)                                  # also faults the output pages in
     reps1 = max(1, min(50, int(target_s / max(t, 1e-6))))
     best1 = min(call(n_one, 1, reps1, None) for _ in range(2))
@@ -163,6 +190,10 @@ def time_cpu_mt(call, n_one, n_all, raw_per_chunk, target_s):
     bc = min(call(n_small, ntp, reps, firsts[:ntp]) for _ in range(3))
     r["value_cache_resident"] = round(n_small * raw_per_chunk / bc / 1e6, 1)
     r["scaling_cache_resident_vs_1thread"] = round(r["value_cache_resident"] / r["value_1thread"], 1)
+    _, thr1 = cgroup_cpu_limit()
+    r["cgroup_cpu_quota_cores"] = quota                    # None: no quota visible to this container
+    if thr0 is not None and thr1 is not None:
+        r["cgroup_throttled_periods_during_run"] = thr1 - thr0
     return r
 
 

@@ -1,5 +1,5 @@
 """The one JSON line `bench.py` prints, checked on the line a default run of the committed build printed on an MI355X
-(profiles/r2_bench_full_*.json): the driver's contract fields, BASELINE.json's metric, the two objects the hot-path tier
+(profiles/r3_bench_full_*.json): the driver's contract fields, BASELINE.json's metric, the two objects the hot-path tier
 asks for (`roofline`, `cpu_baseline`) and a `per_config` entry for every other BASELINE configuration."""
 import glob
 import json
@@ -10,7 +10,7 @@ ROOT = os.path.dirname(HERE)
 
 
 def latest_line():
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r2_bench_full_*.json")), key=os.path.getmtime)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r3_bench_full_*.json")), key=os.path.getmtime)
     assert files, "no committed bench line under profiles/"
     with open(files[-1]) as f:
         return json.load(f)
@@ -45,9 +45,13 @@ def test_roofline_and_cpu_baseline():
     if r["traffic"] is not None:
         assert 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.5      # no wasted re-reads
     c = d["cpu_baseline"]
-    for k in ("value", "unit", "cores", "kind", "sample"):
+    for k in ("value", "unit", "cores", "kind", "sample", "value_1thread", "physical_cores", "logical_cpus", "value_cache_resident"):
         assert k in c, k
     assert c["kind"] == "reference" and c["cores"] >= 1 and c["value"] > 0
+    # the many-thread leg runs in C (oracle/mt_bench.c): one thread per PHYSICAL core, and it must beat one thread by far more
+    # than the 4x the interpreter-lock-bound harness of round 2 managed on 256 threads
+    assert c["cores"] == c["physical_cores"] <= c["logical_cpus"]
+    assert c["value"] > 8 * c["value_1thread"]
 
 
 def test_every_baseline_configuration_has_an_entry():
@@ -63,3 +67,21 @@ def test_every_baseline_configuration_has_an_entry():
         assert v["cpu_baseline"]["kind"] == "reference", v["name"]
         if v["name"].startswith("cfg4_"):
             assert "Huff0" in v["entropy_stage"] and v["huff0_decode_ms"] > 0
+            # algorithmic bytes of the chain = Huff0 blocks in + samples out + offset tables: NOT the Sprintz streams
+            # that cross HBM between the two stages -- those show up as traffic_ratio_by_design
+            r = v["roofline"]
+            assert r["algorithmic_bytes_per_launch"] < v["raw_bytes"] * (1 + 1 / 2.5)
+            assert 1.3 < r["traffic_ratio_by_design"] < 1.8
+
+
+def test_the_tail_of_the_line_names_every_configuration():
+    """the driver keeps the last 2 000 characters of the line: per_config_summary is the LAST key and fits in them"""
+    d = latest_line()
+    assert list(d.keys())[-1] == "per_config_summary"
+    tail = json.dumps(d)[-2000:]
+    s = d["per_config_summary"]
+    for name in ("cfg2", "cfg1", "cfg3_1k", "cfg3_10k", "cfg4_10000", "cfg4_80000", "cfg4_800000", "cfg5"):
+        assert name in s and f'"{name}"' in tail, name
+        dec_ms, dec_frac = s[name][0], s[name][1]
+        assert dec_ms > 0 and 0 < dec_frac <= 1
+    assert len(json.dumps(s)) < 1900
