@@ -82,10 +82,14 @@ const char* sprintz_mi355x_last_error(void);     /* thread-local, never NULL; de
  *                                 1..64, default 1; env SPRINTZ_MI355X_CHUNKS_PER_GROUP
  *   SPRINTZ_OPT_DENSE_MODE        how sprintz_mi355x_compress_batch_dense builds the container: 1 (default) = inside the
  *                                 encode launch (csrc/compact_tail.h), 0 = encode, then scan + copy (A/B runs, tests);
- *                                 env SPRINTZ_MI355X_DENSE_MODE */
+ *                                 env SPRINTZ_MI355X_DENSE_MODE
+ *   SPRINTZ_OPT_HUF0_BIG_BATCH    chunks from which the Huff0 reader's one-table stream kernel runs as 4-wave workgroups with
+ *                                 32-byte stream pieces (faster from ~40 000 chunks on) instead of single waves with 16-byte
+ *                                 pieces (faster below); default 40000, 0 = always (tests) */
 #define SPRINTZ_OPT_NO_FAST 0
 #define SPRINTZ_OPT_CHUNKS_PER_GROUP 1
 #define SPRINTZ_OPT_DENSE_MODE 2
+#define SPRINTZ_OPT_HUF0_BIG_BATCH 3
 int sprintz_mi355x_set_option(int option, int value);
 
 /* ------------------------------------------------------------------------

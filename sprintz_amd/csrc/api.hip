@@ -863,6 +863,11 @@ int sprintz_mi355x_set_option(int option, int value)
         process().dense_mode = value;
         return 0;
     }
+    if (option == SPRINTZ_OPT_HUF0_BIG_BATCH) {
+        if (value < 0) return fail(SPRINTZ_E_INVALID, "the batch size must not be negative");
+        sprintz::huf0_big_batch() = value;
+        return 0;
+    }
     if (option == SPRINTZ_OPT_CHUNKS_PER_GROUP) {
         if (value < 1 || value > 64) return fail(SPRINTZ_E_INVALID, "chunks per group must be in 1..64");
         process().chunks_per_group = value;

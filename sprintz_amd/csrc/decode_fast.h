@@ -190,6 +190,9 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
 #ifndef SPRINTZ_DF_XPOSE32
 #define SPRINTZ_DF_XPOSE32 0
 #endif
+#ifndef SPRINTZ_DF_BATCH_READS
+#define SPRINTZ_DF_BATCH_READS 0
+#endif
     constexpr int kStoreAux = SPRINTZ_STORE_AUX;
     const uint32_t lane16 = (uint32_t)lane_d * 16u;
     uint64_t gabs = 0;                                     // container offset the cursors below are relative to
@@ -535,9 +538,27 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
             const uint32_t sh = off[k] & 7u;
             const uint32_t w1 = nb[k] != 0 ? 1u : 0u;      // width of the sign bit field
             const uint32_t wm = nb[k] - w1;                // width of the magnitude field
+#if SPRINTZ_DF_BATCH_READS
+            // all eight windows of the block requested before the first is looked at: ONE LDS round trip a block instead of four
+            // (hipcc keeps two reads in flight and waits with lgkmcnt(1) between them).  The reads are asm so that their order stands;
+            // the counter wait is ours too -- LDS operations of a wave complete in order, so the compiler's own waits stay sufficient.
+            uint32_t pa[8];
+            uint64_t wv[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) { pa[i] = p; p += row_bytes; }
+#pragma unroll
+            for (int i = 0; i < 8; i++) asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(wv[i]) : "v"(pa[i] & ~3u) : "memory");
+            // (the windows are operands of the wait: nothing that reads one may be scheduled above it)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]), "+v"(wv[4]), "+v"(wv[5]), "+v"(wv[6]), "+v"(wv[7]) :: "memory");
+            p = pa[0];
+#endif
 #pragma unroll
             for (int i = 0; i < 8; i++) {
+#if SPRINTZ_DF_BATCH_READS
+                const uint32_t w = __builtin_amdgcn_alignbyte((uint32_t)(wv[i] >> 32), (uint32_t)wv[i], pa[i]);
+#else
                 const uint32_t w = lds_rd32(p);
+#endif
                 const uint32_t mag = __builtin_amdgcn_ubfe(w, sh + 1u, wm);
                 const int sgn = __builtin_amdgcn_sbfe((int)w, sh, w1);
                 if constexpr (W == 16) {

@@ -24,9 +24,19 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <atomic>
 #include <type_traits>
 
 namespace sprintz { int set_error(int code, const char* what); }   // api.hip: the library's one error sink
+
+namespace sprintz {
+// chunks from which the one-table stream kernel runs as 4-wave workgroups with 32-byte pieces (SPRINTZ_OPT_HUF0_BIG_BATCH)
+std::atomic<long long>& huf0_big_batch()
+{
+    static std::atomic<long long> v{40000};
+    return v;
+}
+}  // namespace sprintz
 
 namespace {
 
@@ -282,14 +292,12 @@ constexpr int kCStride = 256 + 64 + 512 + 4;     // stream kernel, per chunk in 
 // general kernel and 64 for the one-table kernel, which has the LDS to spare (see the note on memory traffic there).
 // (Measured at 800 000 chunks, one-table kernel: 64-byte pieces +13 %, a workgroup of 4 waves around one table +3 %,
 // both together +3 % against 16-byte pieces and a table per wave: what they save in requests they lose in resident waves.)
-#ifndef HUF0_SO_PLOG
-#define HUF0_SO_PLOG 4
-#endif
-#ifndef HUF0_SO_WG
-#define HUF0_SO_WG 1
-#endif
-constexpr int piece_log(bool so) { return so ? HUF0_SO_PLOG : 4; }
-constexpr int ring_stride(bool so) { return 2 * (1 << piece_log(so)) + 8; }
+// (Round 3, with the streams' last bursts in one common round -- see the stream kernel: at 800 000 chunks 32-byte pieces and a
+// workgroup of 4 waves around one table take the stage from 3.44 to 3.05 - 3.13 ms (FETCH_SIZE says why: half the useless lines);
+// 16-byte pieces with the 4-wave workgroup 3.69, 64-byte pieces 4.13 / 3.59 (1 / 4 waves).  At 10 000 chunks the single-wave,
+// 16-byte form is 5 % faster -- a workgroup there is a barrier and a four times longer table build for nothing -- so both are
+// instantiated and the launch picks by batch size.)
+constexpr int ring_stride(int plog) { return 2 * (1 << plog) + 8; }
 
 // Blocks written with one code per SEGMENT of 64 chunks (our writer; any writer that repeats a tree description) need
 // the tree only once per segment.  follow[c] = 1 iff chunk c is not the first of its 64-aligned segment and its tree
@@ -648,18 +656,21 @@ __global__ void __launch_bounds__(256) huf0_share_kernel(const uint8_t* __restri
 #ifndef HUF0_G_WAVES
 #define HUF0_G_WAVES 2
 #endif
-template <bool SO>
-__global__ void __launch_bounds__(SO ? 64 * HUF0_SO_WG : 64) __attribute__((amdgpu_waves_per_eu(SO ? HUF0_SO_WAVES : HUF0_G_WAVES)))
+// WG: wavefronts of a workgroup around the one table (SO only: 1, 2 or 4 -- a workgroup stays inside one 64-chunk segment);
+// PLOG: log2 of the stream piece a lane fetches at once
+template <bool SO, int WG = 1, int PLOG = 4>
+__global__ void __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(SO ? HUF0_SO_WAVES : HUF0_G_WAVES)))
 huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restrict__ boffs,
                                                          uint64_t nchunks, uint8_t* __restrict__ out,
                                                          const uint64_t* __restrict__ ooffs, int64_t* __restrict__ rets,
                                                          const uint8_t* __restrict__ desc, const uint8_t* __restrict__ share)
 {
-    constexpr int kThreads = SO ? 64 * HUF0_SO_WG : 64, kChunks = kThreads / 4;
+    static_assert(SO ? (WG == 1 || WG == 2 || WG == 4) : WG == 1, "a workgroup of the one-table kernel stays inside one 64-chunk segment");
+    constexpr int kThreads = 64 * WG, kChunks = kThreads / 4;
     if ((share[(uint64_t)blockIdx.x * kChunks >> 6] != 0) != SO) return;      // the other instantiation's
     auto sync = [] { if constexpr (SO) __syncthreads(); else wave_sync(); };
     __shared__ __attribute__((aligned(16))) uint8_t s_c[SO ? 336 + (2u << kSharedMaxLog) : 16 * kCStride];
-    constexpr int kPLog = piece_log(SO), kPB = 1 << kPLog, kPL = kPB / 16, kRingStride = ring_stride(SO);
+    constexpr int kPLog = PLOG, kPB = 1 << kPLog, kPL = kPB / 16, kRingStride = ring_stride(PLOG);
     __shared__ __attribute__((aligned(16))) uint8_t s_ring[kThreads * kRingStride];
     const int t = threadIdx.x, q = t >> 2, j = t & 3;
     const uint64_t chunk0 = (uint64_t)blockIdx.x * kChunks;
@@ -987,14 +998,32 @@ huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restric
     for (;;) {
         if (__ballot(left > 0) == 0) break;
         // a stream's first burst only goes up to the next 64-byte line of the output: every later one stores whole lines
-        const uint64_t lim = head != 0 && head < left ? (uint64_t)head : left;
+        const bool head_lim = head != 0 && head < left;
+        const uint64_t lim = head_lim ? (uint64_t)head : left;
         const bool full = lim >= 64;
         uint32_t wb[16];
+#if HUF0_SPECULATIVE_TAIL
+        // Round 3.  A round is 64 symbols a lane.  Masked steps (~130 instructions instead of ~50) are only needed where a lane must
+        // stop after fewer than 64 symbols: a stream's FIRST burst (cut at the next 64-byte line of the output: the same round for
+        // all 64 lanes) and its LAST.  The last bursts are made to fall into ONE round too: a lane that is down to its partial last
+        // burst -- or done -- rides along through the others' full rounds from a parked cursor, its own put back after each, and when no lane has a full burst left one masked round
+        // finishes them all.  (Before: one lane within 64 symbols or 208 bits of its end held all 64 in the masked path -- the ~17 %
+        // of a wave's symbols between the end of its shortest and of its longest stream.)
+        const bool live = left > 0;
+        const bool burst = live && full && !head_lim;             // this lane decodes a whole 64-symbol burst this round
+        const bool fast_round = __ballot(streaming && live && head_lim) == 0 && __ballot(burst) != 0;
+        // (a lane that rides along decodes from cursor 0: `x` below is then far above any piece index, so its ring stays as it is)
+        const int32_t P0 = P;
+        if (fast_round && !burst) P = 0;
+#else
+        constexpr bool fast_round = false;
+        const bool burst = full;
+#endif
         {
             const bool all_full = __ballot(streaming && lim < 64) == 0;      // (lanes without a stream just go through the motions)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
-                if (all_full && __ballot(streaming && P < kFastBits) == 0) {
+                if (fast_round || (all_full && __ballot(streaming && P < kFastBits) == 0)) {
 #pragma unroll
                     for (int i = 0; i < 4; i++) wb[4 * g + i] = fast_step(SH);
                 } else {                                          // the ends of the streams: rolled, so that the bulk's registers set the occupancy
@@ -1010,8 +1039,12 @@ huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restric
                 }
             }
         }
-        const uint32_t cnt = lim < 64 ? (uint32_t)lim : 64u;
-        head = 0;
+#if HUF0_SPECULATIVE_TAIL
+        if (fast_round && !burst) P = P0;                         // rode along: the cursor goes back, nothing is kept
+#endif
+        const uint32_t cnt = fast_round ? (burst ? 64u : 0u) : (lim < 64 ? (uint32_t)lim : 64u);
+        const bool full_out = fast_round ? burst : full;          // stores whole 64-byte lines this round
+        if (!fast_round) head = 0;
         uint32_t v[4][4];
 #pragma unroll
         for (int k = 0; k < 4; k++)
@@ -1033,7 +1066,7 @@ huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restric
                 const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
                 if (odd2) v[k][d] = recv; else v[k + 2][d] = recv;
             }
-        const uint64_t mine = full ? (uint64_t)(uintptr_t)op : 0ull;
+        const uint64_t mine = full_out ? (uint64_t)(uintptr_t)op : 0ull;
         const int mlo = (int)(uint32_t)mine, mhi = (int)(uint32_t)(mine >> 32);
 #pragma unroll
         for (int qq = 0; qq < 4; qq++) {
@@ -1052,7 +1085,7 @@ huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restric
                 __builtin_nontemporal_store(piece, (v4u_a1*)(uintptr_t)(da + 16u * part));   // streamed out once
             }
         }
-        if (!full && cnt) {
+        if (!full_out && cnt) {
 #pragma unroll
             for (int sN = 0; sN < 16; sN++) {
                 const uint32_t done = 4u * sN;
@@ -1119,9 +1152,14 @@ int sprintz_mi355x_huf0_decompress_batch_ws(const void* d_blocks, const uint64_t
                            (const uint8_t*)follow);
         hipLaunchKernelGGL(huf0_share_kernel, dim3((unsigned)((nleaders + 255) / 256)), dim3(256), 0, st, (const uint8_t*)desc, (const uint8_t*)follow, nchunks, share);
     }
-    hipLaunchKernelGGL(huf0_stream_kernel<true>, dim3((unsigned)(HUF0_SO_WG == 4 ? grid1 : grid2)), dim3(64 * HUF0_SO_WG), 0, st, blk, d_block_offsets, nchunks,
-                       (uint8_t*)d_out, d_out_offsets, d_rets, (const uint8_t*)desc, (const uint8_t*)share);
-    hipLaunchKernelGGL(huf0_stream_kernel<false>, dim3((unsigned)grid2), dim3(64), 0, st, blk, d_block_offsets, nchunks,
+    // the one-table kernel: bandwidth-sized batches as 4-wave workgroups with 32-byte stream pieces, small ones wave by wave
+    if (nchunks >= (uint64_t)sprintz::huf0_big_batch().load(std::memory_order_relaxed))
+        hipLaunchKernelGGL((huf0_stream_kernel<true, 4, 5>), dim3((unsigned)grid1), dim3(256), 0, st, blk, d_block_offsets, nchunks,
+                           (uint8_t*)d_out, d_out_offsets, d_rets, (const uint8_t*)desc, (const uint8_t*)share);
+    else
+        hipLaunchKernelGGL((huf0_stream_kernel<true, 1, 4>), dim3((unsigned)grid2), dim3(64), 0, st, blk, d_block_offsets, nchunks,
+                           (uint8_t*)d_out, d_out_offsets, d_rets, (const uint8_t*)desc, (const uint8_t*)share);
+    hipLaunchKernelGGL((huf0_stream_kernel<false, 1, 4>), dim3((unsigned)grid2), dim3(64), 0, st, blk, d_block_offsets, nchunks,
                        (uint8_t*)d_out, d_out_offsets, d_rets, (const uint8_t*)desc, (const uint8_t*)share);
     return hipGetLastError() == hipSuccess ? 0 : sprintz::set_error(SPRINTZ_E_HIP, "Huff0 stage: a HIP call or kernel launch failed");
 }

@@ -5,6 +5,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "decode_kernel.h"
 #include "decode_fast.h"
 #include "decode_uni.h"
@@ -45,6 +47,7 @@ int set_error(int code, const char* what);
 struct HostScratch { hipStream_t stream; uint8_t* dev; uint8_t* pin; };
 int host_scratch(size_t dev_bytes, size_t pin_bytes, HostScratch* out);
 bool have_device();                       // probed once per process
+std::atomic<long long>& huf0_big_batch(); // huf0.hip: batch size from which the one-table stream kernel runs as 4-wave workgroups
 
 hipError_t launch_size_scan(const uint32_t* d_sizes, uint64_t n, uint32_t align, uint64_t* d_offsets, void* d_tmp, hipStream_t st);
 
