@@ -193,6 +193,12 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
 #ifndef SPRINTZ_DF_BATCH_READS
 #define SPRINTZ_DF_BATCH_READS 0
 #endif
+#ifndef SPRINTZ_DF_DROP_UNWANTED
+#define SPRINTZ_DF_DROP_UNWANTED 1
+#endif
+#ifndef SPRINTZ_DF_SPLIT_STORES
+#define SPRINTZ_DF_SPLIT_STORES 0
+#endif
     constexpr int kStoreAux = SPRINTZ_STORE_AUX;
     const uint32_t lane16 = (uint32_t)lane_d * 16u;
     uint64_t gabs = 0;                                     // container offset the cursors below are relative to
@@ -213,7 +219,13 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         for (int j = 0; j < CPL; j++) {
                         // (non-temporal LOADS were tried too: the read-ahead re-reads what neighbouring groups fetched, and with nt
             //  those re-reads go back to HBM -- 0.413 -> 0.461 ms)
+#if SPRINTZ_DF_DROP_UNWANTED
+            // an unwanted unit asks for an offset outside the descriptor: the texture addresser answers zeros without a request to
+            // the cache (a re-read of offset 0 is a real request of 64 lanes, and the addresser's queue is what the block stores wait in)
+            const auto t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, wanted ? gvo + j * ROW16 : 0xfffffff0u, 0, 0);
+#else
             const auto t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, wanted ? gvo + j * ROW16 : 0u, 0, 0);
+#endif
             v[j] = make_uint4(t[0], t[1], t[2], t[3]);
         }
         gvo += wanted ? UNIT : 0u;
@@ -449,7 +461,22 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
             const uint4 t = *(const uint4*)(stage + (in ? u : 0u));
             if (slot >= 0) {
                 held[slot][q] = t;
+#ifdef SPRINTZ_ABL_NO_GSTORE
+                held_vo[slot][q] = kDropStore;             // ablation: every block store is dropped by the descriptor
+#elif defined(SPRINTZ_ABL_STORE_INTERLEAVE)
+                {   // ablation (wrong output on purpose): the 8 groups of a wave write ONE contiguous kilobyte per store instruction
+                    const uint32_t g = (threadIdx.x & 63u) >> LOG2DP, gbase = g * a.chunk_len * ESZ;
+                    held_vo[slot][q] = in ? ((ovo - gbase) >> 7) * 1024u + g * 128u + u : kDropStore;
+                }
+#elif defined(SPRINTZ_ABL_STORE_SLOT0_ONLY)
+                held_vo[slot][q] = (in && slot == 0) ? ovo + u : kDropStore;   // ablation: slot 1's store is dropped
+#elif defined(SPRINTZ_ABL_STORE_HALF_LANES)
+                held_vo[slot][q] = (in && (lane_d & 1) == 0) ? ovo + u : kDropStore;   // ablation: every second lane's 16 bytes are dropped
+#elif defined(SPRINTZ_ABL_STORE_WINDOW)
+                held_vo[slot][q] = in ? ((ovo + u) & 0x3fffu) : kDropStore;   // ablation: a wave's stores all land in its first 16 KB
+#else
                 held_vo[slot][q] = in ? ovo + u : kDropStore;
+#endif
             } else {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, t), orsrc, in ? ovo + u : kDropStore, 0, kStoreAux);
             }
@@ -493,8 +520,10 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
                     q_row(k);
                     pack_row(k, i);
                     rows[i] = pv[k];
+#ifndef SPRINTZ_ABL_NO_STAGE
                     if constexpr (Q != kQueryReduceOnly && !CM && !XP32)
                         *(U*)(stage_k[k] + i * row_stride) = (U)pv[k];
+#endif
                 }
                 xp_store(rows);
                 q_block(k);
@@ -556,6 +585,8 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
             for (int i = 0; i < 8; i++) {
 #if SPRINTZ_DF_BATCH_READS
                 const uint32_t w = __builtin_amdgcn_alignbyte((uint32_t)(wv[i] >> 32), (uint32_t)wv[i], pa[i]);
+#elif defined(SPRINTZ_ABL_NO_FETCH)
+                const uint32_t w = p * 2654435761u;        // ablation: no LDS read, the address arithmetic stays
 #else
                 const uint32_t w = lds_rd32(p);
 #endif
@@ -627,8 +658,12 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
                 q_row(k);
                 pack_row(k, i);
                 rows[i] = pv[k];
+#ifndef SPRINTZ_ABL_NO_STAGE
                 if constexpr (Q != kQueryReduceOnly && !CM && !XP32)
                     *(U*)(stage_k[k] + i * row_stride) = (U)pv[k];
+#else
+                asm volatile("" :: "v"(pv[k]));
+#endif
             }
             xp_store(rows);
             q_block(k);
@@ -806,6 +841,17 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         if (tot1 != 0) fetch_rows(z1, at1, off1, nb1, rb1);
 
         if (tot0 == 0) run_blocks(len0); else packed_block(z0, 0);
+#if SPRINTZ_DF_SPLIT_STORES
+        // slot 0's block leaves NOW, slot 1's at the bottom of the step: all 16 waves of a CU reach their stores together, and a
+        // burst of 32 kilobyte-stores is what fills the texture addresser's queue (SQ_VMEM_TA_ADDR_FIFO_FULL) -- two bursts of 16
+        // queue half as long.  Still unconditional (a slot without a packed block re-stores the previous one), so the compiler's
+        // count of outstanding VMEM operations stays exact.
+        if constexpr (Q != kQueryReduceOnly && !CM) {
+#pragma unroll
+            for (int q = 0; q < PIECES; q++)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, held[0][q]), orsrc, held_vo[0][q], 0, kStoreAux);
+        }
+#endif
         if (!corrupt) { if (tot1 == 0) run_blocks(len1); else packed_block(z1, 1); }
 
         rp += used;
@@ -828,7 +874,7 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
                 for (int k = 0; k < CPL; k++) store_col(cheld[s2][k], cheld_vo[s2][k]);
         } else if constexpr (Q != kQueryReduceOnly) {
 #pragma unroll
-            for (int s2 = 0; s2 < 2; s2++)
+            for (int s2 = SPRINTZ_DF_SPLIT_STORES ? 1 : 0; s2 < 2; s2++)
 #pragma unroll
                 for (int q = 0; q < PIECES; q++)
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, held[s2][q]), orsrc, held_vo[s2][q], 0, kStoreAux);

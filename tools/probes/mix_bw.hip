@@ -1,0 +1,70 @@
+// probe: what does HBM give a kernel that READS r bytes and WRITES w bytes at once, both as coalesced 16-byte-per-lane streams
+// (the headline decoder reads 0.47 GB of streams and writes 1.34 GB of samples per launch)?  A fill of 1.34 GB runs at 6.9 TB/s and a
+// torch copy at 4.8 TB/s on the same part (tools/probes/hbm_bw.py): the ceiling of a MIXED stream is what the decoder is priced against.
+//   ./mix_bw            -> table of (read GB, write GB) -> ms, TB/s;  writes non-temporal like the decoder's
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+
+// every thread: NL loads then NS stores per trip, all 16 bytes, lane-contiguous; trips stride over the buffers
+template <int NL, int NS, bool NT>
+__global__ void __launch_bounds__(256) mix(const v4u* __restrict__ src, uint64_t nsrc, v4u* __restrict__ dst, uint64_t ndst)
+{
+    const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x, nthr = (uint64_t)gridDim.x * 256;
+    const uint64_t trips = ndst / ((uint64_t)NS * nthr);
+    v4u acc = {1, 2, 3, 4};
+    for (uint64_t t = 0; t < trips; t++) {
+        v4u in[NL > 0 ? NL : 1];
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const uint64_t i = (t * NL + k) * nthr + tid;      // (nsrc >= ndst and NL <= NS wherever both are used: in range)
+            in[k] = __builtin_nontemporal_load(src + i);
+        }
+#pragma unroll
+        for (int k = 0; k < NL; k++) acc ^= in[k];
+#pragma unroll
+        for (int k = 0; k < NS; k++) {
+            const uint64_t i = (t * NS + k) * nthr + tid;
+            v4u o = acc;
+            o.x += (uint32_t)k;
+            if (NT) __builtin_nontemporal_store(o, dst + i); else dst[i] = o;
+        }
+    }
+}
+
+template <int NL, int NS, bool NT = true> void run(const v4u* src, uint64_t nsrc, v4u* dst, uint64_t ndst, const char* what, int grid = 256 * 16)
+{
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int w = 0; w < 3; w++) hipLaunchKernelGGL((mix<NL, NS, NT>), dim3(grid), dim3(256), 0, 0, src, nsrc, dst, ndst);
+    hipEventRecord(e0);
+    const int reps = 20;
+    for (int r = 0; r < reps; r++) hipLaunchKernelGGL((mix<NL, NS, NT>), dim3(grid), dim3(256), 0, 0, src, nsrc, dst, ndst);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    const uint64_t nthr = (uint64_t)grid * 256, trips = ndst / ((uint64_t)NS * nthr);
+    const double wb = (double)trips * NS * nthr * 16, rb = (double)trips * NL * nthr * 16;
+    printf("%-28s read %.3f GB + write %.3f GB: %.4f ms -> %.2f TB/s\n", what, rb / 1e9, wb / 1e9, ms, (rb + wb) / ms / 1e9);
+}
+
+int main()
+{
+    const uint64_t wbytes = 1342177280ull, rbytes = 1342177280ull;
+    v4u *src, *dst;
+    hipMalloc(&src, rbytes); hipMalloc(&dst, wbytes);
+    hipMemset(src, 1, rbytes); hipMemset(dst, 0, wbytes);
+    const uint64_t ns = rbytes / 16, nd = wbytes / 16;
+    run<0, 16>(src, ns, dst, nd, "write only, nt");
+    run<0, 16, false>(src, ns, dst, nd, "write only, plain");
+    run<0, 16, false>(src, ns, dst, nd, "write only, plain, 1024 WGs", 1024);
+    run<0, 4, false>(src, ns, dst, nd, "write only, plain, 4/trip", 256 * 64);
+    run<6, 17, false>(src, ns, dst, nd, "decoder's mix, plain");
+    run<6, 17>(src, ns, dst, nd, "decoder's mix (6 : 17)");
+    run<8, 16>(src, ns, dst, nd, "1 : 2");
+    run<16, 16>(src, ns, dst, nd, "copy (1 : 1)");
+    run<6, 17>(src, ns, dst, nd, "decoder's mix, 16384 WGs", 256 * 64);
+    run<6, 17>(src, ns, dst, nd, "decoder's mix, 1024 WGs", 1024);
+    run<3, 8>(src, ns, dst, nd, "3 : 8, 16384 WGs", 256 * 64);
+    run<16, 0 + 16>(src, ns, dst, nd, "copy again");
+    return 0;
+}
