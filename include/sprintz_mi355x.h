@@ -143,7 +143,8 @@ int64_t sprintz_mi355x_decompress_layout(int codec, int elem_bytes, const void* 
  * (2) Batched device API (device pointers, asynchronous on `hip_stream`).
  * ---------------------------------------------------------------------- */
 
-/* Worst-case compressed bytes of one chunk (multiple of 16). */
+/* Worst-case compressed bytes of one chunk (a multiple of 128: slots of this stride start on 128-byte lines, and the
+ * encoders flush whole lines). */
 size_t sprintz_mi355x_compress_bound(int elem_bytes, uint32_t chunk_len, uint16_t ndims);
 
 /* Number of chunks total_len splits into. */

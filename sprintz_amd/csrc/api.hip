@@ -119,6 +119,12 @@ size_t group_bytes_max(int esz, int D)
 
 // ---------------------------------------------------------------- compaction kernels
 
+#ifndef SPRINTZ_BOUND_ALIGN
+#define SPRINTZ_BOUND_ALIGN 128           // sprintz_mi355x_compress_bound is a multiple of this: slots start on 128-byte lines
+#endif
+#ifndef SPRINTZ_ENC_DRAIN_ALIGN
+#define SPRINTZ_ENC_DRAIN_ALIGN 128       // encode_fast.h / encode_wide.h: granularity of the window's flushes to the slot
+#endif
 constexpr int kScanBlock = 1024;
 
 __global__ void __launch_bounds__(kScanBlock) scan_local_kernel(const uint32_t* sizes, uint64_t n, uint32_t align,
@@ -368,7 +374,7 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     a.col_stride = col_stride;
     a.norle = norle ? (codec == SPRINTZ_CODEC_XFF_NORLE ? 2 : 1) : 0;
     a.raw = codec == SPRINTZ_CODEC_BITPACK_NORLE ? 1 : 0;
-    a.cap = next_pow2((uint32_t)group_bytes_max(esz, D) + 48u);
+    a.cap = next_pow2((uint32_t)group_bytes_max(esz, D) + 48u + (uint32_t)(SPRINTZ_ENC_DRAIN_ALIGN - 16));
     const size_t shmem = ((size_t)a.cap + 16) * (kThreads / DP);
     if (shmem > 160 * 1024) return fail(SPRINTZ_E_UNSUPPORTED, "ndims too large for the LDS output ring");
 
@@ -885,7 +891,7 @@ size_t sprintz_mi355x_compress_bound(int elem_bytes, uint32_t chunk_len, uint16_
     const size_t max_groups = chunk_len / (16 * D) + 1;
     // header + per group (header + 2 run bytes worst case beyond raw) + raw payload + flush padding
     const size_t b = 8 + max_groups * (hdr_bytes + 3) + (size_t)chunk_len * esz + 32;
-    return (b + 15) & ~(size_t)15;
+    return (b + (SPRINTZ_BOUND_ALIGN - 1)) & ~(size_t)(SPRINTZ_BOUND_ALIGN - 1);
 }
 
 uint64_t sprintz_mi355x_num_chunks(uint64_t total_len, uint32_t chunk_len)

@@ -57,10 +57,13 @@ __global__ void __launch_bounds__(kThreads) encode_wide_kernel(EncodeArgs a)
             *r = make_uint4(0, 0, 0, 0);
         }
         wave_lds_sync();
-        if (upto != 0 && lane_d == 0 && upto < cap) {
-            const uint4 v = *(uint4*)(win + upto);
-            *(uint4*)(win + upto) = make_uint4(0, 0, 0, 0);
-            *(uint4*)win = v;
+        if (upto != 0 && upto < cap) {                     // what stays (less than the flush granule) moves to the front
+            const uint32_t rest = (wl - upto + 15u) & ~15u;
+            for (uint32_t u = (uint32_t)lane_d * 16u; u < rest && upto + u < cap; u += DP * 16) {
+                const uint4 v = *(uint4*)(win + upto + u);
+                *(uint4*)(win + upto + u) = make_uint4(0, 0, 0, 0);
+                *(uint4*)(win + u) = v;
+            }
         }
         gpos += upto;
         wl -= upto;
@@ -96,7 +99,7 @@ __global__ void __launch_bounds__(kThreads) encode_wide_kernel(EncodeArgs a)
     for (int k = 0; k < CPL; k++) { pv[k] = 0; pd[k] = 0; ctr[k] = 0; }
     auto start_group = [&]() {
         ngroups++;
-        drain(wl & ~15u);
+        drain(wl & ~(uint32_t)(SPRINTZ_ENC_DRAIN_ALIGN - 1));   // whole 128-byte lines (encode_fast.h)
         hdr_pos = wl;
         wl += hdr_bytes;
         slot = 0;
