@@ -297,6 +297,9 @@ constexpr int kCStride = 256 + 64 + 512 + 4;     // stream kernel, per chunk in 
 // 16-byte pieces with the 4-wave workgroup 3.69, 64-byte pieces 4.13 / 3.59 (1 / 4 waves).  At 10 000 chunks the single-wave,
 // 16-byte form is 5 % faster -- a workgroup there is a barrier and a four times longer table build for nothing -- so both are
 // instantiated and the launch picks by batch size.)
+#ifndef HUF0_SPECULATIVE_TAIL
+#define HUF0_SPECULATIVE_TAIL 1           // the streams' last bursts in one common masked round (stream kernel)
+#endif
 constexpr int ring_stride(int plog) { return 2 * (1 << plog) + 8; }
 
 // Blocks written with one code per SEGMENT of 64 chunks (our writer; any writer that repeats a tree description) need
