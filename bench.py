@@ -167,9 +167,15 @@ def time_cpu_mt(call, n_one, n_all, raw_per_chunk, target_s):
     reps1 = max(1, min(50, int(target_s / max(t, 1e-6))))
     best1 = min(call(n_one, 1, reps1, None) for _ in range(2))
     r = {"value_1thread": round(n_one * raw_per_chunk / best1 / 1e6, 1), "physical_cores": len(firsts), "logical_cpus": len(avail)}
+    # a container with a CPU quota (cgroup cpu.max) gets that many CPUs' worth of time however many threads it starts: more threads
+    # than the quota only run in bursts between throttle periods (a burst shorter than one period even reads ABOVE the quota's rate).
+    # The all-core leg therefore uses min(physical cores, quota) threads, and says so.
+    limit = len(firsts) if quota is None else max(1, min(len(firsts), int(quota)))
+    r["threads_limit"] = ("physical cores" if limit == len(firsts) else
+                          f"cgroup cpu quota of {quota:g} CPUs (the host has {len(firsts)} physical cores)")
     legs = {}
-    for name, cpus in (("physical", firsts), ("logical", avail)):
-        if name == "logical" and len(avail) == len(firsts):
+    for name, cpus in (("physical", firsts[:limit]), ("logical", avail)):
+        if name == "logical" and (len(avail) == len(firsts) or limit < len(firsts)):
             continue
         nt = min(len(cpus), n_all)
         t = call(n_all, nt, 1, cpus[:nt])
@@ -186,7 +192,7 @@ def time_cpu_mt(call, n_one, n_all, raw_per_chunk, target_s):
     # DRAM is out of the picture -- the gap between this and `value` is the host's memory system, not the harness
     n_small = min(n_all, ntp * max(1, (256 << 10) // raw_per_chunk))
     t = call(n_small, ntp, 1, firsts[:ntp])
-    reps = max(2, min(2000, int(target_s / max(t, 1e-6))))
+    reps = max(2, min(20000, int(target_s / max(t, 1e-6))))
     bc = min(call(n_small, ntp, reps, firsts[:ntp]) for _ in range(3))
     r["value_cache_resident"] = round(n_small * raw_per_chunk / bc / 1e6, 1)
     r["scaling_cache_resident_vs_1thread"] = round(r["value_cache_resident"] / r["value_1thread"], 1)
@@ -230,7 +236,7 @@ def cpu_baseline(comp_np, offs_np, nchunks, codec_id, esz, chunk_len, target_s, 
     r.update({"unit": "MB/s", "kind": kind,
               "sample": f"{what} per chunk on this configuration's own compressed chunks, data in RAM; all-core legs: {nchunks} chunks "
                         f"({nchunks * chunk_bytes / 1e6:.0f} MB raw), one contiguous chunk range per pinned pthread (oracle/mt_bench.c), sustained "
-                        f"over {r['passes']} passes, best of 3; `value`/`cores` = one thread per physical core; 1-thread leg: first {n_one} chunks; "
+                        f"over {r['passes']} passes, best of 3; `value`/`cores` = one thread per physical core, at most the container's CPU quota; 1-thread leg: first {n_one} chunks; "
                         f"value_cache_resident: the same threads on ~256 KB of samples each (L2-resident)"})
     return r
 
@@ -275,7 +281,7 @@ def cpu_baseline_huf0_chain(blocks_np, boffs_np, sizes_np, nchunks, esz, chunk_l
     r.update({"unit": "MB/s", "kind": kind,
               "sample": f"{hname} then sprintz_decompress_xff_16b per chunk on this configuration's own Huff0 blocks; all-core legs: {nchunks} chunks "
                         f"({nchunks * chunk_bytes / 1e6:.0f} MB raw), one chunk range per pinned pthread, {r['passes']} passes, best of 3; "
-                        f"`value`/`cores` = one thread per physical core; 1-thread leg: first {n_one} chunks"})
+                        f"`value`/`cores` = one thread per physical core, at most the container's CPU quota; 1-thread leg: first {n_one} chunks"})
     return r
 
 
