@@ -19,6 +19,10 @@
 
 namespace sprintz {
 
+#ifndef SPRINTZ_UNI_WINDOW_FAST
+#define SPRINTZ_UNI_WINDOW_FAST 1
+#endif
+
 // Geometry shared by the kernel and its launcher.  A lane refills its ring once every R blocks (a 64-byte piece per
 // refill, so R * STEPMAX <= 64); the ring holds RP pieces so that two refill periods fit behind the cursor's piece.
 // 8-bit univariate streams (BASELINE config 1) take R = 4: one round of loads per 32 samples instead of per 8.
@@ -157,6 +161,19 @@ __global__ void __launch_bounds__(decode_uni_threads(W, ND)) decode_uni_kernel(D
         uint32_t valid = 0;                                // bit b: block b of the window was produced
         const uint32_t win_elems = out_elems;              // output position of the window's first block
         bool wave_done = false;
+        // Round 3, univariate streams: the WINDOW-level fast path.  When every lane of the wave is alive, outside a run, at the same
+        // slot, and has room for a whole window (eight blocks of output, eight steps of stream, four group headers), none of that
+        // needs testing block by block: a block is then "read the header byte" (slot 0 only), "is the width zero anywhere?" (one
+        // ballot: a run or padding slot sends this block, and the rest of the window, down the general path) and four additions.
+        // Chunks start in phase and stay in phase until one of them meets a run, so this is the normal case.
+        bool window_fast = false;
+        int sslot = 0;
+        if constexpr (ND == 1 && SPRINTZ_UNI_WINDOW_FAST) {
+            sslot = __builtin_amdgcn_readfirstlane(slot);
+            const bool ok = alive && run_left == 0 && (slot == 1 || slot == 2) && slot == sslot && groups_left >= (uint32_t)(BW / 2 + 1) &&
+                            out_elems + 8u * BW <= a.chunk_len && (uint64_t)(c - c_begin) + (uint64_t)BW * STEPMAX <= stream_len + 2;
+            window_fast = __ballot(!ok) == 0 && __ballot(true) == ~0ull;
+        }
 #pragma unroll
         for (int b = 0; b < BW; b++) {
 #pragma unroll
@@ -172,7 +189,38 @@ __global__ void __launch_bounds__(decode_uni_threads(W, ND)) decode_uni_kernel(D
             // the general state machine below costs ~130 scalar instructions of exec-mask bookkeeping per block.
             // It still takes every step in which some lane meets a run length, a padding slot or the stream's end.
             bool fast_step = false;
+            if constexpr (ND == 1 && SPRINTZ_UNI_WINDOW_FAST) {
+                if (window_fast) {
+                    if (sslot == 2) {                                           // a group header, then its slot 0
+                        const uint32_t h = rd8(c);
+                        const uint32_t f0 = h & ((1u << HB) - 1u), f1 = (h >> HB) & ((1u << HB) - 1u);
+                        const uint32_t n0 = f0 == (uint32_t)(W - 1) ? (uint32_t)W : f0, n1 = f1 == (uint32_t)(W - 1) ? (uint32_t)W : f1;
+                        if (__ballot(n0 == 0u) != 0) {
+                            window_fast = false;                                // somebody's slot 0 is a run or padding: nothing taken yet
+                        } else {
+                            groups_left--;
+                            nb0[0] = n0; nb1[0] = n1;
+                            nb[0] = n0; nbsum = n0;
+                            cfield = c + (uint32_t)HBYTES;
+                            c += (uint32_t)HBYTES + n0;
+                            slot = 1; sslot = 1;
+                            have = true; fast_step = true;
+                        }
+                    } else {                                                    // slot 1 of the group the lane is in
+                        if (__ballot(nb1[0] == 0u) != 0) {
+                            window_fast = false;
+                        } else {
+                            nb[0] = nb1[0]; nbsum = nb1[0];
+                            cfield = c;
+                            c += nb1[0];
+                            slot = 2; sslot = 2;
+                            have = true; fast_step = true;
+                        }
+                    }
+                }
+            }
             if constexpr (ND == 1) {
+                if (!fast_step) {
                 const bool in_run = alive && run_left > 0;
                 const bool need_hdr = alive && !in_run && slot == 2;
                 uint32_t hpeek = 0;
@@ -201,6 +249,7 @@ __global__ void __launch_bounds__(decode_uni_threads(W, ND)) decode_uni_kernel(D
                     corrupt = corrupt || over;
                     alive = alive && !over;
                     have = have && !over;
+                }
                 }
             }
             if (alive && !fast_step) {
