@@ -175,29 +175,8 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
 #ifndef SPRINTZ_STORE_AUX
 #define SPRINTZ_STORE_AUX 2
 #endif
-#ifndef SPRINTZ_DF_LEAN_REQ
-#define SPRINTZ_DF_LEAN_REQ 0
-#endif
-#ifndef SPRINTZ_DF_ALWAYS_LOAD
-#define SPRINTZ_DF_ALWAYS_LOAD 0
-#endif
-#ifndef SPRINTZ_DF_HDR64
-#define SPRINTZ_DF_HDR64 0
-#endif
 #ifndef SPRINTZ_DF_MERGE8
 #define SPRINTZ_DF_MERGE8 1
-#endif
-#ifndef SPRINTZ_DF_XPOSE32
-#define SPRINTZ_DF_XPOSE32 0
-#endif
-#ifndef SPRINTZ_DF_BATCH_READS
-#define SPRINTZ_DF_BATCH_READS 0
-#endif
-#ifndef SPRINTZ_DF_DROP_UNWANTED
-#define SPRINTZ_DF_DROP_UNWANTED 1
-#endif
-#ifndef SPRINTZ_DF_SPLIT_STORES
-#define SPRINTZ_DF_SPLIT_STORES 0
 #endif
     constexpr int kStoreAux = SPRINTZ_STORE_AUX;
     const uint32_t lane16 = (uint32_t)lane_d * 16u;
@@ -212,20 +191,16 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     uint32_t npend = 0;
 
     // Request one unit (CPL 16-byte pieces per lane).  The loads are UNCONDITIONAL (an
-    // unwanted unit re-reads offset 0) so that the compiler can count the VMEM
-    // operations of a step exactly -- see the wait discussion at the bottom of the loop.
+    // unwanted unit asks for an offset outside the descriptor) so that the compiler can count
+    // the VMEM operations of a step exactly -- see the wait discussion at the bottom of the loop.
     auto request = [&](uint4 (&v)[CPL], bool wanted) {
 #pragma unroll
         for (int j = 0; j < CPL; j++) {
                         // (non-temporal LOADS were tried too: the read-ahead re-reads what neighbouring groups fetched, and with nt
             //  those re-reads go back to HBM -- 0.413 -> 0.461 ms)
-#if SPRINTZ_DF_DROP_UNWANTED
             // an unwanted unit asks for an offset outside the descriptor: the texture addresser answers zeros without a request to
             // the cache (a re-read of offset 0 is a real request of 64 lanes, and the addresser's queue is what the block stores wait in)
             const auto t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, wanted ? gvo + j * ROW16 : 0xfffffff0u, 0, 0);
-#else
-            const auto t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, wanted ? gvo + j * ROW16 : 0u, 0, 0);
-#endif
             v[j] = make_uint4(t[0], t[1], t[2], t[3]);
         }
         gvo += wanted ? UNIT : 0u;
@@ -273,24 +248,6 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     //  bytes at the same address as the genuine lane's; with an odd D the last lane's second byte spills into the next row's
     //  first, which that row's own write -- DS operations of a wave execute in order -- puts right, and after row 7 into padding.)
     constexpr bool MERGE8 = SPRINTZ_DF_MERGE8 && W == 8 && CPL % 2 == 0 && !CM && Q == 0;
-    // 16 bits, one column per lane, every lane a genuine column: the 8 x D block reaches the staging area as FOUR 32-bit
-    // writes per lane instead of eight 16-bit ones (a ds_write costs 4 LDS cycles whatever its width up to 32 bits, and the
-    // LDS is what this kernel saturates first -- DESIGN.md 4.1).  A lane packs its column's rows in pairs (row 2k | row 2k+1),
-    // swaps with its neighbour -- one DPP move and one v_perm_b32 per pair: the even lane keeps both columns of row 2k, the odd
-    // lane of row 2k+1 -- and writes one dword of its row per pair.
-    constexpr bool XP32 = SPRINTZ_DF_XPOSE32 && W == 16 && CPL == 1 && EXACT && !CM && Q == 0;
-    const uint32_t xp_sel = (lane_d & 1) ? 0x03020706u : 0x05040100u;
-    uint8_t* const xp_at = stage + (uint32_t)(lane_d & 1) * (uint32_t)(DCAP * ESZ) + (uint32_t)(lane_d >> 1) * 4u;
-    auto xp_store = [&](const uint32_t (&rows)[8]) {       // rows[i] = this lane's column at row i (garbage above bit 16 allowed)
-        if constexpr (XP32) {
-#pragma unroll
-            for (int k2 = 0; k2 < 4; k2++) {
-                const uint32_t mine = __builtin_amdgcn_perm(rows[2 * k2 + 1], rows[2 * k2], 0x05040100u);
-                const uint32_t other = dpp<DPP_QUAD_PERM(1, 0, 3, 2)>(0, mine);
-                *(uint32_t*)(xp_at + (uint32_t)k2 * 2u * (uint32_t)(DCAP * ESZ)) = __builtin_amdgcn_perm(other, mine, xp_sel);
-            }
-        }
-    };
     const bool merge8 = MERGE8 && (EXACT || (D & 1) == 0);   // rows of an odd number of bytes would make every second 16-bit write misaligned
     int colk[CPL];
     uint8_t* stage_k[CPL];
@@ -472,8 +429,6 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
                 held_vo[slot][q] = (in && slot == 0) ? ovo + u : kDropStore;   // ablation: slot 1's store is dropped
 #elif defined(SPRINTZ_ABL_STORE_HALF_LANES)
                 held_vo[slot][q] = (in && (lane_d & 1) == 0) ? ovo + u : kDropStore;   // ablation: every second lane's 16 bytes are dropped
-#elif defined(SPRINTZ_ABL_STORE_WINDOW)
-                held_vo[slot][q] = in ? ((ovo + u) & 0x3fffu) : kDropStore;   // ablation: a wave's stores all land in its first 16 KB
 #else
                 held_vo[slot][q] = in ? ovo + u : kDropStore;
 #endif
@@ -513,19 +468,16 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
 #pragma unroll
             for (int k = 0; k < CPL; k++) {
                 const int coef = FIRE ? fire_coef<W, false>(ctr[k]) : 0;
-                uint32_t rows[8];
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     run_step(k, coef);
                     q_row(k);
                     pack_row(k, i);
-                    rows[i] = pv[k];
 #ifndef SPRINTZ_ABL_NO_STAGE
-                    if constexpr (Q != kQueryReduceOnly && !CM && !XP32)
+                    if constexpr (Q != kQueryReduceOnly && !CM)
                         *(U*)(stage_k[k] + i * row_stride) = (U)pv[k];
 #endif
                 }
-                xp_store(rows);
                 q_block(k);
             }
             }
@@ -567,25 +519,9 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
             const uint32_t sh = off[k] & 7u;
             const uint32_t w1 = nb[k] != 0 ? 1u : 0u;      // width of the sign bit field
             const uint32_t wm = nb[k] - w1;                // width of the magnitude field
-#if SPRINTZ_DF_BATCH_READS
-            // all eight windows of the block requested before the first is looked at: ONE LDS round trip a block instead of four
-            // (hipcc keeps two reads in flight and waits with lgkmcnt(1) between them).  The reads are asm so that their order stands;
-            // the counter wait is ours too -- LDS operations of a wave complete in order, so the compiler's own waits stay sufficient.
-            uint32_t pa[8];
-            uint64_t wv[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) { pa[i] = p; p += row_bytes; }
-#pragma unroll
-            for (int i = 0; i < 8; i++) asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(wv[i]) : "v"(pa[i] & ~3u) : "memory");
-            // (the windows are operands of the wait: nothing that reads one may be scheduled above it)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]), "+v"(wv[4]), "+v"(wv[5]), "+v"(wv[6]), "+v"(wv[7]) :: "memory");
-            p = pa[0];
-#endif
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-#if SPRINTZ_DF_BATCH_READS
-                const uint32_t w = __builtin_amdgcn_alignbyte((uint32_t)(wv[i] >> 32), (uint32_t)wv[i], pa[i]);
-#elif defined(SPRINTZ_ABL_NO_FETCH)
+#ifdef SPRINTZ_ABL_NO_FETCH
                 const uint32_t w = p * 2654435761u;        // ablation: no LDS read, the address arithmetic stays
 #else
                 const uint32_t w = lds_rd32(p);
@@ -651,21 +587,18 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         for (int k = 0; k < CPL; k++) {
             int grad = 0;
             const int coef = FIRE ? fire_coef<W, false>(ctr[k]) : 0;
-            uint32_t rows[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 col_step(k, i, coef, grad);
                 q_row(k);
                 pack_row(k, i);
-                rows[i] = pv[k];
 #ifndef SPRINTZ_ABL_NO_STAGE
-                if constexpr (Q != kQueryReduceOnly && !CM && !XP32)
+                if constexpr (Q != kQueryReduceOnly && !CM)
                     *(U*)(stage_k[k] + i * row_stride) = (U)pv[k];
 #else
                 asm volatile("" :: "v"(pv[k]));
 #endif
             }
-            xp_store(rows);
             q_block(k);
             if constexpr (FIRE) ctr[k] = wrap_counter<W>(ctr[k] + __builtin_amdgcn_sbfe(grad, 2, W - 2));   // sext_W(grad) >> 2
         }
@@ -732,31 +665,6 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         // ---- request the units that fit now; they are parked at the bottom of this step
         {
             const uint32_t room = RB - ahead;              // ring bytes the parser no longer needs
-#if SPRINTZ_DF_LEAN_REQ
-            // how many whole units fit: one shift and a min instead of a compare and two selects per unit; the k-th load's
-            // k * UNIT rides in the instruction's immediate offset
-            if constexpr ((UNIT & (UNIT - 1)) == 0) {
-                constexpr uint32_t LOG2UNIT = UNIT == 64 ? 6 : UNIT == 128 ? 7 : UNIT == 256 ? 8 : UNIT == 512 ? 9 : UNIT == 1024 ? 10 : UNIT == 2048 ? 11 : 12;
-                static_assert((1u << LOG2UNIT) == UNIT, "unit size");
-                const uint32_t fit = room >> LOG2UNIT;
-                npend = fit < NPEND ? fit : NPEND;
-#pragma unroll
-                for (uint32_t k = 0; k < NPEND; k++) {
-#if SPRINTZ_DF_ALWAYS_LOAD
-                    const uint32_t base = gvo;             // a unit that does not fit yet is fetched anyway and dropped (re-requested later)
-#else
-                    const uint32_t base = k < npend ? gvo : 0u;
-#endif
-#pragma unroll
-                    for (int j = 0; j < CPL; j++) {
-                        const auto t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, base, (int)(k * UNIT + j * ROW16), 0);
-                        pend[k][j] = make_uint4(t[0], t[1], t[2], t[3]);
-                    }
-                }
-                gvo += npend << LOG2UNIT;
-                ahead += npend << LOG2UNIT;
-            } else
-#endif
             {
             npend = 0;
 #pragma unroll
@@ -774,23 +682,6 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         const uint32_t r = ring + rofs;                    // LDS address of the parse cursor
         uint32_t nb_both[CPL], lane_both = 0;
         uint32_t hw0 = 0, hw1 = 0;                         // (two columns of a lane: their header fields sit in one window per slot)
-#if SPRINTZ_DF_HDR64
-        constexpr bool HDR64 = EXACT && CPL == 1 && DCAP * HB == 32;   // slot 0's fields are one dword, slot 1's the next
-#else
-        constexpr bool HDR64 = false;
-#endif
-        if constexpr (HDR64) {
-            // three aligned dwords cover the 8 header bytes wherever they start: one address, two v_alignbyte, and both
-            // slots' fields sit at the same bit of their dword; the W-1 -> W fix-up runs on both halves at once
-            lds_u32* q = (lds_u32*)(uintptr_t)(r & ~3u);
-            const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
-            const uint32_t h0 = __builtin_amdgcn_alignbyte(d1, d0, r), h1 = __builtin_amdgcn_alignbyte(d2, d1, r);
-            const uint32_t sh = (uint32_t)lane_d * HB;
-            uint32_t both = __builtin_amdgcn_ubfe(h0, sh, HB) | (__builtin_amdgcn_ubfe(h1, sh, HB) << 16);
-            both += ((both + 0x00010001u) >> HB) & 0x00010001u;         // a field of 2^HB - 1 = W - 1 means W (:747-749)
-            nb_both[0] = both;
-            lane_both = both;
-        } else
 #pragma unroll
         for (int k = 0; k < CPL; k++) {
             const uint32_t hbit0 = (uint32_t)colk[k] * HB, hbit1 = (uint32_t)(D + colk[k]) * HB;
@@ -841,17 +732,6 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         if (tot1 != 0) fetch_rows(z1, at1, off1, nb1, rb1);
 
         if (tot0 == 0) run_blocks(len0); else packed_block(z0, 0);
-#if SPRINTZ_DF_SPLIT_STORES
-        // slot 0's block leaves NOW, slot 1's at the bottom of the step: all 16 waves of a CU reach their stores together, and a
-        // burst of 32 kilobyte-stores is what fills the texture addresser's queue (SQ_VMEM_TA_ADDR_FIFO_FULL) -- two bursts of 16
-        // queue half as long.  Still unconditional (a slot without a packed block re-stores the previous one), so the compiler's
-        // count of outstanding VMEM operations stays exact.
-        if constexpr (Q != kQueryReduceOnly && !CM) {
-#pragma unroll
-            for (int q = 0; q < PIECES; q++)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, held[0][q]), orsrc, held_vo[0][q], 0, kStoreAux);
-        }
-#endif
         if (!corrupt) { if (tot1 == 0) run_blocks(len1); else packed_block(z1, 1); }
 
         rp += used;
@@ -874,7 +754,7 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
                 for (int k = 0; k < CPL; k++) store_col(cheld[s2][k], cheld_vo[s2][k]);
         } else if constexpr (Q != kQueryReduceOnly) {
 #pragma unroll
-            for (int s2 = SPRINTZ_DF_SPLIT_STORES ? 1 : 0; s2 < 2; s2++)
+            for (int s2 = 0; s2 < 2; s2++)
 #pragma unroll
                 for (int q = 0; q < PIECES; q++)
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, held[s2][q]), orsrc, held_vo[s2][q], 0, kStoreAux);

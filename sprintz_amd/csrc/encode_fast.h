@@ -22,9 +22,6 @@ namespace sprintz {
 #ifndef SPRINTZ_ENC_PAIR_MERGE
 #define SPRINTZ_ENC_PAIR_MERGE 1
 #endif
-#ifndef SPRINTZ_ENC_PACKED16
-#define SPRINTZ_ENC_PACKED16 0
-#endif
 #ifndef SPRINTZ_ENC_DRAIN_ALIGN
 #define SPRINTZ_ENC_DRAIN_ALIGN 128
 #endif
@@ -240,45 +237,6 @@ __device__ __forceinline__ uint32_t encode_fast_body(const EncodeArgs& a, uint32
         const int coef = FIRE ? fire_coef<W, false>(ctr) : 0;
         int grad = 0;
         uint32_t mask = 0;
-        if constexpr (W == 16 && SPRINTZ_ENC_PACKED16) {
-            // Unlike the decoder's, the encoder's rows do not wait for each other: delta and prev_delta both come from the
-            // INPUT (:222-225).  So two rows ride in one register through packed 16-bit VALU -- x, delta, err and zigzag as
-            // (row 2k | row 2k+1 << 16); only FIRE's multiply-high stays one v_mad_i32_i16 per sample (there is no packed
-            // mul-hi): ~7 instructions per sample instead of ~13.  pv / pd keep the previous PAIR; their high halves are
-            // the previous sample / delta.
-            typedef short v2s __attribute__((ext_vector_type(2)));
-            auto pk = [](uint32_t v) { return __builtin_bit_cast(v2s, v); };
-            auto un = [](v2s v) { return __builtin_bit_cast(uint32_t, v); };
-            uint32_t Pp = pv, Dp = (uint32_t)pd;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t P = x[2 * k] | (x[2 * k + 1] << 16);
-                const uint32_t Pm1 = __builtin_amdgcn_alignbit(P, Pp, 16);           // (x[2k-1], x[2k])
-                const uint32_t Dk = un(pk(P) - pk(Pm1));                              // (delta[2k], delta[2k+1]), wrapping at 16 bits
-                uint32_t E = Dk;
-                if constexpr (FIRE) {
-                    const uint32_t Dm1 = __builtin_amdgcn_alignbit(Dk, Dp, 16);       // (delta[2k-1], delta[2k]) = the two prev_deltas
-                    int pa, pb;                                                       // prev_delta * coef, 32 bits each (:225)
-                    asm("v_mad_i32_i16 %0, %1, %2, 0" : "=v"(pa) : "v"(Dm1), "v"(coef));
-                    asm("v_mad_i32_i16 %0, %1, %2, 0 op_sel:[1,0,0,0]" : "=v"(pb) : "v"(Dm1), "v"(coef));
-                    const uint32_t pred = __builtin_amdgcn_perm((uint32_t)pb, (uint32_t)pa, 0x07060302u);   // (pa >> 16, pb >> 16)
-                    E = un(pk(Dk) - pk(pred));
-                    // odd rows: grad += sign(err) * prev_delta (:240-241); row 2k+1's prev_delta is delta[2k] = the low half of Dk
-                    const int sg = sign_of((int)E >> 16);
-                    asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(grad) : "v"(sg), "v"(Dk), "v"(grad));
-                }
-                const v2s e = pk(E);
-                const uint32_t Z = un((v2s)(e << (v2s)(1)) ^ (v2s)(e >> (v2s)(15)));       // zigzag on both halves
-                mask |= Z;
-                z[2 * k] = Z & 0xffffu;
-                z[2 * k + 1] = Z >> 16;
-                Pp = P;
-                Dp = Dk;
-            }
-            mask = (mask | (mask >> 16)) & 0xffffu;
-            pv = Pp >> 16 << 16;              // the loop only looks at the high half
-            pd = (int)Dp;
-        } else
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const int delta = sext<W>((int)(x[i] - pv));
