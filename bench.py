@@ -285,6 +285,25 @@ def cpu_baseline_huf0_chain(blocks_np, boffs_np, sizes_np, nchunks, esz, chunk_l
     return r
 
 
+def streaming_probe():
+    """tools/probes/mix_bw (if it was built): what a kernel that does nothing but coalesced 16-byte loads and non-temporal stores in
+    the headline decoder's 6 : 17 read : write ratio moves on THIS box -- the practical ceiling next to the datasheet's 8 TB/s"""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "probes", "mix_bw")
+    if not os.access(exe, os.X_OK):
+        return None
+    try:
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
+    except Exception:
+        return None
+    rates = [float(m.group(1)) for m in re.finditer(r"decoder's mix[^\n]*-> ([0-9.]+) TB/s", out)]
+    if not rates:
+        return None
+    return {"GBps_best": round(max(rates) * 1e3, 1), "GBps_worst": round(min(rates) * 1e3, 1),
+            "what": "tools/probes/mix_bw.hip: streaming kernels with the decoder's read : write mix (grid sizes 1024 / 4096 / 16384 workgroups, nt and plain stores)"}
+
+
 def roofline(algo_bytes, ms, kernel, extra=None):
     ach = algo_bytes / (ms * 1e-3) / 1e9
     r = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
@@ -789,6 +808,13 @@ def main():
         "host": host_description(),
     }
 
+    if rank == 0 and not args.no_extras:
+        sp = streaming_probe()
+        if sp:
+            moved = (traffic or algo_bytes) / (kernel_ms * 1e-3) / 1e9
+            sp["decoder_GBps_of_traffic"] = round(moved, 1)
+            sp["decoder_vs_best_streaming"] = round(moved / sp["GBps_best"], 3)
+            result["roofline"]["streaming_probe"] = sp
     if not args.no_extras:
         result.update(headline_extras(cx, codec, x, comp, offsets, ws, out, nchunks, total_comp, chunk_len, ndims, esz, wall / args.steps * 1e3))
 

@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-for v in base ablstore ablwin; do
+for v in base ablstore; do   # tools/build_variant.sh base ""; tools/build_variant.sh ablstore "decode_w16" -DSPRINTZ_ABL_NO_GSTORE
 i=0
 while read -r group; do
   [ -z "$group" ] && continue
