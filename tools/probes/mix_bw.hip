@@ -33,6 +33,37 @@ __global__ void __launch_bounds__(256) mix(const v4u* __restrict__ src, uint64_t
     }
 }
 
+// torch's fill: a workgroup per 16 KB tile, a thread four 16-byte stores 4 KB apart, plain stores, no loop
+template <bool NT>
+__global__ void __launch_bounds__(256) tile_fill(v4u* __restrict__ dst)
+{
+    v4u* p = dst + (uint64_t)blockIdx.x * 1024 + threadIdx.x;
+    v4u o = {blockIdx.x, threadIdx.x, 3, 4};
+#pragma unroll
+    for (int k = 0; k < 4; k++) { if (NT) __builtin_nontemporal_store(o, p + 256 * k); else p[256 * k] = o; }
+}
+// the same tile written by ONE wave per kilobyte line group: thread t of wave w writes 16 B; 16 instructions per thread, 64 KB a workgroup
+template <bool NT>
+__global__ void __launch_bounds__(256) tile_fill64(v4u* __restrict__ dst)
+{
+    v4u* p = dst + (uint64_t)blockIdx.x * 4096 + threadIdx.x;
+    v4u o = {blockIdx.x, threadIdx.x, 3, 4};
+#pragma unroll
+    for (int k = 0; k < 16; k++) { if (NT) __builtin_nontemporal_store(o, p + 256 * k); else p[256 * k] = o; }
+}
+template <typename K> void run_fill(K kern, v4u* dst, uint64_t nbytes, uint64_t tile, const char* what)
+{
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const unsigned grid = (unsigned)(nbytes / tile);
+    for (int w = 0; w < 3; w++) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, dst);
+    hipEventRecord(e0);
+    const int reps = 20;
+    for (int r = 0; r < reps; r++) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, dst);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    printf("%-28s write %.3f GB: %.4f ms -> %.2f TB/s\n", what, (double)grid * tile / 1e9, ms, (double)grid * tile / ms / 1e9);
+}
+
 template <int NL, int NS, bool NT = true> void run(const v4u* src, uint64_t nsrc, v4u* dst, uint64_t ndst, const char* what, int grid = 256 * 16)
 {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -54,6 +85,10 @@ int main()
     hipMalloc(&src, rbytes); hipMalloc(&dst, wbytes);
     hipMemset(src, 1, rbytes); hipMemset(dst, 0, wbytes);
     const uint64_t ns = rbytes / 16, nd = wbytes / 16;
+    run_fill(tile_fill<false>, dst, wbytes, 16384, "tile fill 16 KB, plain");
+    run_fill(tile_fill<true>, dst, wbytes, 16384, "tile fill 16 KB, nt");
+    run_fill(tile_fill64<false>, dst, wbytes, 65536, "tile fill 64 KB, plain");
+    run_fill(tile_fill64<true>, dst, wbytes, 65536, "tile fill 64 KB, nt");
     run<0, 16>(src, ns, dst, nd, "write only, nt");
     run<0, 16, false>(src, ns, dst, nd, "write only, plain");
     run<0, 16, false>(src, ns, dst, nd, "write only, plain, 1024 WGs", 1024);
