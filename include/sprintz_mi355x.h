@@ -85,11 +85,15 @@ const char* sprintz_mi355x_last_error(void);     /* thread-local, never NULL; de
  *                                 env SPRINTZ_MI355X_DENSE_MODE
  *   SPRINTZ_OPT_HUF0_BIG_BATCH    chunks from which the Huff0 reader's one-table stream kernel runs as 4-wave workgroups with
  *                                 32-byte stream pieces (faster from ~40 000 chunks on) instead of single waves with 16-byte
- *                                 pieces (faster below); default 40000, 0 = always (tests) */
+ *                                 pieces (faster below); default 40000, 0 = always (tests)
+ *   SPRINTZ_OPT_SPLIT_LANES       1 (default) = 8-bit row-major streams of 65 .. 80 columns decode on 32 lanes a chunk (a pair of
+ *                                 adjacent columns + one single column per lane, two chunks a wavefront), 0 = on 64 lanes x 2
+ *                                 columns like the other shapes up to 128 columns (A/B runs, tests); env SPRINTZ_MI355X_SPLIT_LANES */
 #define SPRINTZ_OPT_NO_FAST 0
 #define SPRINTZ_OPT_CHUNKS_PER_GROUP 1
 #define SPRINTZ_OPT_DENSE_MODE 2
 #define SPRINTZ_OPT_HUF0_BIG_BATCH 3
+#define SPRINTZ_OPT_SPLIT_LANES 4
 int sprintz_mi355x_set_option(int option, int value);
 
 /* ------------------------------------------------------------------------

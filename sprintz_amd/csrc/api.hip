@@ -48,6 +48,7 @@ struct Process {
     std::atomic<int> no_fast{0};            // SPRINTZ_MI355X_NO_FAST: generic kernels only (A/B runs, tests)
     std::atomic<int> chunks_per_group{1};   // SPRINTZ_MI355X_CHUNKS_PER_GROUP (decode_fast read-ahead across chunks)
     std::atomic<int> dense_mode{1};         // SPRINTZ_MI355X_DENSE_MODE: how compress_batch_dense builds the container (see SPRINTZ_OPT_DENSE_MODE)
+    std::atomic<int> split_lanes{1};        // SPRINTZ_MI355X_SPLIT_LANES: 8-bit streams of 65 .. 80 columns on 32 lanes x (pair + single) (see SPRINTZ_OPT_SPLIT_LANES)
 };
 Process& process()
 {
@@ -61,6 +62,7 @@ Process& process()
             const int k = atoi(e);
             p.dense_mode = k <= 0 ? 0 : 1;
         }
+        if (const char* e = getenv("SPRINTZ_MI355X_SPLIT_LANES")) p.split_lanes = atoi(e) != 0 ? 1 : 0;
         if (const char* e = getenv("SPRINTZ_MI355X_CHUNKS_PER_GROUP")) {
             const int k = atoi(e);
             p.chunks_per_group = k < 1 ? 1 : k > 64 ? 64 : k;
@@ -292,7 +294,11 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
     //  8 waves per CU instead of 16, measured 0.494 vs 0.400 ms -- the doubled ILP does not replace the lost waves)
     // (32-bit offsets inside one wavefront's span of the output)
     // and chunks not much shorter than the read-ahead ring (it is filled before the first header is parsed)
-    const size_t fring = decode_fast_lds_bytes(8 * esz, fdp, fcpl, D, cs != 0 && fcpl == 1);
+    // 8 bits, 65 .. 80 columns, plain row-major decode: 32 lanes x (a pair + a single column), two chunks a wavefront, the LDS
+    // carve sized for 80 columns so that 12 wavefronts a CU stay resident (decode_fast.h, SPLIT)
+    int fds = 0;
+    if (esz == 1 && D > 64 && D <= 80 && !cs && qs.q == kQueryOff && process().split_lanes.load(std::memory_order_relaxed)) { fdp = 32; fcpl = 3; fds = 80; }
+    const size_t fring = decode_fast_lds_bytes(8 * esz, fdp, fcpl, D, cs != 0 && fcpl == 1, fds);
     const bool fast_common = !lowdim && !a.raw && !noheader && D <= 256 && 2 * D > fdp * fcpl && (uint64_t)chunk_len * esz * 2 >= fring &&
                              !process().no_fast.load(std::memory_order_relaxed);
     // column-major: a lane's 8 samples per block are one aligned 16-byte (8-byte) piece of its column
@@ -305,7 +311,7 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
         while ((1 << a.log2DP) < fdp) a.log2DP++;
         const size_t fgroups = kThreads / fdp;
         // (padding the stride by 16 / 32 / 48 bytes to move the groups' staging rows onto other banks: no change, 0.4225 ms each)
-        const size_t fstride = decode_fast_lds_bytes(8 * esz, fdp, fcpl, D, cs != 0 && fcpl == 1);
+        const size_t fstride = decode_fast_lds_bytes(8 * esz, fdp, fcpl, D, cs != 0 && fcpl == 1, fds);
         a.lds_group_stride = (uint32_t)fstride;
         // consecutive chunks per lane group.  Measured on MI355X (cfg2, 131072 chunks): k = 1 / 2 / 4 /
         // 8 -> 0.498 / 0.496 / 0.510 / 0.560 ms: one generation of lock-stepped groups is no faster
@@ -874,6 +880,7 @@ int sprintz_mi355x_set_option(int option, int value)
         sprintz::huf0_big_batch() = value;
         return 0;
     }
+    if (option == SPRINTZ_OPT_SPLIT_LANES) { process().split_lanes = value ? 1 : 0; return 0; }
     if (option == SPRINTZ_OPT_CHUNKS_PER_GROUP) {
         if (value < 1 || value > 64) return fail(SPRINTZ_E_INVALID, "chunks per group must be in 1..64");
         process().chunks_per_group = value;

@@ -100,7 +100,12 @@ __device__ __forceinline__ uint32_t add_hi16(uint32_t a, int x)
 // CM: column-major destination (DecodeArgs::col_stride): the 8 samples a lane produces per block
 // are contiguous in ITS column -- packed in registers and stored as one 16-byte (8-byte at
 // W == 8) piece per column, no LDS transpose.
-template <int W, bool FIRE, int DP, int CPL, bool EXACT, int Q = 0, bool CM = false>
+// DS != 0: the LDS carve (ring, apron, requests per step) is sized for streams of at most DS columns instead of the
+// DP*CPL the lanes could hold (the launch checks ndims <= DS) -- what decides how many chunks a CU keeps in flight.
+// CPL == 3 is the SPLIT mapping for 8-bit streams of 65 .. 96 columns on 32 lanes (two chunks a wavefront instead of one
+// on 64 x 2 with 40 lanes busy at 80 columns): lane l owns the PAIR (2l, 2l+1) -- every pair genuine, on an even column,
+// so the paired window / paired staging write of the 8-bit path apply -- and the SINGLE column 64 + l.
+template <int W, bool FIRE, int DP, int CPL, bool EXACT, int Q = 0, bool CM = false, int DS = 0>
 __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
 {
     using U = typename Elem<W>::U;
@@ -111,8 +116,12 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     constexpr int DCAP = DP * CPL;                         // columns a group can hold
     constexpr uint32_t ROW16 = DP * 16;                    // bytes one wave-instruction moves per group
     constexpr uint32_t UNIT = ROW16 * CPL;                 // bytes one refill unit brings in (CPL pieces per lane)
-    constexpr uint32_t HDRMAX = (2 * DCAP * HB + 7) / 8;
-    constexpr uint32_t BLKMAX = 8 * DCAP * ESZ;            // largest block payload = largest decoded block
+    constexpr bool SPLIT = CPL == 3;
+    static_assert(!SPLIT || (W == 8 && DP == 32 && !EXACT && !CM && Q == 0), "the split mapping is built for 8-bit row-major decodes");
+    constexpr int DSZ = DS ? DS : DCAP;                    // columns the LDS carve is sized for
+    static_assert(DSZ <= DCAP, "sizing columns");
+    constexpr uint32_t HDRMAX = (2 * DSZ * HB + 7) / 8;
+    constexpr uint32_t BLKMAX = 8 * DSZ * ESZ;             // largest block payload = largest decoded block
     constexpr int PIECES = (BLKMAX + ROW16 - 1) / ROW16;   // 16-byte pieces of a decoded block per lane
     constexpr uint32_t CG = HDRMAX + 2 * BLKMAX + 4;       // most bytes one group can consume
     constexpr uint32_t NPEND = (CG + UNIT - 1) / UNIT;     // units requested per group step (2 or 3)
@@ -247,17 +256,20 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     //  sample for the field window).  A lane past the last column then stands in for the last PAIR, (D-2, D-1) -- the same two
     //  bytes at the same address as the genuine lane's; with an odd D the last lane's second byte spills into the next row's
     //  first, which that row's own write -- DS operations of a wave execute in order -- puts right, and after row 7 into padding.)
-    constexpr bool MERGE8 = SPRINTZ_DF_MERGE8 && W == 8 && CPL % 2 == 0 && !CM && Q == 0;
+    constexpr bool MERGE8 = SPRINTZ_DF_MERGE8 && W == 8 && (CPL % 2 == 0 || SPLIT) && !CM && Q == 0;
     const bool merge8 = MERGE8 && (EXACT || (D & 1) == 0);   // rows of an odd number of bytes would make every second 16-bit write misaligned
+    constexpr int NPAIR = CPL / 2;                         // columns 2j, 2j+1 (j < NPAIR) of a lane are adjacent in the row
+    int genk[CPL];                                         // the column this lane column IS (>= D: it is a stand-in)
     int colk[CPL];
     uint8_t* stage_k[CPL];
 #pragma unroll
     for (int k = 0; k < CPL; k++) {
-        if (MERGE8 && merge8) {
+        genk[k] = SPLIT ? (k < 2 ? 2 * lane_d + k : 2 * DP + lane_d) : col0 + k;
+        if (MERGE8 && merge8 && !SPLIT) {
             const int pb = (col0 + (k & ~1)) < D ? col0 + (k & ~1) : ((D - 1) & ~1);      // first column of this lane's pair
             colk[k] = EXACT ? col0 + k : (pb + (k & 1) < D ? pb + (k & 1) : D - 1);
         } else {
-            colk[k] = EXACT ? col0 + k : (col0 + k < D ? col0 + k : D - 1);
+            colk[k] = EXACT ? genk[k] : (genk[k] < D ? genk[k] : D - 1);
         }
         stage_k[k] = stage + colk[k] * ESZ;
     }
@@ -266,7 +278,7 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     int pd[CPL], ctr[CPL];
     bool col_ok[CPL];
 #pragma unroll
-    for (int k = 0; k < CPL; k++) { pv[k] = 0; pd[k] = 0; ctr[k] = 0; col_ok[k] = EXACT ? true : (col0 + k) < D; }
+    for (int k = 0; k < CPL; k++) { pv[k] = 0; pd[k] = 0; ctr[k] = 0; col_ok[k] = EXACT ? true : genk[k] < D; }
     uint32_t out_left = 0;                                 // capacity guard (elements)
     bool corrupt = false;
     // query-on-compressed (Q != 0): per-column max and sum of the chunk, kept next to the
@@ -316,7 +328,7 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     uint32_t cbase[CPL];                                   // byte offset of this lane's columns in the descriptor
 #pragma unroll
     for (int k = 0; k < CPL; k++) {
-        cbase[k] = CM ? (uint32_t)((uint64_t)(col0 + k) * a.col_stride * ESZ) : 0u;
+        cbase[k] = CM ? (uint32_t)((uint64_t)genk[k] * a.col_stride * ESZ) : 0u;
 #pragma unroll
         for (int s2 = 0; s2 < 2; s2++) { cheld[s2][k] = make_uint4(0, 0, 0, 0); cheld_vo[s2][k] = kDropStore; }
     }
@@ -453,20 +465,7 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
                     pd[k] = delta;
                 }
             };
-            if (MERGE8 && merge8) {
-#pragma unroll
-                for (int k = 0; k < CPL; k += 2) {
-                    const int coef0 = FIRE ? fire_coef<W, false>(ctr[k]) : 0, coef1 = FIRE ? fire_coef<W, false>(ctr[k + 1]) : 0;
-#pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        run_step(k, coef0);
-                        run_step(k + 1, coef1);
-                        *(uint16_t*)(stage_k[k] + i * row_stride) = (uint16_t)__builtin_amdgcn_perm(pv[k + 1], pv[k], 0x0c0c0400u);
-                    }
-                }
-            } else {
-#pragma unroll
-            for (int k = 0; k < CPL; k++) {
+            auto run_col = [&](int k) {
                 const int coef = FIRE ? fire_coef<W, false>(ctr[k]) : 0;
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
@@ -479,7 +478,23 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
 #endif
                 }
                 q_block(k);
-            }
+            };
+            if (MERGE8 && merge8) {
+#pragma unroll
+                for (int j = 0; j < NPAIR; j++) {
+                    const int k = 2 * j;
+                    const int coef0 = FIRE ? fire_coef<W, false>(ctr[k]) : 0, coef1 = FIRE ? fire_coef<W, false>(ctr[k + 1]) : 0;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        run_step(k, coef0);
+                        run_step(k + 1, coef1);
+                        *(uint16_t*)(stage_k[k] + i * row_stride) = (uint16_t)__builtin_amdgcn_perm(pv[k + 1], pv[k], 0x0c0c0400u);
+                    }
+                }
+                if constexpr (CPL & 1) run_col(CPL - 1);
+            } else {
+#pragma unroll
+                for (int k = 0; k < CPL; k++) run_col(k);
             }
             stage_out(-1);
         }
@@ -491,12 +506,13 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
     // half of the register (SDWA dst_sel:WORD_1), i.e. it yields E = err << 16 directly,
     // which is what the FIRE step and the sign test want (W == 16); for W == 8 one shift follows (FIRE) or none (delta).
     auto fetch_rows = [&](int (&e)[CPL][8], uint32_t at, const uint32_t (&off)[CPL], const uint32_t (&nb)[CPL], uint32_t row_bytes) {
-        if constexpr (W == 8 && CPL % 2 == 0) {
+        if constexpr (W == 8 && CPL >= 2) {
             // 8 bits: a lane's two adjacent columns are two adjacent fields of at most 8 bits, at most 7 + 16 bits from the byte
             // the first one starts in -- ONE 32-bit window per row serves both (an address, a mask and a v_alignbyte less per
             // second column and row).  (A stand-in column repeats the last genuine one: the same window.)
 #pragma unroll
-            for (int k = 0; k < CPL; k += 2) {
+            for (int j = 0; j < NPAIR; j++) {
+                const int k = 2 * j;
                 uint32_t p = at + (off[k] >> 3);
                 const uint32_t sha = off[k] & 7u, shb = off[k + 1] - (off[k] & ~7u);
                 const uint32_t w1a = nb[k] != 0 ? 1u : 0u, wma = nb[k] - w1a;
@@ -511,10 +527,10 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
                     p += row_bytes;
                 }
             }
-            return;
+            if constexpr (CPL % 2 == 0) return;
         }
 #pragma unroll
-        for (int k = 0; k < CPL; k++) {
+        for (int k = (W == 8 && CPL >= 2) ? 2 * NPAIR : 0; k < CPL; k++) {
             uint32_t p = at + (off[k] >> 3);
             const uint32_t sh = off[k] & 7u;
             const uint32_t w1 = nb[k] != 0 ? 1u : 0u;      // width of the sign bit field
@@ -566,25 +582,7 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
                 pd[k] = delta;
             }
         };
-        if (MERGE8 && merge8) {                            // a lane's two adjacent 8-bit columns: one 16-bit staging write per row
-#pragma unroll
-            for (int k = 0; k < CPL; k += 2) {
-                int grad0 = 0, grad1 = 0;
-                const int coef0 = FIRE ? fire_coef<W, false>(ctr[k]) : 0, coef1 = FIRE ? fire_coef<W, false>(ctr[k + 1]) : 0;
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    col_step(k, i, coef0, grad0);
-                    col_step(k + 1, i, coef1, grad1);
-                    *(uint16_t*)(stage_k[k] + i * row_stride) = (uint16_t)__builtin_amdgcn_perm(pv[k + 1], pv[k], 0x0c0c0400u);
-                }
-                if constexpr (FIRE) {
-                    ctr[k] = wrap_counter<W>(ctr[k] + __builtin_amdgcn_sbfe(grad0, 2, W - 2));
-                    ctr[k + 1] = wrap_counter<W>(ctr[k + 1] + __builtin_amdgcn_sbfe(grad1, 2, W - 2));
-                }
-            }
-        } else {
-#pragma unroll
-        for (int k = 0; k < CPL; k++) {
+        auto one_col = [&](int k) {
             int grad = 0;
             const int coef = FIRE ? fire_coef<W, false>(ctr[k]) : 0;
 #pragma unroll
@@ -601,7 +599,28 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
             }
             q_block(k);
             if constexpr (FIRE) ctr[k] = wrap_counter<W>(ctr[k] + __builtin_amdgcn_sbfe(grad, 2, W - 2));   // sext_W(grad) >> 2
-        }
+        };
+        if (MERGE8 && merge8) {                            // a lane's two adjacent 8-bit columns: one 16-bit staging write per row
+#pragma unroll
+            for (int j = 0; j < NPAIR; j++) {
+                const int k = 2 * j;
+                int grad0 = 0, grad1 = 0;
+                const int coef0 = FIRE ? fire_coef<W, false>(ctr[k]) : 0, coef1 = FIRE ? fire_coef<W, false>(ctr[k + 1]) : 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    col_step(k, i, coef0, grad0);
+                    col_step(k + 1, i, coef1, grad1);
+                    *(uint16_t*)(stage_k[k] + i * row_stride) = (uint16_t)__builtin_amdgcn_perm(pv[k + 1], pv[k], 0x0c0c0400u);
+                }
+                if constexpr (FIRE) {
+                    ctr[k] = wrap_counter<W>(ctr[k] + __builtin_amdgcn_sbfe(grad0, 2, W - 2));
+                    ctr[k + 1] = wrap_counter<W>(ctr[k + 1] + __builtin_amdgcn_sbfe(grad1, 2, W - 2));
+                }
+            }
+            if constexpr (CPL & 1) one_col(CPL - 1);
+        } else {
+#pragma unroll
+            for (int k = 0; k < CPL; k++) one_col(k);
         }
         stage_out(slot);
     };
@@ -686,7 +705,7 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
         for (int k = 0; k < CPL; k++) {
             const uint32_t hbit0 = (uint32_t)colk[k] * HB, hbit1 = (uint32_t)(D + colk[k]) * HB;
             uint32_t s0 = hbit0 & 7u, s1 = hbit1 & 7u;
-            if (CPL % 2 == 0 && (k & 1)) {                 // the odd column reads its pair's window
+            if (k & 1) {                                   // the odd column reads its pair's window
                 const uint32_t b0 = (uint32_t)colk[k - 1] * HB, b1 = (uint32_t)(D + colk[k - 1]) * HB;
                 s0 = hbit0 - (b0 & ~7u);
                 s1 = hbit1 - (b1 & ~7u);
@@ -702,13 +721,21 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
             lane_both += col_ok[k] ? nb_both[k] : 0u;
         }
         uint32_t tot_both;
-        uint32_t excl_both = group_scan<DP>(lane_both, lane_d, tot_both);
+        uint32_t excl_both, excl_single = 0;
+        if constexpr (SPLIT) {                             // columns 0 .. 63 are the pairs, lane by lane; the singles follow them
+            uint32_t tot_pairs, tot_singles;
+            excl_both = group_scan<DP>(nb_both[0] + nb_both[1], lane_d, tot_pairs);
+            excl_single = tot_pairs + group_scan<DP>(col_ok[2] ? nb_both[2] : 0u, lane_d, tot_singles);
+            tot_both = tot_pairs + tot_singles;
+        } else {
+            excl_both = group_scan<DP>(lane_both, lane_d, tot_both);
+        }
         const uint32_t tot0 = tot_both & 0xffffu, tot1 = tot_both >> 16;
         uint32_t off0[CPL], off1[CPL], nb0[CPL], nb1[CPL];
 #pragma unroll
         for (int k = 0; k < CPL; k++) {
-            uint32_t o_both = col_ok[k] ? excl_both : tot_both - nb_both[k];         // (a stand-in: where column D-1 starts)
-            if constexpr (MERGE8 && !EXACT) {              // (a stand-in for column D-2 -- the first of the last pair -- starts one field earlier)
+            uint32_t o_both = col_ok[k] ? (SPLIT && k == 2 ? excl_single : excl_both) : tot_both - nb_both[k];   // (a stand-in: where column D-1 starts)
+            if constexpr (MERGE8 && !EXACT && !SPLIT) {    // (a stand-in for column D-2 -- the first of the last pair -- starts one field earlier)
                 if ((k & 1) == 0 && !col_ok[k] && colk[k] != colk[k + 1]) o_both -= nb_both[k + 1];
             }
             off0[k] = o_both & 0xffffu;
@@ -779,12 +806,12 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
 #pragma unroll
             for (int k = 0; k < CPL; k++) {
                 if (!col_ok[k]) continue;
-                for (uint32_t e = (uint32_t)(col0 + k); e < remaining; e += (uint32_t)D) {
+                for (uint32_t e = (uint32_t)genk[k]; e < remaining; e += (uint32_t)D) {
                     const uint32_t x = ESZ == 1 ? (uint32_t)t[e] : (uint32_t)*(const u16_unaligned*)(t + 2 * e);
                     qmax[k] = x > qmax[k] ? x : qmax[k];
                     qsum[k] += x;
                 }
-                if (a.qres) a.qres[chunk * (uint64_t)D + (uint64_t)(col0 + k)] = a.qop == 1 ? (uint64_t)qmax[k] : qsum[k];
+                if (a.qres) a.qres[chunk * (uint64_t)D + (uint64_t)genk[k]] = a.qop == 1 ? (uint64_t)qmax[k] : qsum[k];
             }
         }
     }
@@ -806,11 +833,11 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
 }
 
 // bytes of LDS one group needs in decode_fast_kernel
-constexpr uint32_t decode_fast_lds_bytes(int W, int DP, int CPL, int D, bool colmajor_burst = false)
+constexpr uint32_t decode_fast_lds_bytes(int W, int DP, int CPL, int D, bool colmajor_burst = false, int DS = 0)
 {
     const uint32_t unit = DP * 16 * CPL;
     const uint32_t hb = W == 8 ? 3 : 4;
-    const uint32_t dcap = DP * CPL;
+    const uint32_t dcap = DS ? DS : DP * CPL;
     const uint32_t hdrmax = (2 * dcap * hb + 7) / 8, blkmax = 8 * dcap * (W / 8);
     const uint32_t cg = hdrmax + 2 * blkmax + 4;
     const uint32_t rb = ((2 * (cg + 24) + 3 + unit - 1) / unit + 1) * unit;
