@@ -418,12 +418,15 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     // streams of 65 .. 128 columns (BASELINE config 3): two columns per lane (encode_wide.h)
     if (!lowdim && !a.raw && !col_stride && D > 64 && D <= 128 && blk_bytes % 16 == 0 && ((uint64_t)chunk_len * esz) % 16 == 0 &&
         (uint64_t)chunk_len * esz >= 2 * blk_bytes && ((uintptr_t)d_src % 16) == 0 && !process().no_fast.load(std::memory_order_relaxed)) {
-        const size_t wgroups = kThreads / 64;
+        // (8 bits, 65 .. 80 columns: 32 lanes a chunk -- a pair + a single column per lane -- two chunks a wavefront)
+        const bool wsplit = esz == 1 && D <= 80 && process().split_lanes.load(std::memory_order_relaxed) != 0;
+        const size_t wlanes = wsplit ? 32 : 64, wgroups = kThreads / wlanes;
         a.lds_group_stride = (uint32_t)(a.cap + ((blk_bytes + 15) & ~(size_t)15) + 16);
-        const uint64_t wgrid = (nchunks * 64ull + kThreads - 1) / kThreads;
+        const uint64_t wgrid = (nchunks * (uint64_t)wlanes + kThreads - 1) / kThreads;
         if (wgrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
         const bool wfire = codec == SPRINTZ_CODEC_XFF || codec == SPRINTZ_CODEC_XFF_NORLE;
-        e = esz == 1 ? launch_encode_wide_w8(wfire, D == 128, (unsigned)wgrid, (size_t)a.lds_group_stride * wgroups, st, a)
+        e = wsplit   ? launch_encode_split_w8(wfire, (unsigned)wgrid, (size_t)a.lds_group_stride * wgroups, st, a)
+          : esz == 1 ? launch_encode_wide_w8(wfire, D == 128, (unsigned)wgrid, (size_t)a.lds_group_stride * wgroups, st, a)
                      : launch_encode_wide_w16(wfire, D == 128, (unsigned)wgrid, (size_t)a.lds_group_stride * wgroups, st, a);
         if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "encode_wide kernel launch", e);
         return 0;

@@ -32,6 +32,11 @@ hipError_t launch_encode_uni_w8(bool fire, int nd, unsigned grid, hipStream_t st
     }
     return hipGetLastError();
 }
+hipError_t launch_encode_split_w8(bool fire, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a)
+{
+    if (a.D <= 64 || a.D > 80) return hipErrorInvalidValue;
+    return fire ? launch_one(encode_wide_kernel<8, true, false, true>, grid, shmem, st, a) : launch_one(encode_wide_kernel<8, false, false, true>, grid, shmem, st, a);
+}
 hipError_t launch_encode_wide_w8(bool fire, bool exact, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a)
 {
     if (exact) return fire ? launch_one(encode_wide_kernel<8, true, true>, grid, shmem, st, a) : launch_one(encode_wide_kernel<8, false, true>, grid, shmem, st, a);

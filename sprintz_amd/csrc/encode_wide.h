@@ -13,14 +13,19 @@
 
 namespace sprintz {
 
-template <int W, bool FIRE, bool EXACT>
+// SPLIT (8 bits, 65 .. 80 columns -- 40 of the 64 lanes carry columns at 80): 32 lanes a chunk, two chunks a wavefront; lane l
+// owns the PAIR (2l, 2l + 1) -- merged with its neighbour's exactly as above -- and the SINGLE column 64 + l, whose fields a
+// quad of lanes merges (<= 32 bits) before one of them ORs; one scan carries the pairs' bits in its low half and the singles' in
+// its high half.  The decoder's counterpart is decode_fast.h's SPLIT mapping.
+template <int W, bool FIRE, bool EXACT, bool SPLIT = false>
 __global__ void __launch_bounds__(kThreads) encode_wide_kernel(EncodeArgs a)
 {
-    constexpr int DP = 64, CPL = 2, LOG2DP = 6;
+    constexpr int DP = SPLIT ? 32 : 64, CPL = SPLIT ? 3 : 2, LOG2DP = SPLIT ? 5 : 6;
+    static_assert(!SPLIT || (W == 8 && !EXACT), "the split mapping is built for 8-bit streams of 65 .. 80 columns");
     using U = typename Elem<W>::U;
     constexpr int HB = Elem<W>::HB;
     constexpr int ESZ = W / 8;
-    constexpr int PIECES = ESZ;                  // 16-byte pieces of a block per lane: 8 * 128 * ESZ bytes / (64 * 16)
+    constexpr int PIECES = SPLIT ? 2 : ESZ;      // 16-byte pieces of a block per lane: 8 * 128 * ESZ bytes / (64 * 16); split: 8 * 80 / (32 * 16)
     constexpr bool TAIL_LE = FIRE;               // "<=" at sprintz_xff_rle.cpp:362, "<" at sprintz_delta_rle.cpp:226
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
@@ -34,10 +39,14 @@ __global__ void __launch_bounds__(kThreads) encode_wide_kernel(EncodeArgs a)
     const uint32_t n = (uint32_t)((a.total_len - first < a.chunk_len) ? (a.total_len - first) : a.chunk_len);
     const U* const sc = (const U*)a.src + first;
     uint8_t* const gdst = a.slots + chunk * a.slot_stride;
-    const int col0 = lane_d * CPL;
+    const int col0 = SPLIT ? 2 * lane_d : lane_d * CPL;    // first column of the lane's pair
+    int genk[CPL];
     bool col_ok[CPL];
 #pragma unroll
-    for (int k = 0; k < CPL; k++) col_ok[k] = EXACT ? true : (col0 + k) < D;
+    for (int k = 0; k < CPL; k++) {
+        genk[k] = (SPLIT && k == 2) ? 64 + lane_d : col0 + k;
+        col_ok[k] = EXACT ? true : genk[k] < D;
+    }
 
     // LDS per group: [linear, zero-initialised output window cap | input block staging] (encode_fast.h)
     const uint32_t cap = a.cap;
@@ -133,11 +142,19 @@ __global__ void __launch_bounds__(kThreads) encode_wide_kernel(EncodeArgs a)
         wave_lds_sync();
         load_block(pos_in + blk);
         uint32_t z[CPL][8], nb[CPL], lane_bits = 0;
+        uint32_t xp[8];                                    // 8 bits: the pair's two samples of a row come as ONE 16-bit LDS read
+        if constexpr (W == 8) {                            // (rows are an even number of bytes -- blocks are 16-byte multiples -- and the pair starts on an even column)
+#pragma unroll
+            for (int i = 0; i < 8; i++) xp[i] = col_ok[0] ? (uint32_t)*(const uint16_t*)(stage + (uint32_t)genk[0] + i * row_stride) : 0u;
+        }
 #pragma unroll
         for (int k = 0; k < CPL; k++) {
             uint32_t x[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) x[i] = col_ok[k] ? (uint32_t)((const U*)stage)[(uint32_t)(col0 + k) + i * row_stride] : 0u;
+            for (int i = 0; i < 8; i++) {
+                if (W == 8 && k < 2) x[i] = col_ok[k] ? (k == 0 ? xp[i] & 0xffu : xp[i] >> 8) : 0u;
+                else x[i] = col_ok[k] ? (uint32_t)((const U*)stage)[(uint32_t)genk[k] + i * row_stride] : 0u;
+            }
             const int coef = FIRE ? fire_coef<W, false>(ctr[k]) : 0;
             int grad = 0;
             uint32_t mask = 0;
@@ -160,11 +177,19 @@ __global__ void __launch_bounds__(kThreads) encode_wide_kernel(EncodeArgs a)
             }
             if constexpr (FIRE) ctr[k] = wrap_counter<W>(ctr[k] + __builtin_amdgcn_sbfe(grad, 2, W - 2));
             nb[k] = col_ok[k] ? nbits_of<W, false>(mask) : 0u;
-            lane_bits += nb[k];
+            if (k < 2) lane_bits += nb[k];                 // the pair's bits (the single column of the split mapping is scanned beside them)
         }
         wave_lds_sync();
-        uint32_t total;
-        const uint32_t excl = group_scan<DP>(lane_bits, lane_d, total);
+        uint32_t total, excl, excl_single = 0;
+        if constexpr (SPLIT) {                             // columns 0 .. 63, lane by lane, then the singles: <= 512 and <= 256 bits
+            uint32_t both;
+            const uint32_t r = group_scan<DP>(lane_bits | (nb[2] << 16), lane_d, both);
+            excl = r & 0xffffu;
+            excl_single = (both & 0xffffu) + (r >> 16);
+            total = (both & 0xffffu) + (both >> 16);
+        } else {
+            excl = group_scan<DP>(lane_bits, lane_d, total);
+        }
 
         // ---- RLE state machine (:350-456); group-uniform
         for (;;) {
@@ -190,10 +215,17 @@ __global__ void __launch_bounds__(kThreads) encode_wide_kernel(EncodeArgs a)
             {   // header fields: the lane's two, then four lanes' eight = one 24-bit word (:296)
                 uint32_t f = 0;
 #pragma unroll
-                for (int k = 0; k < CPL; k++) f |= (col_ok[k] ? (nb[k] == (uint32_t)W ? (uint32_t)(W - 1) : nb[k]) : 0u) << (k * HB);
+                for (int k = 0; k < 2; k++) f |= (col_ok[k] ? (nb[k] == (uint32_t)W ? (uint32_t)(W - 1) : nb[k]) : 0u) << (k * HB);
                 f |= dpp<DPP_ROW_SHL(1)>(0, f) << (2 * HB);
                 f |= dpp<DPP_ROW_SHL(2)>(0, f) << (4 * HB);
                 if ((lane_d & 3) == 0) or_bits(hdr_pos * 8u + (uint32_t)(slot * D + col0) * HB, f, 8 * HB);
+                if constexpr (SPLIT) {                     // the singles: eight lanes' fields = one 24-bit word
+                    uint32_t g = col_ok[2] ? (nb[2] == (uint32_t)W ? (uint32_t)(W - 1) : nb[2]) : 0u;
+                    g |= dpp<DPP_ROW_SHL(1)>(0, g) << HB;
+                    g |= dpp<DPP_ROW_SHL(2)>(0, g) << (2 * HB);
+                    g |= dpp<DPP_ROW_SHL(4)>(0, g) << (4 * HB);
+                    if ((lane_d & 7) == 0 && col_ok[2]) or_bits(hdr_pos * 8u + (uint32_t)(slot * D + genk[2]) * HB, g, 8 * HB);
+                }
             }
             const uint32_t row_bits = ((total + 7u) >> 3) << 3;
             uint32_t bp = wl * 8u + excl;
@@ -206,6 +238,18 @@ __global__ void __launch_bounds__(kThreads) encode_wide_kernel(EncodeArgs a)
                     const uint32_t theirs = dpp<DPP_ROW_SHL(1)>(0, mine);
                     if (even) or_bits(bp, mine | (theirs << lane_bits), nb_pair);
                     bp += row_bits;
+                }
+                if constexpr (SPLIT) {                     // a quad of lanes merges its four single-column fields (<= 32 bits)
+                    const uint32_t c1 = nb[2], c2 = c1 + dpp<DPP_ROW_SHL(1)>(0, c1), c4 = c2 + dpp<DPP_ROW_SHL(2)>(0, c2);
+                    const bool lead = (lane_d & 3) == 0;
+                    uint32_t bs = wl * 8u + excl_single;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const uint32_t m2 = z[2][i] | (dpp<DPP_ROW_SHL(1)>(0, z[2][i]) << c1);   // <= 16 bits
+                        const uint32_t m4 = m2 | (c2 < 32u ? dpp<DPP_ROW_SHL(2)>(0, m2) << c2 : 0u);
+                        if (lead) or_bits(bs, m4, c4);
+                        bs += row_bits;
+                    }
                 }
             } else {
 #pragma unroll

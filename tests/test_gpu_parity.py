@@ -256,9 +256,9 @@ def test_consecutive_chunks_per_group(sz, oracle, request, k):
 @pytest.mark.parametrize("codec", ["delta", "xff"])
 @pytest.mark.parametrize("ndims", [65, 66, 68, 70, 72, 74, 76, 78, 79, 80])
 def test_split_lane_mapping_8bit_65_to_80_columns(sz, oracle, request, codec, ndims):
-    """decode_fast's SPLIT mapping (8 bits, 65 .. 80 columns: 32 lanes a chunk, a pair + a single column per lane, LDS carve
-    sized for 80 columns) and the 64 x 2 mapping it replaces, both against the data and on the oracle's own byte-dense
-    streams: every even width of the range (odd widths take the generic decoder: their blocks are not 16-byte multiples),
+    """The SPLIT mapping of decode_fast.h and encode_wide.h (8 bits, 65 .. 80 columns: 32 lanes a chunk, a pair + a single column
+    per lane; the decoder's LDS carve sized for 80 columns) and the 64 x 2 mapping it replaces: stream bytes against the oracle's,
+    decodes against the data and on the oracle's own byte-dense streams: every even width of the range (odd widths take the generic decoder: their blocks are not 16-byte multiples),
     runs, full-width fields, ragged last chunks, chunk lengths just above the fast path's floor."""
     import torch
     from sprintz_amd import _lib
@@ -269,7 +269,6 @@ def test_split_lane_mapping_8bit_65_to_80_columns(sz, oracle, request, codec, nd
         total = nchunks * chunk_len - 5 * ndims - 3
         data = np.concatenate([gen_walk(rng, total // 2, ndims, 1, step, flat_every=3), gen_fuzz(rng, total - total // 2, 1, 2)])
         cd = sz.ChunkedCodec(codec, 1, ndims, chunk_len, device="cuda:0")
-        batch = cd.compress(torch.from_numpy(data).cuda())
         streams = oracle.compress_chunks(codec, data, chunk_len, ndims)
         offs = np.zeros(nchunks + 1, np.int64)
         offs[1:] = np.cumsum([s.size for s in streams])
@@ -277,6 +276,11 @@ def test_split_lane_mapping_8bit_65_to_80_columns(sz, oracle, request, codec, nd
         offs_t = torch.from_numpy(offs).cuda()
         for split in (1, 0):
             _lib.check(_lib.set_option(_lib.OPT_SPLIT_LANES, split))
+            batch = cd.compress(torch.from_numpy(data).cuda())              # the encoder's split mapping (encode_wide.h) / 64 x 2
+            got, goffs, gsizes = batch.data.cpu().numpy(), batch.offsets.cpu().numpy(), batch.sizes.cpu().numpy()
+            for c in range(nchunks):
+                assert gsizes[c] == streams[c].size, (codec, ndims, rows, split, c)
+                assert np.array_equal(got[goffs[c]:goffs[c] + gsizes[c]], streams[c]), (codec, ndims, rows, split, c)
             rets = torch.empty(nchunks, dtype=torch.int64, device="cuda:0")
             out = cd.decompress(batch, rets=rets)
             assert np.array_equal(out.cpu().numpy(), data), (codec, ndims, rows, split, "aligned container")
