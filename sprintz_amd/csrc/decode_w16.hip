@@ -5,8 +5,14 @@ hipError_t launch_decode_w16(bool fire, bool lowdim, int cpl, int q, unsigned gr
 {
     SPRINTZ_DISPATCH(decode_kernel, 16)
 }
-hipError_t launch_decode_fast_w16(bool fire, int dp, int cpl, bool exact, int q, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a)
+hipError_t launch_decode_fast_w16(bool fire, int dp, int cpl, bool exact, int q, int ds, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a)
 {
+    if (ds == 80) {                                        // 65 .. 80 columns on 64 x 2 with the LDS carve of 80 columns: 12 waves a CU instead of 8
+        if (dp != 64 || cpl != 2 || q != kQueryOff || a.col_stride || exact || a.D <= 64 || a.D > 80) return hipErrorInvalidValue;
+        return fire ? launch_one(decode_fast_kernel<16, true, 64, 2, false, kQueryOff, false, 80>, grid, shmem, st, a)
+                    : launch_one(decode_fast_kernel<16, false, 64, 2, false, kQueryOff, false, 80>, grid, shmem, st, a);
+    }
+    if (ds != 0) return hipErrorInvalidValue;
     SPRINTZ_DISPATCH_DECODE_FAST(decode_fast_kernel, 16)
 }
 #define SPRINTZ_UNI_CASE(NDV, QV)                                                                          \

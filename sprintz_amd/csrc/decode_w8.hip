@@ -5,13 +5,14 @@ hipError_t launch_decode_w8(bool fire, bool lowdim, int cpl, int q, unsigned gri
 {
     SPRINTZ_DISPATCH(decode_kernel, 8)
 }
-hipError_t launch_decode_fast_w8(bool fire, int dp, int cpl, bool exact, int q, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a)
+hipError_t launch_decode_fast_w8(bool fire, int dp, int cpl, bool exact, int q, int ds, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a)
 {
     if (dp == 32 && cpl == 3) {                            // the split mapping: 8 bits, 65 .. 80 columns, plain row-major decode only
-        if (q != kQueryOff || a.col_stride || exact || a.D <= 64 || a.D > 80) return hipErrorInvalidValue;
+        if (ds != 80 || q != kQueryOff || a.col_stride || exact || a.D <= 64 || a.D > 80) return hipErrorInvalidValue;
         return fire ? launch_one(decode_fast_kernel<8, true, 32, 3, false, kQueryOff, false, 80>, grid, shmem, st, a)
                     : launch_one(decode_fast_kernel<8, false, 32, 3, false, kQueryOff, false, 80>, grid, shmem, st, a);
     }
+    if (ds != 0) return hipErrorInvalidValue;
     SPRINTZ_DISPATCH_DECODE_FAST(decode_fast_kernel, 8)
 }
 #define SPRINTZ_UNI_CASE(NDV, QV)                                                                          \

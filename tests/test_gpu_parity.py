@@ -253,22 +253,24 @@ def test_consecutive_chunks_per_group(sz, oracle, request, k):
         assert np.array_equal(out2.cpu().numpy(), data), (codec, k, "dense")
 
 
+@pytest.mark.parametrize("esz", [1, 2])
 @pytest.mark.parametrize("codec", ["delta", "xff"])
 @pytest.mark.parametrize("ndims", [65, 66, 68, 70, 72, 74, 76, 78, 79, 80])
-def test_split_lane_mapping_8bit_65_to_80_columns(sz, oracle, request, codec, ndims):
-    """The SPLIT mapping of decode_fast.h and encode_wide.h (8 bits, 65 .. 80 columns: 32 lanes a chunk, a pair + a single column
-    per lane; the decoder's LDS carve sized for 80 columns) and the 64 x 2 mapping it replaces: stream bytes against the oracle's,
-    decodes against the data and on the oracle's own byte-dense streams: every even width of the range (odd widths take the generic decoder: their blocks are not 16-byte multiples),
-    runs, full-width fields, ragged last chunks, chunk lengths just above the fast path's floor."""
+def test_split_lane_mapping_65_to_80_columns(sz, oracle, request, codec, ndims, esz):
+    """8 bits: the SPLIT mapping of decode_fast.h and encode_wide.h (32 lanes a chunk, a pair + a single column per lane; the
+    decoder's LDS carve sized for 80 columns); 16 bits: 64 x 2 with the 80-column carve.  Both against what they replace
+    (SPRINTZ_OPT_SPLIT_LANES 0): stream bytes against the oracle's, decodes against the data and on the oracle's own byte-dense
+    streams -- every even width of the range (odd 8-bit widths take the generic decoder: their blocks are not 16-byte
+    multiples), runs, full-width fields, ragged last chunks, chunk lengths just above the fast path's floor."""
     import torch
     from sprintz_amd import _lib
     request.addfinalizer(lambda: _lib.set_option(_lib.OPT_SPLIT_LANES, 1))
-    rng = np.random.default_rng(1000 + ndims)
-    for rows, nchunks, step in [(128, 41, 3), (56, 70, 60), (136, 19, 1)]:
+    rng = np.random.default_rng(1000 * esz + ndims)
+    for rows, nchunks, step in [(128, 41, 3), (56, 70, 60 if esz == 1 else 9000), (136, 19, 1)]:
         chunk_len = rows * ndims
         total = nchunks * chunk_len - 5 * ndims - 3
-        data = np.concatenate([gen_walk(rng, total // 2, ndims, 1, step, flat_every=3), gen_fuzz(rng, total - total // 2, 1, 2)])
-        cd = sz.ChunkedCodec(codec, 1, ndims, chunk_len, device="cuda:0")
+        data = np.concatenate([gen_walk(rng, total // 2, ndims, esz, step, flat_every=3), gen_fuzz(rng, total - total // 2, esz, 2)])
+        cd = sz.ChunkedCodec(codec, esz, ndims, chunk_len, device="cuda:0")
         streams = oracle.compress_chunks(codec, data, chunk_len, ndims)
         offs = np.zeros(nchunks + 1, np.int64)
         offs[1:] = np.cumsum([s.size for s in streams])
@@ -279,16 +281,16 @@ def test_split_lane_mapping_8bit_65_to_80_columns(sz, oracle, request, codec, nd
             batch = cd.compress(torch.from_numpy(data).cuda())              # the encoder's split mapping (encode_wide.h) / 64 x 2
             got, goffs, gsizes = batch.data.cpu().numpy(), batch.offsets.cpu().numpy(), batch.sizes.cpu().numpy()
             for c in range(nchunks):
-                assert gsizes[c] == streams[c].size, (codec, ndims, rows, split, c)
-                assert np.array_equal(got[goffs[c]:goffs[c] + gsizes[c]], streams[c]), (codec, ndims, rows, split, c)
+                assert gsizes[c] == streams[c].size, (codec, esz, ndims, rows, split, c)
+                assert np.array_equal(got[goffs[c]:goffs[c] + gsizes[c]], streams[c]), (codec, esz, ndims, rows, split, c)
             rets = torch.empty(nchunks, dtype=torch.int64, device="cuda:0")
             out = cd.decompress(batch, rets=rets)
-            assert np.array_equal(out.cpu().numpy(), data), (codec, ndims, rows, split, "aligned container")
+            assert np.array_equal(out.cpu().numpy(), data), (codec, esz, ndims, rows, split, "aligned container")
             r = rets.cpu().numpy()
             assert (r[:-1] == chunk_len).all() and r[-1] == total - (nchunks - 1) * chunk_len
             out2 = torch.full((nchunks * chunk_len,), 0x5a, dtype=cd.dtype, device="cuda:0")
             cd.decompress_into(comp, offs_t, nchunks, out2)
-            assert np.array_equal(out2.cpu().numpy()[:total], data), (codec, ndims, rows, split, "byte-dense container")
+            assert np.array_equal(out2.cpu().numpy()[:total], data), (codec, esz, ndims, rows, split, "byte-dense container")
 
 
 def test_decoder_rejects_wrong_ndims(sz, oracle):
