@@ -88,12 +88,16 @@ const char* sprintz_mi355x_last_error(void);     /* thread-local, never NULL; de
  *                                 pieces (faster below); default 40000, 0 = always (tests)
  *   SPRINTZ_OPT_SPLIT_LANES       1 (default) = 8-bit row-major streams of 65 .. 80 columns decode on 32 lanes a chunk (a pair of
  *                                 adjacent columns + one single column per lane, two chunks a wavefront), 0 = on 64 lanes x 2
- *                                 columns like the other shapes up to 128 columns (A/B runs, tests); env SPRINTZ_MI355X_SPLIT_LANES */
+ *                                 columns like the other shapes up to 128 columns (A/B runs, tests); env SPRINTZ_MI355X_SPLIT_LANES
+ *   SPRINTZ_OPT_ENC_PAIR          1 (default) = row-major streams of 5 .. 64 columns are encoded with two columns per lane (the
+ *                                 65 .. 128-column kernel on 4 .. 32 lanes a chunk), 0 = with one column per lane (A/B runs, tests);
+ *                                 env SPRINTZ_MI355X_ENC_PAIR */
 #define SPRINTZ_OPT_NO_FAST 0
 #define SPRINTZ_OPT_CHUNKS_PER_GROUP 1
 #define SPRINTZ_OPT_DENSE_MODE 2
 #define SPRINTZ_OPT_HUF0_BIG_BATCH 3
 #define SPRINTZ_OPT_SPLIT_LANES 4
+#define SPRINTZ_OPT_ENC_PAIR 5
 int sprintz_mi355x_set_option(int option, int value);
 
 /* ------------------------------------------------------------------------

@@ -48,6 +48,7 @@ struct Process {
     std::atomic<int> no_fast{0};            // SPRINTZ_MI355X_NO_FAST: generic kernels only (A/B runs, tests)
     std::atomic<int> chunks_per_group{1};   // SPRINTZ_MI355X_CHUNKS_PER_GROUP (decode_fast read-ahead across chunks)
     std::atomic<int> dense_mode{1};         // SPRINTZ_MI355X_DENSE_MODE: how compress_batch_dense builds the container (see SPRINTZ_OPT_DENSE_MODE)
+    std::atomic<int> enc_pair{1};           // SPRINTZ_MI355X_ENC_PAIR: two columns per lane in the encoder for row-major streams of 5 .. 64 columns too (see SPRINTZ_OPT_ENC_PAIR)
     std::atomic<int> split_lanes{1};        // SPRINTZ_MI355X_SPLIT_LANES: 8-bit streams of 65 .. 80 columns on 32 lanes x (pair + single) (see SPRINTZ_OPT_SPLIT_LANES)
 };
 Process& process()
@@ -63,6 +64,7 @@ Process& process()
             p.dense_mode = k <= 0 ? 0 : 1;
         }
         if (const char* e = getenv("SPRINTZ_MI355X_SPLIT_LANES")) p.split_lanes = atoi(e) != 0 ? 1 : 0;
+        if (const char* e = getenv("SPRINTZ_MI355X_ENC_PAIR")) p.enc_pair = atoi(e) != 0 ? 1 : 0;
         if (const char* e = getenv("SPRINTZ_MI355X_CHUNKS_PER_GROUP")) {
             const int k = atoi(e);
             p.chunks_per_group = k < 1 ? 1 : k > 64 ? 64 : k;
@@ -395,6 +397,38 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     const bool fast = col_stride ? fast_common && col_stride % 8 == 0 && (chunk_len / (uint32_t)D) % 8 == 0
                                  : fast_common && blk_bytes % 16 == 0 && ((uint64_t)chunk_len * esz) % 16 == 0;
     hipError_t e;
+    // the container built inside the launch (compact_tail.h): every kernel of encode_fast.h / encode_wide.h carries the tail
+    auto arm_dense = [&](uint64_t grid, size_t groups) -> int {
+        if (!(dense && dense->d_dense && groups <= 64)) return 0;
+        a.dn.dense = (uint8_t*)dense->d_dense;
+        a.dn.offsets = dense->d_offsets;
+        a.dn.wg_state = (uint64_t*)dense->d_tmp;
+        a.dn.grid = (uint32_t)grid;
+        HIP_TRY(hipMemsetAsync(dense->d_tmp, 0, ((size_t)grid + 1) * sizeof(uint64_t), st));   // look-back words + the ticket counter
+        dense->fused = true;
+        return 0;
+    };
+    // two columns per lane for narrow row-major streams too (encode_wide.h with 4 .. 32 lanes a chunk): fewer instructions per sample
+    // than encode_fast.h's one column per lane on every shape measured (tools/enc_pair_sweep.sh: -6 % .. -35 %)
+    if (process().enc_pair.load(std::memory_order_relaxed) && fast_common && !col_stride && D >= 5 && blk_bytes % 16 == 0 &&
+        ((uint64_t)chunk_len * esz) % 16 == 0 && (uint64_t)chunk_len * esz >= 2 * blk_bytes) {
+        int pdp = 4;
+        while (2 * pdp < D) pdp <<= 1;
+        const size_t pgroups = kThreads / pdp;
+        // the window as long as it must be (the linear window needs no power of two): 592 instead of 672 bytes a chunk at 8 uint16 columns,
+        // four workgroups a CU instead of three
+        a.cap = ((uint32_t)group_bytes_max(esz, D) + 48u + (uint32_t)(SPRINTZ_ENC_DRAIN_ALIGN - 16) + 15u) & ~15u;
+        a.lds_group_stride = (uint32_t)(a.cap + ((blk_bytes + 15) & ~(size_t)15) + 16);
+        if ((a.lds_group_stride / 16) % 2 == 0) a.lds_group_stride += 16;    // an odd number of 16-byte units: the chunks of a wavefront start on different banks
+        const uint64_t pgrid = (nchunks * (uint64_t)pdp + kThreads - 1) / kThreads;
+        if (pgrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
+        if (int rc = arm_dense(pgrid, pgroups)) return rc;
+        const bool pfire = codec == SPRINTZ_CODEC_XFF || codec == SPRINTZ_CODEC_XFF_NORLE;
+        e = esz == 1 ? launch_encode_pair_w8(pfire, pdp, D == 2 * pdp, (unsigned)pgrid, (size_t)a.lds_group_stride * pgroups, st, a)
+                     : launch_encode_pair_w16(pfire, pdp, D == 2 * pdp, (unsigned)pgrid, (size_t)a.lds_group_stride * pgroups, st, a);
+        if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "encode_wide (pair) kernel launch", e);
+        return 0;
+    }
     if (fast) {
         const size_t fgroups = kThreads / fdp;
         // input staging: one 8 x D block (row-major: LDS transpose) or two bursts of 4 blocks x fdp columns (column-major)
@@ -404,14 +438,7 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
         const uint64_t fthreads = nchunks * (uint64_t)fdp;
         const uint64_t fgrid = (fthreads + kThreads - 1) / kThreads;
         if (fgrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
-        if (dense && dense->d_dense && fgroups <= 64) {
-            a.dn.dense = (uint8_t*)dense->d_dense;
-            a.dn.offsets = dense->d_offsets;
-            a.dn.wg_state = (uint64_t*)dense->d_tmp;
-            a.dn.grid = (uint32_t)fgrid;
-            HIP_TRY(hipMemsetAsync(dense->d_tmp, 0, ((size_t)fgrid + 1) * sizeof(uint64_t), st));   // look-back words + the ticket counter
-            dense->fused = true;
-        }
+        if (int rc = arm_dense(fgrid, fgroups)) return rc;
         e = esz == 1 ? launch_encode_fast_w8((codec == SPRINTZ_CODEC_XFF || codec == SPRINTZ_CODEC_XFF_NORLE), fdp, D == fdp, (unsigned)fgrid, fshmem, st, a)
                      : launch_encode_fast_w16((codec == SPRINTZ_CODEC_XFF || codec == SPRINTZ_CODEC_XFF_NORLE), fdp, D == fdp, (unsigned)fgrid, fshmem, st, a);
         if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "encode_fast kernel launch", e);
@@ -426,6 +453,7 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
         a.lds_group_stride = (uint32_t)(a.cap + ((blk_bytes + 15) & ~(size_t)15) + 16);
         const uint64_t wgrid = (nchunks * (uint64_t)wlanes + kThreads - 1) / kThreads;
         if (wgrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
+        if (int rc = arm_dense(wgrid, wgroups)) return rc;
         const bool wfire = codec == SPRINTZ_CODEC_XFF || codec == SPRINTZ_CODEC_XFF_NORLE;
         e = wsplit   ? launch_encode_split_w8(wfire, (unsigned)wgrid, (size_t)a.lds_group_stride * wgroups, st, a)
           : esz == 1 ? launch_encode_wide_w8(wfire, D == 128, (unsigned)wgrid, (size_t)a.lds_group_stride * wgroups, st, a)
@@ -886,6 +914,7 @@ int sprintz_mi355x_set_option(int option, int value)
         return 0;
     }
     if (option == SPRINTZ_OPT_SPLIT_LANES) { process().split_lanes = value ? 1 : 0; return 0; }
+    if (option == SPRINTZ_OPT_ENC_PAIR) { process().enc_pair = value ? 1 : 0; return 0; }
     if (option == SPRINTZ_OPT_CHUNKS_PER_GROUP) {
         if (value < 1 || value > 64) return fail(SPRINTZ_E_INVALID, "chunks per group must be in 1..64");
         process().chunks_per_group = value;

@@ -24,6 +24,23 @@ hipError_t launch_encode_uni_w16(bool fire, int nd, unsigned grid, hipStream_t s
     }
     return hipGetLastError();
 }
+#define SPRINTZ_PAIR_CASE(DPV)                                                                                                    \
+    case DPV:                                                                                                                      \
+        if (exact) return fire ? launch_one(encode_wide_kernel<16, true, true, false, DPV>, grid, shmem, st, a)                    \
+                               : launch_one(encode_wide_kernel<16, false, true, false, DPV>, grid, shmem, st, a);                  \
+        return fire ? launch_one(encode_wide_kernel<16, true, false, false, DPV>, grid, shmem, st, a)                              \
+                    : launch_one(encode_wide_kernel<16, false, false, false, DPV>, grid, shmem, st, a);
+hipError_t launch_encode_pair_w16(bool fire, int dp, bool exact, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a)
+{
+    switch (dp) {
+        SPRINTZ_PAIR_CASE(4)
+        SPRINTZ_PAIR_CASE(8)
+        SPRINTZ_PAIR_CASE(16)
+        SPRINTZ_PAIR_CASE(32)
+        default: return hipErrorInvalidValue;
+    }
+}
+#undef SPRINTZ_PAIR_CASE
 hipError_t launch_encode_wide_w16(bool fire, bool exact, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a)
 {
     if (exact) return fire ? launch_one(encode_wide_kernel<16, true, true>, grid, shmem, st, a) : launch_one(encode_wide_kernel<16, false, true>, grid, shmem, st, a);

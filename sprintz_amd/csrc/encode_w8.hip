@@ -37,6 +37,23 @@ hipError_t launch_encode_split_w8(bool fire, unsigned grid, size_t shmem, hipStr
     if (a.D <= 64 || a.D > 80) return hipErrorInvalidValue;
     return fire ? launch_one(encode_wide_kernel<8, true, false, true>, grid, shmem, st, a) : launch_one(encode_wide_kernel<8, false, false, true>, grid, shmem, st, a);
 }
+#define SPRINTZ_PAIR_CASE(DPV)                                                                                                    \
+    case DPV:                                                                                                                      \
+        if (exact) return fire ? launch_one(encode_wide_kernel<8, true, true, false, DPV>, grid, shmem, st, a)                    \
+                               : launch_one(encode_wide_kernel<8, false, true, false, DPV>, grid, shmem, st, a);                  \
+        return fire ? launch_one(encode_wide_kernel<8, true, false, false, DPV>, grid, shmem, st, a)                              \
+                    : launch_one(encode_wide_kernel<8, false, false, false, DPV>, grid, shmem, st, a);
+hipError_t launch_encode_pair_w8(bool fire, int dp, bool exact, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a)
+{
+    switch (dp) {
+        SPRINTZ_PAIR_CASE(4)
+        SPRINTZ_PAIR_CASE(8)
+        SPRINTZ_PAIR_CASE(16)
+        SPRINTZ_PAIR_CASE(32)
+        default: return hipErrorInvalidValue;
+    }
+}
+#undef SPRINTZ_PAIR_CASE
 hipError_t launch_encode_wide_w8(bool fire, bool exact, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a)
 {
     if (exact) return fire ? launch_one(encode_wide_kernel<8, true, true>, grid, shmem, st, a) : launch_one(encode_wide_kernel<8, false, true>, grid, shmem, st, a);

@@ -17,10 +17,13 @@ namespace sprintz {
 // owns the PAIR (2l, 2l + 1) -- merged with its neighbour's exactly as above -- and the SINGLE column 64 + l, whose fields a
 // quad of lanes merges (<= 32 bits) before one of them ORs; one scan carries the pairs' bits in its low half and the singles' in
 // its high half.  The decoder's counterpart is decode_fast.h's SPLIT mapping.
-template <int W, bool FIRE, bool EXACT, bool SPLIT = false>
-__global__ void __launch_bounds__(kThreads) encode_wide_kernel(EncodeArgs a)
+// DPT: lanes a chunk when that is not 64 (two columns per lane for NARROW streams too: 4 lanes for 5 .. 8 columns, 16 chunks a wavefront).
+template <int W, bool FIRE, bool EXACT, bool SPLIT, int DPT>
+__device__ __forceinline__ uint32_t encode_wide_body(const EncodeArgs& a, uint32_t wg_number)
 {
-    constexpr int DP = SPLIT ? 32 : 64, CPL = SPLIT ? 3 : 2, LOG2DP = SPLIT ? 5 : 6;
+    constexpr int DP = SPLIT ? 32 : DPT, CPL = SPLIT ? 3 : 2;
+    constexpr int LOG2DP = DP == 4 ? 2 : DP == 8 ? 3 : DP == 16 ? 4 : DP == 32 ? 5 : 6;
+    static_assert(DP == 4 || DP == 8 || DP == 16 || DP == 32 || DP == 64, "lanes a chunk");
     static_assert(!SPLIT || (W == 8 && !EXACT), "the split mapping is built for 8-bit streams of 65 .. 80 columns");
     using U = typename Elem<W>::U;
     constexpr int HB = Elem<W>::HB;
@@ -30,10 +33,10 @@ __global__ void __launch_bounds__(kThreads) encode_wide_kernel(EncodeArgs a)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     const int D = EXACT ? DP * CPL : a.D;
-    const uint64_t gtid = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+    const uint64_t gtid = (uint64_t)wg_number * kThreads + threadIdx.x;
     const uint64_t chunk = gtid >> LOG2DP;
     const int lane_d = (int)(threadIdx.x & (uint32_t)(DP - 1));
-    if (chunk >= a.nchunks) return;
+    if (chunk >= a.nchunks) return 0;
 
     const uint64_t first = chunk * (uint64_t)a.chunk_len;
     const uint32_t n = (uint32_t)((a.total_len - first < a.chunk_len) ? (a.total_len - first) : a.chunk_len);
@@ -301,6 +304,19 @@ __global__ void __launch_bounds__(kThreads) encode_wide_kernel(EncodeArgs a)
         a.sizes[chunk] = total_bytes;
         if (a.rets) a.rets[chunk] = (int64_t)(total_bytes / ESZ);   // element units, floor (:554)
     }
+    return total_bytes;
+}
+
+template <int W, bool FIRE, bool EXACT, bool SPLIT = false, int DPT = 64>
+__global__ void __launch_bounds__(kThreads) encode_wide_kernel(EncodeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr int DP = SPLIT ? 32 : DPT;
+    constexpr uint32_t LOG2DP = DP == 4 ? 2 : DP == 8 ? 3 : DP == 16 ? 4 : DP == 32 ? 5 : 6;
+    const uint32_t wg = workgroup_number(a.dn);
+    const uint32_t size = encode_wide_body<W, FIRE, EXACT, SPLIT, DPT>(a, wg);
+    // the container, built before the workgroup leaves (compact_tail.h); without it the caller compacts the slots
+    if (a.dn.dense) dense_tail(a.dn, wg, a.nchunks, LOG2DP, size, a.slots, a.slot_stride, smem, a.lds_group_stride);
 }
 
 }  // namespace sprintz

@@ -32,6 +32,9 @@ hipError_t launch_decode_uni_w16(bool fire, int nd, int q, unsigned grid, hipStr
 // streams of 65 .. 128 columns, two columns per lane (encode_wide.h)
 hipError_t launch_encode_wide_w8(bool fire, bool exact, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
 hipError_t launch_encode_wide_w16(bool fire, bool exact, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
+// two columns per lane for streams of up to 64 columns: dp = 4 / 8 / 16 / 32 lanes a chunk (encode_wide.h, DPT)
+hipError_t launch_encode_pair_w8(bool fire, int dp, bool exact, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
+hipError_t launch_encode_pair_w16(bool fire, int dp, bool exact, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
 // 8-bit streams of 65 .. 80 columns on 32 lanes a chunk (encode_wide.h, SPLIT)
 hipError_t launch_encode_split_w8(bool fire, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
 hipError_t launch_encode_uni_w8(bool fire, int nd, unsigned grid, hipStream_t st, const EncodeArgs& a);

@@ -600,6 +600,11 @@ def test_generic_kernels_agree_with_the_fast_ones(sz, request, name, codec, esz,
     cd = sz.ChunkedCodec(codec, esz, ndims, chunk_len, device="cuda:0")
     x = torch.from_numpy(data).cuda()
     fast = cd.compress(x)
+    _lib.check(_lib.set_option(_lib.OPT_ENC_PAIR, 0))          # one column per lane (encode_fast.h) where two are the default
+    request.addfinalizer(lambda: _lib.set_option(_lib.OPT_ENC_PAIR, 1))
+    fast1 = cd.compress(x)
+    _lib.check(_lib.set_option(_lib.OPT_ENC_PAIR, 1))
+    assert torch.equal(fast.sizes, fast1.sizes) and torch.equal(fast.data[: fast.total_bytes()], fast1.data[: fast1.total_bytes()])
     _lib.check(_lib.set_option(_lib.OPT_NO_FAST, 1))
     slow = cd.compress(x)
     assert torch.equal(fast.sizes, slow.sizes) and torch.equal(fast.offsets, slow.offsets)
@@ -688,14 +693,20 @@ def test_random_shapes(sz, oracle, seed):
 @pytest.mark.parametrize("codec,esz,ndims,chunk_len,nchunks", [
     ("xff", 2, 8, 5120, 1), ("xff", 2, 8, 5120, 31), ("xff", 2, 8, 5120, 33), ("xff", 2, 8, 5120, 20011), ("xff", 2, 8, 1280, 70001),
     ("delta", 1, 16, 4096, 777), ("xff", 2, 32, 5120, 1000), ("delta", 2, 64, 4096, 130), ("xff", 1, 5, 4000, 300),
-    ("delta", 1, 80, 10240, 97),          # 80 columns: no dense tail in that encoder -- the entry point runs the two launches itself
-    ("delta", 1, 1, 1024, 5000),          # low-dim: idem
+    ("delta", 1, 80, 10240, 97), ("xff", 1, 72, 72 * 64, 1031),       # the split mapping's encoder (8 bits, 65 .. 80 columns)
+    ("xff", 2, 80, 10240, 205), ("delta", 1, 128, 16384, 66),           # 64 lanes x two columns
+    ("xff", 2, 7, 7 * 160, 999),                                         # an odd width at 16 bits: the last lane's pair is half genuine
+    ("delta", 1, 1, 1024, 5000),          # low-dim: no dense tail in that encoder -- the entry point runs the two launches itself
 ])
-def test_container_built_inside_the_encode_launch(sz, oracle, codec, esz, ndims, chunk_len, nchunks):
+@pytest.mark.parametrize("enc_pair", [1, 0])
+def test_container_built_inside_the_encode_launch(sz, oracle, request, codec, esz, ndims, chunk_len, nchunks, enc_pair):
     """sprintz_mi355x_compress_batch_dense (one launch: chained scan over workgroups + in-kernel copy, compact_tail.h) writes
-    the container, offsets and sizes that compress_batch + compact(align 16) write -- and that the oracle specifies"""
+    the container, offsets and sizes that compress_batch + compact(align 16) write -- and that the oracle specifies; with two
+    columns per lane (encode_wide.h, the default for 5 .. 128 columns) and with one (encode_fast.h, SPRINTZ_OPT_ENC_PAIR 0)"""
     import torch
     from sprintz_amd import _lib
+    _lib.check(_lib.set_option(_lib.OPT_ENC_PAIR, enc_pair))
+    request.addfinalizer(lambda: _lib.set_option(_lib.OPT_ENC_PAIR, 1))
     rng = np.random.default_rng(nchunks * 7 + ndims)
     total = nchunks * chunk_len - (chunk_len // 3 if nchunks > 1 else 0)          # a short last chunk
     data = gen_walk(rng, total, ndims, esz, 8, flat_every=4)
