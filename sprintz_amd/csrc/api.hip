@@ -200,6 +200,56 @@ __global__ void __launch_bounds__(kThreads) compact_copy_kernel(const uint8_t* s
     }
 }
 
+// Chunks too short for one stream group (n < 128 or n < 16 * ndims in the general layout: BASELINE config 3 at 1 KB chunks) are
+// their 8-byte header + the samples themselves (sprintz_xff_rle.cpp:116-124, :158-160; encode_kernel.h writes the same bytes
+// into a slot).  Every size is known before the launch, so the 16-byte aligned container needs no scan and no slot: one
+// wavefront per chunk copies the samples to where they end up -- one pass over the data instead of two.
+__global__ void __launch_bounds__(kThreads) verbatim_dense_kernel(const uint8_t* src, uint64_t total_len, uint32_t chunk_len, uint32_t esz, uint32_t D,
+                                                                  uint64_t nchunks, uint8_t* dense, uint64_t* offsets, uint32_t* sizes, int64_t* rets)
+{
+    const uint64_t c = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (c >= nchunks) return;
+    const uint64_t first = c * (uint64_t)chunk_len;
+    const uint32_t n = (uint32_t)(total_len - first < chunk_len ? total_len - first : chunk_len);
+    const uint64_t stride = ((uint64_t)8 + (uint64_t)chunk_len * esz + 15u) & ~(uint64_t)15;     // every chunk but the last is chunk_len long
+    const uint32_t size = 8u + n * esz, asize = (size + 15u) & ~15u;
+    uint8_t* d = dense + c * stride;
+    sprintz::copy_verbatim<true>(src + first * esz, d + 8, n * esz, lane, 64u);
+    for (uint32_t j = size + lane; j < asize; j += 64u) d[j] = 0;                                 // the container's alignment padding is zeros
+    if (lane == 0) {
+        ((uint32_t*)d)[0] = 0;                                                                    // no groups (format.h:36-45)
+        ((uint32_t*)d)[1] = (n & 0xffffu) | (D << 16);
+        sizes[c] = size;
+        if (rets) rets[c] = (int64_t)(size / esz);
+        offsets[c] = c * stride;
+        if (c == nchunks - 1) offsets[nchunks] = c * stride + asize;
+    }
+}
+
+// The way back for such batches (chunk_len < 128 or < 16 * ndims: no stream of a valid batch holds a group): one wavefront per
+// chunk checks the 8-byte header (no groups, ndims, the tail inside the stream and inside the chunk) and copies the samples --
+// instead of decode_kernel.h's whole state machine around the same copy.  A stream that does announce groups cannot be valid
+// at this chunk length (one group is 16 * ndims samples) and is SPRINTZ_E_CORRUPT.
+__global__ void __launch_bounds__(kThreads) verbatim_decode_kernel(const uint8_t* comp, const uint64_t* offsets, uint64_t nchunks, uint32_t chunk_len,
+                                                                   uint32_t esz, uint32_t D, uint8_t* out, int64_t* rets)
+{
+    const uint64_t c = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (c >= nchunks) return;
+    const uint64_t off = offsets[c], slen = offsets[c + 1] - off;
+    const uint8_t* s = comp + off;
+    bool bad = slen < 8;
+    uint32_t remaining = 0;
+    if (!bad) {
+        const uint32_t w0 = sprintz::load_u32_any(s), w1 = sprintz::load_u32_any(s + 4);
+        remaining = w1 & 0xffffu;
+        bad = w0 != 0 || (w1 >> 16) != D || remaining > chunk_len || (uint64_t)remaining * esz > slen - 8;
+    }
+    if (!bad) sprintz::copy_verbatim<true>(s + 8, out + c * (uint64_t)chunk_len * esz, remaining * esz, lane, 64u);
+    if (lane == 0 && rets) rets[c] = bad ? sprintz::kErrCorrupt : (int64_t)remaining;
+}
+
 }  // namespace
 
 namespace sprintz {
@@ -271,6 +321,17 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
     a.raw = codec == SPRINTZ_CODEC_BITPACK_NORLE ? 1 : 0;
     a.col_stride = qs.col_stride;
     const uint64_t cs = qs.col_stride;
+
+    // batches whose chunks are too short for a stream group: header check + copy (verbatim_decode_kernel)
+    if (!norle && !lowdim && !noheader && !cs && qs.q == kQueryOff && (chunk_len < 128u || chunk_len < 16u * (uint32_t)D) &&
+        !process().no_fast.load(std::memory_order_relaxed)) {
+        const uint64_t vgrid = (nchunks * 64 + kThreads - 1) / kThreads;
+        if (vgrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
+        hipLaunchKernelGGL(verbatim_decode_kernel, dim3((unsigned)vgrid), dim3(kThreads), 0, st, (const uint8_t*)d_comp, d_offsets, nchunks, chunk_len,
+                           (uint32_t)esz, (uint32_t)D, (uint8_t*)d_out, d_rets);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
 
     // LDS-transposed 16-byte stores need every 8 x D block of the output 16-byte aligned
     const size_t blk_bytes = (size_t)8 * D * esz;
@@ -987,6 +1048,16 @@ int sprintz_mi355x_compress_batch_dense(int codec, int elem_bytes, const void* d
     // (Tried and dropped, measured on the headline batch: the batch in 4 parts, a part's scan + copy on a second stream while
     //  the next part encodes -- 0.87 ms against 0.79 for the launches in a row; the kernels do not fill each other's gaps.)
     const int mode = process().dense_mode.load(std::memory_order_relaxed);
+    // chunks too short for a group: all of them verbatim, all sizes known -- written straight into the container (see the kernel)
+    if (mode && (codec == SPRINTZ_CODEC_DELTA || codec == SPRINTZ_CODEC_XFF) && !is_lowdim(elem_bytes, ndims) &&
+        (chunk_len < 128u || chunk_len < 16u * (uint32_t)ndims) && chunk_len <= 0xffffu) {
+        const uint64_t grid = (nchunks * 64 + kThreads - 1) / kThreads;
+        if (grid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
+        hipLaunchKernelGGL(verbatim_dense_kernel, dim3((unsigned)grid), dim3(kThreads), 0, st, (const uint8_t*)d_src, total_len, chunk_len,
+                           (uint32_t)elem_bytes, (uint32_t)ndims, nchunks, (uint8_t*)d_dense, d_offsets, d_sizes, d_rets);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     DenseRequest dr;
     dr.d_dense = d_dense;
     dr.d_offsets = d_offsets;

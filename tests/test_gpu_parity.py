@@ -456,6 +456,46 @@ def test_generic_decoder_never_reads_past_a_stream(sz, request, codec, esz, ndim
         assert (out[nchunks * chunk_len:].cpu().numpy() == 0x5A).all(), trial
 
 
+@pytest.mark.parametrize("codec,esz,ndims,chunk_len", [("delta", 1, 80, 1024), ("xff", 2, 8, 100), ("xff", 2, 128, 2040), ("delta", 1, 5, 77)])
+def test_verbatim_batches_decode_and_reject_damaged_headers(sz, oracle, codec, esz, ndims, chunk_len):
+    """batches whose chunks are too short for a stream group take verbatim_dense_kernel / verbatim_decode_kernel (api.hip):
+    the oracle's streams decode to the data; a header that announces groups, another ndims, more samples than the chunk
+    holds or than the stream carries is SPRINTZ_E_CORRUPT for that chunk only, and nothing is written past a chunk's range"""
+    import torch
+    rng = np.random.default_rng(chunk_len + ndims)
+    nchunks = 257
+    total = nchunks * chunk_len - chunk_len // 2
+    data = gen_fuzz(rng, total, esz, 0)
+    cd = sz.ChunkedCodec(codec, esz, ndims, chunk_len, device="cuda:0")
+    streams = oracle.compress_chunks(codec, data, chunk_len, ndims)
+    assert all(s_.size == 8 + min(chunk_len, total - c * chunk_len) * esz for c, s_ in enumerate(streams))     # verbatim indeed
+    batch = cd.compress(torch.from_numpy(data).cuda())
+    got, goffs, gsizes = batch.data.cpu().numpy(), batch.offsets.cpu().numpy(), batch.sizes.cpu().numpy()
+    for c in range(nchunks):
+        assert gsizes[c] == streams[c].size and np.array_equal(got[goffs[c]:goffs[c] + gsizes[c]], streams[c]), c
+    damaged = [s_.copy() for s_ in streams]
+    damaged[3][0] = 1                                                 # announces a group
+    damaged[10][6] ^= 1                                               # another ndims
+    damaged[20][4:6] = np.frombuffer(np.uint16(min(chunk_len + 1, 0xffff)).tobytes(), np.uint8)   # more samples than the chunk holds
+    damaged[30] = damaged[30][:8 + (chunk_len // 2) * esz]           # the stream ends before its samples do
+    offs = np.zeros(nchunks + 1, np.int64)
+    offs[1:] = np.cumsum([s_.size for s_ in damaged])
+    comp = torch.from_numpy(np.concatenate(damaged + [np.zeros(16, np.uint8)])).cuda()
+    out = torch.full((nchunks * chunk_len,), 0x5a, dtype=cd.dtype, device="cuda:0")
+    rets = torch.empty(nchunks, dtype=torch.int64, device="cuda:0")
+    cd.decompress_into(comp, torch.from_numpy(offs).cuda(), nchunks, out, rets)
+    o, r = out.cpu().numpy(), rets.cpu().numpy()
+    fill = np.array([0x5a], dtype=np.uint8).view(np.int8)[0] if esz == 1 else 0x5a
+    for c in range(nchunks):
+        lo, n = c * chunk_len, min(chunk_len, total - c * chunk_len)
+        if c in (3, 10, 20, 30):
+            assert r[c] == -5, (c, r[c])                              # SPRINTZ_E_CORRUPT
+            assert (o[lo:lo + chunk_len].view(np.uint8) == 0x5a).all() if esz == 1 else (o[lo:lo + chunk_len] == 0x5a).all(), c
+        else:
+            assert r[c] == n and np.array_equal(o[lo:lo + n].view(data.dtype), data[lo:lo + n]), c
+            assert (o[lo + n:lo + chunk_len] == 0x5a).all(), c       # the rest of a short last chunk's range is not touched
+
+
 def test_short_verbatim_chunks_leave_zero_padding(sz):
     """chunks too short for one group are stored verbatim (sprintz_xff_rle.cpp:116-124): the 16-byte alignment padding of the
     container must be zeros, not stale workspace bytes"""
@@ -589,7 +629,7 @@ def test_huffman_decoder_survives_damaged_containers(sz):
     assert np.array_equal(r, sizes.astype(np.int64))
 
 
-@pytest.mark.parametrize("name,codec,esz,ndims,chunk_len", [c for c in CONFIGS if c[0] in ("cfg2", "cfg3_10k", "cfg5", "xff8", "cfg1", "uni16_xff", "uni16_delta_ragged", "low8_d2", "low8_d4", "lowdim16", "low16_d2_delta_ragged", "lowdim8", "low8_d3_delta", "wide8_d128_xff", "wide8_d100_delta", "wide8_d66_xff", "wide16_d80_xff", "wide16_d128_delta", "wide16_d72_xff")])
+@pytest.mark.parametrize("name,codec,esz,ndims,chunk_len", [c for c in CONFIGS if c[0] in ("cfg2", "cfg3_1k", "cfg3_10k", "cfg5", "xff8", "cfg1", "uni16_xff", "uni16_delta_ragged", "low8_d2", "low8_d4", "lowdim16", "low16_d2_delta_ragged", "lowdim8", "low8_d3_delta", "wide8_d128_xff", "wide8_d100_delta", "wide8_d66_xff", "wide16_d80_xff", "wide16_d128_delta", "wide16_d72_xff")])
 def test_generic_kernels_agree_with_the_fast_ones(sz, request, name, codec, esz, ndims, chunk_len):
     """SPRINTZ_OPT_NO_FAST routes the same calls to decode_kernel.h / encode_kernel.h: same bytes, same samples"""
     import torch
@@ -697,6 +737,7 @@ def test_random_shapes(sz, oracle, seed):
     ("xff", 2, 80, 10240, 205), ("delta", 1, 128, 16384, 66),           # 64 lanes x two columns
     ("xff", 2, 7, 7 * 160, 999),                                         # an odd width at 16 bits: the last lane's pair is half genuine
     ("delta", 1, 1, 1024, 5000),          # low-dim: no dense tail in that encoder -- the entry point runs the two launches itself
+    ("delta", 1, 80, 1024, 5003), ("xff", 2, 8, 100, 333), ("xff", 2, 128, 2000, 77), ("delta", 1, 5, 77, 1),   # chunks too short for a group: verbatim, written straight into the container
 ])
 @pytest.mark.parametrize("enc_pair", [1, 0])
 def test_container_built_inside_the_encode_launch(sz, oracle, request, codec, esz, ndims, chunk_len, nchunks, enc_pair):
