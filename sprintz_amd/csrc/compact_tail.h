@@ -16,6 +16,10 @@
 
 #include "sprintz_device.h"
 
+#ifndef SPRINTZ_DENSE_NT
+#define SPRINTZ_DENSE_NT 0      // 1: the container is written with non-temporal stores
+#endif
+
 namespace sprintz {
 
 struct DenseArgs {
@@ -119,7 +123,7 @@ __device__ __forceinline__ void dense_tail(const DenseArgs& da, uint32_t wg, uin
         const uint32_t n = (uint32_t)slot_of(gg)[0];
         const uint64_t o = slot_of(gg)[1];
         const uint32_t l = log2_lanes >= 6 ? threadIdx.x & ((1u << log2_lanes) - 1u) : lane;
-        copy_verbatim<false>(slots + cc * slot_stride, da.dense + o, n, l, log2_lanes >= 6 ? 1u << log2_lanes : 64u);
+        copy_verbatim<SPRINTZ_DENSE_NT != 0>(slots + cc * slot_stride, da.dense + o, n, l, log2_lanes >= 6 ? 1u << log2_lanes : 64u);
     }
 }
 
