@@ -44,8 +44,9 @@ extern "C" {
  *   1  round 1: the 8 drop-in entry points, the batched device API, the optional Huffman ("SPZH") and query stages
  *   2  round 2: set_option, *_layout, the Huff0 wire format (huf0_*), online_*, comm_* / gather_layout / layout_bases,
  *      the column-major and run-less codec entry points, the reference's mangled C++ names (sprintz_dropin.hpp)
- *   3  round 3: compress_batch_dense / compress_dense_tmp_bytes, SPRINTZ_OPT_DENSE_MODE, env SPRINTZ_MI355X_RCCL_SONAME */
-#define SPRINTZ_MI355X_ABI_VERSION 3
+ *   3  round 3: compress_batch_dense / compress_dense_tmp_bytes, SPRINTZ_OPT_DENSE_MODE, env SPRINTZ_MI355X_RCCL_SONAME
+ *   4  round 3: compress_batch_colmajor_dense, SPRINTZ_OPT_SPLIT_LANES, SPRINTZ_OPT_ENC_PAIR */
+#define SPRINTZ_MI355X_ABI_VERSION 4
 
 /* codec ids */
 #define SPRINTZ_CODEC_DELTA 0   /* sprintz_*_delta_*  (sprintz_delta_rle.cpp / sprintz_delta_lowdim.cpp) */
@@ -257,6 +258,13 @@ int sprintz_mi355x_huf_decompress_batch(const void* d_huf, const uint64_t* d_huf
 int sprintz_mi355x_compress_batch_colmajor(int codec, int elem_bytes, const void* d_src, uint64_t nrows, uint64_t col_stride,
                                            uint32_t rows_per_chunk, uint16_t ndims, void* d_slots, size_t slot_stride,
                                            uint32_t* d_sizes, int64_t* d_rets, void* hip_stream);
+/* the column-major write path in one call: streams + the 16-byte aligned container + offsets[nchunks + 1], as
+ * sprintz_mi355x_compress_batch_dense does for row-major data (same d_tmp size, same fallback to encode + scan + copy for
+ * the shapes whose encoder carries no container tail) */
+int sprintz_mi355x_compress_batch_colmajor_dense(int codec, int elem_bytes, const void* d_src, uint64_t nrows, uint64_t col_stride,
+                                                 uint32_t rows_per_chunk, uint16_t ndims, void* d_slots, size_t slot_stride,
+                                                 uint32_t* d_sizes, int64_t* d_rets, void* d_dense, uint64_t* d_offsets, void* d_tmp,
+                                                 void* hip_stream);
 int sprintz_mi355x_decompress_batch_colmajor(int codec, int elem_bytes, const void* d_comp, const uint64_t* d_offsets,
                                              uint64_t nchunks, uint32_t rows_per_chunk, uint16_t ndims, uint64_t col_stride,
                                              void* d_out, int64_t* d_rets, void* hip_stream);

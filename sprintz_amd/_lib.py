@@ -51,7 +51,7 @@ def _sig(name, restype, *argtypes):
 
 
 abi_version = _sig("sprintz_mi355x_abi_version", _i)
-ABI_REQUIRED = 3
+ABI_REQUIRED = 4
 if abi_version() < ABI_REQUIRED:      # a stale build would otherwise die below with an AttributeError on the first new symbol
     raise ImportError(f"{LIB_PATH} has ABI version {abi_version()}, this binding needs >= {ABI_REQUIRED}: rebuild it "
                       "(`make -C sprintz_amd/csrc`)")
@@ -114,6 +114,7 @@ query = {
 
 # (5) column-major matrices (BASELINE config 5)
 compress_batch_colmajor = _sig("sprintz_mi355x_compress_batch_colmajor", _i, _i, _i, _vp, _u64, _u64, _u32, _u16, _vp, _sz, _vp, _vp, _vp)
+compress_batch_colmajor_dense = _sig("sprintz_mi355x_compress_batch_colmajor_dense", _i, _i, _i, _vp, _u64, _u64, _u32, _u16, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _vp)
 decompress_batch_colmajor = _sig("sprintz_mi355x_decompress_batch_colmajor", _i, _i, _i, _vp, _vp, _u64, _u32, _u16, _u64, _vp, _vp, _vp)
 
 # (6) stand-alone transforms (delta.h:17-68)
@@ -173,7 +174,7 @@ EXPORTED_SYMBOLS = [
     "sprintz_mi355x_query_batch", "sprintz_mi355x_query_reduce",
     "sprintz_mi355x_query_delta_8b", "sprintz_mi355x_query_xff_8b",
     "sprintz_mi355x_query_delta_16b", "sprintz_mi355x_query_xff_16b",
-    "sprintz_mi355x_compress_batch_colmajor", "sprintz_mi355x_decompress_batch_colmajor",
+    "sprintz_mi355x_compress_batch_colmajor", "sprintz_mi355x_compress_batch_colmajor_dense", "sprintz_mi355x_decompress_batch_colmajor",
     "sprintz_mi355x_transform_tmp_bytes", "sprintz_mi355x_transform_encode_device", "sprintz_mi355x_transform_decode_device",
     "sprintz_mi355x_transform_encode", "sprintz_mi355x_transform_decode", "sprintz_mi355x_transform_last_error",
     "sprintz_mi355x_compress_norle", "sprintz_mi355x_decompress_norle",

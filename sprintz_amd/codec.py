@@ -249,11 +249,20 @@ class ChunkedCodec:
         rows_per_chunk = self.chunk_len // self.ndims
         nchunks = (nrows + rows_per_chunk - 1) // rows_per_chunk
         ws = self.workspace(nchunks)
-        with self._on():
-            _lib.check(_lib.compress_batch_colmajor(_CODEC_ID[self.codec], self.esz, cols.data_ptr(), nrows, col_stride, rows_per_chunk,
-                                                    self.ndims, ws["slots"].data_ptr(), self.slot_stride, ws["sizes"].data_ptr(),
-                                                    ws["rets"].data_ptr(), self._stream()))
-        dense, offsets = self.compact(ws, nchunks)
+        if self.align == 16:                                # encode + container in one call (one launch where the encoder carries the tail)
+            dense = t.empty(nchunks * self.slot_stride + _lib.READ_SLACK, dtype=t.uint8, device=self.device)
+            offsets = t.empty(nchunks + 1, dtype=t.int64, device=self.device)
+            with self._on():
+                _lib.check(_lib.compress_batch_colmajor_dense(_CODEC_ID[self.codec], self.esz, cols.data_ptr(), nrows, col_stride, rows_per_chunk,
+                                                              self.ndims, ws["slots"].data_ptr(), self.slot_stride, ws["sizes"].data_ptr(),
+                                                              ws["rets"].data_ptr(), dense.data_ptr(), offsets.data_ptr(), ws["tmp"].data_ptr(),
+                                                              self._stream()))
+        else:
+            with self._on():
+                _lib.check(_lib.compress_batch_colmajor(_CODEC_ID[self.codec], self.esz, cols.data_ptr(), nrows, col_stride, rows_per_chunk,
+                                                        self.ndims, ws["slots"].data_ptr(), self.slot_stride, ws["sizes"].data_ptr(),
+                                                        ws["rets"].data_ptr(), self._stream()))
+            dense, offsets = self.compact(ws, nchunks)
         total = int(offsets[-1].item())
         return CompressedBatch(dense[: total + _lib.READ_SLACK].clone(), offsets, ws["sizes"].clone(), nchunks,
                                nrows * self.ndims, self.chunk_len, self.ndims)

@@ -460,7 +460,9 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     hipError_t e;
     // the container built inside the launch (compact_tail.h): every kernel of encode_fast.h / encode_wide.h carries the tail
     auto arm_dense = [&](uint64_t grid, size_t groups) -> int {
-        if (!(dense && dense->d_dense && groups <= 64)) return 0;
+        // (column-major sources keep the two-launch path: with the tail in encode_fast<CM> BASELINE config 5 took 0.089 instead of 0.076 ms, its
+        //  8 M-row form 0.407 instead of 0.359 -- eight chunks a workgroup make the chained scan eight times as long per byte as sixty-four do)
+        if (!(dense && dense->d_dense && groups <= 64) || col_stride) return 0;
         a.dn.dense = (uint8_t*)dense->d_dense;
         a.dn.offsets = dense->d_offsets;
         a.dn.wg_state = (uint64_t*)dense->d_tmp;
@@ -1277,6 +1279,38 @@ int sprintz_mi355x_compress_batch_colmajor(int codec, int elem_bytes, const void
     if ((rc = ensure_device())) return rc;
     return encode_launch(codec, elem_bytes, d_src, nrows * (uint64_t)ndims, chunk_len, ndims, d_slots, slot_stride, d_sizes, d_rets,
                          (hipStream_t)hip_stream, 1, col_stride);
+}
+
+int sprintz_mi355x_compress_batch_colmajor_dense(int codec, int elem_bytes, const void* d_src, uint64_t nrows, uint64_t col_stride,
+                                                 uint32_t rows_per_chunk, uint16_t ndims, void* d_slots, size_t slot_stride,
+                                                 uint32_t* d_sizes, int64_t* d_rets, void* d_dense, uint64_t* d_offsets, void* d_tmp,
+                                                 void* hip_stream)
+{
+    int rc = check_common(codec, elem_bytes, ndims);
+    if (rc) return rc;
+    if (rows_per_chunk == 0 || (uint64_t)rows_per_chunk * ndims > (1u << 30))
+        return fail(SPRINTZ_E_INVALID, "rows_per_chunk * ndims must be in 1..2^30");
+    if (col_stride < nrows) return fail(SPRINTZ_E_INVALID, "col_stride < nrows");
+    if (!d_src || !d_slots || !d_sizes || !d_dense || !d_offsets || !d_tmp) return fail(SPRINTZ_E_INVALID, "null device pointer");
+    if (slot_stride % 16 || (uintptr_t)d_slots % 16 || (uintptr_t)d_dense % 16) return fail(SPRINTZ_E_INVALID, "slots and container must be 16-byte aligned/strided");
+    const uint32_t chunk_len = rows_per_chunk * (uint32_t)ndims;
+    if (slot_stride < sprintz_mi355x_compress_bound(elem_bytes, chunk_len, ndims))
+        return fail(SPRINTZ_E_INVALID, "slot_stride below sprintz_mi355x_compress_bound");
+    if ((rc = ensure_device())) return rc;
+    hipStream_t st = (hipStream_t)hip_stream;
+    const uint64_t total_len = nrows * (uint64_t)ndims, nchunks = sprintz_mi355x_num_chunks(total_len, chunk_len);
+    if (nchunks == 0) {
+        HIP_TRY(hipMemsetAsync(d_offsets, 0, 8, st));
+        return 0;
+    }
+    DenseRequest dr;
+    dr.d_dense = d_dense;
+    dr.d_offsets = d_offsets;
+    dr.d_tmp = d_tmp;
+    rc = encode_launch(codec, elem_bytes, d_src, total_len, chunk_len, ndims, d_slots, slot_stride, d_sizes, d_rets, st, 1, col_stride, 0,
+                       process().dense_mode.load(std::memory_order_relaxed) ? &dr : nullptr);
+    if (rc || dr.fused) return rc;
+    return sprintz_mi355x_compact(d_slots, slot_stride, d_sizes, nchunks, 16, d_dense, d_offsets, d_tmp, hip_stream);
 }
 
 int sprintz_mi355x_decompress_batch_colmajor(int codec, int elem_bytes, const void* d_comp, const uint64_t* d_offsets,
