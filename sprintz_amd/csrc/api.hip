@@ -462,7 +462,9 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     auto arm_dense = [&](uint64_t grid, size_t groups) -> int {
         // (column-major sources keep the two-launch path: with the tail in encode_fast<CM> BASELINE config 5 took 0.089 instead of 0.076 ms, its
         //  8 M-row form 0.407 instead of 0.359 -- eight chunks a workgroup make the chained scan eight times as long per byte as sixty-four do)
-        if (!(dense && dense->d_dense && groups <= 64) || col_stride) return 0;
+        //  Measured likewise on the row-major kernels: 8 uint16 columns (64 chunks a workgroup) 0.661 with the tail, 0.670 without; 16 columns (32 chunks)
+        //  0.148 / 0.142; 64 columns (8) 0.158 / 0.144; BASELINE config 3 at 10 KB (8) 0.431 / 0.408 -- the tail pays from 64 chunks a workgroup on.
+        if (!(dense && dense->d_dense && groups == 64) || col_stride) return 0;
         a.dn.dense = (uint8_t*)dense->d_dense;
         a.dn.offsets = dense->d_offsets;
         a.dn.wg_state = (uint64_t*)dense->d_tmp;
