@@ -301,6 +301,21 @@ constexpr int kCStride = 256 + 64 + 512 + 4;     // stream kernel, per chunk in 
 #define HUF0_SPECULATIVE_TAIL 1           // the streams' last bursts in one common masked round (stream kernel)
 #endif
 constexpr int ring_stride(int plog) { return 2 * (1 << plog) + 8; }
+#ifndef HUF0_SMALL_PLOG
+#define HUF0_SMALL_PLOG 6                 // the single-wave one-table kernel of small batches: piece size, and whether it refills on the cadence
+#endif
+#ifndef HUF0_SMALL_CAD
+#define HUF0_SMALL_CAD 1
+#endif
+#ifndef HUF0_BIG_WG
+#define HUF0_BIG_WG 2                     // wavefronts a workgroup of the big-batch one-table kernel
+#endif
+#ifndef HUF0_BIG_PLOG
+#define HUF0_BIG_PLOG 6                   // log2 of the stream piece of the big-batch one-table kernel
+#endif
+#ifndef HUF0_CADENCED
+#define HUF0_CADENCED 1                  // the 4-wave one-table kernel refills on a fixed cadence (template parameter CAD)
+#endif
 
 // Blocks written with one code per SEGMENT of 64 chunks (our writer; any writer that repeats a tree description) need
 // the tree only once per segment.  follow[c] = 1 iff chunk c is not the first of its 64-aligned segment and its tree
@@ -661,20 +676,36 @@ __global__ void __launch_bounds__(256) huf0_share_kernel(const uint8_t* __restri
 #endif
 // WG: wavefronts of a workgroup around the one table (SO only: 1, 2 or 4 -- a workgroup stays inside one 64-chunk segment);
 // PLOG: log2 of the stream piece a lane fetches at once
-template <bool SO, int WG = 1, int PLOG = 4>
-__global__ void __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(SO ? HUF0_SO_WAVES : HUF0_G_WAVES)))
+// CAD: the stream pieces are requested on a FIXED CADENCE instead of when a lane's cursor crosses into its next piece.  A wavefront's 64
+//      lanes cross at different steps, so with the crossing-driven refill some lane parks the piece it had in flight and requests another in
+//      nearly every step, inside a divergent branch: hipcc cannot count those loads and puts `s_waitcnt vmcnt(0)` before every park -- with
+//      gfx950's one in-order counter the whole wave waits, every step, for the request another lane issued a step earlier and for the stores
+//      of the last burst (ablations at 800 000 chunks: the loads cost 1.27 of the stage's 3.20 ms, the stores 0.8, the symbol chain 1.67).
+//      Here (32-byte pieces, a ring of THREE per lane): once per group of four steps -- which take at most 22 bytes, so a cursor crosses at
+//      most one piece boundary per group -- every lane parks the piece it requested one group earlier and requests the next one below what
+//      it holds if the slot is free, through unconditional buffer loads (a lane that requests nothing asks for an offset outside the
+//      descriptor: zeros, no traffic); the block stores are unconditional buffer stores as well.  Every VMEM operation of a round is then
+//      countable and hipcc emits the `vmcnt(N)` that waits for the loads of four steps ago and nothing younger (decode_fast.h's scheme).
+//      Invariant at the top of a group, after the park: pieces cursor .. cursor - 1 are in the ring (the four steps read at most 29 bytes
+//      below the cursor's byte); a request for piece k needs slot k mod 3 free, i.e. k + 3 > the cursor's piece.
+template <bool SO, int WG = 1, int PLOG = 4, bool CAD = false>
+__global__ void __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(SO ? (CAD && PLOG == 6 ? 3 : HUF0_SO_WAVES) : HUF0_G_WAVES)))   // (64-byte pieces: the LDS allows 10 waves a CU)
 huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restrict__ boffs,
                                                          uint64_t nchunks, uint8_t* __restrict__ out,
                                                          const uint64_t* __restrict__ ooffs, int64_t* __restrict__ rets,
                                                          const uint8_t* __restrict__ desc, const uint8_t* __restrict__ share)
 {
     static_assert(SO ? (WG == 1 || WG == 2 || WG == 4) : WG == 1, "a workgroup of the one-table kernel stays inside one 64-chunk segment");
+    static_assert(!CAD || PLOG == 5 || PLOG == 6, "the cadenced refill: 32-byte pieces every four steps or 64-byte pieces every eight");
     constexpr int kThreads = 64 * WG, kChunks = kThreads / 4;
     if ((share[(uint64_t)blockIdx.x * kChunks >> 6] != 0) != SO) return;      // the other instantiation's
     auto sync = [] { if constexpr (SO) __syncthreads(); else wave_sync(); };
     __shared__ __attribute__((aligned(16))) uint8_t s_c[SO ? 336 + (2u << kSharedMaxLog) : 16 * kCStride];
-    constexpr int kPLog = PLOG, kPB = 1 << kPLog, kPL = kPB / 16, kRingStride = ring_stride(PLOG);
-    __shared__ __attribute__((aligned(16))) uint8_t s_ring[kThreads * kRingStride];
+    constexpr int kPLog = PLOG, kPB = 1 << kPLog, kPL = kPB / 16, kRingStride = CAD ? 3 * (1 << PLOG) + 8 : ring_stride(PLOG);
+#ifndef HUF0_CAD_PAD
+#define HUF0_CAD_PAD 0                    // experiment: extra LDS bytes a workgroup of the cadenced kernel claims (fewer resident waves)
+#endif
+    __shared__ __attribute__((aligned(16))) uint8_t s_ring[kThreads * kRingStride + (CAD ? HUF0_CAD_PAD : 0)];
     const int t = threadIdx.x, q = t >> 2, j = t & 3;
     const uint64_t chunk0 = (uint64_t)blockIdx.x * kChunks;
     const uint64_t chunk = chunk0 + (uint64_t)q;
@@ -864,7 +895,74 @@ huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restric
     };
     int32_t cur_b = last_piece;                                   // piece of the cursor's byte
     Piece fl;
-    {
+    // ---- CAD state: the ring holds pieces cur_b .. low_k in slots (piece mod 3); `pend` is the piece requested at the last group top
+    constexpr uint32_t kDrop = 0xfffffff0u;                       // outside every descriptor: a load answers zeros, a store is dropped
+    auto uniform64 = [](uint64_t v) {
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    };
+    const uint64_t wave_first = chunk0 + (uint64_t)(((uint32_t)t >> 6) << 4);
+    const uint64_t wf = wave_first < nchunks ? wave_first : nchunks;
+    const uint64_t in_base = CAD ? uniform64(((uint64_t)(uintptr_t)blocks + boffs[wf]) & ~(uint64_t)31) : 0;
+    const uint64_t in_span = CAD ? uniform64((((uint64_t)(uintptr_t)blocks + boffs[nchunks]) - in_base + 15) & ~(uint64_t)15) : 0;
+    const uint64_t out_base = CAD ? uniform64(((uint64_t)(uintptr_t)out + ooffs[wf]) & ~(uint64_t)15) : 0;
+    const uint64_t out_span = CAD ? uniform64(((uint64_t)(uintptr_t)out + ooffs[nchunks]) - out_base) : 0;
+    const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)in_base, 0, (uint32_t)(in_span < 0xffffffffull ? in_span : 0xffffffffull), 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)out_base, 0, (uint32_t)(out_span < 0xfffffff0ull ? out_span : 0xfffffff0ull), 0x00020000);
+    const uint32_t sp_off = CAD && streaming ? (uint32_t)((uint64_t)(uintptr_t)sp_al - in_base) : 0u;
+    int32_t low_k = 0;                                            // lowest piece in the ring or in flight
+    uint32_t cur_s32 = 0, m1_s32 = 0, low_s32 = 0, pend_s32 = 0;  // byte offset of the ring slot of cur_b / of cur_b - 1 / of low_k / of the piece in flight
+    bool pend_on = false;
+    Piece pend;
+    auto slot_below = [](uint32_t s32) { return s32 == 0u ? 2u * (uint32_t)kPB : s32 - (uint32_t)kPB; };
+    auto park3 = [&](uint32_t s32, const Piece& f) {               // a 32-byte piece -> ring slot s32 / 32 (+ the first 8 bytes of slot 0 again behind slot 2)
+        typedef __attribute__((address_space(3))) uint64_t lds_u64;
+        const uint32_t at = ring + s32;
+#pragma unroll
+        for (int i = 0; i < kPL; i++) {
+            *(lds_u64*)(uintptr_t)(at + 16u * i) = (uint64_t)f.q[i].x | ((uint64_t)f.q[i].y << 32);
+            *(lds_u64*)(uintptr_t)(at + 16u * i + 8u) = (uint64_t)f.q[i].z | ((uint64_t)f.q[i].w << 32);
+        }
+        if (s32 == 0u) *(lds_u64*)(uintptr_t)(ring + 3u * kPB) = (uint64_t)f.q[0].x | ((uint64_t)f.q[0].y << 32);
+    };
+    // the top of every group of four steps.  Preal: the lane's true cursor (a lane that rides along carries a parked one in P)
+    // (64-byte pieces: every second group -- eight steps take at most 44 bytes)
+    auto group_top = [&](int g, int32_t Preal) {
+        if constexpr (CAD) {
+            if (g % (kPB / 32) != 0) return;
+            if (pend_on) park3(pend_s32, pend);
+            const uint32_t xr = ((uint32_t)(Preal > 0 ? Preal - 1 : 0) >> 3) + s_al;
+            if (streaming && (int32_t)(xr >> kPLog) < cur_b) {   // at most one boundary per cadence
+                cur_b--;
+                cur_s32 = slot_below(cur_s32);
+            }
+            m1_s32 = slot_below(cur_s32);
+            const int32_t k = low_k - 1;
+#ifdef ABL_CAD_NO_LOAD
+            const bool want = streaming && k >= 0 && k + 3 > cur_b && k > last_piece;      // ablation: never
+#else
+            const bool want = streaming && k >= 0 && k + 3 > cur_b;
+#endif
+            const uint32_t vo = want ? sp_off + (uint32_t)kPB * (uint32_t)k : kDrop;
+#pragma unroll
+            for (int i = 0; i < kPL; i++) {
+                const auto t0 = __builtin_amdgcn_raw_buffer_load_b128(brsrc, want ? vo + 16u * i : kDrop, 0, 0);
+                pend.q[i] = v4u{t0[0], t0[1], t0[2], t0[3]};
+            }
+            pend_on = want;
+            pend_s32 = slot_below(low_s32);
+            if (want) { low_k = k; low_s32 = pend_s32; }
+        }
+    };
+    if constexpr (CAD) {
+        const Piece f0 = load_piece(cur_b), f1 = load_piece(cur_b - 1);
+        cur_s32 = (uint32_t)kPB * ((uint32_t)(cur_b < 0 ? 0 : cur_b) % 3u);
+        m1_s32 = slot_below(cur_s32);
+        park3(cur_s32, f0);
+        park3(m1_s32, f1);
+        low_k = cur_b - 1;
+        low_s32 = m1_s32;
+        fl = f0;                                                  // (unused in this form)
+    } else {
         const Piece f0 = load_piece(cur_b), f1 = load_piece(cur_b - 1);
         fl = load_piece(cur_b - 2);
         park(cur_b, f0);
@@ -880,17 +978,27 @@ huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restric
         constexpr bool kShared = decltype(SH)::value;
         const int32_t Pc = P;
         const uint32_t x = ((uint32_t)(Pc > 0 ? Pc - 1 : 0) >> 3) + s_al;      // the cursor's byte, counted from piece 0
+        uint32_t o, d0, d1, d2;
+        if constexpr (CAD) {                                      // the cursor's piece is the group top's or the one below: its slot is known
+            const uint32_t sb = (int32_t)(x >> kPLog) == cur_b ? cur_s32 : m1_s32;
+            int32_t oo = (int32_t)(sb + (x & (uint32_t)(kPB - 1))) - 7;
+            oo += oo < 0 ? 3 * kPB : 0;                           // below slot 0 is the end of slot 2; past slot 2 is the copy of slot 0's head
+            o = (uint32_t)oo;
+            const uint32_t a = ring + (o & ~3u);
+            d0 = *(lds_u32c*)(uintptr_t)a; d1 = *(lds_u32c*)(uintptr_t)(a + 4u); d2 = *(lds_u32c*)(uintptr_t)(a + 8u);
+        } else {
         if ((int32_t)(x >> kPLog) < cur_b) {                      // crossed into the piece below: the one in flight takes the freed slot
             park(cur_b - 2, fl);
             cur_b--;
             fl = load_piece(cur_b - 2);
         }
         // the 8 bytes ending at byte x: three aligned dwords of the ring, two v_alignbyte
-        const uint32_t o = x - 7u;                                // may be "negative": bytes before the stream read as what the ring holds, masked below
+        o = x - 7u;                                               // may be "negative": bytes before the stream read as what the ring holds, masked below
         constexpr uint32_t kRM = 2u * kPB - 4u;
-        const uint32_t d0 = *(lds_u32c*)(uintptr_t)(ring + (o & kRM));
-        const uint32_t d1 = *(lds_u32c*)(uintptr_t)(ring + ((o + 4u) & kRM));
-        const uint32_t d2 = *(lds_u32c*)(uintptr_t)(ring + ((o + 8u) & kRM));
+        d0 = *(lds_u32c*)(uintptr_t)(ring + (o & kRM));
+        d1 = *(lds_u32c*)(uintptr_t)(ring + ((o + 4u) & kRM));
+        d2 = *(lds_u32c*)(uintptr_t)(ring + ((o + 8u) & kRM));
+        }
         const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, o & 3u), hi0 = __builtin_amdgcn_alignbyte(d2, d1, o & 3u);
         uint64_t win = (((uint64_t)hi0 << 32) | lo) << (7 - (int)((uint32_t)(Pc - 1) & 7u));
         if (__ballot(Pc < 64) != 0) {                             // only the last steps of a stream: nothing before its first bit
@@ -942,12 +1050,22 @@ huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restric
         constexpr bool kShared = decltype(SH)::value;
         const uint32_t pm1 = (uint32_t)P - 1u;
         const uint32_t x = (pm1 >> 3) + s_al;
+        uint32_t o, a;
+        if constexpr (CAD) {
+            const uint32_t sb = (int32_t)(x >> kPLog) == cur_b ? cur_s32 : m1_s32;
+            int32_t oo = (int32_t)(sb + (x & (uint32_t)(kPB - 1))) - 7;
+            oo += oo < 0 ? 3 * kPB : 0;
+            o = (uint32_t)oo;
+            a = ring + (o & ~3u);
+        } else {
         if ((int32_t)(x >> kPLog) < cur_b) {
             park(cur_b - 2, fl);
             cur_b--;
             fl = load_piece(cur_b - 2);
         }
-        const uint32_t o = x - 7u, a = ring + (o & (2u * kPB - 4u));
+        o = x - 7u;
+        a = ring + (o & (2u * kPB - 4u));
+        }
         const uint32_t d0 = *(lds_u32c*)(uintptr_t)a, d1 = *(lds_u32c*)(uintptr_t)(a + 4u), d2 = *(lds_u32c*)(uintptr_t)(a + 8u);
         const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, o & 3u), hi0 = __builtin_amdgcn_alignbyte(d2, d1, o & 3u);
         uint64_t win = (((uint64_t)hi0 << 32) | lo) << (7u - (pm1 & 7u));
@@ -1026,6 +1144,11 @@ huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restric
             const bool all_full = __ballot(streaming && lim < 64) == 0;      // (lanes without a stream just go through the motions)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
+#if HUF0_SPECULATIVE_TAIL
+                group_top(g, fast_round && !burst ? P0 : P);
+#else
+                group_top(g, P);
+#endif
                 if (fast_round || (all_full && __ballot(streaming && P < kFastBits) == 0)) {
 #pragma unroll
                     for (int i = 0; i < 4; i++) wb[4 * g + i] = fast_step(SH);
@@ -1069,6 +1192,21 @@ huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restric
                 const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
                 if (odd2) v[k][d] = recv; else v[k + 2][d] = recv;
             }
+        if constexpr (CAD) {                                      // four unconditional buffer stores: a lane of the quad without a full line asks for a dropped offset
+#ifdef ABL_CAD_NO_STORE
+            const int moff = (int)kDrop;                          // ablation: every line dropped
+#else
+            const int moff = (int)(full_out ? (uint32_t)((uint64_t)(uintptr_t)op - out_base) : kDrop);
+#endif
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) {
+                const uint32_t dof = (uint32_t)(qq == 0 ? __builtin_amdgcn_mov_dpp(moff, 0x00, 0xf, 0xf, true) : qq == 1 ? __builtin_amdgcn_mov_dpp(moff, 0x55, 0xf, 0xf, true)
+                                              : qq == 2 ? __builtin_amdgcn_mov_dpp(moff, 0xAA, 0xf, 0xf, true) : __builtin_amdgcn_mov_dpp(moff, 0xFF, 0xf, 0xf, true));
+                typedef __attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t v4s;
+                const v4s piece = {v[qq][0], v[qq][1], v[qq][2], v[qq][3]};
+                __builtin_amdgcn_raw_buffer_store_b128(piece, orsrc, dof == kDrop ? kDrop : dof + 16u * part, 0, 2);   // aux 2 = nt: streamed out once
+            }
+        } else {
         const uint64_t mine = full_out ? (uint64_t)(uintptr_t)op : 0ull;
         const int mlo = (int)(uint32_t)mine, mhi = (int)(uint32_t)(mine >> 32);
 #pragma unroll
@@ -1087,6 +1225,7 @@ huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restric
                 v4u piece = {v[qq][0], v[qq][1], v[qq][2], v[qq][3]};
                 __builtin_nontemporal_store(piece, (v4u_a1*)(uintptr_t)(da + 16u * part));   // streamed out once
             }
+        }
         }
         if (!full_out && cnt) {
 #pragma unroll
@@ -1157,10 +1296,11 @@ int sprintz_mi355x_huf0_decompress_batch_ws(const void* d_blocks, const uint64_t
     }
     // the one-table kernel: bandwidth-sized batches as 4-wave workgroups with 32-byte stream pieces, small ones wave by wave
     if (nchunks >= (uint64_t)sprintz::huf0_big_batch().load(std::memory_order_relaxed))
-        hipLaunchKernelGGL((huf0_stream_kernel<true, 4, 5>), dim3((unsigned)grid1), dim3(256), 0, st, blk, d_block_offsets, nchunks,
+        hipLaunchKernelGGL((huf0_stream_kernel<true, HUF0_BIG_WG, HUF0_BIG_PLOG, HUF0_CADENCED != 0>), dim3((unsigned)((nchunks + 16 * HUF0_BIG_WG - 1) / (16 * HUF0_BIG_WG))),
+                           dim3(64 * HUF0_BIG_WG), 0, st, blk, d_block_offsets, nchunks,
                            (uint8_t*)d_out, d_out_offsets, d_rets, (const uint8_t*)desc, (const uint8_t*)share);
     else
-        hipLaunchKernelGGL((huf0_stream_kernel<true, 1, 4>), dim3((unsigned)grid2), dim3(64), 0, st, blk, d_block_offsets, nchunks,
+        hipLaunchKernelGGL((huf0_stream_kernel<true, 1, HUF0_SMALL_PLOG, HUF0_SMALL_CAD != 0>), dim3((unsigned)grid2), dim3(64), 0, st, blk, d_block_offsets, nchunks,
                            (uint8_t*)d_out, d_out_offsets, d_rets, (const uint8_t*)desc, (const uint8_t*)share);
     hipLaunchKernelGGL((huf0_stream_kernel<false, 1, 4>), dim3((unsigned)grid2), dim3(64), 0, st, blk, d_block_offsets, nchunks,
                        (uint8_t*)d_out, d_out_offsets, d_rets, (const uint8_t*)desc, (const uint8_t*)share);
