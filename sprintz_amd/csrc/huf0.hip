@@ -301,6 +301,12 @@ constexpr int kCStride = 256 + 64 + 512 + 4;     // stream kernel, per chunk in 
 #define HUF0_SPECULATIVE_TAIL 1           // the streams' last bursts in one common masked round (stream kernel)
 #endif
 constexpr int ring_stride(int plog) { return 2 * (1 << plog) + 8; }
+#ifndef HUF0_G_PLOG
+#define HUF0_G_PLOG 5                     // the per-chunk-table kernel: piece size, and whether it refills on the cadence
+#endif
+#ifndef HUF0_G_CAD
+#define HUF0_G_CAD 1
+#endif
 #ifndef HUF0_SMALL_PLOG
 #define HUF0_SMALL_PLOG 6                 // the single-wave one-table kernel of small batches: piece size, and whether it refills on the cadence
 #endif
@@ -1302,7 +1308,7 @@ int sprintz_mi355x_huf0_decompress_batch_ws(const void* d_blocks, const uint64_t
     else
         hipLaunchKernelGGL((huf0_stream_kernel<true, 1, HUF0_SMALL_PLOG, HUF0_SMALL_CAD != 0>), dim3((unsigned)grid2), dim3(64), 0, st, blk, d_block_offsets, nchunks,
                            (uint8_t*)d_out, d_out_offsets, d_rets, (const uint8_t*)desc, (const uint8_t*)share);
-    hipLaunchKernelGGL((huf0_stream_kernel<false, 1, 4>), dim3((unsigned)grid2), dim3(64), 0, st, blk, d_block_offsets, nchunks,
+    hipLaunchKernelGGL((huf0_stream_kernel<false, 1, HUF0_G_PLOG, HUF0_G_CAD != 0>), dim3((unsigned)grid2), dim3(64), 0, st, blk, d_block_offsets, nchunks,
                        (uint8_t*)d_out, d_out_offsets, d_rets, (const uint8_t*)desc, (const uint8_t*)share);
     return hipGetLastError() == hipSuccess ? 0 : sprintz::set_error(SPRINTZ_E_HIP, "Huff0 stage: a HIP call or kernel launch failed");
 }
