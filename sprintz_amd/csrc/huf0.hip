@@ -807,7 +807,7 @@ huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restric
             if (idx0 >= size) break;
             while (w < 12u && idx0 >= nxt) { w++; e = tab0[w]; nxt = w < 12u ? (tab0[w + 1] & 0xffffu) : 0xffffffffu; }
             const uint32_t pos = (e >> 16) + ((idx0 - (e & 0xffffu)) >> (w - 1u));
-            full_table[idx0] = (uint16_t)(s_c[pos & 0xffu] | ((tl0 + 1u - w) << 8));
+            full_table[idx0] = (uint16_t)((tl0 + 1u - w) | ((uint32_t)s_c[pos & 0xffu] << 8));      // length | symbol << 8: the length shifts the window as it is
         }
     }
     sync();
@@ -1018,8 +1018,8 @@ huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restric
             if constexpr (kShared) {
                 const uint32_t e = *(lds_u16*)(uintptr_t)(ft + ((hi >> look_shift) << 1));
                 const bool on = (uint32_t)k < m;
-                const uint32_t nb = on ? (e >> 8) : 0u;
-                word |= (on ? (e & 0xffu) : 0u) << (8 * k);
+                const uint32_t nb = on ? (e & 0xffu) : 0u;
+                word |= (on ? (e >> 8) : 0u) << (8 * k);
                 win <<= nb;
                 P -= (int32_t)nb;
                 continue;
@@ -1104,14 +1104,16 @@ huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restric
             return __builtin_amdgcn_perm(w23, w01, 0x05040100u);
         }
         const uint32_t e0 = *(lds_u16*)(uintptr_t)(ft + (((uint32_t)(win >> 32) >> look_shift) << 1));
-        win <<= e0 >> 8;
+        // (an entry is length | symbol << 8: the 64-bit shift takes its count from the low six bits of the entry as it is -- one instruction
+        //  less on the chain of every symbol; the four lengths are the low byte of the entries' sum, the symbols their second bytes)
+        win <<= e0 & 63u;
         const uint32_t e1 = *(lds_u16*)(uintptr_t)(ft + (((uint32_t)(win >> 32) >> look_shift) << 1));
-        win <<= e1 >> 8;
+        win <<= e1 & 63u;
         const uint32_t e2 = *(lds_u16*)(uintptr_t)(ft + (((uint32_t)(win >> 32) >> look_shift) << 1));
-        win <<= e2 >> 8;
+        win <<= e2 & 63u;
         const uint32_t e3 = *(lds_u16*)(uintptr_t)(ft + (((uint32_t)(win >> 32) >> look_shift) << 1));
-        P -= (int32_t)((e0 >> 8) + (e1 >> 8) + (e2 >> 8) + (e3 >> 8));
-        const uint32_t w01 = __builtin_amdgcn_perm(e1, e0, 0x0c0c0400u), w23 = __builtin_amdgcn_perm(e3, e2, 0x0c0c0400u);
+        P -= (int32_t)((e0 + e1 + e2 + e3) & 0xffu);
+        const uint32_t w01 = __builtin_amdgcn_perm(e1, e0, 0x0c0c0501u), w23 = __builtin_amdgcn_perm(e3, e2, 0x0c0c0501u);
         return __builtin_amdgcn_perm(w23, w01, 0x05040100u);
     };
     // The output leaves 64 bytes at a time: a lane collects 16 steps in registers, the quad transposes
