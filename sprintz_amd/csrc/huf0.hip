@@ -313,6 +313,9 @@ constexpr int ring_stride(int plog) { return 2 * (1 << plog) + 8; }
 #ifndef HUF0_SMALL_CAD
 #define HUF0_SMALL_CAD 1
 #endif
+#ifndef HUF0_BIG_NS
+#define HUF0_BIG_NS 3                     // ring slots of the big-batch one-table kernel (2: 64-byte pieces only)
+#endif
 #ifndef HUF0_BIG_WG
 #define HUF0_BIG_WG 2                     // wavefronts a workgroup of the big-batch one-table kernel
 #endif
@@ -694,8 +697,12 @@ __global__ void __launch_bounds__(256) huf0_share_kernel(const uint8_t* __restri
 //      countable and hipcc emits the `vmcnt(N)` that waits for the loads of four steps ago and nothing younger (decode_fast.h's scheme).
 //      Invariant at the top of a group, after the park: pieces cursor .. cursor - 1 are in the ring (the four steps read at most 29 bytes
 //      below the cursor's byte); a request for piece k needs slot k mod 3 free, i.e. k + 3 > the cursor's piece.
-template <bool SO, int WG = 1, int PLOG = 4, bool CAD = false>
-__global__ void __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(SO ? (CAD && PLOG == 6 ? 3 : HUF0_SO_WAVES) : HUF0_G_WAVES)))   // (64-byte pieces: the LDS allows 10 waves a CU)
+// NS: ring slots of the cadenced form.  3 (above); or 2 with 64-byte pieces on the four-step cadence: a lane requests the piece below its
+//     cursor's at the first group top after the cursor entered a piece (the piece above is dead from then on: the window only looks down),
+//     at most 22 bytes in; it is parked one group later, at most 44 bytes in -- before the window (29 bytes of reach per group) or the
+//     cursor gets there.  136 bytes of ring a lane instead of 200.
+template <bool SO, int WG = 1, int PLOG = 4, bool CAD = false, int NS = 3>
+__global__ void __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(SO ? (CAD && PLOG == 6 ? (NS == 2 ? 4 : 3) : HUF0_SO_WAVES) : HUF0_G_WAVES)))   // (64-byte pieces: the LDS allows 10 waves a CU)
 huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restrict__ boffs,
                                                          uint64_t nchunks, uint8_t* __restrict__ out,
                                                          const uint64_t* __restrict__ ooffs, int64_t* __restrict__ rets,
@@ -703,11 +710,12 @@ huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restric
 {
     static_assert(SO ? (WG == 1 || WG == 2 || WG == 4) : WG == 1, "a workgroup of the one-table kernel stays inside one 64-chunk segment");
     static_assert(!CAD || PLOG == 5 || PLOG == 6, "the cadenced refill: 32-byte pieces every four steps or 64-byte pieces every eight");
+    static_assert(NS == 3 || (NS == 2 && CAD && PLOG == 6), "two ring slots: 64-byte pieces");
     constexpr int kThreads = 64 * WG, kChunks = kThreads / 4;
     if ((share[(uint64_t)blockIdx.x * kChunks >> 6] != 0) != SO) return;      // the other instantiation's
     auto sync = [] { if constexpr (SO) __syncthreads(); else wave_sync(); };
     __shared__ __attribute__((aligned(16))) uint8_t s_c[SO ? 336 + (2u << kSharedMaxLog) : 16 * kCStride];
-    constexpr int kPLog = PLOG, kPB = 1 << kPLog, kPL = kPB / 16, kRingStride = CAD ? 3 * (1 << PLOG) + 8 : ring_stride(PLOG);
+    constexpr int kPLog = PLOG, kPB = 1 << kPLog, kPL = kPB / 16, kRingStride = CAD && NS == 3 ? 3 * (1 << PLOG) + 8 : ring_stride(PLOG);
 #ifndef HUF0_CAD_PAD
 #define HUF0_CAD_PAD 0                    // experiment: extra LDS bytes a workgroup of the cadenced kernel claims (fewer resident waves)
 #endif
@@ -932,8 +940,23 @@ huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restric
     };
     // the top of every group of four steps.  Preal: the lane's true cursor (a lane that rides along carries a parked one in P)
     // (64-byte pieces: every second group -- eight steps take at most 44 bytes)
+    int32_t pend_k = 0;
     auto group_top = [&](int g, int32_t Preal) {
-        if constexpr (CAD) {
+        if constexpr (CAD && NS == 2) {
+            if (pend_on) { park(pend_k, pend); low_k = pend_k; }
+            const uint32_t xr = ((uint32_t)(Preal > 0 ? Preal - 1 : 0) >> 3) + s_al;
+            if (streaming && (int32_t)(xr >> kPLog) < cur_b) cur_b--;
+            const int32_t k = cur_b - 1;
+            const bool want = streaming && low_k == cur_b && k >= 0;
+            const uint32_t vo = want ? sp_off + (uint32_t)kPB * (uint32_t)k : kDrop;
+#pragma unroll
+            for (int i = 0; i < kPL; i++) {
+                const auto t0 = __builtin_amdgcn_raw_buffer_load_b128(brsrc, want ? vo + 16u * i : kDrop, 0, 0);
+                pend.q[i] = v4u{t0[0], t0[1], t0[2], t0[3]};
+            }
+            pend_on = want;
+            pend_k = k;
+        } else if constexpr (CAD) {
             if (g % (kPB / 32) != 0) return;
             if (pend_on) park3(pend_s32, pend);
             const uint32_t xr = ((uint32_t)(Preal > 0 ? Preal - 1 : 0) >> 3) + s_al;
@@ -959,7 +982,13 @@ huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restric
             if (want) { low_k = k; low_s32 = pend_s32; }
         }
     };
-    if constexpr (CAD) {
+    if constexpr (CAD && NS == 2) {
+        const Piece f0 = load_piece(cur_b), f1 = load_piece(cur_b - 1);
+        park(cur_b, f0);
+        park(cur_b - 1, f1);
+        low_k = cur_b - 1;
+        fl = f0;                                                  // (unused in this form)
+    } else if constexpr (CAD) {
         const Piece f0 = load_piece(cur_b), f1 = load_piece(cur_b - 1);
         cur_s32 = (uint32_t)kPB * ((uint32_t)(cur_b < 0 ? 0 : cur_b) % 3u);
         m1_s32 = slot_below(cur_s32);
@@ -985,7 +1014,7 @@ huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restric
         const int32_t Pc = P;
         const uint32_t x = ((uint32_t)(Pc > 0 ? Pc - 1 : 0) >> 3) + s_al;      // the cursor's byte, counted from piece 0
         uint32_t o, d0, d1, d2;
-        if constexpr (CAD) {                                      // the cursor's piece is the group top's or the one below: its slot is known
+        if constexpr (CAD && NS == 3) {                           // the cursor's piece is the group top's or the one below: its slot is known
             const uint32_t sb = (int32_t)(x >> kPLog) == cur_b ? cur_s32 : m1_s32;
             int32_t oo = (int32_t)(sb + (x & (uint32_t)(kPB - 1))) - 7;
             oo += oo < 0 ? 3 * kPB : 0;                           // below slot 0 is the end of slot 2; past slot 2 is the copy of slot 0's head
@@ -993,10 +1022,12 @@ huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restric
             const uint32_t a = ring + (o & ~3u);
             d0 = *(lds_u32c*)(uintptr_t)a; d1 = *(lds_u32c*)(uintptr_t)(a + 4u); d2 = *(lds_u32c*)(uintptr_t)(a + 8u);
         } else {
+        if constexpr (!CAD) {
         if ((int32_t)(x >> kPLog) < cur_b) {                      // crossed into the piece below: the one in flight takes the freed slot
             park(cur_b - 2, fl);
             cur_b--;
             fl = load_piece(cur_b - 2);
+        }
         }
         // the 8 bytes ending at byte x: three aligned dwords of the ring, two v_alignbyte
         o = x - 7u;                                               // may be "negative": bytes before the stream read as what the ring holds, masked below
@@ -1057,17 +1088,19 @@ huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restric
         const uint32_t pm1 = (uint32_t)P - 1u;
         const uint32_t x = (pm1 >> 3) + s_al;
         uint32_t o, a;
-        if constexpr (CAD) {
+        if constexpr (CAD && NS == 3) {
             const uint32_t sb = (int32_t)(x >> kPLog) == cur_b ? cur_s32 : m1_s32;
             int32_t oo = (int32_t)(sb + (x & (uint32_t)(kPB - 1))) - 7;
             oo += oo < 0 ? 3 * kPB : 0;
             o = (uint32_t)oo;
             a = ring + (o & ~3u);
         } else {
+        if constexpr (!CAD) {
         if ((int32_t)(x >> kPLog) < cur_b) {
             park(cur_b - 2, fl);
             cur_b--;
             fl = load_piece(cur_b - 2);
+        }
         }
         o = x - 7u;
         a = ring + (o & (2u * kPB - 4u));
@@ -1304,7 +1337,7 @@ int sprintz_mi355x_huf0_decompress_batch_ws(const void* d_blocks, const uint64_t
     }
     // the one-table kernel: bandwidth-sized batches as 4-wave workgroups with 32-byte stream pieces, small ones wave by wave
     if (nchunks >= (uint64_t)sprintz::huf0_big_batch().load(std::memory_order_relaxed))
-        hipLaunchKernelGGL((huf0_stream_kernel<true, HUF0_BIG_WG, HUF0_BIG_PLOG, HUF0_CADENCED != 0>), dim3((unsigned)((nchunks + 16 * HUF0_BIG_WG - 1) / (16 * HUF0_BIG_WG))),
+        hipLaunchKernelGGL((huf0_stream_kernel<true, HUF0_BIG_WG, HUF0_BIG_PLOG, HUF0_CADENCED != 0, HUF0_BIG_NS>), dim3((unsigned)((nchunks + 16 * HUF0_BIG_WG - 1) / (16 * HUF0_BIG_WG))),
                            dim3(64 * HUF0_BIG_WG), 0, st, blk, d_block_offsets, nchunks,
                            (uint8_t*)d_out, d_out_offsets, d_rets, (const uint8_t*)desc, (const uint8_t*)share);
     else
