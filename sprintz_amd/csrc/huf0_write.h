@@ -236,9 +236,20 @@ __global__ void __launch_bounds__(256) huf0_encode_kernel(const uint8_t* __restr
                                                           const uint8_t* __restrict__ recs, const uint64_t* __restrict__ meta,
                                                           uint8_t* __restrict__ out, const uint64_t* __restrict__ boffs)
 {
-    __shared__ uint32_t ring[32 * 256];
+#ifndef HUF0W_RING
+#define HUF0W_RING 64                     // dwords of output ring a lane; a flush is half of it (128 bytes: 64 KB a workgroup, 8 waves a CU)
+#endif
+    constexpr uint32_t kRD = HUF0W_RING, kRM = kRD - 1u, kFlush = kRD / 2u;
+    __shared__ uint32_t ring[kRD * 256];
     __shared__ uint32_t tab[256];                        // val | len << 16
     __shared__ uint8_t hdr[160];
+#ifndef HUF0W_PAD
+#define HUF0W_PAD 0                       // experiment: extra LDS bytes a workgroup claims (fewer resident waves, fewer open lines per L2)
+#endif
+#if HUF0W_PAD
+    __shared__ volatile uint8_t pad_[HUF0W_PAD];
+    pad_[threadIdx.x & 3] = 0;                           // (volatile: keeps the array)
+#endif
     const int t = threadIdx.x, j = t & 3;
     const uint64_t seg = blockIdx.x, c = seg * SEG + (uint64_t)(t >> 2);
     const uint8_t* const rec = recs + seg * kRecBytes;
@@ -280,18 +291,18 @@ __global__ void __launch_bounds__(256) huf0_encode_kernel(const uint8_t* __restr
     };
     auto drain = [&]() {                                  // whole dwords of the accumulator -> ring; whole 64-byte units -> HBM
         if (nbits >= 32) {
-            my[(wd & 31u) << 8] = (uint32_t)acc;
+            my[(wd & kRM) << 8] = (uint32_t)acc;
             wd++;
             acc >>= 32;
             nbits -= 32;
-            if (wd - fd >= 16) {
-                const uint32_t d0 = fd & 31u;
+            if (wd - fd >= kFlush) {
+                const uint32_t d0 = fd & kRM;
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < (int)kFlush / 4; q++) {
                     const u32x4 p = {my[(d0 + 4 * q) << 8], my[(d0 + 4 * q + 1) << 8], my[(d0 + 4 * q + 2) << 8], my[(d0 + 4 * q + 3) << 8]};
                     *(u32x4_a1*)(so + 4u * fd + 16u * q) = p;
                 }
-                fd += 16;
+                fd += kFlush;
             }
         }
     };
@@ -302,12 +313,10 @@ __global__ void __launch_bounds__(256) huf0_encode_kernel(const uint8_t* __restr
     // 16 symbols per trip.  Their 16 table reads do not depend on the bit accumulator and go out together; the accumulator chain
     // is pure VALU; a dword leaves for the ring after every second symbol WITHOUT a branch (the slot is written every time and
     // only counted when 32 bits are there: a slot written early is written again when it is due); the 64-byte flush to memory
-    // is looked at once per trip (<= 6 dwords a trip join the <= 15 waiting: the ring holds 32).  The loop used to carry eight
+    // is looked at once per trip (<= 6 dwords a trip join the < half a ring waiting).  The loop used to carry eight
     // conditional drains a trip, each with its own flush -- 45 s_waitcnt and 15 branches per 16 symbols, 4.5 ms at 800 000
     // chunks for 13 VALU a symbol.
-    while (k > k0) {
-        k -= 16;
-        const u32x4 x = *(const u32x4_a1*)(s + k);
+    auto trip16 = [&](const u32x4& x) {                   // 16 symbols, last first (the comment above)
         uint32_t e[16];
 #pragma unroll
         for (int d = 3; d >= 0; d--) {
@@ -323,27 +332,62 @@ __global__ void __launch_bounds__(256) huf0_encode_kernel(const uint8_t* __restr
             nbits += e[j] >> 16;
             acc |= (uint64_t)(e[j + 1] & 0xffffu) << nbits;
             nbits += e[j + 1] >> 16;
-            my[(wd & 31u) << 8] = (uint32_t)acc;
+            my[(wd & kRM) << 8] = (uint32_t)acc;
             const bool full = nbits >= 32;
             wd += full ? 1u : 0u;
             acc = full ? acc >> 32 : acc;
             nbits -= full ? 32u : 0u;
         }
-        if (wd - fd >= 16) {
-            const uint32_t d0 = fd & 31u;
+        if (wd - fd >= kFlush) {
+            const uint32_t d0 = fd & kRM;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < (int)kFlush / 4; q++) {
                 const u32x4 pq = {my[(d0 + 4 * q) << 8], my[(d0 + 4 * q + 1) << 8], my[(d0 + 4 * q + 2) << 8], my[(d0 + 4 * q + 3) << 8]};
                 *(u32x4_a1*)(so + 4u * fd + 16u * q) = pq;
             }
-            fd += 16;
+            fd += kFlush;
+        }
+    };
+#ifndef HUF0W_TRIP64
+#define HUF0W_TRIP64 1
+#endif
+#if HUF0W_TRIP64
+    // The source is read 64 bytes a lane at a time, one trip ahead: with 16-byte loads a lane came back to the same 128-byte line eight
+    // times, ~45 000 lanes per XCD between two visits, and the line had left the L2 again (FETCH_SIZE x 2 = 13.6 GB for 2.9 GB of streams).
+    while (((k - k0) & 63u) != 0u) {                      // down to a whole number of 64-byte trips
+        k -= 16;
+        const u32x4 x = *(const u32x4_a1*)(s + k);
+        trip16(x);
+    }
+    if (k > k0) {
+        u32x4 nx[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) nx[q] = *(const u32x4_a1*)(s + k - 16u * (q + 1));
+        while (k > k0) {
+            k -= 64;
+            u32x4 x4[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) x4[q] = nx[q];
+            if (k > k0) {                                     // the next trip's 64 bytes, requested before this trip's are coded
+#pragma unroll
+                for (int q = 0; q < 4; q++) nx[q] = *(const u32x4_a1*)(s + k - 16u * (q + 1));
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) trip16(x4[q]);
         }
     }
+#else
+    while (k > k0) {
+        k -= 16;
+        const u32x4 x = *(const u32x4_a1*)(s + k);
+        trip16(x);
+    }
+#endif
     acc |= 1ull << nbits;                                 // the closing 1 bit (BIT_closeCStream)
     nbits += 1;
     drain();
     // what is left: ring dwords [fd, wd), then the accumulator's bytes
-    for (; fd < wd; fd++) *(u32_any*)(so + 4u * fd) = my[(fd & 31u) << 8];
+    for (; fd < wd; fd++) *(u32_any*)(so + 4u * fd) = my[(fd & kRM) << 8];
     uint8_t* tail = so + 4u * wd;
     for (uint32_t b = 0; b < nbits; b += 8) *tail++ = (uint8_t)(acc >> b);
 }
