@@ -117,8 +117,14 @@ __global__ void __launch_bounds__(256) encode_uni_kernel(EncodeArgs a)
         if (q == 2) return (uint32_t)__builtin_amdgcn_mov_dpp(x, 0xAA, 0xf, 0xf, true);
         return (uint32_t)__builtin_amdgcn_mov_dpp(x, 0xFF, 0xf, 0xf, true);
     };
-    uint32_t nxt[WINS][4][4];
-    auto load_window = [&](uint32_t wi) {                                // nxt[.][q] = part `part` of member q's windows WINS*wi ..
+#ifndef SPRINTZ_ENCUNI_PAIR
+#define SPRINTZ_ENCUNI_PAIR 1
+#endif
+    // SPRINTZ_ENCUNI_PAIR: the two 64-byte windows of a 128-byte line are requested TOGETHER (two windows ahead / one ahead) instead of one per
+    // window: requested a window apart, the line had left the L2 again before its second half was asked for (FETCH_SIZE x 2 = 923 MB for
+    // 537 MB of samples on BASELINE config 1)
+    uint32_t nxtA[WINS][4][4], nxtB[WINS][4][4];
+    auto load_window = [&](uint32_t wi, uint32_t (&nxt)[WINS][4][4]) {   // nxt[.][q] = part `part` of member q's windows WINS*wi ..
 #pragma unroll
         for (int wn = 0; wn < WINS; wn++)
 #pragma unroll
@@ -131,12 +137,8 @@ __global__ void __launch_bounds__(256) encode_uni_kernel(EncodeArgs a)
                 nxt[wn][q][0] = x.x; nxt[wn][q][1] = x.y; nxt[wn][q][2] = x.z; nxt[wn][q][3] = x.w;
             }
     };
-    load_window(0);
-
-    for (uint32_t wi = 0;; wi++) {
-        if (__ballot(active) == 0) break;
-        // (member m, piece k) -> (lane k, slot m): two DPP butterfly stages, then this lane owns its window
-        uint32_t vv[WINS][4][4];
+    // (member m, piece k) -> (lane k, slot m): two DPP butterfly stages, then this lane owns its window
+    auto take_window = [&](const uint32_t (&nxt)[WINS][4][4], uint32_t (&vv)[WINS][4][4]) {
 #pragma unroll
         for (int wn = 0; wn < WINS; wn++) {
         uint32_t (&v)[4][4] = vv[wn];
@@ -161,8 +163,8 @@ __global__ void __launch_bounds__(256) encode_uni_kernel(EncodeArgs a)
                 if (odd2) v[k][d] = recv; else v[k + 2][d] = recv;
             }
         }
-        load_window(wi + 1);
-
+    };
+    auto code_window = [&](const uint32_t (&vv)[WINS][4][4]) {
 #pragma unroll
         for (int b = 0; b < BW; b++) {
             if (!active) continue;
@@ -255,6 +257,29 @@ __global__ void __launch_bounds__(256) encode_uni_kernel(EncodeArgs a)
                 }
                 break;
             }
+        }
+    };
+    load_window(0, nxtA);
+    // (three columns: a span is three windows and the second buffer costs 48 registers -- one wave a SIMD, 0.30 -> 0.50 ms: not there)
+    if constexpr (SPRINTZ_ENCUNI_PAIR && WINS == 1) {
+        load_window(1, nxtB);
+        for (uint32_t wi = 0;; wi += 2) {
+            if (__ballot(active) == 0) break;
+            uint32_t vv[WINS][4][4];
+            take_window(nxtA, vv);
+            code_window(vv);
+            take_window(nxtB, vv);
+            load_window(wi + 2, nxtA);                                   // the next line's two halves, back to back
+            load_window(wi + 3, nxtB);
+            code_window(vv);
+        }
+    } else {
+        for (uint32_t wi = 0;; wi++) {
+            if (__ballot(active) == 0) break;
+            uint32_t vv[WINS][4][4];
+            take_window(nxtA, vv);
+            load_window(wi + 1, nxtA);
+            code_window(vv);
         }
     }
 
