@@ -384,7 +384,10 @@ def test_full_size_8bit_configs_roundtrip_and_sample_parity(sz, oracle, name, co
 
 
 @pytest.mark.parametrize("codec,esz,ndims,chunk_len,nchunks", [("xff", 2, 8, 5120, 64), ("xff", 1, 1, 1024, 300), ("delta", 2, 1, 2000, 300),
-                                                               ("xff", 1, 3, 3000, 64), ("xff", 1, 4, 2000, 300), ("delta", 2, 2, 2000, 300)])
+                                                               ("xff", 1, 3, 3000, 64), ("xff", 1, 4, 2000, 300), ("delta", 2, 2, 2000, 300),
+                                                               ("delta", 1, 80, 10240, 40), ("xff", 1, 72, 72 * 64, 40),      # the split lane mapping (decode_fast.h, SPLIT)
+                                                               ("xff", 2, 80, 10240, 24),                                      # 64 x 2 with the 80-column LDS carve
+                                                               ("delta", 1, 80, 1024, 100), ("xff", 2, 8, 100, 100)])          # verbatim batches (verbatim_decode_kernel)
 def test_corrupt_streams_do_not_hang_or_overrun(sz, oracle, codec, esz, ndims, chunk_len, nchunks):
     """bit-flipped / truncated / header-damaged streams: the decoder must terminate, stay inside
     each chunk's output slot and either decode something or report SPRINTZ_E_CORRUPT"""
