@@ -181,22 +181,27 @@ __global__ void __launch_bounds__(kScanBlock) scan_add_kernel(uint64_t* offsets,
     if (i < n) offsets[i] += block_sums[blockIdx.x];
 }
 
-// one wavefront per chunk: slot -> dense
+#ifndef SPRINTZ_COPY_SMALL_LOG2
+#define SPRINTZ_COPY_SMALL_LOG2 5
+#endif
+// one wavefront per chunk: slot -> dense (LOG2L = 5: half a wavefront per chunk -- slots of at most 2 KB, where a chunk's stream is a few
+// hundred bytes and 64 lanes x 16 bytes leave most of the wavefront idle: BASELINE config 1's 440-byte streams 0.133 -> see DESIGN 4.2b)
+template <int LOG2L>
 __global__ void __launch_bounds__(kThreads) compact_copy_kernel(const uint8_t* slots, uint64_t slot_stride, const uint32_t* sizes,
                                                                 const uint64_t* offsets, uint64_t nchunks, uint32_t align,
                                                                 uint8_t* dense)
 {
-    const uint64_t c = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> 6;
-    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t c = ((uint64_t)blockIdx.x * kThreads + threadIdx.x) >> LOG2L;
+    const uint32_t lane = threadIdx.x & ((1u << LOG2L) - 1u);
     if (c >= nchunks) return;
     const uint8_t* s = slots + c * slot_stride;
     uint8_t* d = dense + offsets[c];
     const uint32_t sz = sizes[c];
     if (align == 16) {
         const uint32_t nunits = (sz + 15u) >> 4;     // slots are zero padded to 16
-        sprintz::copy_verbatim<false>(s, d, nunits << 4, lane, 64u);      // (four 16-byte loads a lane in flight before its first store)
+        sprintz::copy_verbatim<false>(s, d, nunits << 4, lane, 1u << LOG2L);      // (four 16-byte loads a lane in flight before its first store)
     } else {
-        for (uint32_t j = lane; j < sz; j += 64) d[j] = s[j];
+        for (uint32_t j = lane; j < sz; j += 1u << LOG2L) d[j] = s[j];
     }
 }
 
@@ -1090,9 +1095,15 @@ int sprintz_mi355x_compact(const void* d_slots, size_t slot_stride, const uint32
         return 0;
     }
     HIP_TRY(launch_size_scan(d_sizes, nchunks, align, d_offsets, d_scan_tmp, st));
-    const uint64_t grid = (nchunks * 64 + kThreads - 1) / kThreads;
-    hipLaunchKernelGGL(compact_copy_kernel, dim3((unsigned)grid), dim3(kThreads), 0, st, (const uint8_t*)d_slots,
-                       (uint64_t)slot_stride, d_sizes, d_offsets, nchunks, align, (uint8_t*)d_dense);
+    if (slot_stride <= 2048) {
+        const uint64_t grid = (nchunks * (1u << SPRINTZ_COPY_SMALL_LOG2) + kThreads - 1) / kThreads;
+        hipLaunchKernelGGL(compact_copy_kernel<SPRINTZ_COPY_SMALL_LOG2>, dim3((unsigned)grid), dim3(kThreads), 0, st, (const uint8_t*)d_slots,
+                           (uint64_t)slot_stride, d_sizes, d_offsets, nchunks, align, (uint8_t*)d_dense);
+    } else {
+        const uint64_t grid = (nchunks * 64 + kThreads - 1) / kThreads;
+        hipLaunchKernelGGL(compact_copy_kernel<6>, dim3((unsigned)grid), dim3(kThreads), 0, st, (const uint8_t*)d_slots,
+                           (uint64_t)slot_stride, d_sizes, d_offsets, nchunks, align, (uint8_t*)d_dense);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
