@@ -183,3 +183,19 @@ def test_unloadable_rccl_is_an_error_code_not_a_crash(lib_path):
     rc, rc2, msg = p.stdout.strip().split(" ", 2)
     assert int(rc) == -4 and int(rc2) == -4              # SPRINTZ_E_UNSUPPORTED
     assert "RCCL not loadable" in msg and "librccl-not-here" in msg
+
+
+def test_options_are_validated_without_a_device():
+    """sprintz_mi355x_set_option: every documented knob takes its documented values on a box without a GPU too, and an unknown
+    option or a value out of range is SPRINTZ_E_INVALID (include/sprintz_mi355x.h: the tuning knobs)"""
+    from sprintz_amd import _lib
+    for opt, good, bad in [(_lib.OPT_NO_FAST, [0, 1], []), (_lib.OPT_CHUNKS_PER_GROUP, [1, 64], [0, 65]), (_lib.OPT_DENSE_MODE, [0, 1], [-1, 2]),
+                           (_lib.OPT_HUF0_BIG_BATCH, [0, 20000], [-1]), (_lib.OPT_SPLIT_LANES, [0, 1], []), (_lib.OPT_ENC_PAIR, [0, 1], [])]:
+        for v in good:
+            assert _lib.set_option(opt, v) == 0, (opt, v)
+        for v in bad:
+            assert _lib.set_option(opt, v) == _lib.E_INVALID, (opt, v)
+    assert _lib.set_option(99, 0) == _lib.E_INVALID
+    for opt, v in [(_lib.OPT_NO_FAST, 0), (_lib.OPT_CHUNKS_PER_GROUP, 1), (_lib.OPT_DENSE_MODE, 1), (_lib.OPT_HUF0_BIG_BATCH, 20000),
+                   (_lib.OPT_SPLIT_LANES, 1), (_lib.OPT_ENC_PAIR, 1)]:
+        assert _lib.set_option(opt, v) == 0                  # back to the defaults
