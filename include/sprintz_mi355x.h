@@ -90,9 +90,10 @@ const char* sprintz_mi355x_last_error(void);     /* thread-local, never NULL; de
  *   SPRINTZ_OPT_SPLIT_LANES       1 (default) = 8-bit row-major streams of 65 .. 80 columns decode on 32 lanes a chunk (a pair of
  *                                 adjacent columns + one single column per lane, two chunks a wavefront), 0 = on 64 lanes x 2
  *                                 columns like the other shapes up to 128 columns (A/B runs, tests); env SPRINTZ_MI355X_SPLIT_LANES
- *   SPRINTZ_OPT_ENC_PAIR          1 (default) = row-major streams of 5 .. 64 columns are encoded with two columns per lane (the
- *                                 65 .. 128-column kernel on 4 .. 32 lanes a chunk), 0 = with one column per lane (A/B runs, tests);
- *                                 env SPRINTZ_MI355X_ENC_PAIR */
+ *   SPRINTZ_OPT_ENC_PAIR          chunks from which row-major streams of 5 .. 64 columns are encoded with two columns per lane (the
+ *                                 65 .. 128-column kernel on 4 .. 32 lanes a chunk: fewer instructions per sample) instead of one (a
+ *                                 chunk's latency is shorter: what counts for a handful of chunks); default 1024, 1 = always,
+ *                                 0 = never (A/B runs, tests); env SPRINTZ_MI355X_ENC_PAIR */
 #define SPRINTZ_OPT_NO_FAST 0
 #define SPRINTZ_OPT_CHUNKS_PER_GROUP 1
 #define SPRINTZ_OPT_DENSE_MODE 2

@@ -48,7 +48,7 @@ struct Process {
     std::atomic<int> no_fast{0};            // SPRINTZ_MI355X_NO_FAST: generic kernels only (A/B runs, tests)
     std::atomic<int> chunks_per_group{1};   // SPRINTZ_MI355X_CHUNKS_PER_GROUP (decode_fast read-ahead across chunks)
     std::atomic<int> dense_mode{1};         // SPRINTZ_MI355X_DENSE_MODE: how compress_batch_dense builds the container (see SPRINTZ_OPT_DENSE_MODE)
-    std::atomic<int> enc_pair{1};           // SPRINTZ_MI355X_ENC_PAIR: two columns per lane in the encoder for row-major streams of 5 .. 64 columns too (see SPRINTZ_OPT_ENC_PAIR)
+    std::atomic<int> enc_pair{1024};        // SPRINTZ_MI355X_ENC_PAIR: chunks from which row-major streams of 5 .. 64 columns are encoded with two columns per lane (0: never; see SPRINTZ_OPT_ENC_PAIR)
     std::atomic<int> split_lanes{1};        // SPRINTZ_MI355X_SPLIT_LANES: 8-bit streams of 65 .. 80 columns on 32 lanes x (pair + single) (see SPRINTZ_OPT_SPLIT_LANES)
 };
 Process& process()
@@ -64,7 +64,7 @@ Process& process()
             p.dense_mode = k <= 0 ? 0 : 1;
         }
         if (const char* e = getenv("SPRINTZ_MI355X_SPLIT_LANES")) p.split_lanes = atoi(e) != 0 ? 1 : 0;
-        if (const char* e = getenv("SPRINTZ_MI355X_ENC_PAIR")) p.enc_pair = atoi(e) != 0 ? 1 : 0;
+        if (const char* e = getenv("SPRINTZ_MI355X_ENC_PAIR")) p.enc_pair = atoi(e) < 0 ? 0 : atoi(e);
         if (const char* e = getenv("SPRINTZ_MI355X_CHUNKS_PER_GROUP")) {
             const int k = atoi(e);
             p.chunks_per_group = k < 1 ? 1 : k > 64 ? 64 : k;
@@ -514,7 +514,10 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     };
     // two columns per lane for narrow row-major streams too (encode_wide.h with 4 .. 32 lanes a chunk): fewer instructions per sample
     // than encode_fast.h's one column per lane on every shape measured (tools/enc_pair_sweep.sh: -6 % .. -35 %)
-    if (process().enc_pair.load(std::memory_order_relaxed) && fast_common && !col_stride && D >= 5 && blk_bytes % 16 == 0 &&
+    // (not for a handful of chunks: there a chunk's latency is what counts, and half the lanes per chunk make it longer -- a single 10 KB
+    //  sprintz_compress_xff_16b call 127 us against 111 with one column per lane; from a thousand chunks on the two are level or better)
+    const int pair_from = process().enc_pair.load(std::memory_order_relaxed);
+    if (pair_from > 0 && nchunks >= (uint64_t)pair_from && fast_common && !col_stride && D >= 5 && blk_bytes % 16 == 0 &&
         ((uint64_t)chunk_len * esz) % 16 == 0 && (uint64_t)chunk_len * esz >= 2 * blk_bytes) {
         int pdp = 4;
         while (2 * pdp < D) pdp <<= 1;
@@ -1018,7 +1021,11 @@ int sprintz_mi355x_set_option(int option, int value)
         return 0;
     }
     if (option == SPRINTZ_OPT_SPLIT_LANES) { process().split_lanes = value ? 1 : 0; return 0; }
-    if (option == SPRINTZ_OPT_ENC_PAIR) { process().enc_pair = value ? 1 : 0; return 0; }
+    if (option == SPRINTZ_OPT_ENC_PAIR) {
+        if (value < 0) return fail(SPRINTZ_E_INVALID, "the batch size must not be negative");
+        process().enc_pair = value;
+        return 0;
+    }
     if (option == SPRINTZ_OPT_CHUNKS_PER_GROUP) {
         if (value < 1 || value > 64) return fail(SPRINTZ_E_INVALID, "chunks per group must be in 1..64");
         process().chunks_per_group = value;

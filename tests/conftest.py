@@ -10,6 +10,12 @@ for p in (HERE, ROOT):
         sys.path.insert(0, p)
 
 
+# The two-column encoder (encode_wide.h) takes row-major batches from 1 024 chunks on by default (SPRINTZ_OPT_ENC_PAIR); most tests are
+# smaller than that, so the test session asks for it from one chunk on -- the tests that compare it with the one-column encoder
+# (encode_fast.h) switch the option themselves.
+os.environ.setdefault("SPRINTZ_MI355X_ENC_PAIR", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
