@@ -742,6 +742,7 @@ def test_random_shapes(sz, oracle, seed):
     ("delta", 1, 1, 1024, 5000),          # low-dim: no dense tail in that encoder -- the entry point runs the two launches itself
     ("delta", 1, 80, 1024, 5003), ("xff", 2, 8, 100, 333), ("xff", 2, 128, 2000, 77), ("delta", 1, 5, 77, 1),   # chunks too short for a group: verbatim, written straight into the container
     ("delta", 1, 8, 128, 16384), ("delta", 1, 8, 128, 16385),          # either side of the one-workgroup size scan (the scan + copy side of the comparison)
+    ("xff", 2, 4, 4000, 500), ("delta", 2, 3, 3000, 257),              # 3 and 4 uint16 columns: encode_fast.h on 4 lanes a chunk, the one shape of it that arms the tail
 ])
 @pytest.mark.parametrize("enc_pair", [1, 0])
 def test_container_built_inside_the_encode_launch(sz, oracle, request, codec, esz, ndims, chunk_len, nchunks, enc_pair):
