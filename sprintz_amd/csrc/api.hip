@@ -539,7 +539,7 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     if (fast) {
         const size_t fgroups = kThreads / fdp;
         // input staging: one 8 x D block (row-major: LDS transpose) or two bursts of 4 blocks x fdp columns (column-major)
-        const size_t in_stage = col_stride ? (size_t)2 * 4 * fdp * (esz == 2 ? 16 : 8) : ((blk_bytes + 15) & ~(size_t)15);
+        const size_t in_stage = col_stride ? (size_t)4 * fdp * (esz == 2 ? 16 : 8) : ((blk_bytes + 15) & ~(size_t)15);
         a.lds_group_stride = (uint32_t)(a.cap + in_stage + 16);
         const size_t fshmem = (size_t)a.lds_group_stride * fgroups;
         const uint64_t fthreads = nchunks * (uint64_t)fdp;

@@ -151,8 +151,10 @@ __device__ __forceinline__ uint32_t encode_fast_body(const EncodeArgs& a, uint32
     // in LDS as cst[buffer][column][slot] (slots rotated by column/4, as in the decoder), and every
     // lane picks up its own column's block from there.
     constexpr uint32_t PB = W == 16 ? 16u : 8u;
-    uint8_t* const cst = stage;                            // 2 buffers x 4 blocks x DP columns x PB bytes
-    auto cst_at = [&](uint32_t buf, uint32_t col, uint32_t b4) { return cst + ((buf * DP + col) * 4u + ((b4 + (col >> 2)) & 3u)) * PB; };
+    uint8_t* const cst = stage;                            // 4 blocks x DP columns x PB bytes
+    // (ONE buffer: a burst is parked at the block boundary where the last block of the burst before it has just been taken, in a
+    //  wavefront-synchronous step -- the second buffer this used to keep only cost LDS, i.e. resident waves)
+    auto cst_at = [&](uint32_t, uint32_t col, uint32_t b4) { return cst + (col * 4u + ((b4 + (col >> 2)) & 3u)) * PB; };
     uint4 burst[4];                                        // this lane's share of the burst in flight
     const uint32_t cs_elems = CM ? (uint32_t)a.col_stride : 0u;
     const U* const cm0 = CM ? (const U*)a.src + first / (uint64_t)D : nullptr;
