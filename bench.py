@@ -495,7 +495,7 @@ def bench_cfg5(cx, nrows_all=1 << 20, name="cfg5"):
            "decompress_ms": round(dec_ms, 4), "decompress_MBps": round(raw / dec_ms / 1e3, 1),
            "compress_ms": round(enc_ms, 4), "compress_MBps": round(raw / enc_ms / 1e3, 1),
            "roofline": roofline(sb + 8 * n + raw, dec_ms, "decode_fast_kernel<16,FIRE,32,1,EXACT,0,CM=true>"),
-           "compress_roofline": roofline(raw + sb + 12 * n, enc_ms, "sprintz_mi355x_compress_batch_colmajor_dense: encode_fast<..CM> + size scan + compaction copy (column-major sources keep the launches in a row: measured faster)",
+           "compress_roofline": roofline(raw + sb + 12 * n, enc_ms, "sprintz_mi355x_compress_batch_colmajor_dense: encode_wide<..CM> (two columns per lane) + size scan + compaction copy (column-major sources keep the launches in a row: measured faster)",
                                          {"algorithmic": "raw samples in + dense container out + sizes/offsets (SURVEY 8d)"}),
            "note": ("64 MiB over %d chunks: one launch is %.0f us end to end, about half of it ramp-up and tail (launch-bound at this size; "
                     "cfg5_8m is the same shape at 512 MiB)" % (n, dec_ms * 1e3)) if nrows_all <= (1 << 20) else

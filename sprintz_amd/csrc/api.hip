@@ -517,15 +517,19 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     // (not for a handful of chunks: there a chunk's latency is what counts, and half the lanes per chunk make it longer -- a single 10 KB
     //  sprintz_compress_xff_16b call 127 us against 111 with one column per lane; from a thousand chunks on the two are level or better)
     const int pair_from = process().enc_pair.load(std::memory_order_relaxed);
-    if (pair_from > 0 && nchunks >= (uint64_t)pair_from && fast_common && !col_stride && D >= 5 && blk_bytes % 16 == 0 &&
-        ((uint64_t)chunk_len * esz) % 16 == 0 && (uint64_t)chunk_len * esz >= 2 * blk_bytes) {
+    // (column-major sources too: encode_fast.h's bursts, two columns' blocks per lane)
+    const bool pair_layout = col_stride ? col_stride % 8 == 0 && (chunk_len / (uint32_t)D) % 8 == 0
+                                        : blk_bytes % 16 == 0 && ((uint64_t)chunk_len * esz) % 16 == 0;
+    if (pair_from > 0 && nchunks >= (uint64_t)pair_from && fast_common && D >= 5 && pair_layout && (uint64_t)chunk_len * esz >= 2 * blk_bytes) {
         int pdp = 4;
         while (2 * pdp < D) pdp <<= 1;
         const size_t pgroups = kThreads / pdp;
         // the window as long as it must be (the linear window needs no power of two): 592 instead of 672 bytes a chunk at 8 uint16 columns,
         // four workgroups a CU instead of three
         a.cap = ((uint32_t)group_bytes_max(esz, D) + 48u + (uint32_t)(SPRINTZ_ENC_DRAIN_ALIGN - 16) + 15u) & ~15u;
-        a.lds_group_stride = (uint32_t)(a.cap + ((blk_bytes + 15) & ~(size_t)15) + 16);
+        // input staging: one 8 x D block (row-major: LDS transpose) or a burst of 4 blocks x (2 * pdp) columns (column-major)
+        const size_t pstage = col_stride ? (size_t)4 * (2 * pdp) * (esz == 2 ? 16 : 8) : ((blk_bytes + 15) & ~(size_t)15);
+        a.lds_group_stride = (uint32_t)(a.cap + pstage + 16);
         if ((a.lds_group_stride / 16) % 2 == 0) a.lds_group_stride += 16;    // an odd number of 16-byte units: the chunks of a wavefront start on different banks
         const uint64_t pgrid = (nchunks * (uint64_t)pdp + kThreads - 1) / kThreads;
         if (pgrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");

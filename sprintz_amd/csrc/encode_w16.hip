@@ -26,6 +26,12 @@ hipError_t launch_encode_uni_w16(bool fire, int nd, unsigned grid, hipStream_t s
 }
 #define SPRINTZ_PAIR_CASE(DPV)                                                                                                    \
     case DPV:                                                                                                                      \
+        if (a.col_stride) {                                                                                                        \
+            if (exact) return fire ? launch_one(encode_wide_kernel<16, true, true, false, DPV, true>, grid, shmem, st, a)          \
+                                   : launch_one(encode_wide_kernel<16, false, true, false, DPV, true>, grid, shmem, st, a);        \
+            return fire ? launch_one(encode_wide_kernel<16, true, false, false, DPV, true>, grid, shmem, st, a)                    \
+                        : launch_one(encode_wide_kernel<16, false, false, false, DPV, true>, grid, shmem, st, a);                  \
+        }                                                                                                                          \
         if (exact) return fire ? launch_one(encode_wide_kernel<16, true, true, false, DPV>, grid, shmem, st, a)                    \
                                : launch_one(encode_wide_kernel<16, false, true, false, DPV>, grid, shmem, st, a);                  \
         return fire ? launch_one(encode_wide_kernel<16, true, false, false, DPV>, grid, shmem, st, a)                              \

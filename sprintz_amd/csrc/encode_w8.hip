@@ -39,6 +39,12 @@ hipError_t launch_encode_split_w8(bool fire, unsigned grid, size_t shmem, hipStr
 }
 #define SPRINTZ_PAIR_CASE(DPV)                                                                                                    \
     case DPV:                                                                                                                      \
+        if (a.col_stride) {                                                                                                        \
+            if (exact) return fire ? launch_one(encode_wide_kernel<8, true, true, false, DPV, true>, grid, shmem, st, a)          \
+                                   : launch_one(encode_wide_kernel<8, false, true, false, DPV, true>, grid, shmem, st, a);        \
+            return fire ? launch_one(encode_wide_kernel<8, true, false, false, DPV, true>, grid, shmem, st, a)                    \
+                        : launch_one(encode_wide_kernel<8, false, false, false, DPV, true>, grid, shmem, st, a);                  \
+        }                                                                                                                          \
         if (exact) return fire ? launch_one(encode_wide_kernel<8, true, true, false, DPV>, grid, shmem, st, a)                    \
                                : launch_one(encode_wide_kernel<8, false, true, false, DPV>, grid, shmem, st, a);                  \
         return fire ? launch_one(encode_wide_kernel<8, true, false, false, DPV>, grid, shmem, st, a)                              \

@@ -18,9 +18,12 @@ namespace sprintz {
 // quad of lanes merges (<= 32 bits) before one of them ORs; one scan carries the pairs' bits in its low half and the singles' in
 // its high half.  The decoder's counterpart is decode_fast.h's SPLIT mapping.
 // DPT: lanes a chunk when that is not 64 (two columns per lane for NARROW streams too: 4 lanes for 5 .. 8 columns, 16 chunks a wavefront).
-template <int W, bool FIRE, bool EXACT, bool SPLIT, int DPT>
+// CM: column-major source (EncodeArgs::col_stride), as in encode_fast.h: a quad of lanes loads one column's 64 contiguous bytes
+// (four blocks; 32 bytes at 8 bits) one burst ahead, the pieces wait in LDS, and a lane takes its two columns' blocks from there.
+template <int W, bool FIRE, bool EXACT, bool SPLIT, int DPT, bool CM = false>
 __device__ __forceinline__ uint32_t encode_wide_body(const EncodeArgs& a, uint32_t wg_number)
 {
+    static_assert(!(CM && SPLIT), "column-major sources: two columns per lane only");
     constexpr int DP = SPLIT ? 32 : DPT, CPL = SPLIT ? 3 : 2;
     constexpr int LOG2DP = DP == 4 ? 2 : DP == 8 ? 3 : DP == 16 ? 4 : DP == 32 ? 5 : 6;
     static_assert(DP == 4 || DP == 8 || DP == 16 || DP == 32 || DP == 64, "lanes a chunk");
@@ -116,6 +119,42 @@ __device__ __forceinline__ uint32_t encode_wide_body(const EncodeArgs& a, uint32
         wl += hdr_bytes;
         slot = 0;
     };
+    // ---- column-major source: bursts of four blocks (encode_fast.h; one staging buffer)
+    constexpr uint32_t PB = W == 16 ? 16u : 8u;           // bytes of one block of one column
+    uint8_t* const cst = stage;                            // DP * CPL columns x 4 blocks x PB bytes
+    auto cst_at = [&](uint32_t col, uint32_t b4) { return cst + (col * 4u + ((b4 + (col >> 2)) & 3u)) * PB; };
+    uint4 burst[CM ? 4 * CPL : 1];
+    const uint32_t cs_elems = CM ? (uint32_t)a.col_stride : 0u;
+    const U* const cm0 = CM ? (const U*)a.src + first / (uint64_t)D : nullptr;      // column 0 at this chunk's first row
+    auto burst_load = [&](uint32_t k) {                    // blocks 4k .. 4k+3 of every column
+        if constexpr (CM) {
+#pragma unroll
+            for (int j = 0; j < 4 * CPL; j++) {
+                const uint32_t pid = (uint32_t)j * DP + (uint32_t)lane_d, col = pid >> 2, part = pid & 3u;
+                const int64_t pos = ((int64_t)k * 4 + part) * (int64_t)(8u * (uint32_t)D);
+                burst[j] = make_uint4(0, 0, 0, 0);
+                if (col < (uint32_t)D && pos + (int64_t)(8u * (uint32_t)D) <= (int64_t)n) {
+                    const U* p = cm0 + (uint64_t)col * cs_elems + (uint32_t)pos / (uint32_t)D;
+                    if constexpr (W == 16) burst[j] = *(const uint4*)p;
+                    else { const uint2 t = *(const uint2*)p; burst[j].x = t.x; burst[j].y = t.y; }
+                }
+            }
+        }
+    };
+    auto burst_park = [&]() {
+        if constexpr (CM) {
+#pragma unroll
+            for (int j = 0; j < 4 * CPL; j++) {
+                const uint32_t pid = (uint32_t)j * DP + (uint32_t)lane_d, col = pid >> 2, part = pid & 3u;
+                if (col < (uint32_t)D) {
+                    if constexpr (W == 16) *(uint4*)cst_at(col, part) = burst[j];
+                    else *(uint2*)cst_at(col, part) = make_uint2(burst[j].x, burst[j].y);
+                }
+            }
+        }
+    };
+    uint32_t bno = 0;                                      // blocks taken so far (= pos_in / blk)
+
     uint4 nxt[PIECES];
     auto load_block = [&](int64_t pos) {
 #pragma unroll
@@ -131,22 +170,47 @@ __device__ __forceinline__ uint32_t encode_wide_body(const EncodeArgs& a, uint32
     for (int q = 0; q < PIECES; q++) nxt[q] = make_uint4(0, 0, 0, 0);
     if (active) {
         start_group();
-        load_block(0);
+        if constexpr (CM) {
+            burst_load(0);
+            burst_park();
+            burst_load(1);
+            wave_lds_sync();
+        } else {
+            load_block(0);
+        }
     }
     const uint32_t row_stride = (uint32_t)D;     // elements
 
     while (active) {
         // ---- the block at pos_in is in `nxt`: transpose it through LDS, request the next one
+        uint4 cmcur[CPL];
+        if constexpr (CM) {
+            if ((bno & 3u) == 0 && bno != 0) {             // a new burst starts: park it (the one before it has been taken), request the one after
+                wave_lds_sync();
+                burst_park();
+                burst_load((bno >> 2) + 1);
+                wave_lds_sync();
+            }
 #pragma unroll
-        for (int q = 0; q < PIECES; q++) {
-            const uint32_t u = lane16 + (uint32_t)q * DP * 16u;
-            if (u < blk_bytes) *(uint4*)(stage + u) = nxt[q];
+            for (int k = 0; k < CPL; k++) {
+                cmcur[k] = make_uint4(0, 0, 0, 0);
+                if (col_ok[k]) {
+                    if constexpr (W == 16) cmcur[k] = *(const uint4*)cst_at((uint32_t)genk[k], bno & 3u);
+                    else { const uint2 t = *(const uint2*)cst_at((uint32_t)genk[k], bno & 3u); cmcur[k].x = t.x; cmcur[k].y = t.y; }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < PIECES; q++) {
+                const uint32_t u = lane16 + (uint32_t)q * DP * 16u;
+                if (u < blk_bytes) *(uint4*)(stage + u) = nxt[q];
+            }
+            wave_lds_sync();
+            load_block(pos_in + blk);
         }
-        wave_lds_sync();
-        load_block(pos_in + blk);
         uint32_t z[CPL][8], nb[CPL], lane_bits = 0;
         uint32_t xp[8];                                    // 8 bits: the pair's two samples of a row come as ONE 16-bit LDS read
-        if constexpr (W == 8) {                            // (rows are an even number of bytes -- blocks are 16-byte multiples -- and the pair starts on an even column)
+        if constexpr (W == 8 && !CM) {                     // (rows are an even number of bytes -- blocks are 16-byte multiples -- and the pair starts on an even column)
 #pragma unroll
             for (int i = 0; i < 8; i++) xp[i] = col_ok[0] ? (uint32_t)*(const uint16_t*)(stage + (uint32_t)genk[0] + i * row_stride) : 0u;
         }
@@ -155,7 +219,15 @@ __device__ __forceinline__ uint32_t encode_wide_body(const EncodeArgs& a, uint32
             uint32_t x[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                if (W == 8 && k < 2) x[i] = col_ok[k] ? (k == 0 ? xp[i] & 0xffu : xp[i] >> 8) : 0u;
+                if constexpr (CM) {                        // the lane's own column block, eight samples in registers
+                    if constexpr (W == 16) {
+                        const uint32_t d = (i >> 1) == 0 ? cmcur[k].x : (i >> 1) == 1 ? cmcur[k].y : (i >> 1) == 2 ? cmcur[k].z : cmcur[k].w;
+                        x[i] = (i & 1) ? d >> 16 : d & 0xffffu;
+                    } else {
+                        const uint32_t d = (i >> 2) == 0 ? cmcur[k].x : cmcur[k].y;
+                        x[i] = (d >> (8 * (i & 3))) & 0xffu;
+                    }
+                } else if (W == 8 && k < 2) x[i] = col_ok[k] ? (k == 0 ? xp[i] & 0xffu : xp[i] >> 8) : 0u;
                 else x[i] = col_ok[k] ? (uint32_t)((const U*)stage)[(uint32_t)genk[k] + i * row_stride] : 0u;
             }
             const int coef = FIRE ? fire_coef<W, false>(ctr[k]) : 0;
@@ -182,7 +254,7 @@ __device__ __forceinline__ uint32_t encode_wide_body(const EncodeArgs& a, uint32
             nb[k] = col_ok[k] ? nbits_of<W, false>(mask) : 0u;
             if (k < 2) lane_bits += nb[k];                 // the pair's bits (the single column of the split mapping is scanned beside them)
         }
-        wave_lds_sync();
+        if constexpr (!CM) wave_lds_sync();
         uint32_t total, excl, excl_single = 0;
         if constexpr (SPLIT) {                             // columns 0 .. 63, lane by lane, then the singles: <= 512 and <= 256 bits
             uint32_t both;
@@ -199,6 +271,7 @@ __device__ __forceinline__ uint32_t encode_wide_body(const EncodeArgs& a, uint32
             if (total == 0 && run < 0x7fffu && !a.norle) {
                 run++;
                 pos_in += blk;
+                bno++;
                 const bool more = TAIL_LE ? (pos_in <= limit) : (pos_in < limit);
                 if (more) break;
                 slot++;
@@ -263,6 +336,7 @@ __device__ __forceinline__ uint32_t encode_wide_body(const EncodeArgs& a, uint32
             }
             wl += row_bits;
             pos_in += blk;
+            bno++;
             slot++;
             if (slot == 2) {
                 if (pos_in <= limit) start_group();
@@ -281,7 +355,16 @@ __device__ __forceinline__ uint32_t encode_wide_body(const EncodeArgs& a, uint32
             drain(wl & ~15u);
             const uint32_t room = cap - 16u - wl;
             const uint32_t m = left < room ? left : room;
-            for (uint32_t j = (uint32_t)lane_d; j < m; j += DP) win[wl + j] = tp[j];
+            if constexpr (CM) {                            // the tail continues the row-major order: element e sits in column e % D
+                const uint32_t done = remaining * ESZ - left;
+                for (uint32_t j = (uint32_t)lane_d; j < m; j += DP) {
+                    const uint32_t tb = done + j, e = (uint32_t)pos_in + tb / ESZ;
+                    const uint32_t xv = (uint32_t)cm0[(uint64_t)(e % (uint32_t)D) * a.col_stride + e / (uint32_t)D];
+                    win[wl + j] = (uint8_t)(xv >> (8u * (tb % ESZ)));
+                }
+            } else {
+                for (uint32_t j = (uint32_t)lane_d; j < m; j += DP) win[wl + j] = tp[j];
+            }
             wl += m;
             tp += m;
             left -= m;
@@ -307,14 +390,14 @@ __device__ __forceinline__ uint32_t encode_wide_body(const EncodeArgs& a, uint32
     return total_bytes;
 }
 
-template <int W, bool FIRE, bool EXACT, bool SPLIT = false, int DPT = 64>
+template <int W, bool FIRE, bool EXACT, bool SPLIT = false, int DPT = 64, bool CM = false>
 __global__ void __launch_bounds__(kThreads) encode_wide_kernel(EncodeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int DP = SPLIT ? 32 : DPT;
     constexpr uint32_t LOG2DP = DP == 4 ? 2 : DP == 8 ? 3 : DP == 16 ? 4 : DP == 32 ? 5 : 6;
     const uint32_t wg = workgroup_number(a.dn);
-    const uint32_t size = encode_wide_body<W, FIRE, EXACT, SPLIT, DPT>(a, wg);
+    const uint32_t size = encode_wide_body<W, FIRE, EXACT, SPLIT, DPT, CM>(a, wg);
     // the container, built before the workgroup leaves (compact_tail.h); without it the caller compacts the slots
     if (a.dn.dense) dense_tail(a.dn, wg, a.nchunks, LOG2DP, size, a.slots, a.slot_stride, smem, a.lds_group_stride);
 }

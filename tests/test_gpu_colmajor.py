@@ -36,9 +36,13 @@ CM_CONFIGS = [
 ]
 
 
+@pytest.mark.parametrize("enc_pair", [1, 0])          # two columns per lane (encode_wide.h, column-major source) / one (encode_fast.h)
 @pytest.mark.parametrize("name,codec,esz,ndims,rpc,nrows,cs", CM_CONFIGS)
-def test_colmajor_matches_oracle_on_the_transposed_view(sz, oracle, name, codec, esz, ndims, rpc, nrows, cs):
+def test_colmajor_matches_oracle_on_the_transposed_view(sz, oracle, request, name, codec, esz, ndims, rpc, nrows, cs, enc_pair):
     import torch
+    from sprintz_amd import _lib
+    _lib.check(_lib.set_option(_lib.OPT_ENC_PAIR, enc_pair))
+    request.addfinalizer(lambda: _lib.set_option(_lib.OPT_ENC_PAIR, 1))
     rng = np.random.default_rng(zlib.crc32(name.encode()))
     cs = cs or nrows
     top = 1 << (8 * esz)
