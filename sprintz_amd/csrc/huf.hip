@@ -867,7 +867,7 @@ int sprintz_mi355x_huf0_compress_batch(const void* d_dense, const uint64_t* d_of
     hipLaunchKernelGGL(huf_build_kernel, dim3((unsigned)nseg), dim3(256), 0, st, (const uint8_t*)d_dense, d_offsets, d_sizes, nchunks,
                        enc_tables, nib);
     hipLaunchKernelGGL(huf0_table_kernel, dim3((unsigned)nseg), dim3(64), 0, st, (const uint8_t*)nib, recs);
-    hipLaunchKernelGGL(huf0_size_kernel, dim3((unsigned)nseg), dim3(256), 0, st, (const uint8_t*)d_dense, d_offsets, d_sizes, nchunks,
+    hipLaunchKernelGGL(huf0_size_kernel, dim3((unsigned)nseg), dim3(256), nseg >= kSizePassPadFrom ? kSizePassPad : 0, st, (const uint8_t*)d_dense, d_offsets, d_sizes, nchunks,
                        (const uint8_t*)recs, bsizes, meta);
     if (launch_size_scan(bsizes, nchunks, 1, d_block_offsets, scan_tmp, st) != hipSuccess) return sprintz::set_error(SPRINTZ_E_HIP, "Huffman stage: a HIP call or kernel launch failed");
     hipLaunchKernelGGL(huf0_encode_kernel, dim3((unsigned)nseg), dim3(256), 0, st, (const uint8_t*)d_dense, d_offsets, d_sizes, nchunks,

@@ -13,6 +13,10 @@
 // per-segment record (H1 -> H2, H3): hlen u32 @0 (0 = no table: the segment's chunks are stored) | tableLog u32 @4 |
 // tree description, <= 160 bytes @8 | code values 256 x u16 @192 | code lengths 256 x u8 @704
 constexpr int kRecBytes = 1024, kRecHdr = 8, kRecTab = 192;
+#ifndef HUF0S_PAD
+#define HUF0S_PAD 40000
+#endif
+constexpr unsigned kSizePassPad = HUF0S_PAD, kSizePassPadFrom = 4096;      // huf0_size_kernel: dynamic LDS claimed (unused) from this many workgroups on
 
 struct BitW {                           // bytes into LDS, LSB first (bitstream.h BIT_CStream_t)
     uint8_t* p; uint64_t acc; int nbits; uint32_t n;
@@ -180,6 +184,12 @@ __global__ void __launch_bounds__(256) huf0_size_kernel(const uint8_t* __restric
                                                         uint64_t* __restrict__ meta)
 {
     __shared__ uint8_t lens[256];
+    // The pass reads every stream once, 64 bytes a lane per trip, and needs no LDS to speak of -- so 32 waves a CU were resident, 65 000 lanes per
+    // XCD each with its own 128-byte line open, and a line had left the 4 MB L2 again before its lane came back for the second half
+    // (FETCH_SIZE x 2 = 4.4 GB for 2.9 GB of streams).  For big batches the launch claims kSizePassPad bytes of dynamic LDS the kernel does
+    // not use: 16 waves a CU, the writer's four passes 6.08 -> 5.65 ms at 800 000 chunks in the first same-box run (8 waves: the same; 24: no
+    // gain), 6.0 -> 5.7 .. 6.0 in later ones.  Not below a few rounds of workgroups: at 80 000 chunks (1 250 workgroups) half the resident slots
+    // cost more than the L2 gives back (0.85 -> 0.91 ms).
     const int t = threadIdx.x, j = t & 3;
     const uint64_t seg = blockIdx.x, c = seg * SEG + (uint64_t)(t >> 2);
     const uint8_t* const rec = recs + seg * kRecBytes;
