@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(kScanBlock) scan_one_kernel(const uint32_t* si
 #define SPRINTZ_COPY_SMALL_LOG2 5
 #endif
 // one wavefront per chunk: slot -> dense (LOG2L = 5: half a wavefront per chunk -- slots of at most 2 KB, where a chunk's stream is a few
-// hundred bytes and 64 lanes x 16 bytes leave most of the wavefront idle: BASELINE config 1's 440-byte streams 0.133 -> see DESIGN 4.2b)
+// hundred bytes and 64 lanes x 16 bytes leave most of the wavefront idle: BASELINE config 1's 440-byte streams, compress 0.434 -> 0.402 ms; a quarter: 0.403)
 template <int LOG2L>
 __global__ void __launch_bounds__(kThreads) compact_copy_kernel(const uint8_t* slots, uint64_t slot_stride, const uint32_t* sizes,
                                                                 const uint64_t* offsets, uint64_t nchunks, uint32_t align,
