@@ -56,10 +56,14 @@ def parse():
     p.add_argument("--configs", default="all", help="per_config entries to run: 'all', 'none' or a comma list of " + ",".join(ALL_CONFIGS))
     p.add_argument("--only", default="", help="profiling aid: run ONLY this per_config entry (no headline), print its JSON")
     p.add_argument("--config-reps", type=int, default=20)
+    p.add_argument("--no-sweep", action="store_true", help="skip data_sweep (the headline shape on uniform / walk300 / walkflat data)")
     p.add_argument("--no-extras", action="store_true", help="skip the Huffman / query / latency extras of the headline batch")
     p.add_argument("--dry-launch", action="store_true",
                    help="launch check only: bring the N ranks up (self-launching them if need be), all-gather the ranks, print one JSON "
                         "line; needs no GPU (gloo without one)")
+    p.add_argument("--rccl", action="store_true",
+                   help="with --dry-launch: also run the library's own layout gather (comm.cpp, ncclAllGather behind the C-ABI) over the N "
+                        "ranks and check what every rank received -- seconds on a multi-GPU box, needs one GPU per rank")
     return p.parse_args()
 
 
@@ -234,7 +238,8 @@ def cpu_baseline(comp_np, offs_np, nchunks, codec_id, esz, chunk_len, target_s, 
     n_one = min(n_one, nchunks)
     r = time_cpu_mt(call, n_one, nchunks, chunk_bytes, target_s)
     r.update({"unit": "MB/s", "kind": kind,
-              "sample": f"{what} per chunk on this configuration's own compressed chunks, data in RAM; all-core legs: {nchunks} chunks "
+              "sample": f"{nchunks} chunks ({nchunks * chunk_bytes / 1e6:.0f} MB raw) of this workload, {r['passes']} passes, best of 3, {r['cores']} pinned pthreads; 1-thread leg: {n_one} chunks",
+              "sample_detail": f"{what} per chunk on this configuration's own compressed chunks, data in RAM; all-core legs: {nchunks} chunks "
                         f"({nchunks * chunk_bytes / 1e6:.0f} MB raw), one contiguous chunk range per pinned pthread (oracle/mt_bench.c), sustained "
                         f"over {r['passes']} passes, best of 3; `value`/`cores` = one thread per physical core, at most the container's CPU quota; 1-thread leg: first {n_one} chunks; "
                         f"value_cache_resident: the same threads on ~256 KB of samples each (L2-resident)"})
@@ -279,7 +284,8 @@ def cpu_baseline_huf0_chain(blocks_np, boffs_np, sizes_np, nchunks, esz, chunk_l
     n_one = min(n_one, nchunks)
     r = time_cpu_mt(call, n_one, nchunks, chunk_bytes, target_s)
     r.update({"unit": "MB/s", "kind": kind,
-              "sample": f"{hname} then sprintz_decompress_xff_16b per chunk on this configuration's own Huff0 blocks; all-core legs: {nchunks} chunks "
+              "sample": f"{nchunks} chunks ({nchunks * chunk_bytes / 1e6:.0f} MB raw) of this workload, {hname} + sprintz decode, {r['passes']} passes, best of 3, {r['cores']} pinned pthreads",
+              "sample_detail": f"{hname} then sprintz_decompress_xff_16b per chunk on this configuration's own Huff0 blocks; all-core legs: {nchunks} chunks "
                         f"({nchunks * chunk_bytes / 1e6:.0f} MB raw), one chunk range per pinned pthread, {r['passes']} passes, best of 3; "
                         f"`value`/`cores` = one thread per physical core, at most the container's CPU quota; 1-thread leg: first {n_one} chunks"})
     return r
@@ -345,8 +351,8 @@ def bench_rowmajor(cx, name, workload, codec, esz, ndims, chunk_len, nchunks_tot
     if rows is not None:
         x = synth_torch(kind, esz, n, rows, ndims, dev, seed=123, step=step, chunk0=lo + (0 if strong else cx.rank * nchunks_total))
     else:                                   # cfg3 at 1024 elements: chunks cut rows (the reference stores them raw anyway)
-        tot_rows = (n * chunk_len + ndims - 1) // ndims
-        x = synth_torch(kind, esz, 1, tot_rows, ndims, dev, seed=123 + cx.rank, step=step)[: n * chunk_len].contiguous()
+        from synth import synth_cut_rows
+        x = synth_cut_rows(kind, esz, n, chunk_len, ndims, dev, seed=123 + cx.rank, step=step)
     if esz == 2:
         x = x.view(torch.int16)
     cd = sprintz_amd.ChunkedCodec(codec, esz, ndims, chunk_len, device=dev)
@@ -436,14 +442,15 @@ def bench_rowmajor(cx, name, workload, codec, esz, ndims, chunk_len, nchunks_tot
         if cx.rank == 0 and not args.no_cpu_baseline:
             ns = min(n, max(64, CPU_SAMPLE_BYTES // (chunk_len * esz)))
             zo = z_offs[: ns + 1].cpu().numpy().astype("uint64")
-            res["cpu_baseline"] = cpu_baseline_huf0_chain(z_buf[: int(zo[ns]) + 64].cpu().numpy(), zo,
-                                                           ws["sizes"][:ns].cpu().numpy().astype("uint32"), ns, esz, chunk_len, 1.0)
+            zb_h, sz_h = z_buf[: int(zo[ns]) + 64].cpu().numpy(), ws["sizes"][:ns].cpu().numpy().astype("uint32")
+            cx.cpu_jobs.append((res, lambda: cpu_baseline_huf0_chain(zb_h, zo, sz_h, ns, esz, chunk_len, 1.0)))
         del z_buf, s_buf
     elif cx.rank == 0 and not args.no_cpu_baseline:
         ns = min(n, max(64, CPU_SAMPLE_BYTES // (chunk_len * esz)))
         o = offs[: ns + 1].cpu().numpy().astype("uint64")
-        res["cpu_baseline"] = cpu_baseline(comp[: int(o[ns]) + 64].cpu().numpy(), o, ns, 1 if codec == "xff" else 0, esz, chunk_len, 1.0,
-                                           f"sprintz_decompress_{codec}_{8 * esz}b", n_one=max(64, (80 << 20) // (chunk_len * esz)))
+        c_h = comp[: int(o[ns]) + 64].cpu().numpy()
+        cx.cpu_jobs.append((res, lambda: cpu_baseline(c_h, o, ns, 1 if codec == "xff" else 0, esz, chunk_len, 1.0,
+                                                      f"sprintz_decompress_{codec}_{8 * esz}b", n_one=max(64, (80 << 20) // (chunk_len * esz)))))
     res["_local"] = (raw, stream_bytes if not huff0 else hbytes, res["decompress_ms"], res["compress_ms"])
     del x, comp, out, src
     cd._ws = {}
@@ -503,9 +510,11 @@ def bench_cfg5(cx, nrows_all=1 << 20, name="cfg5"):
     if cx.rank == 0 and not args.no_cpu_baseline:
         ns = min(n, max(64, CPU_SAMPLE_BYTES // (rpc * D * esz)))
         o = batch.offsets[: ns + 1].cpu().numpy().astype("uint64")
-        res["cpu_baseline"] = cpu_baseline(batch.data[: int(o[ns]) + 64].cpu().numpy(), o, ns, 1, esz, rpc * D, 1.0,
-                                           "sprintz_decompress_xff_16b (row-major flattening: the reference has no column-major entry)",
-                                           last_chunk_len=(nrows - (n - 1) * rpc) * D if ns == n else None)
+        c_h = batch.data[: int(o[ns]) + 64].cpu().numpy()
+        last = (nrows - (n - 1) * rpc) * D if ns == n else None
+        cx.cpu_jobs.append((res, lambda: cpu_baseline(c_h, o, ns, 1, esz, rpc * D, 1.0,
+                                                      "sprintz_decompress_xff_16b (row-major flattening: the reference has no column-major entry)",
+                                                      last_chunk_len=last)))
     res["_local"] = (raw, sb, res["decompress_ms"], res["compress_ms"])
     del cols, batch, out, dense
     cd._ws = {}
@@ -639,10 +648,28 @@ def dry_launch(args, world, rank):
         got = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(got, t)
         seen = [int(g.item()) for g in got]
+    rccl = None
+    if args.rccl:
+        # the product's own exchange (csrc/comm.cpp: ncclAllGather behind the C-ABI) on a real communicator of `world` ranks:
+        # rank r contributes 1000 + r bytes, every rank must see all of them and derive the same bases
+        assert use_gpu and (world == 1 or backend == "nccl"), "--rccl needs one visible GPU per rank (RCCL refuses two ranks on one device)"
+        from sprintz_amd.dist import LayoutGather
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(dev)
+        g = LayoutGather(dev)
+        lay = g.layout(1000 + rank)
+        want = [1000 + r for r in range(world)]
+        assert lay.rank_bytes == want, (lay.rank_bytes, want)
+        assert lay.rank_base == [sum(want[:r]) for r in range(world)] and lay.total_bytes == sum(want)
+        rccl = {"backend": g.backend, "ranks_seen": g.ranks_seen, "c_abi_error": g.c_abi_error, "rank_bytes": lay.rank_bytes}
+        assert world == 1 or g.comm is not None, f"comm.cpp could not bring RCCL up: {g.c_abi_error}"
+        g.close()
+    if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({"dry_launch": True, "n_gpus": args.gpus, "world": world, "ranks": seen, "backend": backend if world > 1 else None,
-                          "self_launched": bool(os.environ.get("BENCH_SELF_LAUNCHED"))}), flush=True)
+                          "self_launched": bool(os.environ.get("BENCH_SELF_LAUNCHED")), "rccl_c_abi": rccl}), flush=True)
 
 
 def main():
@@ -696,13 +723,18 @@ def main():
 
     cx = Ctx()
     cx.torch, cx.device, cx.world, cx.rank, cx.args, cx.timer = torch, device, world, rank, args, Timer(torch)
+    cx.cpu_jobs = []                      # rank 0's host legs: run after the last collective (see the end of main)
+    numa, cx.affinity_before = pin_to_gpu_numa_node(torch, local_rank) if world > 1 else ({"numa": "single rank: not pinned"}, None)
 
     if args.only:
         res = merge_over_ranks(cx, run_config(cx, args.only))
-        if rank == 0:
-            emit(res)
         if world > 1:
+            dist.barrier()
             dist.destroy_process_group()
+        if rank == 0:
+            restore_affinity(cx)
+            run_cpu_jobs(cx)
+            emit(res)
         return
 
     codec_name, esz, ndims, chunk_len = "xff", 2, 8, 5120
@@ -805,7 +837,7 @@ def main():
                      "traffic_source": traffic_label, "algorithmic_bytes_per_launch": algo_bytes,
                      "kernel": "decode_fast_kernel<16,FIRE,8,1,EXACT>"},
         "container_bytes_all_ranks": layout.total_bytes, "rank_bases": layout.bases[:8], "rccl_ranks_seen": gather.ranks_seen,
-        "host": host_description(),
+        "host": {**host_description(), **numa},
     }
 
     if rank == 0 and not args.no_extras:
@@ -822,12 +854,14 @@ def main():
         ns = min(nchunks, max(64, CPU_SAMPLE_BYTES // chunk_bytes))
         offs_np = offsets[: ns + 1].cpu().numpy().astype("uint64")
         comp_np = comp[: int(offs_np[ns]) + 64].cpu().numpy()
-        cb = cpu_baseline(comp_np, offs_np, ns, 1, esz, chunk_len, args.cpu_seconds, "sprintz_decompress_xff_16b")
-        if cb is not None:
-            result["cpu_baseline"] = cb
+        cx.cpu_jobs.append((result, lambda: cpu_baseline(comp_np, offs_np, ns, 1, esz, chunk_len, args.cpu_seconds, "sprintz_decompress_xff_16b")))
     del x, comp, out, src_padded
     codec._ws = {}
     torch.cuda.empty_cache()
+
+    # ---------------- the headline shape on SURVEY 8d's other generators (G0 uniform, G1 +-300, G2 walk + flat spans)
+    if not args.no_sweep:
+        result["data_sweep"] = data_sweep(cx, codec, nchunks, rows, ndims, chunk_len, esz)
 
     # ---------------- every other BASELINE configuration, same process, same clock
     names = [] if args.configs == "none" else (ALL_CONFIGS if args.configs == "all" else [c for c in args.configs.split(",") if c])
@@ -840,8 +874,47 @@ def main():
                 raise
             per.append({"name": nm, "error": f"{type(e).__name__}: {e}"})
     result["per_config"] = per
-    # the LAST key: one short entry per configuration, so that a reader who keeps only the tail of this line sees them all --
-    # [decompress ms, fraction of the HBM roofline over algorithmic bytes, compress ms, compress fraction, CPU all-core MB/s, CPU 1-thread MB/s]
+
+    # ---------------- the last collective is behind us: the ranks part, and ONLY THEN does rank 0 spend its minute of CPU legs
+    # (no rank waits inside RCCL while another one times the host)
+    gather.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+    restore_affinity(cx)
+    run_cpu_jobs(cx)
+    finish_and_emit(result, emit)
+
+
+def run_cpu_jobs(cx):
+    for target, job in cx.cpu_jobs:
+        r = job()
+        if r is not None:
+            target["cpu_baseline"] = r
+    cx.cpu_jobs = []
+
+
+SUMMARY_FIELDS = "dec_ms, dec_frac, enc_ms, enc_frac, cpu_allcore_MBps, cpu_1thread_MBps"
+LINE_LIMIT = 10000          # the driver's parser took a 13.4 KB line and not a 24.5 KB one: stay well inside
+LONG_TEXT_KEYS = ("what", "note", "sample_detail", "algorithmic", "traffic_note", "blocks", "reference_build", "parity", "kernel_detail",
+                  "threads_limit", "entropy_stage")
+
+
+def compact(obj, depth=0):
+    """the line the driver parses: every number, none of the prose (that lives in bench_full.json)"""
+    if isinstance(obj, dict):
+        return {k: compact(v, depth + 1) for k, v in obj.items() if k not in LONG_TEXT_KEYS and k != "per_config"}
+    if isinstance(obj, list):
+        return [compact(v, depth + 1) for v in obj]
+    return obj
+
+
+def finish_and_emit(result, emit):
+    """per_config_summary (LAST key: a reader who keeps only the tail of the line sees every configuration), the full record to
+    bench_full.json + stderr, the compact line to stdout"""
+    per = result["per_config"]
     summ = {"cfg2": [result["kernel_ms"], result["roofline"]["frac"], result["compress"]["ms_per_step_max_rank"], result["compress"]["roofline_frac"],
                      result.get("cpu_baseline", {}).get("value"), result.get("cpu_baseline", {}).get("value_1thread")]}
     for e in per[1:]:
@@ -849,13 +922,98 @@ def main():
             summ[e["name"]] = "error"
             continue
         cb = e.get("cpu_baseline") or {}
-        summ[e["name"]] = [e["decompress_ms"], e["roofline"]["frac"], e["compress_ms"], e["compress_roofline"]["frac"], cb.get("value"), cb.get("value_1thread")]
-    result["per_config_summary"] = {"fields": "dec_ms, dec_frac, enc_ms, enc_frac, cpu_allcore_MBps, cpu_1thread_MBps", **summ}
-    if rank == 0:
-        emit(result)
-    gather.close()
-    if world > 1:
-        dist.destroy_process_group()
+        j = e.get("job") or {}
+        summ[e["name"]] = [j.get("decompress_ms_max_rank", e["decompress_ms"]), e["roofline"]["frac"], j.get("compress_ms_max_rank", e["compress_ms"]),
+                           e["compress_roofline"]["frac"], cb.get("value"), cb.get("value_1thread")]
+    result["per_config_summary"] = {"fields": SUMMARY_FIELDS, **summ}
+    full_path = os.path.join(ROOT, "bench_full.json")
+    result["full_record"] = "bench_full.json next to bench.py (per_config entries, the prose of every field); also on stderr"
+    result["per_config_summary"] = result.pop("per_config_summary")          # stays the last key
+    try:
+        with open(full_path, "w") as f:
+            json.dump(result, f)
+            f.write("\n")
+    except OSError as e:
+        print(f"bench_full.json not written: {e}", file=sys.stderr)
+    print("BENCH_FULL " + json.dumps(result), file=sys.stderr, flush=True)
+    line = compact(result)
+    n = len(json.dumps(line))
+    assert n < LINE_LIMIT, f"the JSON line is {n} bytes: the driver's parser needs it short (per_config and prose belong in bench_full.json)"
+    emit(line)
+
+
+def data_sweep(cx, codec, nchunks, rows, ndims, chunk_len, esz):
+    """SURVEY 8d's generators on the headline shape, same launches as the headline: G0 uniform (the paper's worst case,
+    results.tex:142-146 -- every field 16 bits, stream > input), G1 walk +-300, G2 walk + flat spans (every 4th 64-row span
+    constant: the encoder's RLE state machine and the decoder's run replay, sprintz_xff_rle.cpp:828-958, are on the path).
+    Each: one-launch compress, decode checked against the input, then both timed.  -> {kind: [dec_ms, dec_frac, enc_ms, enc_frac, ratio]}"""
+    torch, dev, timer, args = cx.torch, cx.device, cx.timer, cx.args
+    from sprintz_amd import _lib
+    from sprintz_amd.dist import max_over_ranks
+    from synth import synth_torch
+    out = {"fields": "dec_ms, dec_frac, enc_ms, enc_frac, ratio", "chunks_per_gpu": nchunks}
+    raw = nchunks * chunk_len * esz
+    for name in ("uniform", "walk300", "walkflat"):
+        kind, step = DATA_KINDS[name]
+        x = synth_torch(kind, esz, nchunks, rows, ndims, dev, seed=123, step=step, chunk0=cx.rank * nchunks).view(torch.int16)
+        src = codec._padded_view(x)
+        ws = codec.workspace(nchunks)
+        dense = torch.empty(nchunks * codec.slot_stride + _lib.READ_SLACK, dtype=torch.uint8, device=dev)
+        offs = torch.empty(nchunks + 1, dtype=torch.int64, device=dev)
+        o = torch.empty(nchunks * chunk_len, dtype=torch.int16, device=dev)
+        rets = torch.empty(nchunks, dtype=torch.int64, device=dev)
+        enc_ms = timer(lambda: codec.compress_dense(src, x.numel(), ws, dense, offs), 10)
+        total = int(offs[-1].item())
+        sb = int(ws["sizes"].to(torch.int64).sum().item())
+        codec.decompress_into(dense, offs, nchunks, o, rets)
+        torch.cuda.synchronize()
+        if not args.no_verify:
+            assert torch.equal(o, x), f"data_sweep {name}: GPU decode != input"
+            assert bool((rets == chunk_len).all().item()), name
+        dec_ms = timer(lambda: codec.decompress_into(dense, offs, nchunks, o), 20)
+        enc_ms, dec_ms = max_over_ranks(enc_ms, dev), max_over_ranks(dec_ms, dev)
+        out[name] = [round(dec_ms, 4), round((sb + 8 * nchunks + raw) / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     round(enc_ms, 4), round((raw + total + 12 * nchunks) / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), round(raw / sb, 4)]
+        del x, src, dense, o
+        codec._ws = {}
+        torch.cuda.empty_cache()
+    return out
+
+
+def pin_to_gpu_numa_node(torch, local_rank):
+    """one rank per GPU: run this rank's host threads on the CPUs of the GPU's NUMA node (sysfs: the PCI device's
+    local_cpulist), so that launches and pinned staging stay node-local.  -> (description for `host`, affinity to restore)"""
+    try:
+        before = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return {"numa": "no sched_getaffinity"}, None
+    info = {"numa_node": None, "cpus_pinned": None}
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        base = f"/sys/bus/pci/devices/{bdf}"
+        info["pci"] = bdf
+        info["numa_node"] = int(open(base + "/numa_node").read())
+        cpus = set()
+        for part in open(base + "/local_cpulist").read().strip().split(","):
+            if part:
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= set(before)
+        if cpus and len(cpus) < len(before):
+            os.sched_setaffinity(0, cpus)
+            info["cpus_pinned"] = len(cpus)
+    except Exception as e:                       # no sysfs entry, no such attribute: run unpinned and say so
+        info["numa_error"] = f"{type(e).__name__}: {e}"[:120]
+    return info, before
+
+
+def restore_affinity(cx):
+    if getattr(cx, "affinity_before", None):
+        try:
+            os.sched_setaffinity(0, cx.affinity_before)
+        except OSError:
+            pass
 
 
 def headline_extras(cx, codec, x, comp, offsets, ws, out, nchunks, total_comp, chunk_len, ndims, esz, step_ms):

@@ -25,7 +25,7 @@ def one_db(d):
     return sqlite3.connect(files[0]) if files else None
 
 
-OURS = ("sprintz", "huf", "compact_copy", "scan_", "zigzag_kernel", "dyndelta", "pack_w", "unpack_", "xff_kernel")
+OURS = ("sprintz", "huf", "compact_copy", "scan_", "zigzag_kernel", "dyndelta", "pack_w", "unpack_", "xff_kernel", "verbatim_")
 
 # kernel substring quoted by bench.py -> (workload whose PMC passes hold it, nchunks, data)
 DOMINANT = {"decode_fast_kernel<16, true, 8": ("headline", 131072, "walk8")}

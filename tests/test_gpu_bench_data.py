@@ -33,18 +33,20 @@ def bench_input(name, device):
     from synth import synth_torch
     if name == "cfg2":
         return ("xff", 2, 8, 5120, 131072), synth_torch("walk", 2, 131072, 640, 8, device, seed=123, step=8, chunk0=0)
+    if name.startswith("cfg2_"):               # bench.py's data_sweep: the headline shape on SURVEY 8d's other generators
+        kind, step = {"cfg2_uniform": ("uniform", 0), "cfg2_walk300": ("walk", 300), "cfg2_walkflat": ("walkflat", 8)}[name]
+        return ("xff", 2, 8, 5120, 131072), synth_torch(kind, 2, 131072, 640, 8, device, seed=123, step=step, chunk0=0)
     if name == "cfg1":
         return ("delta", 1, 1, 1024, 524288), synth_torch("walk", 1, 524288, 1024, 1, device, seed=123, step=2, chunk0=0)
     if name == "cfg3_10k":
         return ("delta", 1, 80, 10240, 52429), synth_torch("walk", 1, 52429, 128, 80, device, seed=123, step=2, chunk0=0)
-    if name == "cfg3_1k":                      # 1024 elements do not hold whole rows of 80: one long series, cut every 1024
-        n, chunk_len, ndims = 524288, 1024, 80
-        tot_rows = (n * chunk_len + ndims - 1) // ndims
-        return ("delta", 1, 80, 1024, n), synth_torch("walk", 1, 1, tot_rows, ndims, device, seed=123, step=2)[: n * chunk_len].contiguous()
+    if name == "cfg3_1k":                      # 1024 elements do not hold whole rows of 80: 64-row series, cut every 1024
+        from synth import synth_cut_rows
+        return ("delta", 1, 80, 1024, 524288), synth_cut_rows("walk", 1, 524288, 1024, 80, device, seed=123, step=2)
     raise ValueError(name)
 
 
-@pytest.mark.parametrize("name", ["cfg2", "cfg1", "cfg3_1k", "cfg3_10k"])
+@pytest.mark.parametrize("name", ["cfg2", "cfg2_uniform", "cfg2_walk300", "cfg2_walkflat", "cfg1", "cfg3_1k", "cfg3_10k"])
 def test_bench_inputs_roundtrip_and_sample_parity(sz, oracle, name):
     import torch
     (codec, esz, ndims, chunk_len, nchunks), x = bench_input(name, "cuda:0")
@@ -65,7 +67,8 @@ def test_bench_inputs_roundtrip_and_sample_parity(sz, oracle, name):
         assert np.array_equal(comp[offs[c]:offs[c] + sizes[c]], want), (name, c)
     ratio = x.numel() * esz / float(sizes.astype(np.int64).sum())
     # the ratios bench.py prints for these inputs (BASELINE.md / DESIGN.md 5): a generator that drifted would show here
-    lo, hi = {"cfg2": (2.7, 3.0), "cfg1": (2.2, 2.5), "cfg3_1k": (0.98, 1.0), "cfg3_10k": (2.1, 2.4)}[name]
+    lo, hi = {"cfg2": (2.7, 3.0), "cfg1": (2.2, 2.5), "cfg3_1k": (0.98, 1.0), "cfg3_10k": (2.1, 2.4),
+              "cfg2_uniform": (0.96, 0.98), "cfg2_walk300": (1.4, 1.6), "cfg2_walkflat": (3.0, 6.0)}[name]
     assert lo < ratio < hi, (name, ratio)
 
 

@@ -83,6 +83,16 @@ def synth_torch(kind, esz, nchunks, rows, ndims, device, seed=123, step=8, chunk
     return out
 
 
+def synth_cut_rows(kind, esz, nchunks, chunk_len, ndims, device, seed=123, step=8):
+    """chunks of chunk_len elements that do NOT hold whole rows of ndims (cfg3 at 1 KB: 1024 elements, 80 columns): series of
+    lcm(chunk_len, ndims) elements each -- a whole number of rows AND of chunks -- generated as synth_torch chunks and cut every
+    chunk_len elements.  -> [nchunks * chunk_len]"""
+    import math
+    per = chunk_len * ndims // math.gcd(chunk_len, ndims)
+    nseries = (nchunks * chunk_len + per - 1) // per
+    return synth_torch(kind, esz, nseries, per // ndims, ndims, device, seed=seed, step=step)[: nchunks * chunk_len].contiguous()
+
+
 def synth_c(kind, esz, nchunks, rows, ndims, seed=123, step=8, chunk0=0, lib_path=None):
     """oracle/synth.c through ctypes (test infrastructure)"""
     import ctypes as C
