@@ -45,8 +45,9 @@ extern "C" {
  *   2  round 2: set_option, *_layout, the Huff0 wire format (huf0_*), online_*, comm_* / gather_layout / layout_bases,
  *      the column-major and run-less codec entry points, the reference's mangled C++ names (sprintz_dropin.hpp)
  *   3  round 3: compress_batch_dense / compress_dense_tmp_bytes, SPRINTZ_OPT_DENSE_MODE, env SPRINTZ_MI355X_RCCL_SONAME
- *   4  round 3: compress_batch_colmajor_dense, SPRINTZ_OPT_SPLIT_LANES, SPRINTZ_OPT_ENC_PAIR */
-#define SPRINTZ_MI355X_ABI_VERSION 4
+ *   4  round 3: compress_batch_colmajor_dense, SPRINTZ_OPT_SPLIT_LANES, SPRINTZ_OPT_ENC_PAIR
+ *   5  round 4: SPRINTZ_OPT_HOST_WAIT, SPRINTZ_OPT_LAT_CHUNKS (the single-call entry points work on a mapped staging buffer: one wait per call) */
+#define SPRINTZ_MI355X_ABI_VERSION 5
 
 /* codec ids */
 #define SPRINTZ_CODEC_DELTA 0   /* sprintz_*_delta_*  (sprintz_delta_rle.cpp / sprintz_delta_lowdim.cpp) */
@@ -93,13 +94,21 @@ const char* sprintz_mi355x_last_error(void);     /* thread-local, never NULL; de
  *   SPRINTZ_OPT_ENC_PAIR          chunks from which row-major streams of 5 .. 64 columns are encoded with two columns per lane (the
  *                                 65 .. 128-column kernel on 4 .. 32 lanes a chunk: fewer instructions per sample) instead of one (a
  *                                 chunk's latency is shorter: what counts for a handful of chunks); default 1024, 1 = always,
- *                                 0 = never (A/B runs, tests); env SPRINTZ_MI355X_ENC_PAIR */
+ *                                 0 = never (A/B runs, tests); env SPRINTZ_MI355X_ENC_PAIR
+ *   SPRINTZ_OPT_LAT_CHUNKS        batches of at most this many chunks (general layout, 3 .. 64 columns, chunks of at most 16 KB) decode
+ *                                 with one workgroup per chunk (csrc/decode_lat.h: a chunk's latency is what counts); default 4096,
+ *                                 0 = never (A/B runs, tests); env SPRINTZ_MI355X_LAT_CHUNKS
+ *   SPRINTZ_OPT_HOST_WAIT         how a single-call entry point waits for its launches: 0 (default) = spin (hipStreamSynchronize)
+ *                                 while at most half of the CPUs this process may use are inside the library, otherwise sleep on
+ *                                 a blocking-sync event; 1 = always spin; 2 = always sleep; env SPRINTZ_MI355X_HOST_WAIT */
 #define SPRINTZ_OPT_NO_FAST 0
 #define SPRINTZ_OPT_CHUNKS_PER_GROUP 1
 #define SPRINTZ_OPT_DENSE_MODE 2
 #define SPRINTZ_OPT_HUF0_BIG_BATCH 3
 #define SPRINTZ_OPT_SPLIT_LANES 4
 #define SPRINTZ_OPT_ENC_PAIR 5
+#define SPRINTZ_OPT_HOST_WAIT 6
+#define SPRINTZ_OPT_LAT_CHUNKS 7
 int sprintz_mi355x_set_option(int option, int value);
 
 /* ------------------------------------------------------------------------

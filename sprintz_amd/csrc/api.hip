@@ -14,9 +14,11 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "launch.h"
+#include "decode_lat.h"
 
 using namespace sprintz;
 
@@ -49,6 +51,8 @@ struct Process {
     std::atomic<int> chunks_per_group{1};   // SPRINTZ_MI355X_CHUNKS_PER_GROUP (decode_fast read-ahead across chunks)
     std::atomic<int> dense_mode{1};         // SPRINTZ_MI355X_DENSE_MODE: how compress_batch_dense builds the container (see SPRINTZ_OPT_DENSE_MODE)
     std::atomic<int> enc_pair{1024};        // SPRINTZ_MI355X_ENC_PAIR: chunks from which row-major streams of 5 .. 64 columns are encoded with two columns per lane (0: never; see SPRINTZ_OPT_ENC_PAIR)
+    std::atomic<int> lat_chunks{4096};      // SPRINTZ_MI355X_LAT_CHUNKS: batches of at most this many chunks decode with one workgroup per chunk (decode_lat.h; 0: never)
+    std::atomic<int> host_wait{0};          // SPRINTZ_MI355X_HOST_WAIT: how a single call waits for its launches (see SPRINTZ_OPT_HOST_WAIT)
     std::atomic<int> split_lanes{1};        // SPRINTZ_MI355X_SPLIT_LANES: 8-bit streams of 65 .. 80 columns on 32 lanes x (pair + single) (see SPRINTZ_OPT_SPLIT_LANES)
 };
 Process& process()
@@ -63,6 +67,8 @@ Process& process()
             const int k = atoi(e);
             p.dense_mode = k <= 0 ? 0 : 1;
         }
+        if (const char* e = getenv("SPRINTZ_MI355X_LAT_CHUNKS")) p.lat_chunks = atoi(e) < 0 ? 0 : atoi(e);
+        if (const char* e = getenv("SPRINTZ_MI355X_HOST_WAIT")) p.host_wait = atoi(e) < 0 || atoi(e) > 2 ? 0 : atoi(e);
         if (const char* e = getenv("SPRINTZ_MI355X_SPLIT_LANES")) p.split_lanes = atoi(e) != 0 ? 1 : 0;
         if (const char* e = getenv("SPRINTZ_MI355X_ENC_PAIR")) p.enc_pair = atoi(e) < 0 ? 0 : atoi(e);
         if (const char* e = getenv("SPRINTZ_MI355X_CHUNKS_PER_GROUP")) {
@@ -410,6 +416,18 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
                                ((uintptr_t)d_out % 16) == 0 && (uint64_t)D * cs * esz < 0xf0000000ull
                          : fast_common && a.vec_store && (uint64_t)chunk_len * esz * 64 * 64 < 0xf0000000ull;
     hipError_t e;
+    // small batches: one WORKGROUP per chunk (decode_lat.h) -- a chunk's 40 dependent group steps on one lane group take 50 us
+    // however few chunks there are; split into a header walk, parallel bit extraction, the bare recurrence and a prefix sum it is ~13
+    if (!norle && !lowdim && !noheader && !cs && !a.raw && qs.q == kQueryOff && D <= 64 && (uint64_t)chunk_len * esz <= kLatMaxChunkBytes &&
+        chunk_len >= 16u * (uint32_t)D && ((uintptr_t)d_out % 16) == 0 && ((uint64_t)chunk_len * esz) % 16 == 0 &&
+        nchunks <= (uint64_t)process().lat_chunks.load(std::memory_order_relaxed) && !process().no_fast.load(std::memory_order_relaxed)) {
+        int ldp = 4;
+        while (ldp < D) ldp <<= 1;
+        if (esz == 1 && ldp < 8) ldp = 8;
+        e = launch_decode_lat(8 * esz, codec == SPRINTZ_CODEC_XFF, ldp, (unsigned)nchunks, (uint32_t)sprintz_mi355x_compress_bound(esz, chunk_len, ndims), st, a);
+        if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "decode_lat kernel launch", e);
+        return 0;
+    }
     if (fast) {
         a.log2DP = 0;
         while ((1 << a.log2DP) < fdp) a.log2DP++;
@@ -660,10 +678,37 @@ struct Scratch {
     hipStream_t stream = nullptr;
     uint8_t* dev = nullptr;
     size_t dev_cap = 0;
-    uint8_t* pin = nullptr;
+    uint8_t* pin = nullptr;              // hipHostMallocMapped | Coherent: the kernels of a single call read and write it directly
+    uint8_t* pin_dev = nullptr;          // the same bytes as the device sees them (hipHostGetDevicePointer)
     size_t pin_cap = 0;
+    hipEvent_t done = nullptr;           // blocking-sync event: how a call waits when many host threads are inside the library
 };
 constexpr size_t kPinMax = 4u << 20;     // larger transfers go straight from/to the caller's memory
+
+// ---- waiting for a single call's launches ---------------------------------------------------------
+// hipStreamSynchronize spins: the shortest wait there is while the waiting threads have cores to spin on.  With more
+// callers inside the library than that (lzbench -T64 in a 16-CPU container: 64 spinners on 16 CPUs' worth of quota get
+// throttled, and the one whose kernel HAS finished waits for a time slice) a call records a blocking-sync event and
+// sleeps on it instead.  SPRINTZ_OPT_HOST_WAIT: 0 = by the number of callers (default), 1 = always spin, 2 = always sleep.
+std::atomic<int> g_calls_inside{0};
+int spin_budget()
+{
+    static const int n = [] {
+        long q = (long)std::thread::hardware_concurrency();
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {           // cgroup v2 CPU quota, if any
+            long quota = 0, period = 0;
+            if (fscanf(f, "%ld %ld", &quota, &period) == 2 && quota > 0 && period > 0) q = std::min(q > 0 ? q : quota / period, quota / period);
+            fclose(f);
+        }
+        return (int)std::max(1l, q / 2);                                 // half of them: the callers do other work too
+    }();
+    return n;
+}
+struct CallGuard {
+    int n;
+    CallGuard() : n(g_calls_inside.fetch_add(1, std::memory_order_relaxed) + 1) {}
+    ~CallGuard() { g_calls_inside.fetch_sub(1, std::memory_order_relaxed); }
+};
 
 std::mutex g_scratch_mu;
 std::vector<Scratch*> g_scratch_free;
@@ -707,6 +752,8 @@ int acquire_scratch(size_t dev_bytes, size_t pin_bytes, Scratch** out)
             sc->device = dev;
             hipError_t e = hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking);
             if (e != hipSuccess) { delete sc; return fail(SPRINTZ_E_HIP, "hipStreamCreateWithFlags", e); }
+            e = hipEventCreateWithFlags(&sc->done, hipEventBlockingSync | hipEventDisableTiming);
+            if (e != hipSuccess) { (void)hipStreamDestroy(sc->stream); delete sc; return fail(SPRINTZ_E_HIP, "hipEventCreateWithFlags", e); }
         }
         t_scratch.s = sc;
     }
@@ -723,10 +770,43 @@ int acquire_scratch(size_t dev_bytes, size_t pin_bytes, Scratch** out)
         if (sc->pin) (void)hipHostFree(sc->pin);
         sc->pin = nullptr; sc->pin_cap = 0;
         const size_t want = round_up(pin_bytes + pin_bytes / 2, 1u << 16);
-        HIP_TRY(hipHostMalloc((void**)&sc->pin, want, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&sc->pin, want, hipHostMallocMapped | hipHostMallocCoherent));
         sc->pin_cap = want;
+        HIP_TRY(hipHostGetDevicePointer((void**)&sc->pin_dev, sc->pin, 0));
     }
     *out = sc;
+    return 0;
+}
+
+// wait for everything this call put on the thread's stream
+int wait_call(Scratch* sc, int callers)
+{
+    const int mode = process().host_wait.load(std::memory_order_relaxed);
+    if (mode == 1 || (mode == 0 && callers <= spin_budget())) {
+        HIP_TRY(hipStreamSynchronize(sc->stream));
+    } else {
+        HIP_TRY(hipEventRecord(sc->done, sc->stream));
+        HIP_TRY(hipEventSynchronize(sc->done));
+    }
+    return 0;
+}
+
+// A single call's input, host -> HBM, as ONE wide read of the thread's mapped staging buffer (every lane a 16-byte piece,
+// all requests of the call in flight over PCIe at once): the codec kernels walk their streams in dependent steps, which
+// must find them in HBM/L2 -- a PCIe round trip per step would cost more than the whole call.  Launched on the call's
+// stream right before the codec kernel; n16 = 16-byte pieces.
+typedef uint32_t stage_v4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) stage_in_kernel(const stage_v4* __restrict__ host, stage_v4* __restrict__ dev, uint32_t n16)
+{
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u)
+        dev[i] = __builtin_nontemporal_load(host + i);
+}
+int stage_in(Scratch* sc, size_t pin_off, size_t dev_off, size_t bytes)
+{
+    const uint32_t n16 = (uint32_t)((bytes + 15) / 16);
+    const unsigned grid = std::min<unsigned>((n16 + 255u) / 256u, 1024u);
+    hipLaunchKernelGGL(stage_in_kernel, dim3(grid), dim3(256), 0, sc->stream, (const stage_v4*)(sc->pin_dev + pin_off), (stage_v4*)(sc->dev + dev_off), n16);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 
@@ -760,9 +840,34 @@ int64_t compress_host(int codec, int esz, const void* src, uint32_t len, void* d
         if (write_size) memcpy(dest, h, 8);
         return write_size ? 8 / esz : 0;
     }
-    // device scratch: [source + read slack | size, ret (16 B) | slot]
     const size_t bound = sprintz_mi355x_compress_bound(esz, len, ndims);
     const size_t src_bytes = (size_t)len * esz;
+    CallGuard inside;
+    // ---- the zero-copy call (everything that fits the staging buffer; the RLE codecs, whose encoders only WRITE their slot):
+    // memcpy into the mapped staging buffer -> stage_in + encoder on the thread's stream, the encoder's slot, size and return
+    // value landing straight in the staging buffer -> ONE wait -> memcpy out.  No copy engine, no memset, no second round trip.
+    // staging: [source | size, ret (16 B) | slot]      device: [source + read slack]
+    if (codec <= SPRINTZ_CODEC_XFF && src_bytes + 16 + bound + 512 <= kPinMax) {
+        const size_t p_meta = round_up(src_bytes + 16, 256), p_slot = p_meta + 16;
+        Scratch* sc = nullptr;
+        if ((rc = acquire_scratch(round_up(src_bytes, 16) + SPRINTZ_MI355X_READ_SLACK, p_slot + bound, &sc))) return rc;
+        memcpy(sc->pin, src, src_bytes);
+        uint32_t size = 0xffffffffu;         // a kernel that never reports must read as an error, not as the last call's answer
+        int64_t ret = -1;
+        memcpy(sc->pin + p_meta, &size, 4);
+        memcpy(sc->pin + p_meta + 8, &ret, 8);
+        if ((rc = stage_in(sc, 0, 0, src_bytes))) return rc;
+        rc = encode_launch(codec, esz, sc->dev, len, len, ndims, sc->pin_dev + p_slot, bound, (uint32_t*)(sc->pin_dev + p_meta),
+                           (int64_t*)(sc->pin_dev + p_meta + 8), sc->stream, write_size, 0, layout == SPRINTZ_LAYOUT_GENERAL);
+        if (rc) { (void)hipStreamSynchronize(sc->stream); return rc; }   // stage_in may still be reading sc->pin
+        if ((rc = wait_call(sc, inside.n))) return rc;
+        memcpy(&size, sc->pin + p_meta, 4);
+        memcpy(&ret, sc->pin + p_meta + 8, 8);
+        if (size > bound) return fail(SPRINTZ_E_HIP, "encoder reported a size above its bound");
+        memcpy(dest, sc->pin + p_slot, size);
+        return ret;
+    }
+    // ---- larger calls and the run-less codecs -- device scratch: [source + read slack | size, ret (16 B) | slot]
     const size_t o_meta = round_up(src_bytes + SPRINTZ_MI355X_READ_SLACK, 256), o_slot = o_meta + 16;
     const bool pin_in = src_bytes <= kPinMax, pin_out = 16 + bound <= kPinMax;
     Scratch* sc = nullptr;
@@ -822,6 +927,31 @@ int64_t decode_host_common(int codec, int esz, const uint8_t* s, uint64_t nbytes
     const size_t o_out_meta = round_up(16 + nbytes + SPRINTZ_MI355X_READ_SLACK, 256), o_out = o_out_meta + 16;
     const size_t out_bytes = (size_t)nelems * esz;
     const bool want_out = !qspec || qspec->q != kQueryReduceOnly;
+    CallGuard inside;
+    // ---- the zero-copy call (plain decodes that fit the staging buffer): memcpy the stream into the mapped staging buffer ->
+    // stage_in + decoder on the thread's stream, the decoder writing samples and its return value straight into the staging
+    // buffer -> ONE wait -> memcpy out.   staging: [offsets[2] | stream | ret (16 B) | out]      device: [offsets[2] | stream + slack]
+    if (!qspec && 16 + nbytes + 512 + 16 + out_bytes <= kPinMax) {
+        const size_t p_ret = round_up(16 + nbytes + 16, 256), p_out = p_ret + 16;
+        Scratch* sc = nullptr;
+        int rc = acquire_scratch(round_up(16 + nbytes, 16) + SPRINTZ_MI355X_READ_SLACK, p_out + out_bytes, &sc);
+        if (rc) return rc;
+        const uint64_t meta[2] = {16, 16 + nbytes};
+        int64_t ret = -1;
+        memcpy(sc->pin, meta, 16);
+        memcpy(sc->pin + 16, s, nbytes);
+        memcpy(sc->pin + p_ret, &ret, 8);
+        if ((rc = stage_in(sc, 0, 0, 16 + nbytes))) return rc;
+        rc = decode_launch(codec, esz, sc->dev, (const uint64_t*)sc->dev, 1, (uint32_t)nelems, ndims, sc->pin_dev + p_out,
+                           (int64_t*)(sc->pin_dev + p_ret), sc->stream, noheader, ngroups, remaining, QuerySpec{});
+        if (rc) { (void)hipStreamSynchronize(sc->stream); return rc; }
+        if ((rc = wait_call(sc, inside.n))) return rc;
+        memcpy(&ret, sc->pin + p_ret, 8);
+        if (ret < 0) return fail((int)ret, "decoder rejected the stream");
+        if ((uint64_t)ret > nelems) return fail(SPRINTZ_E_CORRUPT, "decoder rejected the stream");
+        memcpy(dest, sc->pin + p_out, (size_t)ret * esz);
+        return ret;
+    }
     const size_t o_res = round_up(o_out + (want_out ? out_bytes : 0), 256);
     const size_t res_bytes = qspec && qspec->qop ? (size_t)ndims * 8 : 0;
     const bool pin_in = 16 + nbytes <= kPinMax, pin_out = 16 + out_bytes <= kPinMax;
@@ -1028,6 +1158,16 @@ int sprintz_mi355x_set_option(int option, int value)
     if (option == SPRINTZ_OPT_ENC_PAIR) {
         if (value < 0) return fail(SPRINTZ_E_INVALID, "the batch size must not be negative");
         process().enc_pair = value;
+        return 0;
+    }
+    if (option == SPRINTZ_OPT_LAT_CHUNKS) {
+        if (value < 0) return fail(SPRINTZ_E_INVALID, "the batch size must not be negative");
+        process().lat_chunks = value;
+        return 0;
+    }
+    if (option == SPRINTZ_OPT_HOST_WAIT) {
+        if (value < 0 || value > 2) return fail(SPRINTZ_E_INVALID, "host wait must be 0 (by callers), 1 (spin) or 2 (sleep)");
+        process().host_wait = value;
         return 0;
     }
     if (option == SPRINTZ_OPT_CHUNKS_PER_GROUP) {

@@ -1,0 +1,276 @@
+// decode_lat.h -- the LATENCY decoder: one WORKGROUP (256 lanes) per chunk, for batches too small to fill the chip with
+// decode_fast.h's one-lane-per-column mapping (a single drop-in call; BASELINE config 4's 10 000-chunk batches, 1 250 per
+// GPU on eight).  Same streams, same samples, same return values as decode_fast.h / decode_kernel.h
+// (sprintz_xff_rle.cpp:569-1179, sprintz_delta_rle.cpp:418-772), general layout, headered RLE streams, 3 <= ndims <= 64.
+//
+// decode_fast.h walks a chunk's 40 groups in 40 dependent steps of ~600 wave-instructions each: 50 us a chunk however few
+// chunks there are (a lone wave issues one instruction every ~4.5 cycles).  Only two things in the format are serial:
+//   (1) WHERE a group starts -- the sum of the header fields of all groups before it;
+//   (2) the forecast recurrence down a column -- delta[i] = err[i] + ((delta[i-1] * coef) >> W), coef changing per block.
+// Everything else (field offsets, bit extraction, zigzag^-1, the running sum of deltas, the transpose to row-major, the
+// stores) is independent per block or a prefix sum.  So, per chunk, with the whole stream parked in LDS:
+//   A  one wave walks the group headers: per group ~35 instructions (field sum by DPP, run lengths, cursor) -> grp[g] =
+//      (stream position, first output block);
+//   B  256 lanes, a DP-lane group per stream group: header scan, bit fields -> E = err << W (err itself for 8-bit delta
+//      coding) into err[block][column][8 rows]; RUN slots -> zeros (a run block IS a block of zero errors: the recurrence
+//      below then does what sprintz_xff_rle.cpp:828-958 replays, and its gradient is 0 so the counters stand still);
+//   C  FIRE only: lane d < D runs column d's recurrence over all blocks, 29 instructions a block, in place;
+//   D  256 lanes, 256/DP per column: prefix sum of the deltas down each column (mod 2^W), samples to a row-major image in
+//      LDS (over the dead stream), then whole 16-byte stores.
+// ~13 us a chunk instead of 50 (MI355X, uint16 x 8 columns x 640 rows).
+#pragma once
+
+#include "decode_fast.h"
+
+namespace sprintz {
+
+constexpr uint32_t kLatMaxChunkBytes = 16u << 10;     // the stream, the error image and the tables of ONE chunk must fit LDS
+constexpr uint32_t lat_align16(uint32_t x) { return (x + 15u) & ~15u; }
+// LDS carve: [stream: strm_cap + 32 | grp: NG words | err: one int per block element]
+struct LatCarve {
+    uint32_t strm_cap, o_grp, o_err, total;
+};
+inline LatCarve lat_carve(uint32_t bound_bytes, uint32_t chunk_len, uint32_t D)
+{
+    LatCarve c;
+    const uint32_t nb = chunk_len / (8u * D);
+    c.strm_cap = lat_align16(bound_bytes + 32u);
+    c.o_grp = c.strm_cap + 32u;
+    c.o_err = c.o_grp + lat_align16((nb + 3u) * 4u + 16u);
+    c.total = c.o_err + nb * 8u * D * 4u + 16u;
+    return c;
+}
+
+template <int W, bool FIRE, int DP>
+__global__ void __launch_bounds__(256) decode_lat_kernel(DecodeArgs a, uint32_t strm_cap, uint32_t o_grp, uint32_t o_err)
+{
+    using U = typename Elem<W>::U;
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    constexpr int HB = Elem<W>::HB;
+    constexpr int ESZ = W / 8;
+    constexpr int LOG2DP = DP == 4 ? 2 : DP == 8 ? 3 : DP == 16 ? 4 : DP == 32 ? 5 : 6;
+    constexpr int T = 256 / DP;                            // DP-lane groups of a workgroup = lanes per column in phase D
+    constexpr int LOG2T = 8 - LOG2DP;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ uint32_t info[8];                           // corrupt, groups, blocks, tail position, tail elements
+
+    const uint32_t tid = threadIdx.x;
+    const uint64_t chunk = blockIdx.x;
+    const int D = a.D;
+    const uint32_t hdr_bytes = (2u * (uint32_t)D * HB + 7u) >> 3;
+    const uint32_t blk_elems = 8u * (uint32_t)D;
+    const uint32_t NB = a.chunk_len / blk_elems;           // blocks a chunk's output can hold
+    uint8_t* const strm = smem;
+    uint32_t* const grp = (uint32_t*)(smem + o_grp);
+    int* const err = (int*)(smem + o_err);
+    const uint32_t sbase = lds_addr(strm);
+
+    // ---- 0: the stream, 16 bytes a lane, into LDS (from the 16-byte boundary below its first byte; the <= 15 bytes read past
+    // its end are inside SPRINTZ_MI355X_READ_SLACK)
+    const uint64_t off_c = a.offsets[chunk];
+    const uint64_t slen64 = a.offsets[chunk + 1] - off_c;
+    const uint32_t shift = (uint32_t)((uintptr_t)(a.comp + off_c) & 15u);
+    const uint32_t slen = slen64 < (uint64_t)(strm_cap - 16u) ? (uint32_t)slen64 : strm_cap - 16u;   // (a valid stream is shorter: strm_cap covers the bound)
+    const uint32_t send = shift + slen;                    // LDS offset of the stream's end
+    {
+        const uint4* g = (const uint4*)(a.comp + (off_c - shift));
+        const uint32_t n16 = (send + 15u) >> 4;
+        for (uint32_t i = tid; i < n16; i += 256u) ((uint4*)strm)[i] = g[i];
+        if (tid < 2u) ((uint4*)strm)[n16 + tid] = make_uint4(0, 0, 0, 0);     // the unaligned 32-bit windows read up to 7 bytes on
+    }
+    __syncthreads();
+
+    const int lane_d = (int)(tid & (uint32_t)(DP - 1));
+    const bool col_ok = lane_d < D;
+    const int colk = col_ok ? lane_d : D - 1;              // a lane past the last column stands in for it (uniform code)
+    const uint32_t hbit0 = (uint32_t)colk * HB, hbit1 = (uint32_t)(D + colk) * HB;
+    auto fields = [&](uint32_t r) -> uint32_t {            // both slots' nbits of this lane's column: slot 0 | slot 1 << 16
+        const uint32_t hw0 = lds_rd32(r + (hbit0 >> 3)), hw1 = lds_rd32(r + (hbit1 >> 3));
+        uint32_t f0 = __builtin_amdgcn_ubfe(hw0, hbit0 & 7u, HB), f1 = __builtin_amdgcn_ubfe(hw1, hbit1 & 7u, HB);
+        f0 += (f0 == (uint32_t)(W - 1));                   // W-1 means W (:747-749)
+        f1 += (f1 == (uint32_t)(W - 1));
+        return col_ok ? (f0 | (f1 << 16)) : 0u;
+    };
+    auto run_length = [&](uint32_t at, uint32_t& nbytes) -> uint32_t {   // varint in blocks (:829-833)
+        const uint32_t b0 = lds_rd8(at);
+        uint32_t len = b0 & 0x7fu;
+        nbytes = 1;
+        if (b0 & 0x80u) { len |= lds_rd8(at + 1) << 7; nbytes = 2; }
+        return len;
+    };
+
+    // ---- A: where every group starts and which output block it opens (wave 0; its DP-lane groups all compute the same)
+    if (tid < 64u) {
+        uint32_t pos = shift;
+        const uint32_t w0 = lds_rd32(sbase + pos), w1 = lds_rd32(sbase + pos + 4u);
+        const uint32_t groups = w0, remaining = w1 & 0xffffu;
+        pos += 8u;
+        bool corrupt = (int)(w1 >> 16) != D || slen < 8u;
+        // a damaged header must not make the loop spin: every group takes at least its header and two slot bytes out of the stream
+        if ((uint64_t)groups * (hdr_bytes + 2u) > slen64 || groups > NB + 2u) corrupt = true;
+        uint32_t ob = 0, g = 0;
+        if (!corrupt) {
+            for (; g < groups; g++) {
+                if (pos + hdr_bytes > send) { corrupt = true; break; }
+                uint32_t tot_both;
+                (void)group_scan<DP>(fields(sbase + pos), lane_d, tot_both);
+                tot_both = (uint32_t)__builtin_amdgcn_readfirstlane((int)tot_both);
+                const uint32_t tot0 = tot_both & 0xffffu, tot1 = tot_both >> 16;
+                const uint32_t at0 = pos + hdr_bytes;
+                uint32_t len0 = 1, len1 = 1, bytes0, bytes1;
+                if (tot0 == 0) len0 = run_length(sbase + (at0 < send ? at0 : send), bytes0); else bytes0 = ((tot0 + 7u) >> 3) * 8u;
+                const uint32_t at1 = at0 + bytes0;
+                if (tot1 == 0) len1 = run_length(sbase + (at1 < send ? at1 : send), bytes1); else bytes1 = ((tot1 + 7u) >> 3) * 8u;
+                const uint32_t used = hdr_bytes + bytes0 + bytes1;
+                if (pos + used > send || ob + len0 + len1 > NB) { corrupt = true; break; }   // cursor past the stream / more blocks than the chunk holds
+                if (tid == 0) grp[g] = pos | (ob << 16);
+                ob += len0 + len1;
+                pos += used;
+            }
+        }
+        const uint32_t out_left = a.chunk_len - ob * blk_elems;
+        if (!corrupt && (remaining > out_left || pos + remaining * ESZ > send)) corrupt = true;
+        if (tid == 0) { info[0] = corrupt ? 1u : 0u; info[1] = g; info[2] = ob; info[3] = pos; info[4] = remaining; }
+    }
+    __syncthreads();
+    const uint32_t ngroups = info[1], nblk = info[2], tail_pos = info[3], remaining = info[4];
+    if (info[0]) {                                         // nothing of a damaged stream is written
+        if (tid == 0 && a.rets) a.rets[chunk] = kErrCorrupt;
+        return;
+    }
+    uint8_t* const obase = (uint8_t*)a.out + chunk * (uint64_t)a.chunk_len * ESZ;
+    const uint32_t body_bytes = nblk * blk_elems * ESZ;
+
+    // ---- B: bit fields -> errors, a DP-lane group per stream group
+    for (uint32_t g = tid >> LOG2DP; g < ngroups; g += (uint32_t)T) {
+        const uint32_t gw = grp[g];
+        const uint32_t pos = gw & 0xffffu;
+        uint32_t ob = gw >> 16;
+        uint32_t tot_both;
+        const uint32_t nb_both = fields(sbase + pos);
+        const uint32_t excl = group_scan<DP>(nb_both, lane_d, tot_both);
+        uint32_t at = pos + hdr_bytes;
+#pragma unroll
+        for (int slot = 0; slot < 2; slot++) {
+            const uint32_t tot = slot ? tot_both >> 16 : tot_both & 0xffffu;
+            const uint32_t off = slot ? excl >> 16 : excl & 0xffffu;
+            const uint32_t nb = slot ? nb_both >> 16 : nb_both & 0xffffu;
+            if (tot != 0) {
+                const uint32_t rb = (tot + 7u) >> 3;
+                if (col_ok) {
+                    uint32_t p = sbase + at + (off >> 3);
+                    const uint32_t sh = off & 7u;
+                    const uint32_t w1 = nb != 0 ? 1u : 0u, wm = nb - w1;      // widths of the sign bit and of the magnitude
+                    int e[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const uint32_t w = lds_rd32(p);
+                        const uint32_t mag = __builtin_amdgcn_ubfe(w, sh + 1u, wm);      // zigzag^-1 = (z >> 1) ^ -(z & 1), straight from the window
+                        const int sgn = __builtin_amdgcn_sbfe((int)w, sh, w1);
+                        const int x = (int)(mag ^ (uint32_t)sgn);
+                        e[i] = W == 16 ? (int)((uint32_t)x << 16) : (FIRE ? (int)((uint32_t)x << 8) : x);
+                        p += rb;
+                    }
+                    v4i* const q = (v4i*)(err + ((size_t)ob * (uint32_t)D + (uint32_t)lane_d) * 8u);
+                    q[0] = v4i{e[0], e[1], e[2], e[3]};
+                    q[1] = v4i{e[4], e[5], e[6], e[7]};
+                }
+                ob += 1u;
+                at += rb * 8u;
+            } else {
+                uint32_t nbytes;
+                const uint32_t len = run_length(sbase + at, nbytes);
+                if (col_ok) {
+                    for (uint32_t j = 0; j < len; j++) {
+                        v4i* const q = (v4i*)(err + ((size_t)(ob + j) * (uint32_t)D + (uint32_t)lane_d) * 8u);
+                        q[0] = v4i{0, 0, 0, 0};
+                        q[1] = v4i{0, 0, 0, 0};
+                    }
+                }
+                ob += len;
+                at += nbytes;
+            }
+        }
+    }
+    // the verbatim tail (:1171) leaves now: phase D parks the samples where the stream lies
+    for (uint32_t j = tid; j < remaining * ESZ; j += 256u) obase[body_bytes + j] = strm[tail_pos + j];
+    __syncthreads();
+
+    // ---- C: the forecast recurrence, one lane per column, in place (E -> X with delta = X >> 16 at 16 bits; E -> delta at 8)
+    if constexpr (FIRE) {
+        if (tid < (uint32_t)D && nblk > 0) {
+            v4i* e = (v4i*)(err + (size_t)tid * 8u);
+            const uint32_t bstride = (uint32_t)D * 2u;     // v4i per block
+            int pd = 0, ctr = 0;
+            v4i c0 = e[0], c1 = e[1];
+            for (uint32_t b = 0; b < nblk; b++) {
+                v4i n0 = c0, n1 = c1;
+                if (b + 1u < nblk) { n0 = e[bstride]; n1 = e[bstride + 1]; }
+                const int E[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+                int X[8];
+                const int coef = fire_coef<W, false>(ctr);
+                int grad = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    if constexpr (W == 16) {               // X = prev_delta*coef + E; delta = hi16(X): pd carries X (decode_fast.h)
+                        if (i & 1) grad = mad_i16_hi(pd, sign_of(E[i]), grad);
+                        pd = mad_i16_hi(pd, coef, E[i]);
+                    } else {
+                        if (i & 1) grad = mad24(sign_of(E[i]), pd, grad);
+                        pd = __builtin_amdgcn_sbfe(mad24(pd, coef, E[i]), W, W);
+                    }
+                    X[i] = pd;
+                }
+                ctr = wrap_counter<W>(ctr + __builtin_amdgcn_sbfe(grad, 2, W - 2));       // sext_W(grad) >> 2 (:273-275)
+                e[0] = v4i{X[0], X[1], X[2], X[3]};
+                e[1] = v4i{X[4], X[5], X[6], X[7]};
+                e += bstride;
+                c0 = n0;
+                c1 = n1;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- D: samples = running sum of the deltas down each column (mod 2^W): T lanes a column, whole blocks a lane
+    {
+        const uint32_t d = tid >> LOG2T, t = tid & (uint32_t)(T - 1);
+        const bool live = d < (uint32_t)D;
+        const uint32_t nbpt = (nblk + (uint32_t)T - 1u) >> LOG2T;
+        const uint32_t b0 = t * nbpt < nblk ? t * nbpt : nblk, b1 = b0 + nbpt < nblk ? b0 + nbpt : nblk;
+        auto delta_of = [](int x) -> uint32_t { return W == 16 ? (uint32_t)x >> 16 : (uint32_t)x; };
+        uint32_t s = 0;
+        if (live) {
+            for (uint32_t b = b0; b < b1; b++) {
+                const v4i* q = (const v4i*)(err + ((size_t)b * (uint32_t)D + d) * 8u);
+                const v4i x0 = q[0], x1 = q[1];
+                s += delta_of(x0[0]) + delta_of(x0[1]) + delta_of(x0[2]) + delta_of(x0[3]) + delta_of(x1[0]) + delta_of(x1[1]) + delta_of(x1[2]) + delta_of(x1[3]);
+            }
+        }
+        uint32_t total;
+        uint32_t pv = group_scan<T>(s, (int)t, total);
+        U* const img = (U*)strm;                           // (nobody reads the stream after the barrier behind phase B: the image goes over it)
+        if (live) {
+            for (uint32_t b = b0; b < b1; b++) {
+                const v4i* q = (const v4i*)(err + ((size_t)b * (uint32_t)D + d) * 8u);
+                const v4i x0 = q[0], x1 = q[1];
+                const int x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+                U* const o = img + (size_t)b * blk_elems + d;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    pv += delta_of(x[i]);
+                    o[(uint32_t)i * (uint32_t)D] = (U)pv;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t n16 = body_bytes >> 4;
+        for (uint32_t i = tid; i < n16; i += 256u) ((uint4*)obase)[i] = ((const uint4*)strm)[i];
+        for (uint32_t j = (n16 << 4) + tid; j < body_bytes; j += 256u) obase[j] = strm[j];
+    }
+    if (tid == 0 && a.rets) a.rets[chunk] = (int64_t)(nblk * blk_elems + remaining);
+}
+
+}  // namespace sprintz

@@ -20,6 +20,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+@pytest.fixture(params=["lat", "wide"])
+def decode_path(request):
+    """the two row-major decoders of the general layout: batches of up to 4 096 chunks take decode_lat.h (one workgroup per chunk),
+    larger ones decode_fast.h / decode_kernel.h (one lane per column).  The parity modules run every test on both: "wide"
+    switches the small-batch decoder off (SPRINTZ_OPT_LAT_CHUNKS = 0)."""
+    from sprintz_amd import _lib
+    _lib.check(_lib.set_option(_lib.OPT_LAT_CHUNKS, 4096 if request.param == "lat" else 0))
+    yield request.param
+    _lib.set_option(_lib.OPT_LAT_CHUNKS, 4096)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """Our CPU restatement; built on demand (gcc only, a second or two)."""

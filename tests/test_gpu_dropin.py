@@ -16,7 +16,7 @@ import pytest
 from harness import CODECS, gen_fuzz, gen_sparse
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("decode_path")]
 
 # The caller: a job file in, a result file out.  Prototypes exactly as the reference declares them.
 CALLER = r"""

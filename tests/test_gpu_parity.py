@@ -8,7 +8,7 @@ import pytest
 
 from harness import DTYPES, REF_TEST_SIZES, gen_fuzz, gen_patterns, gen_sparse, gen_walk
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("decode_path")]
 
 
 @pytest.fixture(scope="module")
