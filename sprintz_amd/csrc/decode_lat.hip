@@ -10,7 +10,7 @@ hipError_t launch_lat(K kernel, unsigned grid, const LatCarve& c, hipStream_t st
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.total);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), c.total, st, a, c.strm_cap, c.o_grp, c.o_err);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), c.total, st, a, c);
     return hipGetLastError();
 }
 }  // namespace
