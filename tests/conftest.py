@@ -22,13 +22,13 @@ def pytest_configure(config):
 
 @pytest.fixture(params=["lat", "wide"])
 def decode_path(request):
-    """the two row-major decoders of the general layout: batches of up to 4 096 chunks take decode_lat.h (one workgroup per chunk),
-    larger ones decode_fast.h / decode_kernel.h (one lane per column).  The parity modules run every test on both: "wide"
-    switches the small-batch decoder off (SPRINTZ_OPT_LAT_CHUNKS = 0)."""
+    """the two row-major decoders of the general layout: small batches (by default up to 1 280 chunks) take decode_lat.h (one
+    workgroup per chunk), larger ones decode_fast.h / decode_kernel.h (one lane per column).  The parity modules run every test
+    on both: "lat" sends every eligible batch to the small-batch decoder whatever its size, "wide" switches it off."""
     from sprintz_amd import _lib
-    _lib.check(_lib.set_option(_lib.OPT_LAT_CHUNKS, 4096 if request.param == "lat" else 0))
+    _lib.check(_lib.set_option(_lib.OPT_LAT_CHUNKS, (1 << 30) if request.param == "lat" else 0))
     yield request.param
-    _lib.set_option(_lib.OPT_LAT_CHUNKS, 4096)
+    _lib.set_option(_lib.OPT_LAT_CHUNKS, 1280)
 
 
 @pytest.fixture(scope="session")
