@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -52,6 +53,7 @@ struct Process {
     std::atomic<int> dense_mode{1};         // SPRINTZ_MI355X_DENSE_MODE: how compress_batch_dense builds the container (see SPRINTZ_OPT_DENSE_MODE)
     std::atomic<int> enc_pair{1024};        // SPRINTZ_MI355X_ENC_PAIR: chunks from which row-major streams of 5 .. 64 columns are encoded with two columns per lane (0: never; see SPRINTZ_OPT_ENC_PAIR)
     std::atomic<int> lat_chunks{1280};      // SPRINTZ_MI355X_LAT_CHUNKS: batches of at most this many chunks decode with one workgroup per chunk (decode_lat.h; 0: never)
+    std::atomic<int> host_streams{4};       // SPRINTZ_MI355X_HOST_STREAMS: streams the host-pointer calls of all threads share per device (0: one per thread)
     std::atomic<int> host_wait{0};          // SPRINTZ_MI355X_HOST_WAIT: how a single call waits for its launches (see SPRINTZ_OPT_HOST_WAIT)
     std::atomic<int> split_lanes{1};        // SPRINTZ_MI355X_SPLIT_LANES: 8-bit streams of 65 .. 80 columns on 32 lanes x (pair + single) (see SPRINTZ_OPT_SPLIT_LANES)
 };
@@ -68,6 +70,7 @@ Process& process()
             p.dense_mode = k <= 0 ? 0 : 1;
         }
         if (const char* e = getenv("SPRINTZ_MI355X_LAT_CHUNKS")) p.lat_chunks = atoi(e) < 0 ? 0 : atoi(e);
+        if (const char* e = getenv("SPRINTZ_MI355X_HOST_STREAMS")) p.host_streams = atoi(e) < 0 ? 0 : (atoi(e) > 64 ? 64 : atoi(e));
         if (const char* e = getenv("SPRINTZ_MI355X_HOST_WAIT")) p.host_wait = atoi(e) < 0 || atoi(e) > 2 ? 0 : atoi(e);
         if (const char* e = getenv("SPRINTZ_MI355X_SPLIT_LANES")) p.split_lanes = atoi(e) != 0 ? 1 : 0;
         if (const char* e = getenv("SPRINTZ_MI355X_ENC_PAIR")) p.enc_pair = atoi(e) < 0 ? 0 : atoi(e);
@@ -684,6 +687,8 @@ struct Scratch {
     uint8_t* pin_dev = nullptr;          // the same bytes as the device sees them (hipHostGetDevicePointer)
     size_t pin_cap = 0;
     hipEvent_t done = nullptr;           // blocking-sync event: how a call waits when many host threads are inside the library
+    hipEvent_t done_spin = nullptr;      // the same, waited for by spinning (a shared stream: the call waits for ITS launches, not for the stream)
+    bool shared_stream = false;
 };
 constexpr size_t kPinMax = 4u << 20;     // larger transfers go straight from/to the caller's memory
 
@@ -714,6 +719,8 @@ struct CallGuard {
 
 std::mutex g_scratch_mu;
 std::vector<Scratch*> g_scratch_free;
+std::map<int, std::vector<hipStream_t>> g_stream_pool;      // per device: the streams the host-pointer calls share
+std::map<int, size_t> g_stream_next;
 
 struct ScratchHolder {
     Scratch* s = nullptr;
@@ -752,10 +759,27 @@ int acquire_scratch(size_t dev_bytes, size_t pin_bytes, Scratch** out)
         if (!sc) {
             sc = new Scratch();
             sc->device = dev;
-            hipError_t e = hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking);
+            // The threads of a process share a FEW streams (SPRINTZ_OPT_HOST_STREAMS, default 4 = the hardware queues the runtime
+            // maps streams onto): with a private stream per thread, 64 callers made 64 streams that the runtime multiplexes over
+            // its 4 queues with a barrier packet at every switch -- 64 threads got a third of the calls per second of 8.
+            const int k = process().host_streams.load(std::memory_order_relaxed);
+            hipError_t e = hipSuccess;
+            if (k > 0) {
+                std::lock_guard<std::mutex> lk(g_scratch_mu);
+                auto& pool = g_stream_pool[dev];
+                if ((int)pool.size() < k) {
+                    hipStream_t st = nullptr;
+                    e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+                    if (e == hipSuccess) pool.push_back(st);
+                }
+                if (e == hipSuccess) { sc->stream = pool[g_stream_next[dev]++ % pool.size()]; sc->shared_stream = true; }
+            } else {
+                e = hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking);
+            }
             if (e != hipSuccess) { delete sc; return fail(SPRINTZ_E_HIP, "hipStreamCreateWithFlags", e); }
             e = hipEventCreateWithFlags(&sc->done, hipEventBlockingSync | hipEventDisableTiming);
-            if (e != hipSuccess) { (void)hipStreamDestroy(sc->stream); delete sc; return fail(SPRINTZ_E_HIP, "hipEventCreateWithFlags", e); }
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&sc->done_spin, hipEventDisableTiming);
+            if (e != hipSuccess) { if (!sc->shared_stream) (void)hipStreamDestroy(sc->stream); delete sc; return fail(SPRINTZ_E_HIP, "hipEventCreateWithFlags", e); }
         }
         t_scratch.s = sc;
     }
@@ -785,7 +809,12 @@ int wait_call(Scratch* sc, int callers)
 {
     const int mode = process().host_wait.load(std::memory_order_relaxed);
     if (mode == 1 || (mode == 0 && callers <= spin_budget())) {
-        HIP_TRY(hipStreamSynchronize(sc->stream));
+        if (sc->shared_stream) {
+            HIP_TRY(hipEventRecord(sc->done_spin, sc->stream));
+            HIP_TRY(hipEventSynchronize(sc->done_spin));
+        } else {
+            HIP_TRY(hipStreamSynchronize(sc->stream));
+        }
     } else {
         HIP_TRY(hipEventRecord(sc->done, sc->stream));
         HIP_TRY(hipEventSynchronize(sc->done));
@@ -1165,6 +1194,11 @@ int sprintz_mi355x_set_option(int option, int value)
     if (option == SPRINTZ_OPT_LAT_CHUNKS) {
         if (value < 0) return fail(SPRINTZ_E_INVALID, "the batch size must not be negative");
         process().lat_chunks = value;
+        return 0;
+    }
+    if (option == SPRINTZ_OPT_HOST_STREAMS) {
+        if (value < 0 || value > 64) return fail(SPRINTZ_E_INVALID, "host streams must be in 0..64");
+        process().host_streams = value;                     // (threads that already hold a scratch keep their stream)
         return 0;
     }
     if (option == SPRINTZ_OPT_HOST_WAIT) {
