@@ -20,6 +20,7 @@
 
 #include "launch.h"
 #include "decode_lat.h"
+#include "encode_lat.h"
 
 using namespace sprintz;
 
@@ -520,6 +521,19 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     const bool fast = col_stride ? fast_common && col_stride % 8 == 0 && (chunk_len / (uint32_t)D) % 8 == 0
                                  : fast_common && blk_bytes % 16 == 0 && ((uint64_t)chunk_len * esz) % 16 == 0;
     hipError_t e;
+    // small batches: one WORKGROUP per chunk (encode_lat.h), the counterpart of decode_lat.h -- 90 us for ONE 10 KB chunk on a lane
+    // group, ~20 with the coefficient chain and the RLE state machine as the only serial parts (the container, if one was asked
+    // for, is then built by the scan + copy passes: dense->fused stays false)
+    if (!norle && !lowdim && !col_stride && !a.raw && D <= 64 && (uint64_t)chunk_len * esz <= kEncLatMaxChunkBytes &&
+        ((uintptr_t)d_src % 16) == 0 && ((uint64_t)chunk_len * esz) % 16 == 0 && slot_stride % 16 == 0 && ((uintptr_t)d_slots % 16) == 0 &&
+        nchunks <= (uint64_t)process().lat_chunks.load(std::memory_order_relaxed) / (D > 16 ? 2u : 1u) && !process().no_fast.load(std::memory_order_relaxed)) {
+        int ldp = 4;
+        while (ldp < D) ldp <<= 1;
+        if (esz == 1 && ldp < 8) ldp = 8;
+        e = launch_encode_lat(8 * esz, codec == SPRINTZ_CODEC_XFF, ldp, (unsigned)nchunks, (uint32_t)sprintz_mi355x_compress_bound(esz, chunk_len, ndims), st, a);
+        if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "encode_lat kernel launch", e);
+        return 0;
+    }
     // the container built inside the launch (compact_tail.h): every kernel of encode_fast.h / encode_wide.h carries the tail
     auto arm_dense = [&](uint64_t grid, size_t groups) -> int {
         // (column-major sources keep the two-launch path: with the tail in encode_fast<CM> BASELINE config 5 took 0.089 instead of 0.076 ms, its

@@ -1,0 +1,37 @@
+// encode_lat.hip -- instantiations of the latency encoder (encode_lat.h): one workgroup per chunk.
+#include "launch.h"
+#include "encode_lat.h"
+namespace sprintz {
+namespace {
+template <typename K>
+hipError_t launch_enc_lat(K kernel, unsigned grid, const EncLatCarve& c, hipStream_t st, const EncodeArgs& a)
+{
+    if (c.total > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.total);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), c.total, st, a, c);
+    return hipGetLastError();
+}
+}  // namespace
+#define SPRINTZ_ENC_LAT_CASE(WV, DPV)                                                                     \
+    if (w == WV && dp == DPV)                                                                             \
+        return fire ? launch_enc_lat(encode_lat_kernel<WV, true, DPV>, grid, c, st, a)                    \
+                    : launch_enc_lat(encode_lat_kernel<WV, false, DPV>, grid, c, st, a);
+hipError_t launch_encode_lat(int w, bool fire, int dp, unsigned grid, uint32_t bound_bytes, hipStream_t st, const EncodeArgs& a)
+{
+    const EncLatCarve c = enc_lat_carve(bound_bytes, a.chunk_len, (uint32_t)a.D, (uint32_t)w / 8u);
+    if (c.total > 150 * 1024) return hipErrorInvalidValue;
+    SPRINTZ_ENC_LAT_CASE(16, 4)
+    SPRINTZ_ENC_LAT_CASE(16, 8)
+    SPRINTZ_ENC_LAT_CASE(16, 16)
+    SPRINTZ_ENC_LAT_CASE(16, 32)
+    SPRINTZ_ENC_LAT_CASE(16, 64)
+    SPRINTZ_ENC_LAT_CASE(8, 8)
+    SPRINTZ_ENC_LAT_CASE(8, 16)
+    SPRINTZ_ENC_LAT_CASE(8, 32)
+    SPRINTZ_ENC_LAT_CASE(8, 64)
+    return hipErrorInvalidValue;
+}
+#undef SPRINTZ_ENC_LAT_CASE
+}  // namespace sprintz
