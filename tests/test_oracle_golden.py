@@ -52,5 +52,15 @@ def test_reference_decoder_quirk_is_modelled(oracle, golden):
     stream = arrays[f"out_{m['idx']}"]
     dec, _ = oracle.decompress("xff", stream, 2, data.size)
     assert np.array_equal(dec, data)
-    quirk, _ = oracle.decompress("xff", stream, 2, data.size, quirk=1)
+    quirk, qret = oracle.decompress("xff", stream, 2, data.size, quirk=1)
     assert not np.array_equal(quirk, data)
+    # ... and the quirk mode IS the reference decoder: its actual output for this stream, stored when the fixtures were minted
+    # (oracle/gen_golden_refdec.py), so this holds wherever the tests run -- not only where oracle/_ref exists
+    import json
+    import os
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    cases = json.load(open(os.path.join(gdir, "golden_refdec_v1.json")))["cases"]
+    refdec = np.load(os.path.join(gdir, "golden_refdec_v1.npz"))
+    assert [c["idx"] for c in cases] == [m["idx"]]
+    assert qret == cases[0]["dec_ret"] == m["dec_ret"]
+    assert np.array_equal(quirk, refdec[f"refdec_{m['idx']}"])
