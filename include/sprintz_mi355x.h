@@ -85,12 +85,13 @@ const char* sprintz_mi355x_last_error(void);     /* thread-local, never NULL; de
  *   SPRINTZ_OPT_DENSE_MODE        how sprintz_mi355x_compress_batch_dense builds the container: 1 (default) = inside the
  *                                 encode launch (csrc/compact_tail.h), 0 = encode, then scan + copy (A/B runs, tests);
  *                                 env SPRINTZ_MI355X_DENSE_MODE
- *   SPRINTZ_OPT_HUF0_BIG_BATCH    chunks from which the Huff0 reader's one-table stream kernel runs as 2-wave workgroups
- *                                 (faster from ~20 000 chunks on) instead of single waves (as fast below); default 20000,
- *                                 0 = always (tests)
+ *   SPRINTZ_OPT_HUF0_BIG_BATCH    chunks from which the Huff0 reader's one-table stream kernel runs as 2-wave workgroups with
+ *                                 64-byte stream pieces (the built defaults HUF0_BIG_WG = 2, HUF0_BIG_PLOG = 6; faster from
+ *                                 ~20 000 chunks on) instead of single waves (as fast below); default 20000, 0 = always (tests)
  *   SPRINTZ_OPT_SPLIT_LANES       1 (default) = 8-bit row-major streams of 65 .. 80 columns decode on 32 lanes a chunk (a pair of
  *                                 adjacent columns + one single column per lane, two chunks a wavefront), 0 = on 64 lanes x 2
- *                                 columns like the other shapes up to 128 columns (A/B runs, tests); env SPRINTZ_MI355X_SPLIT_LANES
+ *                                 columns like the other shapes up to 128 columns; 0 also sizes the LDS carve of 16-bit streams of
+ *                                 65 .. 80 columns for 128 columns again instead of 80 (A/B runs, tests); env SPRINTZ_MI355X_SPLIT_LANES
  *   SPRINTZ_OPT_ENC_PAIR          chunks from which row-major streams of 5 .. 64 columns are encoded with two columns per lane (the
  *                                 65 .. 128-column kernel on 4 .. 32 lanes a chunk: fewer instructions per sample) instead of one (a
  *                                 chunk's latency is shorter: what counts for a handful of chunks); default 1024, 1 = always,

@@ -372,7 +372,9 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
     const uint64_t cs = qs.col_stride;
 
     // batches whose chunks are too short for a stream group: header check + copy (verbatim_decode_kernel)
-    if (!norle && !lowdim && !noheader && !cs && qs.q == kQueryOff && (chunk_len < 128u || chunk_len < 16u * (uint32_t)D) &&
+    // (only where a chunk cannot hold a group at all, chunk_len < 16 D: a stream of 16 D <= chunk_len < 128 elements that announces
+    //  groups is one the reference ENCODER never writes but its decoder reads -- that one goes to the decoders below)
+    if (!norle && !lowdim && !noheader && !cs && qs.q == kQueryOff && chunk_len < 16u * (uint32_t)D &&
         !process().no_fast.load(std::memory_order_relaxed)) {
         const uint64_t vgrid = (nchunks * 64 + kThreads - 1) / kThreads;
         if (vgrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
@@ -508,7 +510,11 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     a.col_stride = col_stride;
     a.norle = norle ? (codec == SPRINTZ_CODEC_XFF_NORLE ? 2 : 1) : 0;
     a.raw = codec == SPRINTZ_CODEC_BITPACK_NORLE ? 1 : 0;
-    a.cap = next_pow2((uint32_t)group_bytes_max(esz, D) + 48u + (uint32_t)(SPRINTZ_ENC_DRAIN_ALIGN - 16));
+    // the generic kernel's window is a power-of-two RING flushed in 16-byte pieces; the kernels that flush whole 128-byte lines
+    // (encode_fast.h, encode_wide.h) need that much more room in front of the write position: cap_drain (theirs alone -- added
+    // to every encoder it doubled the generic ring wherever the group sat just under a power of two)
+    a.cap = next_pow2((uint32_t)group_bytes_max(esz, D) + 48u);
+    const uint32_t cap_drain = next_pow2((uint32_t)group_bytes_max(esz, D) + 48u + (uint32_t)(SPRINTZ_ENC_DRAIN_ALIGN - 16));
     const size_t shmem = ((size_t)a.cap + 16) * (kThreads / DP);
     if (shmem > 160 * 1024) return fail(SPRINTZ_E_UNSUPPORTED, "ndims too large for the LDS output ring");
 
@@ -579,6 +585,7 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     }
     if (fast) {
         const size_t fgroups = kThreads / fdp;
+        a.cap = cap_drain;
         // input staging: one 8 x D block (row-major: LDS transpose) or two bursts of 4 blocks x fdp columns (column-major)
         const size_t in_stage = col_stride ? (size_t)4 * fdp * (esz == 2 ? 16 : 8) : ((blk_bytes + 15) & ~(size_t)15);
         a.lds_group_stride = (uint32_t)(a.cap + in_stage + 16);
@@ -598,6 +605,7 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
         // (8 bits, 65 .. 80 columns: 32 lanes a chunk -- a pair + a single column per lane -- two chunks a wavefront)
         const bool wsplit = esz == 1 && D <= 80 && process().split_lanes.load(std::memory_order_relaxed) != 0;
         const size_t wlanes = wsplit ? 32 : 64, wgroups = kThreads / wlanes;
+        a.cap = cap_drain;
         a.lds_group_stride = (uint32_t)(a.cap + ((blk_bytes + 15) & ~(size_t)15) + 16);
         const uint64_t wgrid = (nchunks * (uint64_t)wlanes + kThreads - 1) / kThreads;
         if (wgrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
@@ -1540,7 +1548,8 @@ int sprintz_mi355x_compress_batch_colmajor_dense(int codec, int elem_bytes, cons
         return fail(SPRINTZ_E_INVALID, "rows_per_chunk * ndims must be in 1..2^30");
     if (col_stride < nrows) return fail(SPRINTZ_E_INVALID, "col_stride < nrows");
     if (!d_src || !d_slots || !d_sizes || !d_dense || !d_offsets || !d_tmp) return fail(SPRINTZ_E_INVALID, "null device pointer");
-    if (slot_stride % 16 || (uintptr_t)d_slots % 16 || (uintptr_t)d_dense % 16) return fail(SPRINTZ_E_INVALID, "slots and container must be 16-byte aligned/strided");
+    if (slot_stride % 16 || (uintptr_t)d_slots % 16 || (uintptr_t)d_dense % 16 || (uintptr_t)d_tmp % 8)
+        return fail(SPRINTZ_E_INVALID, "slots and the container must be 16-byte aligned/strided, d_tmp 8-byte aligned");
     const uint32_t chunk_len = rows_per_chunk * (uint32_t)ndims;
     if (slot_stride < sprintz_mi355x_compress_bound(elem_bytes, chunk_len, ndims))
         return fail(SPRINTZ_E_INVALID, "slot_stride below sprintz_mi355x_compress_bound");

@@ -30,7 +30,7 @@
 namespace sprintz { int set_error(int code, const char* what); }   // api.hip: the library's one error sink
 
 namespace sprintz {
-// chunks from which the one-table stream kernel runs as 4-wave workgroups with 32-byte pieces (SPRINTZ_OPT_HUF0_BIG_BATCH)
+// chunks from which the one-table stream kernel runs as workgroups of HUF0_BIG_WG (built: 2) waves with 2^HUF0_BIG_PLOG (built: 64) byte pieces (SPRINTZ_OPT_HUF0_BIG_BATCH)
 std::atomic<long long>& huf0_big_batch()
 {
     static std::atomic<long long> v{20000};      // (tools/huf0_threshold_sweep.sh: equal up to 20 000 chunks, 0.174 vs 0.235 ms at 40 000)
@@ -1335,7 +1335,7 @@ int sprintz_mi355x_huf0_decompress_batch_ws(const void* d_blocks, const uint64_t
                            (const uint8_t*)follow);
         hipLaunchKernelGGL(huf0_share_kernel, dim3((unsigned)((nleaders + 255) / 256)), dim3(256), 0, st, (const uint8_t*)desc, (const uint8_t*)follow, nchunks, share);
     }
-    // the one-table kernel: bandwidth-sized batches as 4-wave workgroups with 32-byte stream pieces, small ones wave by wave
+    // the one-table kernel: bandwidth-sized batches as workgroups of HUF0_BIG_WG waves with 2^HUF0_BIG_PLOG-byte stream pieces (built: 2 waves, 64 bytes), small ones wave by wave
     if (nchunks >= (uint64_t)sprintz::huf0_big_batch().load(std::memory_order_relaxed))
         hipLaunchKernelGGL((huf0_stream_kernel<true, HUF0_BIG_WG, HUF0_BIG_PLOG, HUF0_CADENCED != 0, HUF0_BIG_NS>), dim3((unsigned)((nchunks + 16 * HUF0_BIG_WG - 1) / (16 * HUF0_BIG_WG))),
                            dim3(64 * HUF0_BIG_WG), 0, st, blk, d_block_offsets, nchunks,

@@ -56,7 +56,7 @@ int set_error(int code, const char* what);
 struct HostScratch { hipStream_t stream; uint8_t* dev; uint8_t* pin; };
 int host_scratch(size_t dev_bytes, size_t pin_bytes, HostScratch* out);
 bool have_device();                       // probed once per process
-std::atomic<long long>& huf0_big_batch(); // huf0.hip: batch size from which the one-table stream kernel runs as 4-wave workgroups
+std::atomic<long long>& huf0_big_batch(); // huf0.hip: batch size from which the one-table stream kernel runs as workgroups of HUF0_BIG_WG (2) waves
 
 hipError_t launch_size_scan(const uint32_t* d_sizes, uint64_t n, uint32_t align, uint64_t* d_offsets, void* d_tmp, hipStream_t st);
 
