@@ -303,11 +303,17 @@ def streaming_probe():
         out = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
     except Exception:
         return None
-    rates = [float(m.group(1)) for m in re.finditer(r"decoder's mix[^\n]*-> ([0-9.]+) TB/s", out)]
+    rates = [float(m.group(1)) for m in re.finditer(r"(?:decoder's mix|mix tiles)[^\n]*-> ([0-9.]+) TB/s", out)]
+    copies = [float(m.group(1)) for m in re.finditer(r"tile copy[^\n]*-> ([0-9.]+) TB/s", out)]
     if not rates:
         return None
-    return {"GBps_best": round(max(rates) * 1e3, 1), "GBps_worst": round(min(rates) * 1e3, 1),
-            "what": "tools/probes/mix_bw.hip: streaming kernels with the decoder's read : write mix (grid sizes 1024 / 4096 / 16384 workgroups, nt and plain stores)"}
+    r = {"GBps_best": round(max(rates) * 1e3, 1), "GBps_worst": round(min(rates) * 1e3, 1),
+         "what": "tools/probes/mix_bw.hip: streaming kernels with the decoder's read : write mix -- grid-stride loops over 1024 / 4096 / 16384 "
+                 "workgroups and one-tile-per-workgroup forms, nt and plain stores; copy_GBps_best = the same probe's 1 : 1 tile copy (the "
+                 "calibration against MI355X_MICROARCH.md's 6.29 TB/s float4 copy)"}
+    if copies:
+        r["copy_GBps_best"] = round(max(copies) * 1e3, 1)
+    return r
 
 
 def roofline(algo_bytes, ms, kernel, extra=None):

@@ -51,6 +51,46 @@ __global__ void __launch_bounds__(256) tile_fill64(v4u* __restrict__ dst)
 #pragma unroll
     for (int k = 0; k < 16; k++) { if (NT) __builtin_nontemporal_store(o, p + 256 * k); else p[256 * k] = o; }
 }
+// CALIBRATION (round 4): the guide's 6.29 TB/s is a float4 copy whose workgroups each move ONE tile and leave -- grid = exact
+// tiles, NL loads in flight per thread before the first store, no loop.  copy_tile<NL>: 256 threads x NL x 16 B = NL x 4 KB a tile.
+template <int NL, bool NT>
+__global__ void __launch_bounds__(256) copy_tile(const v4u* __restrict__ src, v4u* __restrict__ dst)
+{
+    const uint64_t base = (uint64_t)blockIdx.x * (256u * NL) + threadIdx.x;
+    v4u in[NL];
+#pragma unroll
+    for (int k = 0; k < NL; k++) in[k] = __builtin_nontemporal_load(src + base + 256u * k);
+#pragma unroll
+    for (int k = 0; k < NL; k++) { if (NT) __builtin_nontemporal_store(in[k], dst + base + 256u * k); else dst[base + 256u * k] = in[k]; }
+}
+// the decoder's mix as tiles: a workgroup reads 6 KB... (NL = 3 pieces of 4 KB x 1/2: see mix_tile) and writes NS x 4 KB, then leaves
+template <int NL, int NS, bool NT>
+__global__ void __launch_bounds__(256) mix_tile(const v4u* __restrict__ src, v4u* __restrict__ dst)
+{
+    const uint64_t rb = (uint64_t)blockIdx.x * (256u * NL) + threadIdx.x, wb = (uint64_t)blockIdx.x * (256u * NS) + threadIdx.x;
+    v4u acc = {1, 2, 3, 4};
+    v4u in[NL];
+#pragma unroll
+    for (int k = 0; k < NL; k++) in[k] = __builtin_nontemporal_load(src + rb + 256u * k);
+#pragma unroll
+    for (int k = 0; k < NL; k++) acc ^= in[k];
+#pragma unroll
+    for (int k = 0; k < NS; k++) { v4u o = acc; o.x += (uint32_t)k; if (NT) __builtin_nontemporal_store(o, dst + wb + 256u * k); else dst[wb + 256u * k] = o; }
+}
+template <typename K> void run_tiles(K kern, const v4u* src, v4u* dst, uint64_t wbytes, uint64_t rtile, uint64_t wtile, const char* what)
+{
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const unsigned grid = (unsigned)(wbytes / wtile);
+    for (int w = 0; w < 3; w++) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, src, dst);
+    hipEventRecord(e0);
+    const int reps = 20;
+    for (int r = 0; r < reps; r++) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, src, dst);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+    const double rbs = (double)grid * rtile, wbs = (double)grid * wtile;
+    printf("%-28s read %.3f GB + write %.3f GB: %.4f ms -> %.2f TB/s\n", what, rbs / 1e9, wbs / 1e9, ms, (rbs + wbs) / ms / 1e9);
+}
+
 template <typename K> void run_fill(K kern, v4u* dst, uint64_t nbytes, uint64_t tile, const char* what)
 {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -101,5 +141,15 @@ int main()
     run<6, 17>(src, ns, dst, nd, "decoder's mix, 1024 WGs", 1024);
     run<3, 8>(src, ns, dst, nd, "3 : 8, 16384 WGs", 256 * 64);
     run<16, 0 + 16>(src, ns, dst, nd, "copy again");
+    // calibration against the guide's 6.29 TB/s float4 copy: one tile per workgroup, the workgroup leaves after it
+    run_tiles(copy_tile<4, false>, src, dst, wbytes, 16384, 16384, "tile copy 16 KB, plain");
+    run_tiles(copy_tile<4, true>, src, dst, wbytes, 16384, 16384, "tile copy 16 KB, nt");
+    run_tiles(copy_tile<8, false>, src, dst, wbytes, 32768, 32768, "tile copy 32 KB, plain");
+    run_tiles(copy_tile<8, true>, src, dst, wbytes, 32768, 32768, "tile copy 32 KB, nt");
+    run_tiles(copy_tile<2, false>, src, dst, wbytes, 8192, 8192, "tile copy 8 KB, plain");
+    run_tiles(copy_tile<1, false>, src, dst, wbytes, 4096, 4096, "tile copy 4 KB, plain");
+    run_tiles(mix_tile<3, 8, false>, src, dst, wbytes, 12288, 32768, "decoder's mix as tiles, plain");
+    run_tiles(mix_tile<3, 8, true>, src, dst, wbytes, 12288, 32768, "decoder's mix as tiles, nt");
+    run_tiles(mix_tile<6, 17, true>, src, dst, wbytes / 17 * 17 / 69632 * 69632, 24576, 69632, "mix tiles 6:17 (24+68 KB), nt");
     return 0;
 }
