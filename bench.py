@@ -340,6 +340,17 @@ def load_traffic(kernel_substr):
                                          "nchunks": ent.get("nchunks"), "data": ent.get("data")}
 
 
+def chain_traffic(name, algo_bytes, world):
+    """PMC-measured HBM bytes of a cfg4 decode chain (profiles/hbm_traffic.json, entry "chain:<name>": the sum over the chain's
+    kernels, last profiled build) next to the ratio the two-stage design implies: what the chain REALLY moves"""
+    if world != 1:
+        return {}
+    t, label = load_traffic("chain:" + name)
+    if not t:
+        return {}
+    return {"traffic": t, "traffic_ratio_measured": round(t / algo_bytes, 3), "traffic_source": label}
+
+
 # ------------------------------------------------------------------------------------------ per-config legs
 class Ctx:
     pass
@@ -440,6 +451,7 @@ def bench_rowmajor(cx, name, workload, codec, esz, ndims, chunk_len, nchunks_tot
                     "roofline": roofline(algo_chain, chain_ms, "Huff0 stage (tree passes + stream kernels, sprintz_mi355x_huf0_decompress_batch_ws) + sprintz decode; the Sprintz streams cross HBM between the two",
                                          {"algorithmic": "Huff0 blocks in + samples out + offset tables (SURVEY 8d); the intermediate Sprintz streams are NOT counted",
                                           "traffic_ratio_by_design": round(moved_chain / algo_chain, 3),
+                                          **chain_traffic(name, algo_chain, cx.world),
                                           "huff0_decode_frac": round((hbytes + stream_bytes + 16 * n) / (h_dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})})
         if cx.rank == 0 and cx.world == 1 and not args.no_cpu_baseline:
             pt = huf0_private_trees(cx, comp, offs, ws["sizes"], n, timer, reps)
@@ -1109,8 +1121,9 @@ def headline_extras(cx, codec, x, comp, offsets, ws, out, nchunks, total_comp, c
         res["single_call_latency_10KB"] = {
             "decompress_us_median": round(lat_d[150] * 1e6, 1), "decompress_us_p10": round(lat_d[30] * 1e6, 1),
             "compress_us_median": round(lat_c[150] * 1e6, 1), "compress_us_p10": round(lat_c[30] * 1e6, 1),
-            "what": "sprintz_decompress_xff_16b / sprintz_compress_xff_16b on host buffers through ctypes: memcpy to pinned staging, one H2D, "
-                    "one kernel (one chunk = 8 lanes), one D2H, one stream sync; pooled per-thread device scratch, no hipMalloc per call"}
+            "what": "sprintz_decompress_xff_16b / sprintz_compress_xff_16b on host buffers through ctypes: memcpy into the thread's MAPPED staging "
+                    "buffer, stage_in + the one-workgroup-per-chunk kernel (decode_lat.h / encode_lat.h) reading and writing that buffer directly, "
+                    "one event wait, memcpy out; no copy engine, no memset, no hipMalloc per call"}
         # ---------------- the same drop-in symbols from many host threads at once (each thread has its own pooled scratch and stream
         # inside the library; ctypes releases the interpreter lock around the call): calls per second of the whole process
         def many_threads(nthreads, calls):
@@ -1139,8 +1152,9 @@ def headline_extras(cx, codec, x, comp, offsets, ws, out, nchunks, total_comp, c
             assert ok, "a thread's single-call decode differs from the input"
             res["single_call_threads"][str(nt)] = {"calls_per_s": round(rate), "MBps_of_samples": round(rate * chunk_bytes / 1e6, 1)}
         res["single_call_threads"]["what"] = ("N host threads, each alternating sprintz_decompress_xff_16b / sprintz_compress_xff_16b on its own 10 KB "
-                                              "chunk: what a multi-threaded lzbench-style driver gets out of the single-call boundary; the batched "
-                                              "device API is the fast path")
+                                              "chunk: what a multi-threaded lzbench-style driver gets out of the single-call boundary (the threads share "
+                                              "4 streams per device, SPRINTZ_OPT_HOST_STREAMS; each call waits on its own event); the batched device "
+                                              "API is the fast path")
         # ---------------- online.hpp's u16 coders: ONE stream of 64 Mi samples per call, device buffers
         res["online_coders"] = online_leg(cx)
         # ---------------- PCIe-inclusive: host buffers in and out through the chunked host entry points

@@ -29,6 +29,10 @@ OURS = ("sprintz", "huf", "compact_copy", "scan_", "zigzag_kernel", "dyndelta", 
 
 # kernel substring quoted by bench.py -> (workload whose PMC passes hold it, nchunks, data)
 DOMINANT = {"decode_fast_kernel<16, true, 8": ("headline", 131072, "walk8")}
+# workloads whose decode is a CHAIN of kernels: the chain's HBM bytes = the sum over its kernels of the average bytes per dispatch
+# (every distinct kernel runs once per chain; FETCH_SIZE doubled for all of them: their reads are 16 bytes a lane and contiguous)
+CHAIN_KERNELS = ("huf0_follow", "huf0_copy", "huf0_tree", "huf0_share", "huf0_stream", "decode_fast_kernel", "decode_lat_kernel")
+CHAINS = ("cfg4_10000", "cfg4_80000", "cfg4_800000")
 
 
 def main():
@@ -84,6 +88,21 @@ def main():
                 entries[sub] = dict(kernel=k, nchunks=nchunks, data=data, fetch_bytes_corrected=int(fetch), write_bytes=int(write),
                                     bytes_per_launch=int(fetch + write), source=os.path.basename(a.out_prefix) + f"_{w}_pmc.csv", build=a.build,
                                     method="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950), KiB->B")
+        if w in CHAINS and pmc:
+            tot_f = tot_w = 0.0
+            parts = {}
+            for k in pmc:
+                if not any(c in k for c in CHAIN_KERNELS):
+                    continue
+                f = pmc[k].get("FETCH_SIZE", (0, 0))[1] * 1024 * 2
+                wv = pmc[k].get("WRITE_SIZE", (0, 0))[1] * 1024
+                tot_f += f
+                tot_w += wv
+                parts[k[:70]] = int(f + wv)
+            if parts:
+                entries["chain:" + w] = dict(kernel="the decode chain of " + w, fetch_bytes_corrected=int(tot_f), write_bytes=int(tot_w),
+                                             bytes_per_launch=int(tot_f + tot_w), parts=parts, source=os.path.basename(a.out_prefix) + f"_{w}_pmc.csv",
+                                             build=a.build, method="sum over the chain's kernels of (FETCH_SIZE x2 + WRITE_SIZE) per dispatch, separate --pmc passes")
     if entries:
         with open(a.traffic_json or os.path.join(os.path.dirname(a.out_prefix) or ".", "hbm_traffic.json"), "w") as f:
             json.dump({"entries": entries}, f, indent=1)

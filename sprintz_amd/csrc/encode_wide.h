@@ -85,12 +85,18 @@ __device__ __forceinline__ uint32_t encode_wide_body(const EncodeArgs& a, uint32
         wave_lds_sync();
     };
     auto or_bits = [&](uint32_t bp, uint32_t v, uint32_t nb) {      // low nb (<= 32) bits of v at window bit bp
+#ifndef SPRINTZ_ENC_OR_NOZERO
         if (nb == 0) return;
+#endif
         const uint64_t x = (uint64_t)v << (bp & 31u);
         __attribute__((address_space(3))) uint32_t* q =
             (__attribute__((address_space(3))) uint32_t*)(uintptr_t)(win_a + ((bp >> 3) & ~3u));
         __hip_atomic_fetch_or(q, (uint32_t)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#ifdef SPRINTZ_ENC_OR_BOTH
+        __hip_atomic_fetch_or(q + 1, (uint32_t)(x >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#else
         if ((uint32_t)(x >> 32)) __hip_atomic_fetch_or(q + 1, (uint32_t)(x >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#endif
     };
     auto put_run = [&](uint32_t run) {           // sprintz_xff_rle.cpp:377-384
         if (lane_d == 0) {

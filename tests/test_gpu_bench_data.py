@@ -131,10 +131,12 @@ def test_cfg4_chain_at_800000_chunks(sz, oracle):
             assert ret == sz_h[c] and np.array_equal(plain, comp[o:o + int(sz_h[c])]), c
 
 
-def test_cfg4_chain_on_libzstd_blocks_at_80000_chunks(sz):
+@pytest.mark.parametrize("nt", [80000, 800000])
+def test_cfg4_chain_on_libzstd_blocks(sz, nt):
     """the blocks lzbench's huff0 would hand over: HUF_compress of the host's libzstd, one call per chunk, a tree of its own in
     every block (the writer of this library repeats a tree per 64-chunk segment, which its reader exploits).  2 048 distinct
-    chunks' streams coded on the host, tiled to 80 000 blocks, decoded on the GPU to streams and on to samples."""
+    chunks' streams coded on the host, tiled to 80 000 / 800 000 blocks (the largest batch bench.py runs), decoded on the GPU to
+    streams and on to samples."""
     import torch
     from synth import synth_torch
     try:
@@ -145,7 +147,7 @@ def test_cfg4_chain_on_libzstd_blocks_at_80000_chunks(sz):
         z.HUF_isError.argtypes = [C.c_size_t]
     except (OSError, AttributeError):
         pytest.skip("no libzstd.so.1 exporting HUF_compress on this host")
-    nd, nt, chunk_len, ndims = 2048, 80000, 5120, 8
+    nd, chunk_len, ndims = 2048, 5120, 8
     x = synth_torch("walk", 2, nd, chunk_len // ndims, ndims, "cuda:0", seed=123, step=8, chunk0=0)
     cd = sz.ChunkedCodec("xff", 2, ndims, chunk_len, device="cuda:0")
     batch = cd.compress(x)
