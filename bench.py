@@ -667,7 +667,12 @@ def dry_launch(args, world, rank):
         dist.all_gather(got, t)
         seen = [int(g.item()) for g in got]
     rccl = None
+    json_fd = None
     if args.rccl:
+        # (stdout carries the JSON line alone: RCCL prints its version banner there when the first communicator comes up)
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
         # the product's own exchange (csrc/comm.cpp: ncclAllGather behind the C-ABI) on a real communicator of `world` ranks:
         # rank r contributes 1000 + r bytes, every rank must see all of them and derive the same bases
         assert use_gpu and (world == 1 or backend == "nccl"), "--rccl needs one visible GPU per rank (RCCL refuses two ranks on one device)"
@@ -686,8 +691,17 @@ def dry_launch(args, world, rank):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps({"dry_launch": True, "n_gpus": args.gpus, "world": world, "ranks": seen, "backend": backend if world > 1 else None,
-                          "self_launched": bool(os.environ.get("BENCH_SELF_LAUNCHED")), "rccl_c_abi": rccl}), flush=True)
+        line = json.dumps({"dry_launch": True, "n_gpus": args.gpus, "world": world, "ranks": seen, "backend": backend if world > 1 else None,
+                           "self_launched": bool(os.environ.get("BENCH_SELF_LAUNCHED")), "rccl_c_abi": rccl})
+        if json_fd is not None:
+            sys.stdout.flush()
+            try:
+                C.CDLL(None).fflush(None)
+            except Exception:
+                pass
+            os.write(json_fd, (line + "\n").encode())
+        else:
+            print(line, flush=True)
 
 
 def main():
