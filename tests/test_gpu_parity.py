@@ -52,6 +52,39 @@ def test_golden_vectors_single_call(sz, golden):
         assert (dec[data.size:] == dec[-1]).all(), "decoder wrote past the decoded length"
 
 
+@pytest.mark.parametrize("wait_mode", [0, 1, 2])
+def test_single_calls_from_many_threads(sz, oracle, wait_mode, request):
+    """the drop-in symbols are re-entrant (sprintz.h: one call = one thread, any number at once): 24 host threads, each with its own
+    shape and data, compress and decompress through the single-call entry points at the same time -- the threads share the
+    library's stream pool and wait on their own events (spin / sleep / by the number of callers) -- and every stream and every
+    sample is the oracle's"""
+    import threading
+    from sprintz_amd import _lib
+    _lib.check(_lib.set_option(_lib.OPT_HOST_WAIT, wait_mode))
+    request.addfinalizer(lambda: _lib.set_option(_lib.OPT_HOST_WAIT, 0))
+    shapes = [("xff", 2, 8, 5120), ("delta", 1, 80, 10240), ("xff", 1, 1, 1024), ("delta", 2, 3, 3000), ("xff", 2, 32, 5120), ("xff", 1, 16, 4096)]
+    nthreads, rounds = 24, 12
+    errors = []
+
+    def work(k):
+        try:
+            codec, esz, ndims, n = shapes[k % len(shapes)]
+            rng = np.random.default_rng(1000 + k)
+            for r in range(rounds):
+                data = gen_walk(rng, n - (r % 3) * ndims, ndims, esz, 8, flat_every=4 if r % 2 else 0)
+                want, wret = oracle.compress(codec, data, ndims)
+                dest, ret = gpu_compress(sz, codec, data, ndims)
+                assert ret == wret and np.array_equal(dest[:want.size], want), (k, r, "stream")
+                dec, dret = gpu_decompress(sz, codec, want, esz, data.size)
+                assert dret == data.size and np.array_equal(dec[:data.size], data.ravel()), (k, r, "samples")
+        except BaseException as e:                      # noqa: BLE001 -- reported by the main thread
+            errors.append((k, repr(e)))
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(nthreads)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errors, errors[:3]
+
+
 @pytest.mark.parametrize("esz", [1, 2])
 @pytest.mark.parametrize("codec", ["delta", "xff"])
 def test_reference_test_matrix_single_call(sz, oracle, codec, esz):
