@@ -46,7 +46,7 @@ extern "C" {
  *      the column-major and run-less codec entry points, the reference's mangled C++ names (sprintz_dropin.hpp)
  *   3  round 3: compress_batch_dense / compress_dense_tmp_bytes, SPRINTZ_OPT_DENSE_MODE, env SPRINTZ_MI355X_RCCL_SONAME
  *   4  round 3: compress_batch_colmajor_dense, SPRINTZ_OPT_SPLIT_LANES, SPRINTZ_OPT_ENC_PAIR
- *   5  round 4: SPRINTZ_OPT_HOST_WAIT, SPRINTZ_OPT_LAT_CHUNKS, SPRINTZ_OPT_HOST_STREAMS (the single-call entry points work on a mapped staging buffer: one wait per call) */
+ *   5  round 4: SPRINTZ_OPT_HOST_WAIT, SPRINTZ_OPT_LAT_CHUNKS, SPRINTZ_OPT_HOST_STREAMS, SPRINTZ_OPT_REF_DECODER_QUIRK (the single-call entry points work on a mapped staging buffer: one wait per call) */
 #define SPRINTZ_MI355X_ABI_VERSION 5
 
 /* codec ids */
@@ -99,6 +99,12 @@ const char* sprintz_mi355x_last_error(void);     /* thread-local, never NULL; de
  *   SPRINTZ_OPT_HOST_STREAMS      streams the single-call entry points of ALL host threads share per device (each call waits for its own
  *                                 launches through an event); default 4, 0 = a private stream per thread; read when a thread makes its
  *                                 first call; env SPRINTZ_MI355X_HOST_STREAMS
+ *   SPRINTZ_OPT_REF_DECODER_QUIRK 0 (default) = every decoder is the true inverse of the reference ENCODER; 1 = runs of 16-bit
+ *                                 general-layout FIRE streams are replayed as the reference DECODER replays them (coefficient
+ *                                 shifted by 4 instead of 12, odd columns reading the counters' high halves:
+ *                                 sprintz_xff_rle.cpp:893-901) -- not lossless on streams whose runs start with a non-zero
+ *                                 prediction, but sample-for-sample what sprintz_decompress_xff_16b of the reference returns;
+ *                                 env SPRINTZ_MI355X_REF_DECODER_QUIRK
  *   SPRINTZ_OPT_LAT_CHUNKS        batches of at most this many chunks (general layout, 3 .. 64 columns, chunks of at most 16 KB) decode
  *                                 with one workgroup per chunk (csrc/decode_lat.h: a chunk's latency is what counts; half as many from 17 columns on); default 1280,
  *                                 0 = never (A/B runs, tests); env SPRINTZ_MI355X_LAT_CHUNKS
@@ -114,6 +120,7 @@ const char* sprintz_mi355x_last_error(void);     /* thread-local, never NULL; de
 #define SPRINTZ_OPT_HOST_WAIT 6
 #define SPRINTZ_OPT_LAT_CHUNKS 7
 #define SPRINTZ_OPT_HOST_STREAMS 8
+#define SPRINTZ_OPT_REF_DECODER_QUIRK 9
 int sprintz_mi355x_set_option(int option, int value);
 
 /* ------------------------------------------------------------------------

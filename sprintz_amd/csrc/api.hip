@@ -54,6 +54,7 @@ struct Process {
     std::atomic<int> dense_mode{1};         // SPRINTZ_MI355X_DENSE_MODE: how compress_batch_dense builds the container (see SPRINTZ_OPT_DENSE_MODE)
     std::atomic<int> enc_pair{1024};        // SPRINTZ_MI355X_ENC_PAIR: chunks from which row-major streams of 5 .. 64 columns are encoded with two columns per lane (0: never; see SPRINTZ_OPT_ENC_PAIR)
     std::atomic<int> lat_chunks{1280};      // SPRINTZ_MI355X_LAT_CHUNKS: batches of at most this many chunks decode with one workgroup per chunk (decode_lat.h; 0: never)
+    std::atomic<int> ref_quirk{0};          // SPRINTZ_MI355X_REF_DECODER_QUIRK: decode as the reference DECODER does where it differs from the inverse of its encoder
     std::atomic<int> host_streams{4};       // SPRINTZ_MI355X_HOST_STREAMS: streams the host-pointer calls of all threads share per device (0: one per thread)
     std::atomic<int> host_wait{0};          // SPRINTZ_MI355X_HOST_WAIT: how a single call waits for its launches (see SPRINTZ_OPT_HOST_WAIT)
     std::atomic<int> split_lanes{1};        // SPRINTZ_MI355X_SPLIT_LANES: 8-bit streams of 65 .. 80 columns on 32 lanes x (pair + single) (see SPRINTZ_OPT_SPLIT_LANES)
@@ -71,6 +72,7 @@ Process& process()
             p.dense_mode = k <= 0 ? 0 : 1;
         }
         if (const char* e = getenv("SPRINTZ_MI355X_LAT_CHUNKS")) p.lat_chunks = atoi(e) < 0 ? 0 : atoi(e);
+        if (const char* e = getenv("SPRINTZ_MI355X_REF_DECODER_QUIRK")) p.ref_quirk = atoi(e) != 0 ? 1 : 0;
         if (const char* e = getenv("SPRINTZ_MI355X_HOST_STREAMS")) p.host_streams = atoi(e) < 0 ? 0 : (atoi(e) > 64 ? 64 : atoi(e));
         if (const char* e = getenv("SPRINTZ_MI355X_HOST_WAIT")) p.host_wait = atoi(e) < 0 || atoi(e) > 2 ? 0 : atoi(e);
         if (const char* e = getenv("SPRINTZ_MI355X_SPLIT_LANES")) p.split_lanes = atoi(e) != 0 ? 1 : 0;
@@ -370,6 +372,8 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
     a.raw = codec == SPRINTZ_CODEC_BITPACK_NORLE ? 1 : 0;
     a.col_stride = qs.col_stride;
     const uint64_t cs = qs.col_stride;
+    // (only 16-bit general-layout FIRE streams have the divergence: sprintz_xff_rle.cpp:893-901)
+    a.quirk = (esz == 2 && codec == SPRINTZ_CODEC_XFF && !lowdim && process().ref_quirk.load(std::memory_order_relaxed)) ? 1 : 0;
 
     // batches whose chunks are too short for a stream group: header check + copy (verbatim_decode_kernel)
     // (only where a chunk cannot hold a group at all, chunk_len < 16 D: a stream of 16 D <= chunk_len < 128 elements that announces
@@ -424,7 +428,7 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
     hipError_t e;
     // small batches: one WORKGROUP per chunk (decode_lat.h) -- a chunk's 40 dependent group steps on one lane group take 50 us
     // however few chunks there are; split into a header walk, parallel bit extraction, the bare recurrence and a prefix sum it is ~13
-    if (!norle && !lowdim && !noheader && !cs && !a.raw && qs.q == kQueryOff && D <= 64 && (uint64_t)chunk_len * esz <= kLatMaxChunkBytes &&
+    if (!norle && !lowdim && !noheader && !cs && !a.raw && !a.quirk && qs.q == kQueryOff && D <= 64 && (uint64_t)chunk_len * esz <= kLatMaxChunkBytes &&
         chunk_len >= 16u * (uint32_t)D && ((uintptr_t)d_out % 16) == 0 && ((uint64_t)chunk_len * esz) % 16 == 0 &&
         // (one round of workgroups on the chip is where it wins: 5 a CU at 8 columns -- measured 36 vs 48 us at 1 250 chunks, 45 vs 48 at
         //  2 048, 84 vs 48 at 4 096; with more columns a chunk has fewer groups to walk and the lane-per-column kernel catches up sooner)
@@ -1218,6 +1222,7 @@ int sprintz_mi355x_set_option(int option, int value)
         process().lat_chunks = value;
         return 0;
     }
+    if (option == SPRINTZ_OPT_REF_DECODER_QUIRK) { process().ref_quirk = value ? 1 : 0; return 0; }
     if (option == SPRINTZ_OPT_HOST_STREAMS) {
         if (value < 0 || value > 64) return fail(SPRINTZ_E_INVALID, "host streams must be in 0..64");
         process().host_streams = value;                     // (threads that already hold a scratch keep their stream)

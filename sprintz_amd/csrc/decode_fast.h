@@ -466,7 +466,10 @@ __global__ void __launch_bounds__(kThreads) decode_fast_kernel(DecodeArgs a)
                 }
             };
             auto run_col = [&](int k) {
-                const int coef = FIRE ? fire_coef<W, false>(ctr[k]) : 0;
+                int coef = FIRE ? fire_coef<W, false>(ctr[k]) : 0;
+                if constexpr (FIRE && W == 16) {
+                    if (a.quirk) coef = fire_coef_ref_run16(ctr[k], genk[k]);      // the reference decoder's run replay, on request
+                }
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     run_step(k, coef);

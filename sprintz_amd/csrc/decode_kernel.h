@@ -40,6 +40,7 @@ struct DecodeArgs {
     // len/(16 D) groups, an all-zero block has no payload and no run length; raw: bit-packing only
     int norle;
     int raw;
+    int quirk;                  // 1: replay the runs of 16-bit general-layout FIRE streams as the REFERENCE DECODER does (fire_coef_ref_run16)
     int qop;                    // 1: max, 2: sum (what lands in qres)
     uint64_t* qres;             // [nchunks][D] per-chunk, per-column partial results
 };
@@ -137,9 +138,11 @@ __global__ void __launch_bounds__(kThreads) decode_kernel(DecodeArgs a)
             for (int k = 0; k < CPL; k++) z[i][k] = 0;
 
         bool have = false;
+        bool run_block = false;                  // this block is one of a RUN
         if (run_left > 0) {                      // inside a RUN: zero errors (sprintz_xff_rle.cpp:828-958)
             run_left--;
             have = true;
+            run_block = true;
         } else {
             for (;;) {
                 if (slot == 2) {
@@ -182,7 +185,7 @@ __global__ void __launch_bounds__(kThreads) decode_kernel(DecodeArgs a)
                     if (b0 & 0x80u) { len |= load_u8(s + pos + 1) << 7; pos += 2; }
                     else pos += 1;
                     slot++;
-                    if (len > 0) { run_left = len - 1; have = true; break; }
+                    if (len > 0) { run_left = len - 1; have = true; run_block = true; break; }
                     // len == 0: padding slot, look at the next one
                 } else {                         // packed block
                     uint32_t cur[CPL], lane_bits = 0;
@@ -226,7 +229,10 @@ __global__ void __launch_bounds__(kThreads) decode_kernel(DecodeArgs a)
         uint32_t v[8][CPL];
 #pragma unroll
         for (int k = 0; k < CPL; k++) {
-            const int coef = FIRE ? fire_coef<W, LOWDIM>(ctr[k]) : 0;
+            int coef = FIRE ? fire_coef<W, LOWDIM>(ctr[k]) : 0;
+            if constexpr (FIRE && W == 16 && !LOWDIM) {
+                if (a.quirk && run_block) coef = fire_coef_ref_run16(ctr[k], lane_d * CPL + k);
+            }
             int grad = 0;
             uint32_t pvk = pv[k];
             int pdk = pd[k];

@@ -50,6 +50,17 @@ template <int W, bool LOWDIM> __device__ __forceinline__ int fire_coef(int ctr)
     else return (int)(int16_t)((uint32_t)(ctr >> (1 + (W - 4))) << (W - 4));
 }
 
+// The reference DECODER's coefficient while it replays a RUN of a 16-bit general-layout FIRE stream (sprintz_xff_rle.cpp:893-901):
+// the 32-bit counters >> 13, read as 16-bit lanes -- an even column sees its low half, an odd column the HIGH half (the counters
+// are not repositioned for the odd columns) -- shifted left by 4 instead of 12.  It does not invert the reference encoder; it is
+// what a caller needs who must reproduce the reference decoder sample for sample (SPRINTZ_OPT_REF_DECODER_QUIRK).
+__device__ __forceinline__ int fire_coef_ref_run16(int ctr, int column)
+{
+    const uint32_t k = (uint32_t)(ctr >> 13);
+    const uint32_t lane = (column & 1) ? k >> 16 : k & 0xffffu;
+    return (int)(int16_t)(uint16_t)(lane << 4);
+}
+
 // prediction = (prev_delta * coef) >> W truncated to W bits (sprintz_xff_rle.cpp:225).
 // Both operands fit 24 bits except in the 16-bit low-dim codec, whose 32-bit
 // coefficient needs the full (wrapping) multiply (sprintz_xff_lowdim.cpp:183).

@@ -3,6 +3,8 @@ the oracle and the golden vectors.  Bar: bit-exact stream bytes, byte lengths,
 return values and decoded samples.  Nothing here reads /root/reference."""
 import zlib
 
+import os
+
 import numpy as np
 import pytest
 
@@ -50,6 +52,66 @@ def test_golden_vectors_single_call(sz, golden):
         assert dret == data.size, (m, sz.last_error())
         assert np.array_equal(dec[:data.size], data), m
         assert (dec[data.size:] == dec[-1]).all(), "decoder wrote past the decoded length"
+
+
+def test_reference_decoder_quirk_on_request(sz, oracle, golden, request):
+    """SPRINTZ_OPT_REF_DECODER_QUIRK: the decoders replay the runs of 16-bit general-layout FIRE streams as the REFERENCE DECODER
+    does (sprintz_xff_rle.cpp:893-901) -- sample for sample what the compiled reference returned for the golden stream it does
+    not invert (tests/golden/golden_refdec_v1), and what the oracle's model of it returns on batches with runs; every other
+    codec / width / layout is untouched by the switch"""
+    import json
+    import torch
+    from sprintz_amd import _lib
+    _lib.check(_lib.set_option(_lib.OPT_REF_DECODER_QUIRK, 1))
+    request.addfinalizer(lambda: _lib.set_option(_lib.OPT_REF_DECODER_QUIRK, 0))
+    manifest, arrays = golden
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    cases = json.load(open(os.path.join(gdir, "golden_refdec_v1.json")))["cases"]
+    refdec = np.load(os.path.join(gdir, "golden_refdec_v1.npz"))
+    for c in cases:
+        m = [mm for mm in manifest if mm["idx"] == c["idx"]][0]
+        data, stream = arrays[f"in_{m['idx']}"], arrays[f"out_{m['idx']}"]
+        dec, dret = gpu_decompress(sz, m["codec"], stream, m["esz"], data.size)
+        assert dret == c["dec_ret"]
+        assert np.array_equal(dec[:data.size], refdec[f"refdec_{m['idx']}"]), m["name"]
+        assert not np.array_equal(dec[:data.size], data.ravel())
+    rng = np.random.default_rng(41)
+
+    def oscillate_then_run(nchunks, rows, ndims):
+        """golden_v1's fire16_run_nonzero_pred over and over: an oscillation (the counters go negative), the decay FIRE predicts,
+        48 constant rows (RUN blocks that start with a non-zero prediction), noise"""
+        out = np.zeros((nchunks, rows, ndims), np.int64)
+        for c in range(nchunks):
+            v, seq = 1000 + int(rng.integers(0, 500)), []
+            while len(seq) < rows:
+                for i in range(8):
+                    v += 100 if i % 2 == 0 else -100
+                    seq.append([v] * ndims)
+                for dl in (6, -1, 0, 0, 0, 0, 0, 0):
+                    v += dl
+                    seq.append([v] * ndims)
+                seq += [[v] * ndims] * 48
+                seq += [list(rng.integers(0, 50, ndims) + v) for _ in range(32)]
+            out[c] = np.array(seq[:rows])
+        return np.mod(out, 65536).astype(np.uint16).reshape(-1)
+    for ndims, chunk_len, nchunks in ((3, 3000, 40), (8, 5120, 40), (8, 5120, 2000), (17, 17 * 320, 30), (80, 10240, 24)):
+        data = oscillate_then_run(nchunks, chunk_len // ndims, ndims)
+        cd = sz.ChunkedCodec("xff", 2, ndims, chunk_len, device="cuda:0")
+        batch = cd.compress(torch.from_numpy(data.view(np.int16)).cuda().view(torch.uint16))
+        out = cd.decompress(batch).cpu().numpy().view(np.uint16)
+        comp, offs, sizes = batch.data.cpu().numpy(), batch.offsets.cpu().numpy(), batch.sizes.cpu().numpy()
+        differs = 0
+        for c in list(range(0, nchunks, max(1, nchunks // 40))):
+            want, _ = oracle.decompress("xff", comp[offs[c]:offs[c] + sizes[c]], 2, chunk_len, quirk=1)
+            got = out[c * chunk_len:(c + 1) * chunk_len]
+            assert np.array_equal(got, want), (ndims, nchunks, c)
+            differs += int(not np.array_equal(got, data[c * chunk_len:(c + 1) * chunk_len]))
+        assert differs > 0, (ndims, "the inputs were meant to hit the divergence")
+    for codec, esz, ndims in (("delta", 2, 8), ("xff", 1, 8), ("xff", 2, 2)):     # not 16-bit general-layout FIRE: no divergence exists
+        d = gen_walk(rng, 20 * 4096, ndims, esz, 8, flat_every=3)
+        cd = sz.ChunkedCodec(codec, esz, ndims, 4096, device="cuda:0")
+        t = torch.from_numpy(d.view(np.int8 if esz == 1 else np.int16)).cuda().view(cd.dtype)
+        assert torch.equal(cd.decompress(cd.compress(t)).view(torch.uint8), t.view(torch.uint8)), (codec, esz, ndims)
 
 
 @pytest.mark.parametrize("wait_mode", [0, 1, 2])
