@@ -428,15 +428,15 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
     hipError_t e;
     // small batches: one WORKGROUP per chunk (decode_lat.h) -- a chunk's 40 dependent group steps on one lane group take 50 us
     // however few chunks there are; split into a header walk, parallel bit extraction, the bare recurrence and a prefix sum it is ~13
-    if (!norle && !lowdim && !noheader && !cs && !a.raw && !a.quirk && qs.q == kQueryOff && D <= 64 && (uint64_t)chunk_len * esz <= kLatMaxChunkBytes &&
+    if (!norle && !noheader && !cs && !a.raw && !a.quirk && qs.q == kQueryOff && D <= 64 && (uint64_t)chunk_len * esz <= kLatMaxChunkBytes &&
         chunk_len >= 16u * (uint32_t)D && ((uintptr_t)d_out % 16) == 0 && ((uint64_t)chunk_len * esz) % 16 == 0 &&
         // (one round of workgroups on the chip is where it wins: 5 a CU at 8 columns -- measured 36 vs 48 us at 1 250 chunks, 45 vs 48 at
         //  2 048, 84 vs 48 at 4 096; with more columns a chunk has fewer groups to walk and the lane-per-column kernel catches up sooner)
         nchunks <= (uint64_t)process().lat_chunks.load(std::memory_order_relaxed) / (D > 16 ? 2u : 1u) && !process().no_fast.load(std::memory_order_relaxed)) {
         int ldp = 4;
         while (ldp < D) ldp <<= 1;
-        if (esz == 1 && ldp < 8) ldp = 8;
-        e = launch_decode_lat(8 * esz, codec == SPRINTZ_CODEC_XFF, ldp, (unsigned)nchunks, (uint32_t)sprintz_mi355x_compress_bound(esz, chunk_len, ndims), st, a);
+        if (esz == 1 && ldp < 8 && !lowdim) ldp = 8;
+        e = launch_decode_lat(8 * esz, codec == SPRINTZ_CODEC_XFF, ldp, lowdim, (unsigned)nchunks, (uint32_t)sprintz_mi355x_compress_bound(esz, chunk_len, ndims), st, a);
         if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "decode_lat kernel launch", e);
         return 0;
     }
@@ -534,13 +534,13 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     // small batches: one WORKGROUP per chunk (encode_lat.h), the counterpart of decode_lat.h -- 90 us for ONE 10 KB chunk on a lane
     // group, ~20 with the coefficient chain and the RLE state machine as the only serial parts (the container, if one was asked
     // for, is then built by the scan + copy passes: dense->fused stays false)
-    if (!norle && !lowdim && !col_stride && !a.raw && D <= 64 && (uint64_t)chunk_len * esz <= kEncLatMaxChunkBytes &&
+    if (!norle && !col_stride && !a.raw && D <= 64 && (uint64_t)chunk_len * esz <= kEncLatMaxChunkBytes &&
         ((uintptr_t)d_src % 16) == 0 && ((uint64_t)chunk_len * esz) % 16 == 0 && slot_stride % 16 == 0 && ((uintptr_t)d_slots % 16) == 0 &&
         nchunks <= (uint64_t)process().lat_chunks.load(std::memory_order_relaxed) / (D > 16 ? 2u : 1u) && !process().no_fast.load(std::memory_order_relaxed)) {
         int ldp = 4;
         while (ldp < D) ldp <<= 1;
-        if (esz == 1 && ldp < 8) ldp = 8;
-        e = launch_encode_lat(8 * esz, codec == SPRINTZ_CODEC_XFF, ldp, (unsigned)nchunks, (uint32_t)sprintz_mi355x_compress_bound(esz, chunk_len, ndims), st, a);
+        if (esz == 1 && ldp < 8 && !lowdim) ldp = 8;
+        e = launch_encode_lat(8 * esz, codec == SPRINTZ_CODEC_XFF, ldp, lowdim, (unsigned)nchunks, (uint32_t)sprintz_mi355x_compress_bound(esz, chunk_len, ndims), st, a);
         if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "encode_lat kernel launch", e);
         return 0;
     }

@@ -1,7 +1,8 @@
 // decode_lat.h -- the LATENCY decoder: one WORKGROUP (256 lanes) per chunk, for batches too small to fill the chip with
 // decode_fast.h's one-lane-per-column mapping (a single drop-in call; one GPU's 1 250-chunk share of BASELINE config 4's
 // 10 000-chunk batches on eight).  Same streams, same samples, same return values as decode_fast.h / decode_kernel.h
-// (sprintz_xff_rle.cpp:569-1179, sprintz_delta_rle.cpp:418-772), general layout, headered RLE streams, 3 <= ndims <= 64.
+// (sprintz_xff_rle.cpp:569-1179, sprintz_delta_rle.cpp:418-772; the low-dim layouts of sprintz_{delta,xff}_lowdim.cpp as template
+// parameter LOW), headered RLE streams, ndims <= 64, chunks of at most 16 KB.
 //
 // decode_fast.h walks a chunk's 40 groups in 40 dependent steps of ~600 wave-instructions each: 50 us a chunk however few
 // chunks there are (a lone wave issues an instruction every 4 .. 8 cycles).  Only two things in the format are serial:
@@ -47,7 +48,10 @@ inline LatCarve lat_carve(uint32_t bound_bytes, uint32_t chunk_len, uint32_t D)
     return c;
 }
 
-template <int W, bool FIRE, int DP>
+// LOW: the low-dim layout (D <= 4 at 8 bits, <= 2 at 16: sprintz_{delta,xff}_lowdim.cpp) -- column-major payload (a column's 8 values in
+// nbits bytes), no row padding, untruncated FIRE coefficient (counter >> 1; 32-bit multiply at 16 bits).  Its errors travel
+// unscaled (E = err): the general layout's "delta is the high half of prev_delta*coef + E" needs a 16-bit coefficient.
+template <int W, bool FIRE, int DP, bool LOW = false>
 __global__ void __launch_bounds__(256) decode_lat_kernel(DecodeArgs a, LatCarve cv)
 {
     using U = typename Elem<W>::U;
@@ -128,6 +132,7 @@ __global__ void __launch_bounds__(256) decode_lat_kernel(DecodeArgs a, LatCarve 
     // (the hand-off words: DS operations of a wave execute in issue order, so a wave that sees a counter sees what was written
     //  before it; the fences keep the compiler from moving accesses across)
     // (plain LDS accesses: a `volatile __shared__` word compiles to system-scope FLAT loads -- 0.3 us a poll, measured)
+    auto slot_bytes = [&](uint32_t tot) -> uint32_t { return LOW ? tot : ((tot + 7u) >> 3) * 8u; };   // payload bytes of a packed block
     auto publish = [&](uint32_t word, uint32_t value) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if ((tid & 63u) == 0) __hip_atomic_store(&ctl[word], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -154,11 +159,11 @@ __global__ void __launch_bounds__(256) decode_lat_kernel(DecodeArgs a, LatCarve 
                 (void)group_scan<DP>(fields(sbase + (pos + hdr_bytes <= send ? pos : shift)), lane_d, tot_both);
                 tot_both = (uint32_t)__builtin_amdgcn_readfirstlane((int)tot_both);
                 const uint32_t tot0 = tot_both & 0xffffu, tot1 = tot_both >> 16;
-                uint32_t npos = pos + hdr_bytes + ((tot0 + 7u) >> 3) * 8u + ((tot1 + 7u) >> 3) * 8u, nob = ob + 2u;
+                uint32_t npos = pos + hdr_bytes + slot_bytes(tot0) + slot_bytes(tot1), nob = ob + 2u;
                 if (__builtin_expect(tot0 == 0 || tot1 == 0 || npos > send || nob > NB, 0)) {
                     if (pos + hdr_bytes > send) { corrupt = true; break; }
                     const uint32_t at0 = pos + hdr_bytes;
-                    uint32_t len0 = 1, len1 = 1, bytes0 = ((tot0 + 7u) >> 3) * 8u, bytes1 = ((tot1 + 7u) >> 3) * 8u;
+                    uint32_t len0 = 1, len1 = 1, bytes0 = slot_bytes(tot0), bytes1 = slot_bytes(tot1);
                     if (tot0 == 0) len0 = run_length(sbase + (at0 < send ? at0 : send), bytes0);
                     const uint32_t at1 = at0 + bytes0;
                     if (tot1 == 0) len1 = run_length(sbase + (at1 < send ? at1 : send), bytes1);
@@ -210,25 +215,37 @@ __global__ void __launch_bounds__(256) decode_lat_kernel(DecodeArgs a, LatCarve 
                     if (tot != 0) {
                         const uint32_t rb = (tot + 7u) >> 3;
                         if (col_ok) {
-                            uint32_t p = sbase + at + (off >> 3);
-                            const uint32_t sh = off & 7u;
                             const uint32_t w1 = nb != 0 ? 1u : 0u, wm = nb - w1;      // widths of the sign bit and of the magnitude
                             int e[8];
+                            if constexpr (LOW) {           // column-major: this column's 8 values in nb bytes behind the columns before it (:561-603)
+                                const uint32_t base = sbase + at + off;                 // (off: a sum of byte counts here)
 #pragma unroll
-                            for (int i = 0; i < 8; i++) {
-                                const uint32_t wd = lds_rd32(p);
-                                const uint32_t mag = __builtin_amdgcn_ubfe(wd, sh + 1u, wm);      // zigzag^-1 = (z >> 1) ^ -(z & 1), straight from the window
-                                const int sgn = __builtin_amdgcn_sbfe((int)wd, sh, w1);
-                                const int x = (int)(mag ^ (uint32_t)sgn);
-                                e[i] = W == 16 ? (int)((uint32_t)x << 16) : (FIRE ? (int)((uint32_t)x << 8) : x);
-                                p += rb;
+                                for (int i = 0; i < 8; i++) {
+                                    const uint32_t bit = (uint32_t)i * nb;
+                                    const uint32_t wd = lds_rd32(base + (bit >> 3));
+                                    const uint32_t mag = __builtin_amdgcn_ubfe(wd, (bit & 7u) + 1u, wm);
+                                    const int sgn = __builtin_amdgcn_sbfe((int)wd, bit & 7u, w1);
+                                    e[i] = (int)(mag ^ (uint32_t)sgn);
+                                }
+                            } else {
+                                uint32_t p = sbase + at + (off >> 3);
+                                const uint32_t sh = off & 7u;
+#pragma unroll
+                                for (int i = 0; i < 8; i++) {
+                                    const uint32_t wd = lds_rd32(p);
+                                    const uint32_t mag = __builtin_amdgcn_ubfe(wd, sh + 1u, wm);      // zigzag^-1 = (z >> 1) ^ -(z & 1), straight from the window
+                                    const int sgn = __builtin_amdgcn_sbfe((int)wd, sh, w1);
+                                    const int x = (int)(mag ^ (uint32_t)sgn);
+                                    e[i] = W == 16 ? (int)((uint32_t)x << 16) : (FIRE ? (int)((uint32_t)x << 8) : x);
+                                    p += rb;
+                                }
                             }
                             v4i* const q = (v4i*)(err + ((size_t)ob * (uint32_t)D + (uint32_t)lane_d) * 8u);
                             q[0] = v4i{e[0], e[1], e[2], e[3]};
                             q[1] = v4i{e[4], e[5], e[6], e[7]};
                         }
                         ob += 1u;
-                        at += rb * 8u;
+                        at += LOW ? tot : rb * 8u;
                     } else {
                         uint32_t nbytes;
                         const uint32_t len = run_length(sbase + at, nbytes);
@@ -288,11 +305,14 @@ __global__ void __launch_bounds__(256) decode_lat_kernel(DecodeArgs a, LatCarve 
                 const v4i n0 = e[bstride], n1 = e[bstride + 1];
                 const int E[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
                 int X[8];
-                const int coef = fire_coef<W, false>(ctr);
+                const int coef = fire_coef<W, LOW>(ctr);
                 int grad = 0;
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
-                    if constexpr (W == 16) {               // X = prev_delta*coef + E; delta = hi16(X): pd carries X (decode_fast.h)
+                    if constexpr (LOW) {                   // plain errors, the low-dim predictor (sprintz_xff_lowdim.cpp:170-183)
+                        if (i & 1) grad = mad24(sign_of(E[i]), pd, grad);
+                        pd = sext<W>(E[i] + fire_predict<W, true>(pd, coef));
+                    } else if constexpr (W == 16) {        // X = prev_delta*coef + E; delta = hi16(X): pd carries X (decode_fast.h)
                         if (i & 1) grad = mad_i16_hi(pd, sign_of(E[i]), grad);
                         pd = mad_i16_hi(pd, coef, E[i]);
                     } else {
@@ -325,7 +345,7 @@ __global__ void __launch_bounds__(256) decode_lat_kernel(DecodeArgs a, LatCarve 
     for (uint32_t j = tid; j < remaining * ESZ; j += 256u) obase[body_bytes + j] = strm[tail_pos + j];
 
     // ---- D: samples = running sum of the deltas down each column (mod 2^W)
-    auto delta_of = [](int x) -> uint32_t { return W == 16 ? (uint32_t)x >> 16 : (uint32_t)x; };
+    auto delta_of = [](int x) -> uint32_t { return (W == 16 && !LOW) ? (uint32_t)x >> 16 : (uint32_t)x; };
     const uint32_t NBS = NB | 1u;                          // bsum[column][block], odd pitch (banks)
     // D1: the sum of every (block, column)'s eight deltas; lanes as in phase B (adjacent lanes = adjacent columns: no bank conflicts)
     for (uint32_t b = tid >> LOG2DP; b < nblk; b += (uint32_t)T) {

@@ -1,7 +1,7 @@
 // encode_lat.h -- the LATENCY encoder: one WORKGROUP (256 lanes) per chunk, the counterpart of decode_lat.h for batches too
 // small to fill the chip (a single drop-in call above all: encode_fast.h's lane group takes 90 us for one 10 KB chunk).  Same
 // stream bytes, sizes and return values as encode_fast.h / encode_kernel.h (sprintz_xff_rle.cpp:61-555,
-// sprintz_delta_rle.cpp:55-404), general layout, 3 <= ndims <= 64, chunks of at most 16 KB.
+// sprintz_delta_rle.cpp:55-404; the low-dim layouts as template parameter LOW), ndims <= 64, chunks of at most 16 KB.
 //
 // What is serial in the encoder is little:
 //   (1) the forecast's coefficient: coef[b+1] depends on the gradient of block b, i.e. on the signs of block b's errors in
@@ -35,7 +35,7 @@ inline EncLatCarve enc_lat_carve(uint32_t bound_bytes, uint32_t chunk_len, uint3
     c.o_dl = al(chunk_len * esz + 16u);
     c.o_zz = c.o_dl + al(body + 16u);
     c.o_coef = c.o_zz + al(body + 16u);
-    c.o_nbx = c.o_coef + al(nb * D * 2u + 16u);
+    c.o_nbx = c.o_coef + al(nb * D * 4u + 16u);
     c.o_rb = c.o_nbx + al(nb * D * 4u + 16u);
     c.o_wo = c.o_rb + al(nb * 4u + 16u);
     c.o_img = c.o_wo + al(nb * 8u + 16u);
@@ -44,7 +44,9 @@ inline EncLatCarve enc_lat_carve(uint32_t bound_bytes, uint32_t chunk_len, uint3
     return c;
 }
 
-template <int W, bool FIRE, int DP>
+// LOW: the low-dim layout (D <= 4 at 8 bits, <= 2 at 16; sprintz_{delta,xff}_lowdim.cpp:39-400): column-major payload, widths rounded
+// only W-1 -> W, untruncated coefficient (32-bit multiply at 16 bits), "<" in the tail test of both codecs.
+template <int W, bool FIRE, int DP, bool LOW = false>
 __global__ void __launch_bounds__(256) encode_lat_kernel(EncodeArgs a, EncLatCarve cv)
 {
     using U = typename Elem<W>::U;
@@ -53,7 +55,7 @@ __global__ void __launch_bounds__(256) encode_lat_kernel(EncodeArgs a, EncLatCar
     constexpr int ESZ = W / 8;
     constexpr int LOG2DP = DP == 4 ? 2 : DP == 8 ? 3 : DP == 16 ? 4 : DP == 32 ? 5 : 6;
     constexpr int T = 256 / DP;
-    constexpr bool TAIL_LE = FIRE;               // "<=" at sprintz_xff_rle.cpp:362, "<" at sprintz_delta_rle.cpp:226
+    constexpr bool TAIL_LE = FIRE && !LOW;       // "<=" at sprintz_xff_rle.cpp:362, "<" in the other three codecs
     constexpr int RL = DP <= 16 ? 4 : 1;         // lanes that share a column in phase 2 (one per odd row)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ uint32_t info[8];                 // groups, elements consumed, bytes written before the tail
@@ -69,7 +71,7 @@ __global__ void __launch_bounds__(256) encode_lat_kernel(EncodeArgs a, EncLatCar
     U* const raw = (U*)smem;
     U* const dl = (U*)(smem + cv.o_dl);
     U* const zz = (U*)(smem + cv.o_zz);
-    int16_t* const coefs = (int16_t*)(smem + cv.o_coef);
+    int32_t* const coefs = (int32_t*)(smem + cv.o_coef);       // (the low-dim coefficient is counter >> 1: up to 31 bits at 16-bit data)
     uint32_t* const nbx = (uint32_t*)(smem + cv.o_nbx);
     uint32_t* const rbits = (uint32_t*)(smem + cv.o_rb);
     uint2* const wofs = (uint2*)(smem + cv.o_wo);
@@ -120,10 +122,10 @@ __global__ void __launch_bounds__(256) encode_lat_kernel(EncodeArgs a, EncLatCar
                 uint32_t cur = NB ? pair_at(0) : 0u;
                 for (uint32_t b = 0; b < NB; b++) {
                     const uint32_t nxt = pair_at(b + 1u < NB ? b + 1u : b);
-                    const int coef = fire_coef<W, false>(ctr);
-                    coefs[(size_t)b * (uint32_t)D + dd] = (int16_t)coef;         // (four lanes, one value, one place)
+                    const int coef = fire_coef<W, LOW>(ctr);
+                    coefs[(size_t)b * (uint32_t)D + dd] = coef;                  // (four lanes, one value, one place)
                     const int lo = __builtin_amdgcn_sbfe((int)cur, 0, W), hi = __builtin_amdgcn_sbfe((int)cur, W, W);
-                    const int pred = __builtin_amdgcn_sbfe(mad24(lo, coef, 0), W, W);
+                    const int pred = LOW ? fire_predict<W, true>(lo, coef) : __builtin_amdgcn_sbfe(mad24(lo, coef, 0), W, W);
                     const int err = __builtin_amdgcn_sbfe(hi - pred, 0, W);
                     uint32_t g = (uint32_t)mad24(sign_of(err), lo, 0);
                     g += dpp<DPP_QUAD_PERM(1, 0, 3, 2)>(0, g);
@@ -134,13 +136,13 @@ __global__ void __launch_bounds__(256) encode_lat_kernel(EncodeArgs a, EncLatCar
             } else {
                 for (uint32_t b = 0; b < NB; b++) {
                     const U* const q = dl + ((size_t)b * (uint32_t)D + dd) * 8u;
-                    const int coef = fire_coef<W, false>(ctr);
-                    coefs[(size_t)b * (uint32_t)D + dd] = (int16_t)coef;
+                    const int coef = fire_coef<W, LOW>(ctr);
+                    coefs[(size_t)b * (uint32_t)D + dd] = coef;
                     int grad = 0;
 #pragma unroll
                     for (int i = 1; i < 8; i += 2) {
                         const int lo = sext<W>((int)q[i - 1]), hi = sext<W>((int)q[i]);
-                        const int pred = __builtin_amdgcn_sbfe(mad24(lo, coef, 0), W, W);
+                        const int pred = LOW ? fire_predict<W, true>(lo, coef) : __builtin_amdgcn_sbfe(mad24(lo, coef, 0), W, W);
                         const int err = __builtin_amdgcn_sbfe(hi - pred, 0, W);
                         grad = mad24(sign_of(err), lo, grad);
                     }
@@ -162,12 +164,12 @@ __global__ void __launch_bounds__(256) encode_lat_kernel(EncodeArgs a, EncLatCar
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const int delta = sext<W>((int)q[i]);
-            const int pred = FIRE ? __builtin_amdgcn_sbfe(mad24(pd, coef, 0), W, W) : 0;
+            const int pred = FIRE ? (LOW ? fire_predict<W, true>(pd, coef) : __builtin_amdgcn_sbfe(mad24(pd, coef, 0), W, W)) : 0;
             z[i] = zigzag<W>(sext<W>(delta - pred));
             mask |= z[i];
             pd = delta;
         }
-        const uint32_t nb = col_ok ? nbits_of<W, false>(mask) : 0u;
+        const uint32_t nb = col_ok ? nbits_of<W, LOW>(mask) : 0u;
         uint32_t total;
         const uint32_t excl = group_scan<DP>(nb, lane_d, total);
         if (col_ok) {
@@ -222,7 +224,7 @@ __global__ void __launch_bounds__(256) encode_lat_kernel(EncodeArgs a, EncLatCar
                 const bool me = tid == b - base;                     // (a lane write: compare + select on scalars)
                 wo_x = me ? (int)wl : wo_x;
                 wo_y = me ? (int)(hdr_pos * 8u + slot * (uint32_t)D * HB) : wo_y;
-                wl += ((rb + 7u) >> 3) << 3;                         // 8 rows of ceil(rb / 8) bytes
+                wl += LOW ? rb : ((rb + 7u) >> 3) << 3;              // 8 rows of ceil(rb / 8) bytes; low-dim: a column's 8 values are nbits bytes
                 b++;
                 slot++;
                 if (slot == 2) {
@@ -254,11 +256,11 @@ __global__ void __launch_bounds__(256) encode_lat_kernel(EncodeArgs a, EncLatCar
         const uint32_t row_bits = ((rbits[b] + 7u) >> 3) << 3;
         or_bits(wo.y + (uint32_t)lane_d * HB, nb == (uint32_t)W ? (uint32_t)(W - 1) : nb, HB);     // :296
         const U* const zq = zz + ((size_t)b * (uint32_t)D + (uint32_t)lane_d) * 8u;
-        uint32_t bp = wo.x * 8u + excl;
+        uint32_t bp = LOW ? (wo.x + excl) * 8u : wo.x * 8u + excl;          // low-dim: this column's bytes behind the columns before it
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             or_bits(bp, (uint32_t)zq[i], nb);
-            bp += row_bits;
+            bp += LOW ? nb : row_bits;
         }
     }
     {

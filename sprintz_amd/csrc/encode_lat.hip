@@ -18,10 +18,15 @@ hipError_t launch_enc_lat(K kernel, unsigned grid, const EncLatCarve& c, hipStre
     if (w == WV && dp == DPV)                                                                             \
         return fire ? launch_enc_lat(encode_lat_kernel<WV, true, DPV>, grid, c, st, a)                    \
                     : launch_enc_lat(encode_lat_kernel<WV, false, DPV>, grid, c, st, a);
-hipError_t launch_encode_lat(int w, bool fire, int dp, unsigned grid, uint32_t bound_bytes, hipStream_t st, const EncodeArgs& a)
+hipError_t launch_encode_lat(int w, bool fire, int dp, bool lowdim, unsigned grid, uint32_t bound_bytes, hipStream_t st, const EncodeArgs& a)
 {
     const EncLatCarve c = enc_lat_carve(bound_bytes, a.chunk_len, (uint32_t)a.D, (uint32_t)w / 8u);
     if (c.total > 150 * 1024) return hipErrorInvalidValue;
+    if (lowdim) {                                          // D <= 4 at 8 bits, <= 2 at 16: four lanes a group
+        if (dp != 4) return hipErrorInvalidValue;
+        if (w == 8) return fire ? launch_enc_lat(encode_lat_kernel<8, true, 4, true>, grid, c, st, a) : launch_enc_lat(encode_lat_kernel<8, false, 4, true>, grid, c, st, a);
+        return fire ? launch_enc_lat(encode_lat_kernel<16, true, 4, true>, grid, c, st, a) : launch_enc_lat(encode_lat_kernel<16, false, 4, true>, grid, c, st, a);
+    }
     SPRINTZ_ENC_LAT_CASE(16, 4)
     SPRINTZ_ENC_LAT_CASE(16, 8)
     SPRINTZ_ENC_LAT_CASE(16, 16)
