@@ -300,9 +300,7 @@ __global__ void __launch_bounds__(256) decode_lat_kernel(DecodeArgs a, LatCarve 
             if (b == 0) LAT_DBG(6);
             // the tight part: blocks b .. ready-1, the next block's errors requested before this one's are used (the read past the
             // last ready block lands on bytes nobody waits for, inside the carve)
-            v4i c0 = e[0], c1 = e[1];
-            for (uint32_t n = ready - b; n > 0; n--) {
-                const v4i n0 = e[bstride], n1 = e[bstride + 1];
+            auto one_block = [&](const v4i& c0, const v4i& c1) {
                 const int E[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
                 int X[8];
                 const int coef = fire_coef<W, LOW>(ctr);
@@ -325,9 +323,19 @@ __global__ void __launch_bounds__(256) decode_lat_kernel(DecodeArgs a, LatCarve 
                 e[0] = v4i{X[0], X[1], X[2], X[3]};
                 e[1] = v4i{X[4], X[5], X[6], X[7]};
                 e += bstride;
-                c0 = n0;
-                c1 = n1;
+            };
+            // (two blocks a trip, each with its own registers: rotating one set costs five moves a block on a chain of 33 instructions)
+            uint32_t n = ready - b;
+            v4i a0 = e[0], a1 = e[1];
+            while (n >= 2u) {
+                const v4i b0 = e[bstride], b1 = e[bstride + 1];
+                one_block(a0, a1);
+                a0 = e[bstride];                           // (e has moved on: the block after the next one)
+                a1 = e[bstride + 1];
+                one_block(b0, b1);
+                n -= 2u;
             }
+            if (n) one_block(a0, a1);
             b = ready;
         }
         LAT_DBG(7);
