@@ -106,7 +106,7 @@ const char* sprintz_mi355x_last_error(void);     /* thread-local, never NULL; de
  *                                 prediction, but sample-for-sample what sprintz_decompress_xff_16b of the reference returns;
  *                                 env SPRINTZ_MI355X_REF_DECODER_QUIRK
  *   SPRINTZ_OPT_LAT_CHUNKS        batches of at most this many chunks (general layout, 3 .. 64 columns, chunks of at most 16 KB) decode
- *                                 with one workgroup per chunk (csrc/decode_lat.h: a chunk's latency is what counts; half as many from 17 columns on); default 1280,
+ *                                 with one workgroup per chunk (csrc/decode_lat.h: a chunk's latency is what counts; a third as many from 17 columns on); default 2048,
  *                                 0 = never (A/B runs, tests); env SPRINTZ_MI355X_LAT_CHUNKS
  *   SPRINTZ_OPT_HOST_WAIT         how a single-call entry point waits for its launches: 0 (default) = spin (hipStreamSynchronize)
  *                                 while at most half of the CPUs this process may use are inside the library, otherwise sleep on

@@ -53,7 +53,7 @@ struct Process {
     std::atomic<int> chunks_per_group{1};   // SPRINTZ_MI355X_CHUNKS_PER_GROUP (decode_fast read-ahead across chunks)
     std::atomic<int> dense_mode{1};         // SPRINTZ_MI355X_DENSE_MODE: how compress_batch_dense builds the container (see SPRINTZ_OPT_DENSE_MODE)
     std::atomic<int> enc_pair{1024};        // SPRINTZ_MI355X_ENC_PAIR: chunks from which row-major streams of 5 .. 64 columns are encoded with two columns per lane (0: never; see SPRINTZ_OPT_ENC_PAIR)
-    std::atomic<int> lat_chunks{1280};      // SPRINTZ_MI355X_LAT_CHUNKS: batches of at most this many chunks decode with one workgroup per chunk (decode_lat.h; 0: never)
+    std::atomic<int> lat_chunks{2048};      // SPRINTZ_MI355X_LAT_CHUNKS: batches of at most this many chunks decode with one workgroup per chunk (decode_lat.h; 0: never)
     std::atomic<int> ref_quirk{0};          // SPRINTZ_MI355X_REF_DECODER_QUIRK: decode as the reference DECODER does where it differs from the inverse of its encoder
     std::atomic<int> host_streams{4};       // SPRINTZ_MI355X_HOST_STREAMS: streams the host-pointer calls of all threads share per device (0: one per thread)
     std::atomic<int> host_wait{0};          // SPRINTZ_MI355X_HOST_WAIT: how a single call waits for its launches (see SPRINTZ_OPT_HOST_WAIT)
@@ -430,9 +430,10 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
     // however few chunks there are; split into a header walk, parallel bit extraction, the bare recurrence and a prefix sum it is ~13
     if (!norle && !noheader && !cs && !a.raw && !a.quirk && qs.q == kQueryOff && D <= 64 && (uint64_t)chunk_len * esz <= kLatMaxChunkBytes &&
         chunk_len >= 16u * (uint32_t)D && ((uintptr_t)d_out % 16) == 0 && ((uint64_t)chunk_len * esz) % 16 == 0 &&
-        // (one round of workgroups on the chip is where it wins: 5 a CU at 8 columns -- measured 36 vs 48 us at 1 250 chunks, 45 vs 48 at
-        //  2 048, 84 vs 48 at 4 096; with more columns a chunk has fewer groups to walk and the lane-per-column kernel catches up sooner)
-        nchunks <= (uint64_t)process().lat_chunks.load(std::memory_order_relaxed) / (D > 16 ? 2u : 1u) && !process().no_fast.load(std::memory_order_relaxed)) {
+        // (about one round of workgroups on the chip is where it wins: 5 a CU at 8 columns -- measured 33 vs 47 us at 1 250 chunks, 41 vs 47
+        //  at 2 048, 59 vs 47 at 3 072; with more columns a chunk has fewer groups to walk and the lane-per-column kernel catches up
+        //  sooner: 32 columns 11.6 vs 14.7 at 640 chunks, 19.7 vs 14.8 at 1 250 -- a third of the limit from 17 columns on)
+        nchunks <= (uint64_t)process().lat_chunks.load(std::memory_order_relaxed) / (D > 16 ? 3u : 1u) && !process().no_fast.load(std::memory_order_relaxed)) {
         int ldp = 4;
         while (ldp < D) ldp <<= 1;
         if (esz == 1 && ldp < 8 && !lowdim) ldp = 8;
@@ -536,7 +537,7 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     // for, is then built by the scan + copy passes: dense->fused stays false)
     if (!norle && !col_stride && !a.raw && D <= 64 && (uint64_t)chunk_len * esz <= kEncLatMaxChunkBytes &&
         ((uintptr_t)d_src % 16) == 0 && ((uint64_t)chunk_len * esz) % 16 == 0 && slot_stride % 16 == 0 && ((uintptr_t)d_slots % 16) == 0 &&
-        nchunks <= (uint64_t)process().lat_chunks.load(std::memory_order_relaxed) / (D > 16 ? 2u : 1u) && !process().no_fast.load(std::memory_order_relaxed)) {
+        nchunks <= (uint64_t)process().lat_chunks.load(std::memory_order_relaxed) / (D > 16 ? 3u : 1u) && !process().no_fast.load(std::memory_order_relaxed)) {
         int ldp = 4;
         while (ldp < D) ldp <<= 1;
         if (esz == 1 && ldp < 8 && !lowdim) ldp = 8;

@@ -22,13 +22,13 @@ def pytest_configure(config):
 
 @pytest.fixture(params=["lat", "wide"])
 def decode_path(request):
-    """the two row-major decoders of the general layout: small batches (by default up to 1 280 chunks) take decode_lat.h (one
+    """the two row-major decoders of the general layout: small batches (by default up to 2 048 chunks) take decode_lat.h (one
     workgroup per chunk), larger ones decode_fast.h / decode_kernel.h (one lane per column).  The parity modules run every test
     on both: "lat" sends every eligible batch to the small-batch decoder whatever its size, "wide" switches it off."""
     from sprintz_amd import _lib
     _lib.check(_lib.set_option(_lib.OPT_LAT_CHUNKS, (1 << 30) if request.param == "lat" else 0))
     yield request.param
-    _lib.set_option(_lib.OPT_LAT_CHUNKS, 1280)
+    _lib.set_option(_lib.OPT_LAT_CHUNKS, 2048)
 
 
 @pytest.fixture(scope="session")
