@@ -63,6 +63,14 @@ __global__ void __launch_bounds__(256) encode_lat_kernel(EncodeArgs a, EncLatCar
     const uint32_t tid = threadIdx.x;
     const uint64_t chunk = blockIdx.x;
     const int D = a.D;
+#ifdef SPRINTZ_LAT_TIMING                                  // experiment builds: phase durations (20 ns ticks, 9 bits each) instead of the return value
+    uint64_t stamp[8];
+    int nstamp = 0;
+#define ENC_STAMP() stamp[nstamp++] = wall_clock64()
+#else
+#define ENC_STAMP()
+#endif
+    ENC_STAMP();
     const uint64_t first = chunk * (uint64_t)a.chunk_len;
     const uint32_t n = (uint32_t)((a.total_len - first < a.chunk_len) ? (a.total_len - first) : a.chunk_len);
     const uint32_t blk = 8u * (uint32_t)D;
@@ -90,6 +98,7 @@ __global__ void __launch_bounds__(256) encode_lat_kernel(EncodeArgs a, EncLatCar
         for (uint32_t i = tid; i < NB; i += 256u) wofs[i] = make_uint2(0xffffffffu, 0u);
     }
     __syncthreads();
+    ENC_STAMP();
 
     // ---- 1: deltas (:197-205), [block][column][row]
     for (uint32_t b = tid >> LOG2DP; b < NB; b += (uint32_t)T) {
@@ -106,6 +115,7 @@ __global__ void __launch_bounds__(256) encode_lat_kernel(EncodeArgs a, EncLatCar
         }
     }
     __syncthreads();
+    ENC_STAMP();
 
     // ---- 2: the coefficient chain (:217, :240-241, :273-275): wave 0; RL lanes a column, one odd row each
     if constexpr (FIRE) {
@@ -152,6 +162,7 @@ __global__ void __launch_bounds__(256) encode_lat_kernel(EncodeArgs a, EncLatCar
         }
         __syncthreads();
     }
+    ENC_STAMP();
 
     // ---- 3: errors, zigzag, widths (:225-298), the scan of the widths over the columns
     for (uint32_t b = tid >> LOG2DP; b < NB; b += (uint32_t)T) {
@@ -181,62 +192,144 @@ __global__ void __launch_bounds__(256) encode_lat_kernel(EncodeArgs a, EncLatCar
         if (lane_d == 0) rbits[b] = total;
     }
     __syncthreads();
+    ENC_STAMP();
 
-    // ---- 4: the RLE / group state machine (:350-456), scalar: the blocks' row widths sit in the lanes of one
-    // register, 64 blocks at a time; where a packed block goes comes back the same way
+    // ---- 4: the RLE / group state machine (:350-456) -- as SCANS.  Run as the reference writes it (one block at a
+    // time, ~45 scalar instructions and ten branches each) it was the longest phase of a chunk: >= 10 us for 80 blocks, 150 for a
+    // univariate chunk's 1 280.  But its decisions are functions of positions only:
+    //   * a SLOT is a block that is not all zero, or a maximal run of all-zero blocks (the 32 767-block cap cannot bind: a chunk has
+    //     at most 2 048 blocks); slot k goes to group k / 2, and a group's header sits in front of its first slot;
+    //   * the walk STOPS after the first block b that is (i) all zero with b + 1 past the run limit -- "<=" against
+    //     last_full_group_start in the general FIRE codec, "<" in the other three (:362) -- or (ii) packed, second slot of its
+    //     group, with b + 1 past last_full_group_start (:450); a run closed by a packed block opens the next group WITHOUT that
+    //     test (:430-450), which is just the slot arithmetic; a run that stops the stream in a group's first slot leaves one 0x00
+    //     for the second (:386-391);
+    //   * a run's varint sits where the run ENDS (its length is the distance to the last packed block before it).
+    // So: wave 0, lane l owns blocks [l P, (l + 1) P), P = ceil(blocks / 64); slot numbers, the stop block, byte offsets and
+    // header positions are one wave scan each with a short pass over the lane's own blocks in between.
     if (tid < 64u) {
-        const int64_t limit = (int64_t)n - 2 * (int64_t)blk;        // last_full_group_start (:158)
-        uint32_t wl = a.write_size ? 8u : 0u;                        // bytes of stream so far
-        uint32_t ngroups = 0, run = 0, hdr_pos = 0, slot = 0, b = 0;
-        bool active = n >= 128u && limit >= 0;                       // :116 and the loop guard :160
-        auto start_group = [&]() { ngroups++; hdr_pos = wl; wl += hdr_bytes; slot = 0; };
-        auto put_run = [&](uint32_t r) {                             // :377-384
-            if (tid == 0) {
-                img[wl] = (uint8_t)((r & 0x7fu) | (r > 0x7fu ? 0x80u : 0u));
-                if (r > 0x7fu) img[wl + 1] = (uint8_t)(r >> 7);
-            }
-            wl += r > 0x7fu ? 2u : 1u;
-        };
-        if (active) start_group();
-        for (uint32_t base = 0; active && base < NB; base += 64u) {
-            const int widths = base + tid < NB ? (int)rbits[base + tid] : 0;
-            int wo_x = -1, wo_y = 0;
-            while (active && b < base + 64u) {
-                const uint32_t rb = (uint32_t)__builtin_amdgcn_readlane(widths, (int)(b - base));
-                if (rb == 0 && run < 0x7fffu) {
-                    run++;
-                    b++;
-                    const int64_t pos_in = (int64_t)b * blk;
-                    if (TAIL_LE ? (pos_in <= limit) : (pos_in < limit)) continue;
-                    slot++;
-                    put_run(run);
-                    wl += 2u - slot;                                 // one 0x00 per slot the group still has (:386-391)
-                    run = 0;
-                    active = false;
-                    break;
-                }
-                if (run > 0) {                                       // a block that is not all zero closes the run
-                    slot++;
-                    put_run(run);
-                    run = 0;
-                    if (slot == 2) start_group();                    // :430-450 (no look at the limit here)
-                }
-                const bool me = tid == b - base;                     // (a lane write: compare + select on scalars)
-                wo_x = me ? (int)wl : wo_x;
-                wo_y = me ? (int)(hdr_pos * 8u + slot * (uint32_t)D * HB) : wo_y;
-                wl += LOW ? rb : ((rb + 7u) >> 3) << 3;              // 8 rows of ceil(rb / 8) bytes; low-dim: a column's 8 values are nbits bytes
-                b++;
-                slot++;
-                if (slot == 2) {
-                    if ((int64_t)b * blk <= limit) start_group();
-                    else active = false;
+        const int64_t limit = (int64_t)n - 2 * (int64_t)blk;        // last_full_group_start (:158), in elements
+        const int32_t lim_le = limit >= 0 ? (int32_t)(limit / (int64_t)blk) : -1;              // pos_in <= limit  <=>  b <= lim_le
+        const int32_t lim_lt = limit > 0 ? (int32_t)((limit - 1) / (int64_t)blk) : -1;         // pos_in <  limit  <=>  b <= lim_lt
+        const int32_t lim_run = TAIL_LE ? lim_le : lim_lt;
+        const uint32_t base_wl = a.write_size ? 8u : 0u;
+        const uint32_t slot_bits = (uint32_t)D * HB;
+        if (!(n >= 128u && limit >= 0)) {                            // :116 and the loop guard :160: header + verbatim samples
+            if (tid == 0) { info[0] = 0; info[1] = 0; info[2] = base_wl; }
+        } else {
+            const uint32_t P = (NB + 63u) >> 6;
+            const uint32_t i0 = tid * P < NB ? tid * P : NB, i1 = i0 + P < NB ? i0 + P : NB;
+            auto payload = [&](uint32_t rb) -> uint32_t { return LOW ? rb : ((rb + 7u) >> 3) << 3; };
+            const bool first_prev = i0 == 0 ? true : rbits[i0 - 1] != 0;      // (block 0 starts a slot whatever it is)
+            // pass 1: slot starts and the last packed block of the lane's piece
+            uint32_t starts = 0;
+            int lnz = -1;
+            {
+                bool prev = first_prev;
+                for (uint32_t bb = i0; bb < i1; bb++) {
+                    const bool nz = rbits[bb] != 0;
+                    starts += (nz || prev) ? 1u : 0u;
+                    lnz = nz ? (int)bb : lnz;
+                    prev = nz;
                 }
             }
-            if (base + tid < NB) wofs[base + tid] = make_uint2((uint32_t)wo_x, (uint32_t)wo_y);
+            uint32_t starts_total;
+            const uint32_t starts_before = group_scan<64>(starts, (int)tid, starts_total);
+            int lnz_before = lnz;                                    // exclusive max-scan: the last packed block before the piece
+            {
+                int incl = lnz;
+                for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if ((int)tid >= off) incl = incl > t ? incl : t; }
+                lnz_before = __shfl_up(incl, 1, 64);
+                if (tid == 0) lnz_before = -1;
+            }
+            // pass 2: the block the walk stops after
+            uint32_t cand = 0xffffffffu;
+            {
+                bool prev = first_prev;
+                uint32_t sid = starts_before;                        // slots started so far
+                for (uint32_t bb = i0; bb < i1; bb++) {
+                    const bool nz = rbits[bb] != 0;
+                    sid += (nz || prev) ? 1u : 0u;
+                    const bool second = ((sid - 1u) & 1u) != 0;
+                    const bool stop = nz ? (second && (int32_t)(bb + 1u) > lim_le) : ((int32_t)(bb + 1u) > lim_run);
+                    cand = (stop && bb < cand) ? bb : cand;
+                    prev = nz;
+                }
+            }
+            for (int off = 32; off > 0; off >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)cand, off, 64); cand = t < cand ? t : cand; }
+            const uint32_t stop_b = cand < NB ? cand : NB - 1u;      // (it always exists: the last two blocks trip one of the tests)
+            // pass 3: bytes of the lane's piece -- group headers in front of even slots, payloads, run lengths where runs end
+            uint32_t bytes = 0;
+            {
+                bool prev = first_prev;
+                uint32_t sid = starts_before;
+                int last = lnz_before;
+                for (uint32_t bb = i0; bb < i1 && bb <= stop_b; bb++) {
+                    const uint32_t rb = rbits[bb];
+                    const bool nz = rb != 0, st = nz || prev;
+                    sid += st ? 1u : 0u;
+                    if (st && ((sid - 1u) & 1u) == 0) bytes += hdr_bytes;
+                    if (nz) { bytes += payload(rb); last = (int)bb; }
+                    else if (bb == stop_b || rbits[bb + 1u] != 0) bytes += ((int)bb - last) > 127 ? 2u : 1u;
+                    prev = nz;
+                }
+            }
+            uint32_t bytes_total;
+            const uint32_t bytes_before = group_scan<64>(bytes, (int)tid, bytes_total);
+            // pass 4a: where the last group header of the piece sits; carried to the lanes behind by a max-scan (positions only grow)
+            uint32_t hp = 0;
+            {
+                bool prev = first_prev;
+                uint32_t sid = starts_before, off = base_wl + bytes_before;
+                int last = lnz_before;
+                for (uint32_t bb = i0; bb < i1 && bb <= stop_b; bb++) {
+                    const uint32_t rb = rbits[bb];
+                    const bool nz = rb != 0, st = nz || prev;
+                    sid += st ? 1u : 0u;
+                    if (st && ((sid - 1u) & 1u) == 0) { hp = off; off += hdr_bytes; }
+                    if (nz) { off += payload(rb); last = (int)bb; }
+                    else if (bb == stop_b || rbits[bb + 1u] != 0) off += ((int)bb - last) > 127 ? 2u : 1u;
+                    prev = nz;
+                }
+            }
+            uint32_t hp_before;
+            {
+                uint32_t incl = hp;
+                for (int off = 1; off < 64; off <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, off, 64); if ((int)tid >= off) incl = incl > t ? incl : t; }
+                hp_before = (uint32_t)__shfl_up((int)incl, 1, 64);
+                if (tid == 0) hp_before = 0;
+            }
+            // pass 4b: the packed blocks' places, the run lengths themselves, the totals
+            {
+                bool prev = first_prev;
+                uint32_t sid = starts_before, off = base_wl + bytes_before, cur_hp = hp_before;
+                int last = lnz_before;
+                for (uint32_t bb = i0; bb < i1 && bb <= stop_b; bb++) {
+                    const uint32_t rb = rbits[bb];
+                    const bool nz = rb != 0, st = nz || prev;
+                    sid += st ? 1u : 0u;
+                    const uint32_t par = (sid - 1u) & 1u;
+                    if (st && par == 0) { cur_hp = off; off += hdr_bytes; }
+                    uint32_t pad = 0;
+                    if (nz) {
+                        wofs[bb] = make_uint2(off, cur_hp * 8u + par * slot_bits);
+                        off += payload(rb);
+                        last = (int)bb;
+                    } else if (bb == stop_b || rbits[bb + 1u] != 0) {
+                        const uint32_t r = (uint32_t)((int)bb - last);                 // :377-384
+                        img[off] = (uint8_t)((r & 0x7fu) | (r > 0x7fu ? 0x80u : 0u));
+                        if (r > 0x7fu) img[off + 1] = (uint8_t)(r >> 7);
+                        off += r > 0x7fu ? 2u : 1u;
+                        if (bb == stop_b) pad = 1u - par;            // one 0x00 per slot the group still has (:386-391)
+                    }
+                    if (bb == stop_b) { info[0] = ((sid - 1u) >> 1) + 1u; info[1] = (stop_b + 1u) * blk; info[2] = base_wl + bytes_total + pad; }
+                    prev = nz;
+                }
+            }
         }
-        if (tid == 0) { info[0] = ngroups; info[1] = b * blk; info[2] = wl; }
     }
     __syncthreads();
+    ENC_STAMP();
     const uint32_t ngroups = info[0], pos_in = info[1], wl = info[2];
     const uint32_t remaining = n - pos_in;
 
@@ -273,14 +366,24 @@ __global__ void __launch_bounds__(256) encode_lat_kernel(EncodeArgs a, EncLatCar
         ((uint32_t*)img)[1] = (remaining & 0xffffu) | ((uint32_t)D << 16);
     }
     __syncthreads();
+    ENC_STAMP();
 
     // ---- 6: the stream leaves in 16-byte pieces (the slot is 16-byte aligned and holds the bound)
     const uint32_t total_bytes = wl + remaining * ESZ;
     for (uint32_t i = tid; i < ((total_bytes + 15u) >> 4); i += 256u) ((uint4*)gdst)[i] = ((const uint4*)img)[i];
+    ENC_STAMP();
     if (tid == 0) {
         a.sizes[chunk] = total_bytes;
         if (a.rets) a.rets[chunk] = (int64_t)(total_bytes / ESZ);
+#ifdef SPRINTZ_LAT_TIMING
+        if (a.rets) {
+            uint64_t r = 0;
+            for (int k = 0; k < 7; k++) { const uint64_t dt = (stamp[k + 1] - stamp[k]) >> 1; r |= (dt < 511 ? dt : 511) << (9 * k); }
+            a.rets[chunk] = (int64_t)r;
+        }
+#endif
     }
+#undef ENC_STAMP
 }
 
 }  // namespace sprintz
