@@ -139,7 +139,7 @@ int sprintz_mi355x_set_option(int option, int value);
  * exactly the decoded elements (it never over-runs like the reference does).
  * write_size == 0 omits the 8-byte header (sprintz_xff_rle.cpp:119-127).
  * Re-entrant from any number of host threads on disjoint buffers, like the reference (sprintz.h: one call = one thread).
- * Cost of a call (MI355X, 10 KB of uint16 x 8): 32 us decompress / 43 us compress -- memcpy into the calling thread's mapped
+ * Cost of a call (MI355X, 10 KB of uint16 x 8): 32 us decompress / 32 us compress -- memcpy into the calling thread's mapped
  * staging buffer, two launches (stage-in + the one-workgroup-per-chunk kernel, which reads and writes that buffer directly),
  * one event wait, memcpy out; chunks above 16 KB or of more than 64 columns take the batched kernels' lane-per-column form
  * (a chunk's latency then grows with its groups: ~1.2 us each).  The batched API below is the fast path.
