@@ -1138,6 +1138,25 @@ def headline_extras(cx, codec, x, comp, offsets, ws, out, nchunks, total_comp, c
             "what": "sprintz_decompress_xff_16b / sprintz_compress_xff_16b on host buffers through ctypes: memcpy into the thread's MAPPED staging "
                     "buffer, stage_in + the one-workgroup-per-chunk kernel (decode_lat.h / encode_lat.h) reading and writing that buffer directly, "
                     "one event wait, memcpy out; no copy engine, no memset, no hipMalloc per call"}
+        # ---------------- BASELINE configs[0]'s shape through the same symbols: uint8, 1 variable, 1 KB chunks (the low-dim layout)
+        from synth import synth_numpy
+        u1 = synth_numpy("walk", 1, 1, 1024, 1, seed=123, step=2)
+        u1c = np.zeros(1024 * 3 // 2 + 64, np.int8)
+        u1d = np.zeros(1024 + 64, np.uint8)
+        dfn8, cfn8 = _lib.decompress[("delta", 1)], _lib.compress[("delta", 1)]
+        for _ in range(20):
+            cfn8(u1.ctypes.data, 1024, u1c.ctypes.data, 1, 1)
+            dfn8(u1c.ctypes.data, u1d.ctypes.data)
+        l8d, l8c = [], []
+        for _ in range(300):
+            t0 = time.perf_counter(); cfn8(u1.ctypes.data, 1024, u1c.ctypes.data, 1, 1); l8c.append(time.perf_counter() - t0)
+            t0 = time.perf_counter(); r = dfn8(u1c.ctypes.data, u1d.ctypes.data); l8d.append(time.perf_counter() - t0)
+            assert r == 1024
+        assert np.array_equal(u1d[:1024], u1)
+        l8d.sort(); l8c.sort()
+        res["single_call_latency_cfg1_1KB"] = {"decompress_us_median": round(l8d[150] * 1e6, 1), "compress_us_median": round(l8c[150] * 1e6, 1),
+                                               "what": "sprintz_{de,}compress_delta_8b on one 1 KB univariate chunk (BASELINE configs[0]'s shape; low-dim layout, "
+                                                       "the same one-workgroup-per-chunk kernels)"}
         # ---------------- the same drop-in symbols from many host threads at once (each thread has its own pooled scratch and stream
         # inside the library; ctypes releases the interpreter lock around the call): calls per second of the whole process
         def many_threads(nthreads, calls):
