@@ -537,7 +537,9 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     // for, is then built by the scan + copy passes: dense->fused stays false)
     if (!norle && !col_stride && !a.raw && D <= 64 && (uint64_t)chunk_len * esz <= kEncLatMaxChunkBytes &&
         ((uintptr_t)d_src % 16) == 0 && ((uint64_t)chunk_len * esz) % 16 == 0 && slot_stride % 16 == 0 && ((uintptr_t)d_slots % 16) == 0 &&
-        nchunks <= (uint64_t)process().lat_chunks.load(std::memory_order_relaxed) / (D > 16 ? 3u : 1u) && !process().no_fast.load(std::memory_order_relaxed)) {
+        // (the encoder's crossover sits higher than the decoder's -- the lane-per-column encoders take ~100 us (uint16 x 8) / ~175 us (uint8 x 8)
+        //  for ANY batch up to ~16 000 chunks: 75 vs 100 us at 3 072 chunks, 105 vs 101 at 4 096; 32 columns: 24 vs 26 at 1 024 -- tools/lat_sweep_enc.py)
+        nchunks <= (uint64_t)process().lat_chunks.load(std::memory_order_relaxed) * (D > 16 ? 1u : 3u) / (D > 16 ? 3u : 2u) && !process().no_fast.load(std::memory_order_relaxed)) {
         int ldp = 4;
         while (ldp < D) ldp <<= 1;
         if (esz == 1 && ldp < 8 && !lowdim) ldp = 8;
