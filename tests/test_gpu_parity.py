@@ -54,6 +54,53 @@ def test_golden_vectors_single_call(sz, golden):
         assert (dec[data.size:] == dec[-1]).all(), "decoder wrote past the decoded length"
 
 
+def test_random_shapes_against_oracle(sz, oracle):
+    """both kernel families (decode_path) over random shapes the fixed matrices do not list: every lanes-per-chunk bucket of both
+    layouts (1 .. 64 columns, both widths, both codecs), chunk lengths that are and are not whole groups, a ragged last chunk, data
+    with noise, runs (some longer than 127 blocks), constant columns and full-width fields -- stream bytes, sizes and samples the oracle's"""
+    import torch
+    rng = np.random.default_rng(20240929)
+    for trial in range(70):
+        esz = int(rng.choice([1, 2]))
+        ndims = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 15, 16, 17, 24, 31, 32, 33, 48, 63, 64]))
+        codec = str(rng.choice(["delta", "xff"]))
+        rows = int(rng.integers(3, 1 + max(4, min(2000, (16384 // esz) // ndims))))
+        chunk_len = rows * ndims
+        if rng.random() < 0.5:
+            chunk_len = max(16, (chunk_len * esz // 16) * 16 // esz)          # 16-byte multiples take the one-workgroup-per-chunk kernels
+        nchunks = int(rng.integers(1, 7))
+        total = nchunks * chunk_len - int(rng.integers(0, max(1, chunk_len // 2)))
+        kind = trial % 5
+        nrows = (total + ndims - 1) // ndims
+        if kind == 0:
+            x = gen_walk(rng, total, ndims, esz, int(rng.integers(1, 40)), flat_every=int(rng.integers(0, 4)))
+        elif kind == 1:
+            x = rng.integers(0, 1 << (8 * esz), size=total).astype(DTYPES[esz])                       # full-width fields
+        elif kind == 2:                                                                                 # long runs: constant, then a step
+            m = np.zeros((nrows, ndims), np.int64) + rng.integers(0, 200, size=(1, ndims))
+            m[nrows // 2:] += 3
+            x = np.mod(m, 1 << (8 * esz)).astype(DTYPES[esz]).ravel()[:total]
+        elif kind == 3:                                                                                 # some columns constant, some noisy
+            m = np.cumsum(rng.integers(-3, 4, size=(nrows, ndims)), axis=0) * (rng.random(ndims) < 0.5)[None, :] + 77
+            x = np.mod(m, 1 << (8 * esz)).astype(DTYPES[esz]).ravel()[:total]
+        else:                                                                                           # oscillation: the forecast's counters move
+            m = (np.arange(nrows)[:, None] % 2) * int(rng.integers(1, 120)) + rng.integers(0, 3, size=(nrows, ndims))
+            x = np.mod(m, 1 << (8 * esz)).astype(DTYPES[esz]).ravel()[:total]
+        cd = sz.ChunkedCodec(codec, esz, ndims, chunk_len, device="cuda:0")
+        t = torch.from_numpy(x.view(np.int8 if esz == 1 else np.int16)).cuda().view(cd.dtype)
+        batch = cd.compress(t)
+        comp, offs, sizes = batch.data.cpu().numpy(), batch.offsets.cpu().numpy(), batch.sizes.cpu().numpy()
+        for c in range(nchunks):
+            want, _ = oracle.compress(codec, x[c * chunk_len:min((c + 1) * chunk_len, total)], ndims)
+            assert sizes[c] == want.size, (trial, codec, esz, ndims, chunk_len, c)
+            assert np.array_equal(comp[offs[c]:offs[c] + sizes[c]], want), (trial, codec, esz, ndims, chunk_len, c)
+        rets = torch.empty(nchunks, dtype=torch.int64, device="cuda:0")
+        out = cd.decompress(batch, rets=rets).cpu().numpy()
+        assert np.array_equal(out.view(DTYPES[esz]), x), (trial, codec, esz, ndims, chunk_len)
+        r = rets.cpu().numpy()
+        assert (r[:-1] == chunk_len).all() and r[-1] == total - (nchunks - 1) * chunk_len
+
+
 def test_reference_decoder_quirk_on_request(sz, oracle, golden, request):
     """SPRINTZ_OPT_REF_DECODER_QUIRK: the decoders replay the runs of 16-bit general-layout FIRE streams as the REFERENCE DECODER
     does (sprintz_xff_rle.cpp:893-901) -- sample for sample what the compiled reference returned for the golden stream it does
