@@ -63,10 +63,10 @@ extern "C" {
 #define SPRINTZ_E_INVALID    (-1)   /* bad argument; also what the reference returns for ndims == 0 (sprintz.cpp:36) */
 #define SPRINTZ_E_NO_DEVICE  (-2)   /* no HIP device / HIP runtime error at init */
 #define SPRINTZ_E_HIP        (-3)   /* a HIP call failed (see sprintz_mi355x_last_error) */
-#define SPRINTZ_E_UNSUPPORTED (-4)  /* ndims above SPRINTZ_MI355X_MAX_NDIMS */
+#define SPRINTZ_E_UNSUPPORTED (-4)  /* ndims above SPRINTZ_MI355X_MAX_NDIMS (or above 512 where only the lane-group kernels exist) */
 #define SPRINTZ_E_CORRUPT    (-5)   /* decoder: stream header disagrees with the arguments */
 
-#define SPRINTZ_MI355X_MAX_NDIMS 512
+#define SPRINTZ_MI355X_MAX_NDIMS 2047   /* 513 .. 2047: the four RLE codec pairs, row-major, no query (csrc/any_ndims.hip); everything else <= 512 */
 
 /* Extra readable bytes the decoder may touch after the last stream byte and
  * the encoder after the last input element (aligned 8-byte windows; the

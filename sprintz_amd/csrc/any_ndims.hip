@@ -1,0 +1,394 @@
+// any_ndims.hip -- the general layout for streams of 513 .. 2047 columns: ONE WORKGROUP (256 lanes) per chunk, lane t owns the
+// columns [t * cpl, (t + 1) * cpl), cpl = ceil(ndims / 256) <= 8.
+//
+// The reference takes any uint16 ndims that fits the header (format.h:36-45; its tests stop at 129, test/compress_testing.hpp:20-21);
+// the lane-group kernels of this library carry at most 64 lanes x 8 columns.  These two kernels are the same codecs
+// (sprintz_xff_rle.cpp:61-555 / :569-1179, sprintz_delta_rle.cpp:55-404 / :418-772) written for completeness, not speed: the per-block
+// width scan and the slot totals are workgroup-wide (a wave scan + four partial sums through LDS), the encoder's fields are OR-ed
+// into an LDS image of ONE stream group (<= 66 KB at 2047 uint16 columns) that is flushed in 16-byte pieces when the next group
+// starts, the decoder reads its fields from global memory.  Control flow is uniform across the workgroup (every decision is a
+// function of header totals and cursors all lanes hold alike), so the barriers inside the loops are met by all 256 lanes.
+#include "launch.h"
+
+namespace sprintz {
+namespace {
+
+constexpr int kAnyCpl = 8;
+
+// exclusive prefix of v over the 256 lanes of the workgroup (lane order), and the total; s4: 4 words of LDS
+__device__ __forceinline__ uint32_t wg_scan(uint32_t v, uint32_t& total, uint32_t* s4)
+{
+    const uint32_t tid = threadIdx.x;
+    uint32_t wave_total;
+    const uint32_t ex = group_scan<64>(v, (int)(tid & 63u), wave_total);
+    __syncthreads();                                   // (s4 may still be read from the scan before)
+    if ((tid & 63u) == 0) s4[tid >> 6] = wave_total;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 4; w++) {
+        const uint32_t x = s4[w];
+        base += w < (tid >> 6) ? x : 0u;
+        tot += x;
+    }
+    total = tot;
+    return ex + base;
+}
+
+template <int W, bool FIRE>
+__global__ void __launch_bounds__(256) decode_any_kernel(DecodeArgs a)
+{
+    using U = typename Elem<W>::U;
+    constexpr int HB = Elem<W>::HB;
+    constexpr uint32_t MASK = Elem<W>::MASK;
+    constexpr int ESZ = W / 8;
+    __shared__ uint32_t s4[4];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t chunk = blockIdx.x;
+    const int D = a.D;
+    const int cpl = (D + 255) / 256;
+    const int col0 = (int)tid * cpl;
+
+    const uint64_t off_c = a.offsets[chunk];
+    const uint8_t* const s = a.comp + off_c;
+    const uint64_t slen64 = a.offsets[chunk + 1] - off_c;
+    const uint32_t stream_len = slen64 < 0xffffffffull ? (uint32_t)slen64 : 0xffffffffu;
+    U* const o = (U*)a.out + chunk * (uint64_t)a.chunk_len;
+
+    // ---- 8-byte stream header (format.h:48-62), or the caller's numbers (sprintz_xff.h:56-58)
+    uint32_t groups_left, remaining, pos;
+    bool corrupt = false;
+    if (!a.noheader) {
+        if (stream_len < 8u) { corrupt = true; groups_left = 0; remaining = 0; pos = 0; }
+        else {
+            const uint32_t w0 = load_u32_any(s), w1 = load_u32_any(s + 4);
+            groups_left = w0;
+            remaining = w1 & 0xffffu;
+            pos = 8;
+            if ((int)(w1 >> 16) != D) corrupt = true;
+        }
+    } else {
+        groups_left = a.nh_ngroups;
+        remaining = a.nh_remaining;
+        pos = 0;
+    }
+    const uint32_t hdr_bytes = (2u * (uint32_t)D * HB + 7u) >> 3;
+    const uint32_t blk_elems = 8u * (uint32_t)D;
+    if (groups_left > a.chunk_len / blk_elems + 2u) corrupt = true;      // a damaged header must not make the loop spin
+    if (corrupt) groups_left = 0;
+
+    uint32_t pv[kAnyCpl];
+    int pd[kAnyCpl], ctr[kAnyCpl];
+    uint32_t nbs[2][kAnyCpl];
+#pragma unroll
+    for (int k = 0; k < kAnyCpl; k++) { pv[k] = 0; pd[k] = 0; ctr[k] = 0; nbs[0][k] = 0; nbs[1][k] = 0; }
+    uint32_t out_elems = 0;
+
+    // one block of errors z (zigzagged; run blocks: zeros) -> samples, stored (:993-1150; runs :828-958)
+    auto emit_block = [&](const uint32_t (&z)[8][kAnyCpl], bool run_block) {
+        U* const ob = o + out_elems;
+#pragma unroll
+        for (int k = 0; k < kAnyCpl; k++) {
+            const int col = col0 + k;
+            if (k >= cpl || col >= D) continue;
+            int coef = FIRE ? fire_coef<W, false>(ctr[k]) : 0;
+            if constexpr (FIRE && W == 16) {
+                if (a.quirk && run_block) coef = fire_coef_ref_run16(ctr[k], col);
+            }
+            int grad = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int err = unzigzag(z[i][k]);
+                const int pred = FIRE ? fire_predict<W, false>(pd[k], coef) : 0;
+                const int delta = sext<W>(err + pred);
+                if (FIRE && (i & 1)) grad += sign_times(err, pd[k]);
+                pv[k] = (pv[k] + (uint32_t)delta) & MASK;
+                pd[k] = delta;
+                ob[(uint32_t)i * (uint32_t)D + (uint32_t)col] = (U)pv[k];
+            }
+            if (FIRE) ctr[k] = wrap_counter<W>(ctr[k] + (sext<W>(grad) >> 2));       // :1120-1128
+        }
+        out_elems += blk_elems;
+    };
+
+    while (groups_left > 0 && !corrupt) {
+        groups_left--;
+        if (hdr_bytes > stream_len - pos) { corrupt = true; break; }
+        // ---- group header: 2 D fields of HB bits, LSB first (:713-735)
+        uint32_t both = 0;
+#pragma unroll
+        for (int k = 0; k < kAnyCpl; k++) {
+            const int col = col0 + k;
+            uint32_t f0 = 0, f1 = 0;
+            if (k < cpl && col < D) {
+                f0 = fetch_bits(s + pos, (uint32_t)col * HB, HB);
+                f1 = fetch_bits(s + pos, (uint32_t)(D + col) * HB, HB);
+            }
+            nbs[0][k] = f0 == (uint32_t)(W - 1) ? (uint32_t)W : f0;      // :747-749, :763-765
+            nbs[1][k] = f1 == (uint32_t)(W - 1) ? (uint32_t)W : f1;
+            both += nbs[0][k] | (nbs[1][k] << 16);                        // (a slot's total is at most 2047 * 16 < 2^16)
+        }
+        uint32_t tot_both;
+        const uint32_t excl_both = wg_scan(both, tot_both, s4);
+        pos += hdr_bytes;
+        for (int slot = 0; slot < 2 && !corrupt; slot++) {
+            const uint32_t total = slot ? tot_both >> 16 : tot_both & 0xffffu;
+            if (total == 0) {                                             // RUN slot: varint length in blocks (:829-833)
+                if (stream_len - pos < 2u) {
+                    if (stream_len == pos || (load_u8(s + pos) & 0x80u)) { corrupt = true; break; }
+                }
+                const uint32_t b0 = load_u8(s + pos);
+                uint32_t len = b0 & 0x7fu;
+                if (b0 & 0x80u) { len |= load_u8(s + pos + 1) << 7; pos += 2; }
+                else pos += 1;
+                uint32_t zero[8][kAnyCpl];
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+#pragma unroll
+                    for (int k = 0; k < kAnyCpl; k++) zero[i][k] = 0;
+                for (; len > 0; len--) {
+                    if (out_elems + blk_elems > a.chunk_len) { corrupt = true; break; }
+                    emit_block(zero, true);
+                }
+            } else {                                                      // packed block: 8 rows of ceil(total / 8) bytes (:961-990)
+                const uint32_t row_bits = ((total + 7u) >> 3) << 3;
+                if (row_bits > stream_len - pos || out_elems + blk_elems > a.chunk_len) { corrupt = true; break; }
+                uint32_t off = slot ? excl_both >> 16 : excl_both & 0xffffu;
+                uint32_t z[8][kAnyCpl];
+#pragma unroll
+                for (int k = 0; k < kAnyCpl; k++) {
+                    const uint32_t nb = nbs[slot][k];
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+                        z[i][k] = (k < cpl && col0 + k < D) ? fetch_bits(s + pos, (uint32_t)i * row_bits + off, nb) : 0u;
+                    off += nb;
+                }
+                emit_block(z, false);
+                pos += row_bits;
+            }
+        }
+    }
+
+    // ---- verbatim tail (:1171)
+    if (!corrupt && (out_elems + remaining > a.chunk_len || (uint64_t)remaining * ESZ > (uint64_t)(stream_len - pos))) corrupt = true;
+    if (!corrupt) {
+        const uint8_t* const t = s + pos;
+        uint8_t* const d = (uint8_t*)(o + out_elems);
+        for (uint32_t j = tid; j < remaining * ESZ; j += 256u) d[j] = t[j];
+    }
+    if (tid == 0 && a.rets) a.rets[chunk] = corrupt ? kErrCorrupt : (int64_t)out_elems + remaining;
+}
+
+template <int W, bool FIRE>
+__global__ void __launch_bounds__(256) encode_any_kernel(EncodeArgs a)
+{
+    using U = typename Elem<W>::U;
+    typedef __attribute__((address_space(3))) uint32_t lds_word;
+    constexpr int HB = Elem<W>::HB;
+    constexpr int ESZ = W / 8;
+    constexpr bool TAIL_LE = FIRE;               // "<=" at sprintz_xff_rle.cpp:362, "<" at sprintz_delta_rle.cpp:226
+    extern __shared__ __attribute__((aligned(16))) uint8_t win[];        // the stream from gpos (a multiple of 16) on: a.cap bytes, zeroed
+    __shared__ uint32_t s4[4];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t chunk = blockIdx.x;
+    const int D = a.D;
+    const int cpl = (D + 255) / 256;
+    const int col0 = (int)tid * cpl;
+    const uint64_t first = chunk * (uint64_t)a.chunk_len;
+    const uint32_t n = (uint32_t)((a.total_len - first < a.chunk_len) ? (a.total_len - first) : a.chunk_len);
+    const U* const sc = (const U*)a.src + first;
+    uint8_t* const gdst = a.slots + chunk * a.slot_stride;
+    const uint32_t cap = a.cap;
+    const uint32_t win_a = lds_addr(win);
+
+    for (uint32_t u = tid; u < (cap >> 4); u += 256u) ((uint4*)win)[u] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    uint32_t wl = a.write_size ? 8u : 0u;        // write position inside the window (bytes)
+    uint32_t gpos = 0;                           // stream offset of the window's first byte
+    // whole 16-byte pieces below `upto` (a multiple of 16) leave for the slot; what stays moves to the front
+    auto drain = [&](uint32_t upto) {
+        __syncthreads();
+        for (uint32_t u = tid * 16u; u < upto; u += 256u * 16u) {
+            uint4* const r = (uint4*)(win + u);
+            *(uint4*)(gdst + gpos + u) = *r;
+            *r = make_uint4(0, 0, 0, 0);
+        }
+        __syncthreads();
+        // (every caller passes wl rounded down or up to 16: what stays is LESS than one piece, and nothing has been written above wl)
+        if (upto != 0 && wl > upto && tid == 0) {
+            const uint4 v = *(uint4*)(win + upto);
+            *(uint4*)(win + upto) = make_uint4(0, 0, 0, 0);
+            *(uint4*)win = v;
+        }
+        gpos += upto;
+        wl -= upto;
+        __syncthreads();
+    };
+    auto or_bits = [&](uint32_t bp, uint32_t v, uint32_t nb) {           // the low nb (<= 16) bits of v at window bit position bp
+        if (nb == 0) return;
+        const uint64_t x = (uint64_t)v << (bp & 31u);
+        lds_word* q = (lds_word*)(uintptr_t)(win_a + ((bp >> 3) & ~3u));
+        __hip_atomic_fetch_or(q, (uint32_t)x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((uint32_t)(x >> 32)) __hip_atomic_fetch_or(q + 1, (uint32_t)(x >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto put_run = [&](uint32_t run) {           // :377-384
+        if (tid == 0) {
+            win[wl] = (uint8_t)((run & 0x7fu) | (run > 0x7fu ? 0x80u : 0u));
+            if (run > 0x7fu) win[wl + 1] = (uint8_t)(run >> 7);
+        }
+        wl += run > 0x7fu ? 2u : 1u;
+    };
+
+    const uint32_t hdr_bytes = (2u * (uint32_t)D * HB + 7u) >> 3;
+    const uint32_t blk = 8u * (uint32_t)D;
+    const int64_t limit = (int64_t)n - 2 * (int64_t)blk;                 // last_full_group_start (:158)
+    int64_t pos_in = 0;
+    uint32_t ngroups = 0, run = 0, hdr_pos = 0;
+    int slot = 0;
+    uint32_t pv[kAnyCpl];
+    int pd[kAnyCpl], ctr[kAnyCpl];
+#pragma unroll
+    for (int k = 0; k < kAnyCpl; k++) { pv[k] = 0; pd[k] = 0; ctr[k] = 0; }
+    auto start_group = [&]() {
+        ngroups++;
+        drain(wl & ~15u);
+        hdr_pos = wl;
+        wl += hdr_bytes;
+        slot = 0;
+    };
+    bool active = n >= 128u && limit >= 0;       // :116 and the loop guard :160
+    if (active) start_group();
+
+    while (active) {
+        // ---- the block at pos_in: forecast, zigzag, widths (:197-298)
+        uint32_t z[8][kAnyCpl], nb[kAnyCpl];
+        uint32_t lane_bits = 0;
+#pragma unroll
+        for (int k = 0; k < kAnyCpl; k++) {
+            const int col = col0 + k;
+            nb[k] = 0;
+            if (k >= cpl || col >= D) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) z[i][k] = 0;
+                continue;
+            }
+            const int coef = FIRE ? fire_coef<W, false>(ctr[k]) : 0;
+            int grad = 0;
+            uint32_t mask = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t x = (uint32_t)sc[pos_in + (int64_t)i * D + col];
+                const int delta = sext<W>((int)(x - pv[k]));
+                const int pred = FIRE ? fire_predict<W, false>(pd[k], coef) : 0;
+                const int err = sext<W>(delta - pred);
+                if (FIRE && (i & 1)) grad += sign_times(err, pd[k]);
+                z[i][k] = zigzag<W>(err);
+                mask |= z[i][k];
+                pv[k] = x;
+                pd[k] = delta;
+            }
+            if (FIRE) ctr[k] = wrap_counter<W>(ctr[k] + (sext<W>(grad) >> 2));
+            nb[k] = nbits_of<W, false>(mask);
+            lane_bits += nb[k];
+        }
+        uint32_t total;
+        const uint32_t excl = wg_scan(lane_bits, total, s4);
+
+        // ---- RLE state machine (:350-456); the same in every lane
+        for (;;) {
+            if (total == 0 && run < 0x7fffu) {
+                run++;
+                pos_in += blk;
+                const bool more = TAIL_LE ? (pos_in <= limit) : (pos_in < limit);
+                if (more) break;
+                slot++;
+                __syncthreads();
+                put_run(run);
+                wl += (uint32_t)(2 - slot);          // one 0x00 per slot the group still has (:386-391)
+                run = 0;
+                active = false;
+                break;
+            }
+            if (run > 0) {
+                slot++;
+                __syncthreads();
+                put_run(run);
+                run = 0;
+                if (slot == 2) start_group();        // :430-450
+                continue;
+            }
+            const uint32_t row_bits = ((total + 7u) >> 3) << 3;
+            uint32_t off = excl;
+#pragma unroll
+            for (int k = 0; k < kAnyCpl; k++) {
+                const int col = col0 + k;
+                if (k < cpl && col < D) {
+                    or_bits(hdr_pos * 8u + (uint32_t)(slot * D + col) * HB, nb[k] == (uint32_t)W ? (uint32_t)(W - 1) : nb[k], HB);      // :296
+#pragma unroll
+                    for (int i = 0; i < 8; i++) or_bits(wl * 8u + (uint32_t)i * row_bits + off, z[i][k], nb[k]);
+                    off += nb[k];
+                }
+            }
+            wl += row_bits;                          // 8 rows of row_bits / 8 bytes
+            pos_in += blk;
+            slot++;
+            if (slot == 2) {
+                if (pos_in <= limit) start_group();
+                else active = false;
+            }
+            break;
+        }
+    }
+
+    // ---- verbatim tail through the window (:553)
+    const uint32_t remaining = (uint32_t)((int64_t)n - pos_in);
+    {
+        const uint8_t* tp = (const uint8_t*)(sc + pos_in);
+        uint32_t left = remaining * ESZ;
+        while (left > 0) {
+            drain(wl & ~15u);
+            const uint32_t room = cap - 16u - wl;
+            const uint32_t m = left < room ? left : room;
+            for (uint32_t j = tid; j < m; j += 256u) win[wl + j] = tp[j];
+            wl += m;
+            tp += m;
+            left -= m;
+        }
+    }
+    const uint32_t total_bytes = gpos + wl;
+    drain((wl + 15u) & ~15u);
+    if (tid == 0) {                                  // format.h:36-45 (the window's first pieces have left: straight to the slot)
+        if (a.write_size) {
+            ((uint32_t*)gdst)[0] = ngroups;
+            ((uint32_t*)gdst)[1] = (remaining & 0xffffu) | ((uint32_t)D << 16);
+        }
+        a.sizes[chunk] = total_bytes;
+        if (a.rets) a.rets[chunk] = (int64_t)(total_bytes / ESZ);
+    }
+}
+
+template <typename K, typename A>
+hipError_t launch_any(K kernel, unsigned grid, size_t shmem, hipStream_t st, const A& a)
+{
+    if (shmem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), shmem, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_decode_any(int w, bool fire, unsigned grid, hipStream_t st, const DecodeArgs& a)
+{
+    if (w == 8) return fire ? launch_any(decode_any_kernel<8, true>, grid, 0, st, a) : launch_any(decode_any_kernel<8, false>, grid, 0, st, a);
+    return fire ? launch_any(decode_any_kernel<16, true>, grid, 0, st, a) : launch_any(decode_any_kernel<16, false>, grid, 0, st, a);
+}
+hipError_t launch_encode_any(int w, bool fire, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a)
+{
+    if (w == 8) return fire ? launch_any(encode_any_kernel<8, true>, grid, shmem, st, a) : launch_any(encode_any_kernel<8, false>, grid, shmem, st, a);
+    return fire ? launch_any(encode_any_kernel<16, true>, grid, shmem, st, a) : launch_any(encode_any_kernel<16, false>, grid, shmem, st, a);
+}
+
+}  // namespace sprintz

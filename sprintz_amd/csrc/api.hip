@@ -375,6 +375,15 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
     // (only 16-bit general-layout FIRE streams have the divergence: sprintz_xff_rle.cpp:893-901)
     a.quirk = (esz == 2 && codec == SPRINTZ_CODEC_XFF && !lowdim && process().ref_quirk.load(std::memory_order_relaxed)) ? 1 : 0;
 
+    // 513 .. 2047 columns: one workgroup per chunk (any_ndims.hip) -- the RLE codecs, row-major, plain decode
+    if (D > 512) {
+        if (norle || cs || qs.q != kQueryOff) return fail(SPRINTZ_E_UNSUPPORTED, "more than 512 columns: the RLE codecs, row-major, without query only");
+        if (nchunks > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
+        const hipError_t ea = launch_decode_any(8 * esz, codec == SPRINTZ_CODEC_XFF, (unsigned)nchunks, st, a);
+        if (ea != hipSuccess) return fail(SPRINTZ_E_HIP, "decode_any kernel launch", ea);
+        return 0;
+    }
+
     // batches whose chunks are too short for a stream group: header check + copy (verbatim_decode_kernel)
     // (only where a chunk cannot hold a group at all, chunk_len < 16 D: a stream of 16 D <= chunk_len < 128 elements that announces
     //  groups is one the reference ENCODER never writes but its decoder reads -- that one goes to the decoders below)
@@ -515,6 +524,15 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     a.col_stride = col_stride;
     a.norle = norle ? (codec == SPRINTZ_CODEC_XFF_NORLE ? 2 : 1) : 0;
     a.raw = codec == SPRINTZ_CODEC_BITPACK_NORLE ? 1 : 0;
+    // 513 .. 2047 columns: one workgroup per chunk, the window holds one stream group (any_ndims.hip)
+    if (D > 512) {
+        if (norle || col_stride) return fail(SPRINTZ_E_UNSUPPORTED, "more than 512 columns: the RLE codecs, row-major only");
+        if (nchunks > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
+        a.cap = ((uint32_t)group_bytes_max(esz, D) + 64u + 15u) & ~15u;
+        const hipError_t ea = launch_encode_any(8 * esz, codec == SPRINTZ_CODEC_XFF, (unsigned)nchunks, a.cap, st, a);
+        if (ea != hipSuccess) return fail(SPRINTZ_E_HIP, "encode_any kernel launch", ea);
+        return 0;
+    }
     // the generic kernel's window is a power-of-two RING flushed in 16-byte pieces; the kernels that flush whole 128-byte lines
     // (encode_fast.h, encode_wide.h) need that much more room in front of the write position: cap_drain (theirs alone -- added
     // to every encoder it doubled the generic ring wherever the group sat just under a power of two)

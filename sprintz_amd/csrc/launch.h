@@ -29,6 +29,9 @@ hipError_t launch_decode_fast_w16(bool fire, int dp, int cpl, bool exact, int q,
 // small batches: one workgroup per chunk, general layout, 3 .. 64 columns (decode_lat.h); bound_bytes = the longest stream a chunk can have
 hipError_t launch_decode_lat(int w, bool fire, int dp, bool lowdim, unsigned grid, uint32_t bound_bytes, hipStream_t st, const DecodeArgs& a);
 hipError_t launch_encode_lat(int w, bool fire, int dp, bool lowdim, unsigned grid, uint32_t bound_bytes, hipStream_t st, const EncodeArgs& a);   // encode_lat.h
+// streams of 513 .. 2047 columns: one workgroup per chunk, <= 8 columns per lane (any_ndims.hip); shmem = the encoder's group window
+hipError_t launch_decode_any(int w, bool fire, unsigned grid, hipStream_t st, const DecodeArgs& a);
+hipError_t launch_encode_any(int w, bool fire, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
 // low-dim streams with 1, 2 or 4 columns (8 bits) / 1 or 2 (16 bits), one lane per chunk (decode_uni.h)
 hipError_t launch_decode_uni_w8(bool fire, int nd, int q, unsigned grid, hipStream_t st, const DecodeArgs& a);
 hipError_t launch_decode_uni_w16(bool fire, int nd, int q, unsigned grid, hipStream_t st, const DecodeArgs& a);

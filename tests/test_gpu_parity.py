@@ -101,6 +101,57 @@ def test_random_shapes_against_oracle(sz, oracle):
         assert (r[:-1] == chunk_len).all() and r[-1] == total - (nchunks - 1) * chunk_len
 
 
+@pytest.mark.parametrize("codec,esz,ndims", [("xff", 2, 513), ("delta", 1, 600), ("xff", 1, 1000), ("delta", 2, 1000), ("xff", 2, 2047), ("xff", 1, 2047)])
+def test_streams_of_513_to_2047_columns(sz, oracle, codec, esz, ndims):
+    """the reference takes any uint16 ndims (format.h:36-45; its own tests stop at 129): 513 .. 2047 columns go through
+    csrc/any_ndims.hip -- single calls and batches, whole and ragged chunks, noise / runs (> 127 blocks too) / full-width fields,
+    stream bytes and samples the oracle's; a damaged stream is rejected or stays inside its slot"""
+    import torch
+    rng = np.random.default_rng(ndims * 7 + esz)
+    for rows, kind in ((8 * 40 + 5, "walk"), (16, "walk"), (8 * 300, "flat"), (48, "uniform"), (100, "walkflat")):
+        n = rows * ndims
+        if kind == "uniform":
+            x = rng.integers(0, 1 << (8 * esz), size=n).astype(DTYPES[esz])
+        elif kind == "flat":
+            m = np.zeros((rows, ndims), np.int64) + rng.integers(0, 200, size=(1, ndims))
+            m[8 * 280:] += rng.integers(0, 5, size=(rows - 8 * 280, ndims))
+            x = np.mod(m, 1 << (8 * esz)).astype(DTYPES[esz]).ravel()
+        else:
+            x = gen_walk(rng, n, ndims, esz, 6, flat_every=3 if kind == "walkflat" else 0)
+        want, wret = oracle.compress(codec, x, ndims)
+        dest, ret = gpu_compress(sz, codec, x, ndims)
+        assert ret == wret, (codec, esz, ndims, rows, kind, sz.last_error())
+        assert np.array_equal(dest[:want.size], want), (codec, esz, ndims, rows, kind)
+        dec, dret = gpu_decompress(sz, codec, want, esz, n)
+        assert dret == n and np.array_equal(dec[:n], x), (codec, esz, ndims, rows, kind)
+    # a batch: 5 chunks of 24 rows, the last one ragged
+    chunk_len, nchunks = 24 * ndims, 5
+    total = nchunks * chunk_len - 3 * ndims - 1
+    x = gen_walk(rng, total, ndims, esz, 9, flat_every=2)
+    cd = sz.ChunkedCodec(codec, esz, ndims, chunk_len, device="cuda:0")
+    t = torch.from_numpy(x.view(np.int8 if esz == 1 else np.int16)).cuda().view(cd.dtype)
+    batch = cd.compress(t)
+    comp, offs, sizes = batch.data.cpu().numpy(), batch.offsets.cpu().numpy(), batch.sizes.cpu().numpy()
+    for c in range(nchunks):
+        w, _ = oracle.compress(codec, x[c * chunk_len:min((c + 1) * chunk_len, total)], ndims)
+        assert sizes[c] == w.size and np.array_equal(comp[offs[c]:offs[c] + sizes[c]], w), (codec, esz, ndims, c)
+    rets = torch.empty(nchunks, dtype=torch.int64, device="cuda:0")
+    out = cd.decompress(batch, rets=rets).cpu().numpy()
+    assert np.array_equal(out.view(DTYPES[esz]), x)
+    assert rets.cpu().numpy().tolist() == [chunk_len] * (nchunks - 1) + [total - (nchunks - 1) * chunk_len]
+    # damage: flipped bits and a cut stream -- E_CORRUPT or a count inside the slot, the guard words untouched
+    bad = comp.copy()
+    idx = rng.integers(0, bad.size - 16, bad.size // 60)
+    bad[idx] ^= rng.integers(1, 256, idx.size).astype(np.uint8)
+    guard = 4096
+    o2 = torch.full((nchunks * chunk_len + guard,), 0x5A, dtype=torch.int16 if esz == 2 else torch.int8, device="cuda:0")
+    r2 = torch.zeros(nchunks, dtype=torch.int64, device="cuda:0")
+    cd.decompress_into(torch.from_numpy(bad).cuda(), batch.offsets, nchunks, o2, r2)
+    r = r2.cpu().numpy()
+    assert ((r == sz._lib.E_CORRUPT) | ((r >= 0) & (r <= chunk_len))).all(), r
+    assert (o2[nchunks * chunk_len:].cpu().numpy() == 0x5A).all()
+
+
 def test_reference_decoder_quirk_on_request(sz, oracle, golden, request):
     """SPRINTZ_OPT_REF_DECODER_QUIRK: the decoders replay the runs of 16-bit general-layout FIRE streams as the REFERENCE DECODER
     does (sprintz_xff_rle.cpp:893-901) -- sample for sample what the compiled reference returned for the golden stream it does
