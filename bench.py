@@ -27,6 +27,7 @@ import ctypes as C
 import json
 import os
 import platform
+import re
 import sys
 import time
 
@@ -974,6 +975,32 @@ def finish_and_emit(result, emit):
     emit(line)
 
 
+def native_threads_leg(counts=(1, 8, 64)):
+    """tools/probes/single_call_mt.cpp built with g++ into a temp dir and run as a subprocess -> {threads: calls_per_s}."""
+    import shutil
+    import subprocess
+    import tempfile
+    src = os.path.join(ROOT, "tools", "probes", "single_call_mt.cpp")
+    lib = os.path.join(ROOT, "sprintz_amd", "libsprintz_mi355x.so")
+    if not shutil.which("g++") or not os.path.exists(src):
+        return {"skipped": "no g++ or no tools/probes/single_call_mt.cpp"}
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "single_call_mt")
+        try:
+            subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, src, "-ldl", "-lpthread"], check=True, timeout=120,
+                           stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            r = subprocess.run([exe, lib] + [str(c) for c in counts], check=True, timeout=120, stdin=subprocess.DEVNULL,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        except (subprocess.CalledProcessError, subprocess.TimeoutExpired) as e:
+            return {"failed": str(e)[:200]}
+    out = {}
+    for m in re.finditer(r"(\d+) threads:\s+(\d+) calls/s", r.stdout):
+        out[m.group(1)] = {"calls_per_s": int(m.group(2))}
+    if "FAILED" in r.stdout or not out:
+        return {"failed": r.stdout[-200:]}
+    return out
+
+
 def data_sweep(cx, codec, nchunks, rows, ndims, chunk_len, esz):
     """SURVEY 8d's generators on the headline shape, same launches as the headline: G0 uniform (the paper's worst case,
     results.tex:142-146 -- every field 16 bits, stream > input), G1 walk +-300, G2 walk + flat spans (every 4th 64-row span
@@ -1136,8 +1163,9 @@ def headline_extras(cx, codec, x, comp, offsets, ws, out, nchunks, total_comp, c
             "decompress_us_median": round(lat_d[150] * 1e6, 1), "decompress_us_p10": round(lat_d[30] * 1e6, 1),
             "compress_us_median": round(lat_c[150] * 1e6, 1), "compress_us_p10": round(lat_c[30] * 1e6, 1),
             "what": "sprintz_decompress_xff_16b / sprintz_compress_xff_16b on host buffers through ctypes: memcpy into the thread's MAPPED staging "
-                    "buffer, stage_in + the one-workgroup-per-chunk kernel (decode_lat.h / encode_lat.h) reading and writing that buffer directly, "
-                    "one event wait, memcpy out; no copy engine, no memset, no hipMalloc per call"}
+                    "buffer, ONE launch of the one-workgroup-per-chunk kernel (decode_lat.h / encode_lat.h) reading and writing that buffer directly "
+                    "and ending with the call's ticket in a mapped host word the caller polls, memcpy out; no staging kernel, no runtime wait, no copy "
+                    "engine, no memset, no hipMalloc per call"}
         # ---------------- BASELINE configs[0]'s shape through the same symbols: uint8, 1 variable, 1 KB chunks (the low-dim layout)
         from synth import synth_numpy
         u1 = synth_numpy("walk", 1, 1, 1024, 1, seed=123, step=2)
@@ -1184,10 +1212,12 @@ def headline_extras(cx, codec, x, comp, offsets, ws, out, nchunks, total_comp, c
             rate, ok = many_threads(nt, 200 if nt < 64 else 60)
             assert ok, "a thread's single-call decode differs from the input"
             res["single_call_threads"][str(nt)] = {"calls_per_s": round(rate), "MBps_of_samples": round(rate * chunk_bytes / 1e6, 1)}
-        res["single_call_threads"]["what"] = ("N host threads, each alternating sprintz_decompress_xff_16b / sprintz_compress_xff_16b on its own 10 KB "
-                                              "chunk: what a multi-threaded lzbench-style driver gets out of the single-call boundary (the threads share "
-                                              "4 streams per device, SPRINTZ_OPT_HOST_STREAMS; each call waits on its own event); the batched device "
-                                              "API is the fast path")
+        res["single_call_threads"]["what"] = ("N PYTHON threads (ctypes releases the interpreter lock around a call, not between calls), each alternating "
+                                              "sprintz_decompress_xff_16b / sprintz_compress_xff_16b on its own 10 KB chunk; 'native' = the same loop from N "
+                                              "pthreads (tools/probes/single_call_mt.cpp, a subprocess): what a multi-threaded lzbench-style driver gets out "
+                                              "of the single-call boundary (the threads share 4 streams per device, SPRINTZ_OPT_HOST_STREAMS; up to 4 callers "
+                                              "spin on their call's flag word, more sleep and poll it); the batched device API is the fast path")
+        res["single_call_threads"]["native"] = native_threads_leg()
         # ---------------- online.hpp's u16 coders: ONE stream of 64 Mi samples per call, device buffers
         res["online_coders"] = online_leg(cx)
         # ---------------- PCIe-inclusive: host buffers in and out through the chunked host entry points

@@ -109,8 +109,11 @@ const char* sprintz_mi355x_last_error(void);     /* thread-local, never NULL; de
  *                                 with one workgroup per chunk (csrc/decode_lat.h: a chunk's latency is what counts; a third as many from 17 columns on); default 2048,
  *                                 0 = never (A/B runs, tests); env SPRINTZ_MI355X_LAT_CHUNKS
  *   SPRINTZ_OPT_HOST_WAIT         how a single-call entry point waits for its launches: 0 (default) = spin (hipStreamSynchronize)
- *                                 while at most half of the CPUs this process may use are inside the library, otherwise sleep on
- *                                 a blocking-sync event; 1 = always spin; 2 = always sleep; env SPRINTZ_MI355X_HOST_WAIT */
+ *                                 while at most 4 callers (and at most half of the CPUs this process may use) are inside the library,
+ *                                 otherwise sleep and poll a mapped host word that a one-thread kernel at the end of the call writes
+ *                                 (no runtime wait: 64 threads on 16 CPUs get 4x the calls per second of either runtime wait; a
+ *                                 thread that waits this way gets its timer slack set to 1 us, prctl(PR_SET_TIMERSLACK)); 1 = always
+ *                                 spin; 2 = always sleep and poll; env SPRINTZ_MI355X_HOST_WAIT */
 #define SPRINTZ_OPT_NO_FAST 0
 #define SPRINTZ_OPT_CHUNKS_PER_GROUP 1
 #define SPRINTZ_OPT_DENSE_MODE 2

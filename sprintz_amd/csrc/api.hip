@@ -9,6 +9,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <ctime>
+#include <sys/prctl.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -334,13 +337,44 @@ int check_common(int codec, int esz, uint16_t ndims)
 }
 
 // query-on-compressed options of one decode launch (decode_kernel.h: Q template parameter)
+// a single call served straight from the caller thread's mapped host buffer by ONE launch of a workgroup-per-chunk kernel
+// (decode_lat.h / encode_lat.h): no staging kernel in front, no runtime wait behind -- the kernel's last store is the
+// call's ticket into a mapped host word
+struct HostCall {
+    uint64_t off0 = 0, off1 = 0;   // decode: the stream is comp[off0, off1)
+    uint64_t* flag = nullptr;      // device view of the word
+    uint64_t ticket = 0;
+};
+
 struct QuerySpec {
     int q = kQueryOff;          // kQueryOff / kQueryMaterialize / kQueryReduceOnly
     int qop = 0;                // 1 max, 2 sum
     uint64_t* qres = nullptr;   // [nchunks][ndims]
     int general = 0;            // 1: general row-major layout for every ndims (the reference's *_rowmajor_*_rle_* family)
     uint64_t col_stride = 0;    // != 0: column-major destination (DecodeArgs::col_stride)
+    const HostCall* hc = nullptr;
 };
+
+bool decode_ref_quirk(int codec, int esz, bool lowdim)
+{
+    // (only 16-bit general-layout FIRE streams have the divergence: sprintz_xff_rle.cpp:893-901)
+    return esz == 2 && codec == SPRINTZ_CODEC_XFF && !lowdim && process().ref_quirk.load(std::memory_order_relaxed);
+}
+
+// small batches: one WORKGROUP per chunk (decode_lat.h) -- a chunk's 40 dependent group steps on one lane group take 50 us
+// however few chunks there are; split into a header walk, parallel bit extraction, the bare recurrence and a prefix sum it is ~13
+bool decode_lat_fits(int codec, int esz, uint64_t nchunks, uint32_t chunk_len, int D, int noheader, const QuerySpec& qs, const void* d_out)
+{
+    const bool norle = codec >= SPRINTZ_CODEC_DELTA_NORLE;
+    const bool lowdim = (qs.general || norle) ? false : is_lowdim(esz, D);
+    return !norle && !noheader && !qs.col_stride && !decode_ref_quirk(codec, esz, lowdim) && qs.q == kQueryOff && D <= 64 &&
+           (uint64_t)chunk_len * esz <= kLatMaxChunkBytes && chunk_len >= 16u * (uint32_t)D && ((uintptr_t)d_out % 16) == 0 &&
+           ((uint64_t)chunk_len * esz) % 16 == 0 &&
+           // (about one round of workgroups on the chip is where it wins: 5 a CU at 8 columns -- measured 33 vs 47 us at 1 250 chunks, 41 vs 47
+           //  at 2 048, 59 vs 47 at 3 072; with more columns a chunk has fewer groups to walk and the lane-per-column kernel catches up
+           //  sooner: 32 columns 11.6 vs 14.7 at 640 chunks, 19.7 vs 14.8 at 1 250 -- a third of the limit from 17 columns on)
+           nchunks <= (uint64_t)process().lat_chunks.load(std::memory_order_relaxed) / (D > 16 ? 3u : 1u) && !process().no_fast.load(std::memory_order_relaxed);
+}
 
 int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offsets, uint64_t nchunks,
                   uint32_t chunk_len, uint16_t ndims, void* d_out, int64_t* d_rets, hipStream_t st,
@@ -372,8 +406,8 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
     a.raw = codec == SPRINTZ_CODEC_BITPACK_NORLE ? 1 : 0;
     a.col_stride = qs.col_stride;
     const uint64_t cs = qs.col_stride;
-    // (only 16-bit general-layout FIRE streams have the divergence: sprintz_xff_rle.cpp:893-901)
-    a.quirk = (esz == 2 && codec == SPRINTZ_CODEC_XFF && !lowdim && process().ref_quirk.load(std::memory_order_relaxed)) ? 1 : 0;
+    a.quirk = decode_ref_quirk(codec, esz, lowdim) ? 1 : 0;
+    if (qs.hc && !decode_lat_fits(codec, esz, nchunks, chunk_len, D, noheader, qs, d_out)) return fail(SPRINTZ_E_HIP, "internal: host call on a kernel that cannot end it");
 
     // 513 .. 2047 columns: one workgroup per chunk (any_ndims.hip) -- the RLE codecs, row-major, plain decode
     if (D > 512) {
@@ -435,14 +469,8 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
                                ((uintptr_t)d_out % 16) == 0 && (uint64_t)D * cs * esz < 0xf0000000ull
                          : fast_common && a.vec_store && (uint64_t)chunk_len * esz * 64 * 64 < 0xf0000000ull;
     hipError_t e;
-    // small batches: one WORKGROUP per chunk (decode_lat.h) -- a chunk's 40 dependent group steps on one lane group take 50 us
-    // however few chunks there are; split into a header walk, parallel bit extraction, the bare recurrence and a prefix sum it is ~13
-    if (!norle && !noheader && !cs && !a.raw && !a.quirk && qs.q == kQueryOff && D <= 64 && (uint64_t)chunk_len * esz <= kLatMaxChunkBytes &&
-        chunk_len >= 16u * (uint32_t)D && ((uintptr_t)d_out % 16) == 0 && ((uint64_t)chunk_len * esz) % 16 == 0 &&
-        // (about one round of workgroups on the chip is where it wins: 5 a CU at 8 columns -- measured 33 vs 47 us at 1 250 chunks, 41 vs 47
-        //  at 2 048, 59 vs 47 at 3 072; with more columns a chunk has fewer groups to walk and the lane-per-column kernel catches up
-        //  sooner: 32 columns 11.6 vs 14.7 at 640 chunks, 19.7 vs 14.8 at 1 250 -- a third of the limit from 17 columns on)
-        nchunks <= (uint64_t)process().lat_chunks.load(std::memory_order_relaxed) / (D > 16 ? 3u : 1u) && !process().no_fast.load(std::memory_order_relaxed)) {
+    if (decode_lat_fits(codec, esz, nchunks, chunk_len, D, noheader, qs, d_out)) {     // (a.raw is a run-less codec)
+        if (qs.hc) { a.offsets = nullptr; a.one_off0 = qs.hc->off0; a.one_off1 = qs.hc->off1; a.host_flag = qs.hc->flag; a.host_ticket = qs.hc->ticket; }
         int ldp = 4;
         while (ldp < D) ldp <<= 1;
         if (esz == 1 && ldp < 8 && !lowdim) ldp = 8;
@@ -497,9 +525,22 @@ struct DenseRequest {
     bool fused = false;
 };
 
+// small batches: one WORKGROUP per chunk (encode_lat.h), the counterpart of decode_lat.h -- 90 us for ONE 10 KB chunk on a lane
+// group, ~20 with the coefficient chain and the RLE state machine as the only serial parts (the container, if one was asked
+// for, is then built by the scan + copy passes: dense->fused stays false)
+bool encode_lat_fits(int codec, int esz, uint64_t nchunks, uint32_t chunk_len, int D, uint64_t col_stride, const void* d_src, const void* d_slots, size_t slot_stride)
+{
+    const bool norle = codec >= SPRINTZ_CODEC_DELTA_NORLE;
+    return !norle && !col_stride && D <= 64 && (uint64_t)chunk_len * esz <= kEncLatMaxChunkBytes &&
+           ((uintptr_t)d_src % 16) == 0 && ((uint64_t)chunk_len * esz) % 16 == 0 && slot_stride % 16 == 0 && ((uintptr_t)d_slots % 16) == 0 &&
+           // (the encoder's crossover sits higher than the decoder's -- the lane-per-column encoders take ~100 us (uint16 x 8) / ~175 us (uint8 x 8)
+           //  for ANY batch up to ~16 000 chunks: 75 vs 100 us at 3 072 chunks, 105 vs 101 at 4 096; 32 columns: 24 vs 26 at 1 024 -- tools/lat_sweep_enc.py)
+           nchunks <= (uint64_t)process().lat_chunks.load(std::memory_order_relaxed) * (D > 16 ? 1u : 3u) / (D > 16 ? 3u : 2u) && !process().no_fast.load(std::memory_order_relaxed);
+}
+
 int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uint32_t chunk_len, uint16_t ndims,
                   void* d_slots, size_t slot_stride, uint32_t* d_sizes, int64_t* d_rets, hipStream_t st, int write_size,
-                  uint64_t col_stride = 0, int general = 0, DenseRequest* dense = nullptr)
+                  uint64_t col_stride = 0, int general = 0, DenseRequest* dense = nullptr, const HostCall* hc = nullptr)
 {
     const uint64_t nchunks = sprintz_mi355x_num_chunks(total_len, chunk_len);
     if (nchunks == 0) return 0;
@@ -550,14 +591,9 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     const bool fast = col_stride ? fast_common && col_stride % 8 == 0 && (chunk_len / (uint32_t)D) % 8 == 0
                                  : fast_common && blk_bytes % 16 == 0 && ((uint64_t)chunk_len * esz) % 16 == 0;
     hipError_t e;
-    // small batches: one WORKGROUP per chunk (encode_lat.h), the counterpart of decode_lat.h -- 90 us for ONE 10 KB chunk on a lane
-    // group, ~20 with the coefficient chain and the RLE state machine as the only serial parts (the container, if one was asked
-    // for, is then built by the scan + copy passes: dense->fused stays false)
-    if (!norle && !col_stride && !a.raw && D <= 64 && (uint64_t)chunk_len * esz <= kEncLatMaxChunkBytes &&
-        ((uintptr_t)d_src % 16) == 0 && ((uint64_t)chunk_len * esz) % 16 == 0 && slot_stride % 16 == 0 && ((uintptr_t)d_slots % 16) == 0 &&
-        // (the encoder's crossover sits higher than the decoder's -- the lane-per-column encoders take ~100 us (uint16 x 8) / ~175 us (uint8 x 8)
-        //  for ANY batch up to ~16 000 chunks: 75 vs 100 us at 3 072 chunks, 105 vs 101 at 4 096; 32 columns: 24 vs 26 at 1 024 -- tools/lat_sweep_enc.py)
-        nchunks <= (uint64_t)process().lat_chunks.load(std::memory_order_relaxed) * (D > 16 ? 1u : 3u) / (D > 16 ? 3u : 2u) && !process().no_fast.load(std::memory_order_relaxed)) {
+    if (hc && !encode_lat_fits(codec, esz, nchunks, chunk_len, D, col_stride, d_src, d_slots, slot_stride)) return fail(SPRINTZ_E_HIP, "internal: host call on a kernel that cannot end it");
+    if (encode_lat_fits(codec, esz, nchunks, chunk_len, D, col_stride, d_src, d_slots, slot_stride)) {
+        if (hc) { a.host_flag = hc->flag; a.host_ticket = hc->ticket; }
         int ldp = 4;
         while (ldp < D) ldp <<= 1;
         if (esz == 1 && ldp < 8 && !lowdim) ldp = 8;
@@ -733,17 +769,21 @@ struct Scratch {
     uint8_t* pin = nullptr;              // hipHostMallocMapped | Coherent: the kernels of a single call read and write it directly
     uint8_t* pin_dev = nullptr;          // the same bytes as the device sees them (hipHostGetDevicePointer)
     size_t pin_cap = 0;
-    hipEvent_t done = nullptr;           // blocking-sync event: how a call waits when many host threads are inside the library
-    hipEvent_t done_spin = nullptr;      // the same, waited for by spinning (a shared stream: the call waits for ITS launches, not for the stream)
+    hipEvent_t done_spin = nullptr;      // waited for by spinning (a shared stream: the call waits for ITS launches, not for the stream)
     bool shared_stream = false;
+    uint64_t* flag = nullptr;            // one mapped host word: the flag kernel that ends a polled call writes the call's ticket here
+    uint64_t* flag_dev = nullptr;
+    uint64_t ticket = 0;
+    uint64_t last_wait_ns = 0;           // how long the last polled call of this thread waited
 };
 constexpr size_t kPinMax = 4u << 20;     // larger transfers go straight from/to the caller's memory
 
 // ---- waiting for a single call's launches ---------------------------------------------------------
 // hipStreamSynchronize spins: the shortest wait there is while the waiting threads have cores to spin on.  With more
 // callers inside the library than that (lzbench -T64 in a 16-CPU container: 64 spinners on 16 CPUs' worth of quota get
-// throttled, and the one whose kernel HAS finished waits for a time slice) a call records a blocking-sync event and
-// sleeps on it instead.  SPRINTZ_OPT_HOST_WAIT: 0 = by the number of callers (default), 1 = always spin, 2 = always sleep.
+// throttled, and the one whose kernel HAS finished waits for a time slice) a call ends with a kernel that writes the call's
+// ticket into a mapped host word, and the caller sleeps and polls that word instead (a blocking-sync event was no better
+// than spinning: the runtime's wait is where the CPU time went).  SPRINTZ_OPT_HOST_WAIT: 0 = by the number of callers (default), 1 = always spin, 2 = always sleep.
 std::atomic<int> g_calls_inside{0};
 int spin_budget()
 {
@@ -754,7 +794,8 @@ int spin_budget()
             if (fscanf(f, "%ld %ld", &quota, &period) == 2 && quota > 0 && period > 0) q = std::min(q > 0 ? q : quota / period, quota / period);
             fclose(f);
         }
-        return (int)std::max(1l, q / 2);                                 // half of them: the callers do other work too
+        return (int)std::min(4l, std::max(1l, q / 2));                   // half of them (the callers do other work too), and no more than 4: from 5
+                                                                         // callers on the sleeping wait is the faster one (tools/mt_cmd.sh)
     }();
     return n;
 }
@@ -824,8 +865,9 @@ int acquire_scratch(size_t dev_bytes, size_t pin_bytes, Scratch** out)
                 e = hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking);
             }
             if (e != hipSuccess) { delete sc; return fail(SPRINTZ_E_HIP, "hipStreamCreateWithFlags", e); }
-            e = hipEventCreateWithFlags(&sc->done, hipEventBlockingSync | hipEventDisableTiming);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&sc->done_spin, hipEventDisableTiming);
+            e = hipEventCreateWithFlags(&sc->done_spin, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipHostMalloc((void**)&sc->flag, 64, hipHostMallocMapped | hipHostMallocCoherent);
+            if (e == hipSuccess) { *sc->flag = 0; e = hipHostGetDevicePointer((void**)&sc->flag_dev, sc->flag, 0); }
             if (e != hipSuccess) { if (!sc->shared_stream) (void)hipStreamDestroy(sc->stream); delete sc; return fail(SPRINTZ_E_HIP, "hipEventCreateWithFlags", e); }
         }
         t_scratch.s = sc;
@@ -851,22 +893,75 @@ int acquire_scratch(size_t dev_bytes, size_t pin_bytes, Scratch** out)
     return 0;
 }
 
+// ends a polled call: one word, the call's ticket, into the thread's mapped flag (after the codec kernel in stream order; a kernel's
+// end makes its stores to host memory visible before the next kernel of the stream starts)
+__global__ void flag_kernel(uint64_t* flag, uint64_t ticket)
+{
+    __hip_atomic_store(flag, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// sleep, then look at the thread's flag word until it holds `want`: no runtime wait at all (tools/mt_cmd.sh, 16-CPU container:
+// 64 threads 200k calls/s this way, 48k on a blocking-sync event, 52k spinning).  spin: look without sleeping (few callers).
+int wait_flag(Scratch* sc, uint64_t want, bool spin)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    if (spin) {
+        for (uint32_t it = 1;; ++it) {
+            if (__atomic_load_n(sc->flag, __ATOMIC_ACQUIRE) == want) break;
+            __builtin_ia32_pause();
+            if ((it & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+                HIP_TRY(hipStreamSynchronize(sc->stream));               // a fault surfaces here
+                if (__atomic_load_n(sc->flag, __ATOMIC_ACQUIRE) != want) return fail(SPRINTZ_E_HIP, "the call's completion flag was never written");
+                break;
+            }
+        }
+    } else {
+        static thread_local bool slack_set = false;      // the default 50 us of timer slack would make every 20 us sleep a 75 us one
+        if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000ul, 0, 0, 0); slack_set = true; }
+        // first sleep: three quarters of what the thread's last call waited (with many callers a call queues behind the others' for
+        // hundreds of microseconds), never under 15 us (no call is shorter); then 5, 10, 20 ... 160 us: 128 threads that each woke
+        // every 5 us would spend the container's CPUs on waking up
+        struct timespec ts{0, (long)std::min<uint64_t>(std::max<uint64_t>(15000, sc->last_wait_ns * 3 / 4), 2000000)};
+        long step = 5000;
+        for (uint32_t it = 0;; ++it) {
+            nanosleep(&ts, nullptr);
+            if (__atomic_load_n(sc->flag, __ATOMIC_ACQUIRE) == want) break;
+            ts.tv_nsec = step;
+            step = std::min(step * 2, 160000l);
+            if ((it & 15) == 15 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+                HIP_TRY(hipStreamSynchronize(sc->stream));
+                if (__atomic_load_n(sc->flag, __ATOMIC_ACQUIRE) != want) return fail(SPRINTZ_E_HIP, "the call's completion flag was never written");
+                break;
+            }
+        }
+        sc->last_wait_ns = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    }
+    if ((want & 63) == 0) (void)hipStreamQuery(sc->stream);          // the runtime retires finished launches when asked about them
+    return 0;
+}
+
+bool spin_wait(int callers)
+{
+    const int mode = process().host_wait.load(std::memory_order_relaxed);
+    return mode == 1 || (mode == 0 && callers <= spin_budget());
+}
+
 // wait for everything this call put on the thread's stream
 int wait_call(Scratch* sc, int callers)
 {
-    const int mode = process().host_wait.load(std::memory_order_relaxed);
-    if (mode == 1 || (mode == 0 && callers <= spin_budget())) {
+    if (spin_wait(callers)) {
         if (sc->shared_stream) {
             HIP_TRY(hipEventRecord(sc->done_spin, sc->stream));
             HIP_TRY(hipEventSynchronize(sc->done_spin));
         } else {
             HIP_TRY(hipStreamSynchronize(sc->stream));
         }
-    } else {
-        HIP_TRY(hipEventRecord(sc->done, sc->stream));
-        HIP_TRY(hipEventSynchronize(sc->done));
+        return 0;
     }
-    return 0;
+    const uint64_t want = ++sc->ticket;
+    hipLaunchKernelGGL(flag_kernel, dim3(1), dim3(1), 0, sc->stream, sc->flag_dev, want);
+    HIP_TRY(hipGetLastError());
+    return wait_flag(sc, want, false);
 }
 
 // A single call's input, host -> HBM, as ONE wide read of the thread's mapped staging buffer (every lane a 16-byte piece,
@@ -934,11 +1029,23 @@ int64_t compress_host(int codec, int esz, const void* src, uint32_t len, void* d
         int64_t ret = -1;
         memcpy(sc->pin + p_meta, &size, 4);
         memcpy(sc->pin + p_meta + 8, &ret, 8);
-        if ((rc = stage_in(sc, 0, 0, src_bytes))) return rc;
-        rc = encode_launch(codec, esz, sc->dev, len, len, ndims, sc->pin_dev + p_slot, bound, (uint32_t*)(sc->pin_dev + p_meta),
-                           (int64_t*)(sc->pin_dev + p_meta + 8), sc->stream, write_size, 0, layout == SPRINTZ_LAYOUT_GENERAL);
-        if (rc) { (void)hipStreamSynchronize(sc->stream); return rc; }   // stage_in may still be reading sc->pin
-        if ((rc = wait_call(sc, inside.n))) return rc;
+        // one chunk the workgroup-per-chunk encoder takes: it reads the staging buffer itself (one wide read, as stage_in's) and
+        // ends the call by writing the ticket -- ONE launch, no runtime wait
+        if (encode_lat_fits(codec, esz, 1, len, ndims, 0, sc->pin_dev, sc->pin_dev + p_slot, bound)) {
+            HostCall hc;
+            hc.flag = sc->flag_dev;
+            hc.ticket = ++sc->ticket;
+            rc = encode_launch(codec, esz, sc->pin_dev, len, len, ndims, sc->pin_dev + p_slot, bound, (uint32_t*)(sc->pin_dev + p_meta),
+                               (int64_t*)(sc->pin_dev + p_meta + 8), sc->stream, write_size, 0, layout == SPRINTZ_LAYOUT_GENERAL, nullptr, &hc);
+            if (rc) return rc;
+            if ((rc = wait_flag(sc, hc.ticket, spin_wait(inside.n)))) return rc;
+        } else {
+            if ((rc = stage_in(sc, 0, 0, src_bytes))) return rc;
+            rc = encode_launch(codec, esz, sc->dev, len, len, ndims, sc->pin_dev + p_slot, bound, (uint32_t*)(sc->pin_dev + p_meta),
+                               (int64_t*)(sc->pin_dev + p_meta + 8), sc->stream, write_size, 0, layout == SPRINTZ_LAYOUT_GENERAL);
+            if (rc) { (void)hipStreamSynchronize(sc->stream); return rc; }   // stage_in may still be reading sc->pin
+            if ((rc = wait_call(sc, inside.n))) return rc;
+        }
         memcpy(&size, sc->pin + p_meta, 4);
         memcpy(&ret, sc->pin + p_meta + 8, 8);
         if (size > bound) return fail(SPRINTZ_E_HIP, "encoder reported a size above its bound");
@@ -1019,11 +1126,24 @@ int64_t decode_host_common(int codec, int esz, const uint8_t* s, uint64_t nbytes
         memcpy(sc->pin, meta, 16);
         memcpy(sc->pin + 16, s, nbytes);
         memcpy(sc->pin + p_ret, &ret, 8);
-        if ((rc = stage_in(sc, 0, 0, 16 + nbytes))) return rc;
-        rc = decode_launch(codec, esz, sc->dev, (const uint64_t*)sc->dev, 1, (uint32_t)nelems, ndims, sc->pin_dev + p_out,
-                           (int64_t*)(sc->pin_dev + p_ret), sc->stream, noheader, ngroups, remaining, QuerySpec{});
-        if (rc) { (void)hipStreamSynchronize(sc->stream); return rc; }
-        if ((rc = wait_call(sc, inside.n))) return rc;
+        if (decode_lat_fits(codec, esz, 1, (uint32_t)nelems, ndims, noheader, QuerySpec{}, sc->pin_dev + p_out)) {   // (see compress_host)
+            HostCall hc;
+            hc.off0 = 16; hc.off1 = 16 + nbytes;
+            hc.flag = sc->flag_dev;
+            hc.ticket = ++sc->ticket;
+            QuerySpec qs;
+            qs.hc = &hc;
+            rc = decode_launch(codec, esz, sc->pin_dev, nullptr, 1, (uint32_t)nelems, ndims, sc->pin_dev + p_out,
+                               (int64_t*)(sc->pin_dev + p_ret), sc->stream, noheader, ngroups, remaining, qs);
+            if (rc) return rc;
+            if ((rc = wait_flag(sc, hc.ticket, spin_wait(inside.n)))) return rc;
+        } else {
+            if ((rc = stage_in(sc, 0, 0, 16 + nbytes))) return rc;
+            rc = decode_launch(codec, esz, sc->dev, (const uint64_t*)sc->dev, 1, (uint32_t)nelems, ndims, sc->pin_dev + p_out,
+                               (int64_t*)(sc->pin_dev + p_ret), sc->stream, noheader, ngroups, remaining, QuerySpec{});
+            if (rc) { (void)hipStreamSynchronize(sc->stream); return rc; }
+            if ((rc = wait_call(sc, inside.n))) return rc;
+        }
         memcpy(&ret, sc->pin + p_ret, 8);
         if (ret < 0) return fail((int)ret, "decoder rejected the stream");
         if ((uint64_t)ret > nelems) return fail(SPRINTZ_E_CORRUPT, "decoder rejected the stream");

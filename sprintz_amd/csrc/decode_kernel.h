@@ -43,6 +43,11 @@ struct DecodeArgs {
     int quirk;                  // 1: replay the runs of 16-bit general-layout FIRE streams as the REFERENCE DECODER does (fire_coef_ref_run16)
     int qop;                    // 1: max, 2: sum (what lands in qres)
     uint64_t* qres;             // [nchunks][D] per-chunk, per-column partial results
+    // a single call on the caller thread's mapped host buffer (decode_lat.h alone): offsets == null -> the one chunk's stream is
+    // comp[one_off0, one_off1); host_flag != null -> the kernel ends by writing host_ticket there, after every lane's stores
+    uint64_t one_off0, one_off1;
+    uint64_t* host_flag;
+    uint64_t host_ticket;
 };
 
 // Q (template): 0 = plain decode; 1 = decode + reduce; 2 = reduce only (nothing is written

@@ -95,8 +95,8 @@ __global__ void __launch_bounds__(256) decode_lat_kernel(DecodeArgs a, LatCarve 
 
     // ---- 0: the stream, 16 bytes a lane, into LDS (from the 16-byte boundary below its first byte; the <= 15 bytes read past
     // its end are inside SPRINTZ_MI355X_READ_SLACK)
-    const uint64_t off_c = a.offsets[chunk];
-    const uint64_t slen64 = a.offsets[chunk + 1] - off_c;
+    const uint64_t off_c = a.offsets ? a.offsets[chunk] : a.one_off0;
+    const uint64_t slen64 = (a.offsets ? a.offsets[chunk + 1] : a.one_off1) - off_c;
     const uint32_t shift = (uint32_t)((uintptr_t)(a.comp + off_c) & 15u);
     const uint32_t slen = slen64 < (uint64_t)(cv.strm_cap - 16u) ? (uint32_t)slen64 : cv.strm_cap - 16u;   // (a valid stream is shorter: strm_cap covers the bound)
     const uint32_t send = shift + slen;                    // LDS offset of the stream's end
@@ -343,8 +343,20 @@ __global__ void __launch_bounds__(256) decode_lat_kernel(DecodeArgs a, LatCarve 
     __syncthreads();
     LAT_STAMP();
     const uint32_t nblk = info[2], tail_pos = info[3], remaining = info[4];
+    // the call's last word: the return value, and for a single call on mapped host memory the caller's ticket behind every
+    // lane's stores (the host polls that word instead of asking the runtime)
+    auto finish = [&](int64_t r) {
+        if (a.host_flag) { __threadfence_system(); __syncthreads(); }
+        if (tid == 0) {
+            if (a.rets) a.rets[chunk] = r;
+            if (a.host_flag) {
+                __threadfence_system();
+                __hip_atomic_store(a.host_flag, a.host_ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    };
     if (info[0]) {                                         // nothing of a damaged stream is written
-        if (tid == 0 && a.rets) a.rets[chunk] = kErrCorrupt;
+        finish(kErrCorrupt);
         return;
     }
     uint8_t* const obase = (uint8_t*)a.out + chunk * (uint64_t)a.chunk_len * ESZ;
@@ -420,7 +432,7 @@ __global__ void __launch_bounds__(256) decode_lat_kernel(DecodeArgs a, LatCarve 
         return;
     }
 #endif
-    if (tid == 0 && a.rets) a.rets[chunk] = (int64_t)(nblk * blk_elems + remaining);
+    finish((int64_t)(nblk * blk_elems + remaining));
 #undef LAT_STAMP
 #undef LAT_DBG
 }

@@ -42,6 +42,10 @@ struct EncodeArgs {
     int raw;
     // the dense container written by the encode launch itself (compact_tail.h; encode_fast only): dn.dense == null -> slots only
     DenseArgs dn;
+    // a single call on the caller thread's mapped host buffer (encode_lat.h alone): the kernel ends by writing host_ticket to
+    // host_flag, after every lane's stores
+    uint64_t* host_flag;
+    uint64_t host_ticket;
 };
 
 template <int W, bool FIRE, bool LOWDIM, int CPL>

@@ -372,9 +372,14 @@ __global__ void __launch_bounds__(256) encode_lat_kernel(EncodeArgs a, EncLatCar
     const uint32_t total_bytes = wl + remaining * ESZ;
     for (uint32_t i = tid; i < ((total_bytes + 15u) >> 4); i += 256u) ((uint4*)gdst)[i] = ((const uint4*)img)[i];
     ENC_STAMP();
+    if (a.host_flag) { __threadfence_system(); __syncthreads(); }      // a single call on mapped host memory: every lane's stores, then the ticket
     if (tid == 0) {
         a.sizes[chunk] = total_bytes;
         if (a.rets) a.rets[chunk] = (int64_t)(total_bytes / ESZ);
+        if (a.host_flag) {
+            __threadfence_system();
+            __hip_atomic_store(a.host_flag, a.host_ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
 #ifdef SPRINTZ_LAT_TIMING
         if (a.rets) {
             uint64_t r = 0;
