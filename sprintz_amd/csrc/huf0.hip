@@ -82,6 +82,69 @@ __device__ __forceinline__ uint32_t hb32(const uint8_t* hb, uint32_t bitpos)    
 }
 __device__ __forceinline__ uint32_t nib_shift(uint32_t i) { return 8u * ((i & 7u) >> 1) + ((i & 1u) ? 0u : 4u); }   // weight i in its dword
 // first half: the weights of all symbols but the last (osize of them) -> wq; returns the header bytes, 0 if damaged
+#ifdef HUF0_TREE_TIMING                         // experiment builds: where a leader's wave spends its time (block 0, lane 0; 10 ns ticks)
+__device__ uint64_t g_tree_ts[16];
+#define TREE_TS(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_tree_ts[k] = wall_clock64(); } while (0)
+#else
+#define TREE_TS(k) do {} while (0)
+#endif
+
+// FSE_readNCount (entropy_common.c) on the header copy: norm[0..15] (zeroed by the caller), table log, last symbol, bytes read
+// UNI: every lane of the wave runs it on the same bytes -- the bit fields go through readfirstlane, which puts the whole walk on the scalar unit
+template <bool UNI = false>
+__device__ __forceinline__ bool fse_read_ncount(const uint8_t* hb0, uint32_t isize, int16_t* norm, uint32_t& tl_out, uint32_t& max_sv_out, uint32_t& hl_out)
+{
+    auto bits_at = [&](uint32_t bitpos) -> uint32_t {
+        const uint32_t v = hb32(hb0, bitpos);
+        if constexpr (UNI) return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); else return v;
+    };
+    // FSE_readNCount: bit 0 of the description is bit 72 of hb (8 lead bytes + the size byte)
+    constexpr uint32_t F0 = 72;
+    uint32_t bp = 0;
+    int nb = (int)(bits_at(F0 + bp) & 0xf) + 5;
+    if (nb > 6) return false;                                     // tableLog > maxLog (6)
+    bp += 4;
+    tl_out = (uint32_t)nb;
+    int remaining = (1 << nb) + 1, threshold = 1 << nb;
+    nb++;
+    uint32_t charnum = 0;
+    bool previous0 = false;
+    const uint32_t bit_end = 8u * isize;
+    while (remaining > 1 && charnum <= 255u) {
+        if (previous0) {
+            uint32_t n0 = charnum;
+            while ((bits_at(F0 + bp) & 0xffffu) == 0xffffu) { n0 += 24; bp += 16; if (bp > bit_end) return false; }
+            while ((bits_at(F0 + bp) & 3u) == 3u) { n0 += 3; bp += 2; if (bp > bit_end) return false; }
+            n0 += bits_at(F0 + bp) & 3u;
+            bp += 2;
+            if (n0 > 255u) return false;
+            charnum = n0;                                     // norm is zero there already
+        }
+        const uint32_t bits = bits_at(F0 + bp);
+        const int max = (2 * threshold - 1) - remaining;
+        int count;
+        if ((int)(bits & (uint32_t)(threshold - 1)) < max) {
+            count = (int)(bits & (uint32_t)(threshold - 1));
+            bp += (uint32_t)(nb - 1);
+        } else {
+            count = (int)(bits & (uint32_t)(2 * threshold - 1));
+            if (count >= threshold) count -= max;
+            bp += (uint32_t)nb;
+        }
+        count--;
+        remaining -= count < 0 ? -count : count;
+        if (charnum > 255u || bp > bit_end) return false;
+        if (charnum >= 16u) { if (count != 0) return false; charnum++; }
+        else norm[charnum++] = (int16_t)count;
+        previous0 = count == 0;
+        while (remaining < threshold) { nb--; threshold >>= 1; }
+    }
+    if (remaining != 1 || bp > bit_end || charnum == 0) return false;
+    max_sv_out = (charnum < 16u ? charnum : 16u) - 1;
+    hl_out = (bp + 7) >> 3;
+    return hl_out < isize;
+}
+
 __device__ uint32_t read_weights(const uint8_t* hb, uint32_t n, uint32_t* wq, uint8_t* s, uint32_t& osize_out)
 {
     const uint8_t* const h = hb + 8;
@@ -98,50 +161,9 @@ __device__ uint32_t read_weights(const uint8_t* hb, uint32_t n, uint32_t* wq, ui
         uint16_t* const next = (uint16_t*)(s + 32);
         uint16_t* const fse = (uint16_t*)(s + 64);                // symbol | nbits << 4 | new_state << 8
         for (int k = 0; k < 8; k++) ((uint32_t*)norm)[k] = 0;
-        // FSE_readNCount: bit 0 of the description is bit 72 of hb (8 lead bytes + the size byte)
-        constexpr uint32_t F0 = 72;
-        uint32_t bp = 0;
-        int nb = (int)(hb32(hb, F0 + bp) & 0xf) + 5;
-        if (nb > 6) return 0;                                     // tableLog > maxLog (6)
-        bp += 4;
-        const uint32_t tl = (uint32_t)nb;
-        int remaining = (1 << nb) + 1, threshold = 1 << nb;
-        nb++;
-        uint32_t charnum = 0;
-        bool previous0 = false;
-        const uint32_t bit_end = 8u * isize;
-        while (remaining > 1 && charnum <= 255u) {
-            if (previous0) {
-                uint32_t n0 = charnum;
-                while ((hb32(hb, F0 + bp) & 0xffffu) == 0xffffu) { n0 += 24; bp += 16; if (bp > bit_end) return 0; }
-                while ((hb32(hb, F0 + bp) & 3u) == 3u) { n0 += 3; bp += 2; if (bp > bit_end) return 0; }
-                n0 += hb32(hb, F0 + bp) & 3u;
-                bp += 2;
-                if (n0 > 255u) return 0;
-                charnum = n0;                                     // norm is zero there already
-            }
-            const uint32_t bits = hb32(hb, F0 + bp);
-            const int max = (2 * threshold - 1) - remaining;
-            int count;
-            if ((int)(bits & (uint32_t)(threshold - 1)) < max) {
-                count = (int)(bits & (uint32_t)(threshold - 1));
-                bp += (uint32_t)(nb - 1);
-            } else {
-                count = (int)(bits & (uint32_t)(2 * threshold - 1));
-                if (count >= threshold) count -= max;
-                bp += (uint32_t)nb;
-            }
-            count--;
-            remaining -= count < 0 ? -count : count;
-            if (charnum > 255u || bp > bit_end) return 0;
-            if (charnum >= 16u) { if (count != 0) return 0; charnum++; }
-            else norm[charnum++] = (int16_t)count;
-            previous0 = count == 0;
-            while (remaining < threshold) { nb--; threshold >>= 1; }
-        }
-        if (remaining != 1 || bp > bit_end || charnum == 0) return 0;
-        const uint32_t max_sv = (charnum < 16u ? charnum : 16u) - 1, hl = (bp + 7) >> 3;
-        if (hl >= isize) return 0;
+        uint32_t tl = 0, max_sv = 0, hl = 0;
+        if (!fse_read_ncount(hb, isize, norm, tl, max_sv, hl)) return 0;
+        TREE_TS(2);
         // FSE_buildDTable
         const uint32_t size = 1u << tl;
         uint32_t high = size - 1;
@@ -167,6 +189,7 @@ __device__ uint32_t read_weights(const uint8_t* hb, uint32_t n, uint32_t* wq, ui
             const uint32_t nbits = tl - (uint32_t)highbit(ns);
             fse[u] = (uint16_t)(sy | (nbits << 4) | (((ns << nbits) - size) << 8));
         }
+        TREE_TS(3);
         // FSE_decompress_usingDTable: two interleaved states; the stream ends by running dry
         const uint8_t* const b = h + 1 + hl;
         const uint32_t bn = isize - hl;
@@ -221,6 +244,7 @@ __device__ uint32_t read_weights(const uint8_t* hb, uint32_t n, uint32_t* wq, ui
             if (over) wq[q0 + 1] = spill;
         }
     }
+    TREE_TS(4);
     osize_out = osize;
     return isize + 1;
 }
@@ -273,6 +297,149 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- the same first half for huf0_tree_wave_kernel: the WAVE reads one description.  FSE_readNCount and the two-state weight
+// decode stay serial (every lane runs them on the same LDS bytes: uniform control flow, nothing to broadcast); FSE_buildDTable
+// -- 12 of the lane version's 49 us -- is spread over the lanes: lane k holds step k of the symbol spread (cell (k * step) &
+// mask, skipped if above `high`; its rank among the cells not skipped says which symbol lands there), then lane u holds cell u
+// (its `next` value = norm[symbol] + the cells of the same symbol below it, one ballot per symbol).  The weight decode runs
+// without a branch inside a trip of eight weights: the step after which the cursor goes negative is looked up afterwards
+// (the symbol emitted after the stream runs dry is the next step's symbol anyway -- it depends on the state alone).
+// Same results and the same rejections as read_weights.  Call with all 64 lanes; t = lane.
+__device__ uint32_t read_weights_wave(const uint8_t* hb, uint32_t n, uint32_t* wq, uint8_t* s, uint32_t& osize_out, const int t)
+{
+    const uint8_t* const h = hb + 8;
+    if (n < 1) return 0;
+    uint32_t isize = h[0], osize;
+    auto below = [&](uint64_t m) -> uint32_t { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
+    if (isize >= 128) {                                           // 4-bit weights
+        osize = isize - 127;
+        isize = (osize + 1) / 2;
+        if (isize + 1 > n) return 0;
+        if (8u * (uint32_t)t < osize) wq[t] = hb32(hb, 72u + 32u * (uint32_t)t);
+        osize_out = osize;
+        return isize + 1;
+    }
+    if (isize + 1 > n) return 0;
+    int16_t* const norm = (int16_t*)s;
+    uint16_t* const fse = (uint16_t*)(s + 64);                    // symbol | nbits << 4 | new_state << 8
+    if (t < 8) ((uint32_t*)norm)[t] = 0;
+    wave_sync();
+    uint32_t tl = 0, max_sv = 0, hl = 0;
+    if (!fse_read_ncount<true>(hb, isize, norm, tl, max_sv, hl)) return 0;
+    wave_sync();
+    TREE_TS(2);
+    const uint32_t size = 1u << tl, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+    {
+        // cum[sy] = cells of the symbols below sy that go through the spread; the symbols of probability "-1" take the top cells
+        uint32_t cum[17], nlp = 0, lp_below = 0;
+        cum[0] = 0;
+#pragma unroll
+        for (int sy = 0; sy < 16; sy++) {
+            const int c = (uint32_t)sy <= max_sv ? (int)norm[sy] : 0;
+            lp_below += (c == -1 && sy < t) ? 1u : 0u;
+            nlp += c == -1 ? 1u : 0u;
+            cum[sy + 1] = cum[sy] + (c > 0 ? (uint32_t)c : 0u);
+        }
+        if (cum[16] + nlp != size) return 0;                      // (FSE_buildDTable's "placed > size" / "pos != 0")
+        const uint32_t high = size - 1 - nlp;
+        if (t < 16 && (uint32_t)t <= max_sv && norm[t] == -1) fse[size - 1 - lp_below] = (uint16_t)t;
+        const uint32_t pk = ((uint32_t)t * step) & mask;
+        const bool valid = (uint32_t)t < size && pk <= high;
+        const uint32_t r = below(__ballot(valid));
+        if (valid) {
+            uint32_t sym = 0;
+#pragma unroll
+            for (int sy = 1; sy < 16; sy++) sym += r >= cum[sy] ? 1u : 0u;
+            fse[pk] = (uint16_t)sym;
+        }
+    }
+    wave_sync();
+    {
+        const bool in = (uint32_t)t < size;
+        const uint32_t sy = in ? (uint32_t)fse[t] & 0xfu : 16u;
+        uint32_t same_below = 0;
+#pragma unroll
+        for (int sv = 0; sv < 16; sv++) {
+            const uint64_t m = __ballot(sy == (uint32_t)sv);
+            same_below = sy == (uint32_t)sv ? below(m) : same_below;
+        }
+        bool bad = false;
+        uint32_t entry = 0;
+        if (in) {
+            const int c = (int)norm[sy];
+            const uint32_t ns = (c == -1 ? 1u : (uint32_t)c) + same_below;
+            bad = ns == 0 || ns >= 2 * size;
+            const uint32_t nbits = tl - (uint32_t)highbit(ns | 1u);
+            entry = sy | (nbits << 4) | (((ns << nbits) - size) << 8);
+        }
+        if (__ballot(bad)) return 0;
+        wave_sync();                                              // every lane has read its cell's symbol
+        if (in) fse[t] = (uint16_t)entry;
+    }
+    wave_sync();
+    TREE_TS(3);
+    // FSE_decompress_usingDTable: two interleaved states; the stream ends by running dry.  The table rides in a register (lane u
+    // = cell u) and is read with v_readlane; states, window and cursor are wave-uniform, so the chain runs on the scalar unit
+    const auto uni = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    const uint32_t tabv = (uint32_t)t < size ? (uint32_t)fse[t] : 0u;
+    const uint8_t* const b = h + 1 + hl;
+    const uint32_t bn = isize - hl;
+    const uint32_t lastb = uni(b[bn - 1]);
+    if (lastb == 0) return 0;
+    int P = 8 * (int)(bn - 1) + highbit(lastb);
+    uint32_t s1 = uni(back_look(b, P, (int)tl)); P -= (int)tl;
+    uint32_t s2 = uni(back_look(b, P, (int)tl)); P -= (int)tl;
+    const uint32_t B0 = 8u + 1u + hl;                             // byte offset of the bit stream in hb
+    int endk = -1;                                                // the step (= weight index) after which the cursor is negative
+    for (uint32_t trip = 0; trip < 32u; trip++) {                 // eight weights a trip: one dword of nibbles
+        uint64_t win = 0;                                         // the stream's next 64 bits (8 x 6 bits <= the 57 a refill guarantees)
+        if (P > 0) {
+            const uint32_t a = B0 + ((uint32_t)(P - 1) >> 3) - 7u;
+            const uint32_t* const q = (const uint32_t*)hb + (a >> 2);
+            const uint32_t d0 = uni(q[0]), d1 = uni(q[1]), d2 = uni(q[2]);
+            const uint64_t lo = ((((uint64_t)d1 << 32) | d0) >> (8u * (a & 3u))) & 0xffffffffull, hi = ((((uint64_t)d2 << 32) | d1) >> (8u * (a & 3u))) & 0xffffffffull;
+            win = ((hi << 32) | lo) << (7 - ((P - 1) & 7));
+            if (P < 64) win &= ~0ull << (64 - P);                 // nothing before the stream's first bit
+        }
+        uint32_t pack = 0, neg = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)tabv, (int)s1), e2 = (uint32_t)__builtin_amdgcn_readlane((int)tabv, (int)s2);
+            uint32_t nbt = (e1 >> 4) & 0xfu;
+            pack |= (e1 & 0xfu) << (8 * r + 4);
+            s1 = (e1 >> 8) + (uint32_t)(((win >> 32) << nbt) >> 32);
+            win <<= nbt;
+            P -= (int)nbt;
+            neg |= (uint32_t)(P >> 31) & (1u << (2 * r));
+            nbt = (e2 >> 4) & 0xfu;
+            pack |= (e2 & 0xfu) << (8 * r);
+            s2 = (e2 >> 8) + (uint32_t)(((win >> 32) << nbt) >> 32);
+            win <<= nbt;
+            P -= (int)nbt;
+            neg |= (uint32_t)(P >> 31) & (1u << (2 * r + 1));
+        }
+        if (neg) {
+            const uint32_t j = (uint32_t)__builtin_ctz(neg);      // steps 0 .. j of this trip are the stream's, step j + 1 is the symbol emitted after it ran dry
+            endk = (int)(8u * trip + j);
+            if (j == 7u) {
+                wq[trip] = pack;
+                wq[trip + 1] = ((uint32_t)__builtin_amdgcn_readlane((int)tabv, (int)s1) & 0xfu) << 4;
+            } else {
+                const uint32_t m = j + 1u;                        // weights 0 .. m of the dword stay
+                const uint32_t keep = (m & 1u) ? ((m >> 1) == 3u ? 0xffffffffu : (1u << (8u * ((m >> 1) + 1u))) - 1u)
+                                               : ((1u << (8u * (m >> 1))) - 1u) | (0xf0u << (8u * (m >> 1)));
+                wq[trip] = pack & keep;
+            }
+            break;
+        }
+        wq[trip] = pack;
+    }
+    if (endk < 0 || endk > 253) return 0;                          // (read_weights: "osize + 2 > 255" before a weight is taken)
+    TREE_TS(4);
+    osize_out = (uint32_t)endk + 2u;
+    return isize + 1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -381,9 +548,9 @@ __global__ void __launch_bounds__(256) huf0_copy_kernel(uint8_t* __restrict__ de
 // MODE 1: lane t of workgroup g parses the segment leader 64 (64 g + t).  MODE 2: lane t parses chunk 64 g + t unless it is a
 // leader or a follower.
 template <int MODE>
-__global__ void __launch_bounds__(64) huf0_tree_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restrict__ boffs,
-                                                       const uint64_t* __restrict__ ooffs, uint64_t nchunks, uint8_t* __restrict__ desc,
-                                                       const uint8_t* __restrict__ follow)
+__device__ __forceinline__ void huf0_tree_body(const uint8_t* __restrict__ blocks, const uint64_t* __restrict__ boffs,
+                                               const uint64_t* __restrict__ ooffs, uint64_t nchunks, uint8_t* __restrict__ desc,
+                                               const uint8_t* __restrict__ follow, const uint64_t group)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_w[64 * kWStride];
     __shared__ __attribute__((aligned(16))) uint8_t s_r[64 * kRStride];
@@ -391,7 +558,7 @@ __global__ void __launch_bounds__(64) huf0_tree_kernel(const uint8_t* __restrict
     __shared__ uint32_t s_hc[64];
     __shared__ uint64_t s_chunk[64];                              // the chunk a lane works on, or ~0: nothing to write back
     const int t = threadIdx.x;
-    const uint64_t lane_item = (uint64_t)blockIdx.x * 64 + (uint64_t)t;
+    const uint64_t lane_item = group * 64 + (uint64_t)t;
     const uint64_t chunk = MODE == 1 ? lane_item * 64 : lane_item;
     bool exists = chunk < nchunks;
     if (MODE == 2 && exists) exists = (chunk & 63) != 0 && follow[chunk] == 0;
@@ -494,11 +661,20 @@ __global__ void __launch_bounds__(64) huf0_tree_kernel(const uint8_t* __restrict
     }
 }
 
+template <int MODE>
+__global__ void __launch_bounds__(64) huf0_tree_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restrict__ boffs,
+                                                       const uint64_t* __restrict__ ooffs, uint64_t nchunks, uint8_t* __restrict__ desc,
+                                                       const uint8_t* __restrict__ follow)
+{
+    huf0_tree_body<MODE>(blocks, boffs, ooffs, nchunks, desc, follow, (uint64_t)blockIdx.x);
+}
+
 // One WAVE per segment leader.  A lane's tree parse is ~112 us of dependent LDS round trips however few lanes run, and the
 // leaders are few (157 at BASELINE config 4's 10 000 chunks): lane 0 keeps what is serial -- FSE_readNCount, the FSE
 // table, the two-state weight decode (read_weights) -- and the wave does the rest in a handful of ballots: header copy,
 // weight statistics (HUF_readStats' checks, all kept), the per-weight prefix and the counting sort (a symbol's slot =
 // its weight's running offset + the set lanes below it in the ballot of that weight).  Same descriptor, byte for byte.
+template <bool MERGE>
 __global__ void __launch_bounds__(64) huf0_tree_wave_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restrict__ boffs,
                                                             const uint64_t* __restrict__ ooffs, uint64_t nchunks, uint8_t* __restrict__ desc,
                                                             uint8_t* __restrict__ follow, uint8_t* __restrict__ share)
@@ -510,6 +686,7 @@ __global__ void __launch_bounds__(64) huf0_tree_wave_kernel(const uint8_t* __res
     const int t = threadIdx.x;
     const uint64_t chunk = (uint64_t)blockIdx.x * 64;
     if (chunk >= nchunks) return;
+    TREE_TS(0);
     const uint64_t b0 = boffs[chunk], b1 = boffs[chunk + 1], o0 = ooffs[chunk], o1 = ooffs[chunk + 1];
     const uint64_t csize = b1 - b0, dsize = o1 - o0;
     const bool coded = b1 >= b0 && o1 >= o0 && csize > 1 && csize < dsize;      // HUF_decompress's third case
@@ -526,22 +703,21 @@ __global__ void __launch_bounds__(64) huf0_tree_wave_kernel(const uint8_t* __res
     }
     if (t == 0) s_red = 0;
     wave_sync();
+    TREE_TS(1);
     // lane t is also chunk t of the segment: does it follow the leader?  (what huf0_follow_kernel, huf0_copy_kernel and
     // huf0_share_kernel do for large batches happens here: three launches less where a launch is 2 % of the job)
     const uint64_t mine_c = chunk + (uint64_t)t;
     const bool mine_exists = mine_c < nchunks;
     uint8_t fol = 0;
     uint32_t hl = 0, osize = 0;
-    if (t == 0) {
-        if (coded) {
-            hl = read_weights(s_hb, hcopy, s_wq, s_hb + 152, osize);
-            if (hl >= csize) hl = 0;
-        }
-    } else if (mine_exists) {
-        fol = follows_leader(blocks, boffs, ooffs, mine_c);
+    if (t != 0 && mine_exists) fol = follows_leader(blocks, boffs, ooffs, mine_c);
+    if (coded) {                                               // (wave-uniform: the leader's sizes)
+        hl = read_weights_wave(s_hb, hcopy, s_wq, s_hb + 152, osize, t);
+        if (hl >= csize) hl = 0;
     }
     if (mine_exists) follow[mine_c] = fol;
     wave_sync();
+    TREE_TS(5);
     hl = (uint32_t)__builtin_amdgcn_readlane((int)hl, 0);
     osize = (uint32_t)__builtin_amdgcn_readlane((int)osize, 0);
     auto weight_of = [&](uint32_t sy) -> uint32_t { return (s_wq[sy >> 3] >> nib_shift(sy)) & 0xfu; };
@@ -607,6 +783,7 @@ __global__ void __launch_bounds__(64) huf0_tree_wave_kernel(const uint8_t* __res
     }
     ((uint32_t*)s_sorted)[t] = 0;
     wave_sync();
+    TREE_TS(6);
     if (hl) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -621,6 +798,7 @@ __global__ void __launch_bounds__(64) huf0_tree_wave_kernel(const uint8_t* __res
         }
     }
     wave_sync();
+    TREE_TS(7);
     uint8_t* const d = desc + chunk * kDescStride;
     *(uint32_t*)(d + 4 * t) = ((const uint32_t*)s_sorted)[t];
     if (t < 16) {
@@ -643,6 +821,14 @@ __global__ void __launch_bounds__(64) huf0_tree_wave_kernel(const uint8_t* __res
     // huf0_share_kernel's verdict for this segment
     const bool all_follow = __ballot(mine_exists && t != 0 && !fol) == 0;
     if (t == 0) share[blockIdx.x] = (all_follow && nchunks - chunk > 1 && hl != 0 && tl != 0 && tl <= kSharedMaxLog) ? 1 : 0;
+    TREE_TS(8);
+    // chunks of this segment that are neither its leader nor followers (a writer with a tree per chunk: all of them) parse their own
+    // description, a lane each -- huf0_tree_kernel<2>'s work, here instead of in a launch of its own that finds nothing to do
+    // (the lanes read back the follow flags they wrote themselves)
+    // (MERGE: up to 1 024 leaders -- the lane-per-chunk parse holds 32 KB of LDS a wave, which would cost larger batches resident waves)
+    if constexpr (MERGE) {
+        if (!all_follow) huf0_tree_body<2>(blocks, boffs, ooffs, nchunks, desc, follow, (uint64_t)blockIdx.x);
+    }
 }
 
 // share[s] = 1 iff the chunks of segment s (64, fewer in the last one) all follow the segment's leader (one tree, so one descriptor)
@@ -702,11 +888,10 @@ __global__ void __launch_bounds__(256) huf0_share_kernel(const uint8_t* __restri
 //     at most 22 bytes in; it is parked one group later, at most 44 bytes in -- before the window (29 bytes of reach per group) or the
 //     cursor gets there.  136 bytes of ring a lane instead of 200.
 template <bool SO, int WG = 1, int PLOG = 4, bool CAD = false, int NS = 3>
-__global__ void __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(SO ? (CAD && PLOG == 6 ? (NS == 2 ? 4 : 3) : HUF0_SO_WAVES) : HUF0_G_WAVES)))   // (64-byte pieces: the LDS allows 10 waves a CU)
-huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restrict__ boffs,
-                                                         uint64_t nchunks, uint8_t* __restrict__ out,
-                                                         const uint64_t* __restrict__ ooffs, int64_t* __restrict__ rets,
-                                                         const uint8_t* __restrict__ desc, const uint8_t* __restrict__ share)
+__device__ __forceinline__ void huf0_stream_body(const uint8_t* __restrict__ blocks, const uint64_t* __restrict__ boffs,
+                                                 uint64_t nchunks, uint8_t* __restrict__ out,
+                                                 const uint64_t* __restrict__ ooffs, int64_t* __restrict__ rets,
+                                                 const uint8_t* __restrict__ desc, const uint8_t* __restrict__ share)
 {
     static_assert(SO ? (WG == 1 || WG == 2 || WG == 4) : WG == 1, "a workgroup of the one-table kernel stays inside one 64-chunk segment");
     static_assert(!CAD || PLOG == 5 || PLOG == 6, "the cadenced refill: 32-byte pieces every four steps or 64-byte pieces every eight");
@@ -1291,6 +1476,24 @@ huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restric
     }
 }
 
+template <bool SO, int WG = 1, int PLOG = 4, bool CAD = false, int NS = 3>
+__global__ void __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(SO ? (CAD && PLOG == 6 ? (NS == 2 ? 4 : 3) : HUF0_SO_WAVES) : HUF0_G_WAVES)))   // (64-byte pieces: the LDS allows 10 waves a CU)
+huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restrict__ boffs, uint64_t nchunks, uint8_t* __restrict__ out,
+                   const uint64_t* __restrict__ ooffs, int64_t* __restrict__ rets, const uint8_t* __restrict__ desc, const uint8_t* __restrict__ share)
+{
+    huf0_stream_body<SO, WG, PLOG, CAD, NS>(blocks, boffs, nchunks, out, ooffs, rets, desc, share);
+}
+
+// small batches: both single-wave forms in ONE launch, a wave takes the one its segment's share flag names (where a launch is 2 - 3 %
+// of the job, a second one in which every wave reads its flag and leaves is not free)
+__global__ void __launch_bounds__(64) huf0_stream_small_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restrict__ boffs, uint64_t nchunks,
+                                                               uint8_t* __restrict__ out, const uint64_t* __restrict__ ooffs, int64_t* __restrict__ rets,
+                                                               const uint8_t* __restrict__ desc, const uint8_t* __restrict__ share)
+{
+    if (share[(uint64_t)blockIdx.x * 16 >> 6] != 0) huf0_stream_body<true, 1, HUF0_SMALL_PLOG, HUF0_SMALL_CAD != 0>(blocks, boffs, nchunks, out, ooffs, rets, desc, share);
+    else huf0_stream_body<false, 1, HUF0_G_PLOG, HUF0_G_CAD != 0>(blocks, boffs, nchunks, out, ooffs, rets, desc, share);
+}
+
 std::string g_err0;
 
 }  // namespace
@@ -1321,11 +1524,15 @@ int sprintz_mi355x_huf0_decompress_batch_ws(const void* d_blocks, const uint64_t
     // Few leaders (<= 4096 segments): ONE kernel, a wave per segment, does the follow test, the leader's tree, the followers'
     // copies and the share flag (46 us instead of 112 for the leader's tree at 157 .. 1 250 leaders, and three launches less).
     // Many: the follow pass, a LANE per leader (0.13 ms at 12 500 leaders; the wave kernel takes 0.22), the copy pass, the
-    // share pass.  Either way huf0_tree_kernel<2> then parses every chunk that is neither leader nor follower.
+    // share pass, then huf0_tree_kernel<2> for every chunk that is neither leader nor follower (the wave kernel does those itself).
     if (nleaders <= 4096) {
-        hipLaunchKernelGGL(huf0_tree_wave_kernel, dim3((unsigned)nleaders), dim3(64), 0, st, blk, d_block_offsets, d_out_offsets, nchunks, desc, follow, share);
-        hipLaunchKernelGGL(huf0_tree_kernel<2>, dim3((unsigned)grid1), dim3(64), 0, st, blk, d_block_offsets, d_out_offsets, nchunks, desc,
-                           (const uint8_t*)follow);
+        if (nleaders <= 1024) {
+            hipLaunchKernelGGL(huf0_tree_wave_kernel<true>, dim3((unsigned)nleaders), dim3(64), 0, st, blk, d_block_offsets, d_out_offsets, nchunks, desc, follow, share);
+        } else {
+            hipLaunchKernelGGL(huf0_tree_wave_kernel<false>, dim3((unsigned)nleaders), dim3(64), 0, st, blk, d_block_offsets, d_out_offsets, nchunks, desc, follow, share);
+            hipLaunchKernelGGL(huf0_tree_kernel<2>, dim3((unsigned)grid1), dim3(64), 0, st, blk, d_block_offsets, d_out_offsets, nchunks, desc,
+                               (const uint8_t*)follow);
+        }
     } else {
         hipLaunchKernelGGL(huf0_follow_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, st, blk, d_block_offsets, d_out_offsets, nchunks, follow);
         hipLaunchKernelGGL(huf0_tree_kernel<1>, dim3((unsigned)((nleaders + 63) / 64)), dim3(64), 0, st, blk, d_block_offsets, d_out_offsets, nchunks, desc,
@@ -1335,18 +1542,24 @@ int sprintz_mi355x_huf0_decompress_batch_ws(const void* d_blocks, const uint64_t
                            (const uint8_t*)follow);
         hipLaunchKernelGGL(huf0_share_kernel, dim3((unsigned)((nleaders + 255) / 256)), dim3(256), 0, st, (const uint8_t*)desc, (const uint8_t*)follow, nchunks, share);
     }
-    // the one-table kernel: bandwidth-sized batches as workgroups of HUF0_BIG_WG waves with 2^HUF0_BIG_PLOG-byte stream pieces (built: 2 waves, 64 bytes), small ones wave by wave
-    if (nchunks >= (uint64_t)sprintz::huf0_big_batch().load(std::memory_order_relaxed))
+    // the one-table kernel: bandwidth-sized batches as workgroups of HUF0_BIG_WG waves with 2^HUF0_BIG_PLOG-byte stream pieces (built: 2 waves, 64 bytes),
+    // then the per-chunk-table kernel for the segments that are not its; small batches: both wave by wave in one launch
+    if (nchunks >= (uint64_t)sprintz::huf0_big_batch().load(std::memory_order_relaxed)) {
         hipLaunchKernelGGL((huf0_stream_kernel<true, HUF0_BIG_WG, HUF0_BIG_PLOG, HUF0_CADENCED != 0, HUF0_BIG_NS>), dim3((unsigned)((nchunks + 16 * HUF0_BIG_WG - 1) / (16 * HUF0_BIG_WG))),
                            dim3(64 * HUF0_BIG_WG), 0, st, blk, d_block_offsets, nchunks,
                            (uint8_t*)d_out, d_out_offsets, d_rets, (const uint8_t*)desc, (const uint8_t*)share);
-    else
-        hipLaunchKernelGGL((huf0_stream_kernel<true, 1, HUF0_SMALL_PLOG, HUF0_SMALL_CAD != 0>), dim3((unsigned)grid2), dim3(64), 0, st, blk, d_block_offsets, nchunks,
+        hipLaunchKernelGGL((huf0_stream_kernel<false, 1, HUF0_G_PLOG, HUF0_G_CAD != 0>), dim3((unsigned)grid2), dim3(64), 0, st, blk, d_block_offsets, nchunks,
                            (uint8_t*)d_out, d_out_offsets, d_rets, (const uint8_t*)desc, (const uint8_t*)share);
-    hipLaunchKernelGGL((huf0_stream_kernel<false, 1, HUF0_G_PLOG, HUF0_G_CAD != 0>), dim3((unsigned)grid2), dim3(64), 0, st, blk, d_block_offsets, nchunks,
-                       (uint8_t*)d_out, d_out_offsets, d_rets, (const uint8_t*)desc, (const uint8_t*)share);
+    } else {
+        hipLaunchKernelGGL(huf0_stream_small_kernel, dim3((unsigned)grid2), dim3(64), 0, st, blk, d_block_offsets, nchunks,
+                           (uint8_t*)d_out, d_out_offsets, d_rets, (const uint8_t*)desc, (const uint8_t*)share);
+    }
     return hipGetLastError() == hipSuccess ? 0 : sprintz::set_error(SPRINTZ_E_HIP, "Huff0 stage: a HIP call or kernel launch failed");
 }
+
+#ifdef HUF0_TREE_TIMING
+int sprintz_mi355x_dbg_tree_stamps(uint64_t* out16) { return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_tree_ts), 16 * sizeof(uint64_t)); }
+#endif
 
 // the ABI-1 form without a workspace argument: stream-ordered allocation of the descriptors
 int sprintz_mi355x_huf0_decompress_batch(const void* d_blocks, const uint64_t* d_block_offsets, uint64_t nchunks, void* d_out,
