@@ -86,8 +86,9 @@ const char* sprintz_mi355x_last_error(void);     /* thread-local, never NULL; de
  *                                 encode launch (csrc/compact_tail.h), 0 = encode, then scan + copy (A/B runs, tests);
  *                                 env SPRINTZ_MI355X_DENSE_MODE
  *   SPRINTZ_OPT_HUF0_BIG_BATCH    chunks from which the Huff0 reader's one-table stream kernel runs as 2-wave workgroups with
- *                                 64-byte stream pieces (the built defaults HUF0_BIG_WG = 2, HUF0_BIG_PLOG = 6; faster from
- *                                 ~20 000 chunks on) instead of single waves (as fast below); default 20000, 0 = always (tests)
+ *                                 64-byte stream pieces (the built defaults HUF0_BIG_WG = 2, HUF0_BIG_PLOG = 6) instead of single waves,
+ *                                 which are faster while each has a SIMD to itself (16 chunks a wave, 1 024 SIMDs); default 16385,
+ *                                 0 = always (tests)
  *   SPRINTZ_OPT_SPLIT_LANES       1 (default) = 8-bit row-major streams of 65 .. 80 columns decode on 32 lanes a chunk (a pair of
  *                                 adjacent columns + one single column per lane, two chunks a wavefront), 0 = on 64 lanes x 2
  *                                 columns like the other shapes up to 128 columns; 0 also sizes the LDS carve of 16-bit streams of

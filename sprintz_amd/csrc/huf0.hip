@@ -33,7 +33,9 @@ namespace sprintz {
 // chunks from which the one-table stream kernel runs as workgroups of HUF0_BIG_WG (built: 2) waves with 2^HUF0_BIG_PLOG (built: 64) byte pieces (SPRINTZ_OPT_HUF0_BIG_BATCH)
 std::atomic<long long>& huf0_big_batch()
 {
-    static std::atomic<long long> v{20000};      // (tools/huf0_threshold_sweep.sh: equal up to 20 000 chunks, 0.174 vs 0.235 ms at 40 000)
+    // one more than 16 chunks x the chip's 1 024 SIMDs: while every wave of the single-wave form has a SIMD to itself that form is the faster one
+    // (tools/huf0_threshold.py: 16 384 chunks 127 vs 136 us, 17 000 chunks 188 vs 137)
+    static std::atomic<long long> v{16385};
     return v;
 }
 }  // namespace sprintz
@@ -887,7 +889,9 @@ __global__ void __launch_bounds__(256) huf0_share_kernel(const uint8_t* __restri
 //     cursor's at the first group top after the cursor entered a piece (the piece above is dead from then on: the window only looks down),
 //     at most 22 bytes in; it is parked one group later, at most 44 bytes in -- before the window (29 bytes of reach per group) or the
 //     cursor gets there.  136 bytes of ring a lane instead of 200.
-template <bool SO, int WG = 1, int PLOG = 4, bool CAD = false, int NS = 3>
+// UA: a stream's 64-byte bursts start where the stream's output starts, not at the next 64-byte line (small batches: the first burst is
+//     then a full one like the others instead of a masked round, ~5 us of a lane's ~80; the lines that straddle cost nothing there)
+template <bool SO, int WG = 1, int PLOG = 4, bool CAD = false, int NS = 3, bool UA = false>
 __device__ __forceinline__ void huf0_stream_body(const uint8_t* __restrict__ blocks, const uint64_t* __restrict__ boffs,
                                                  uint64_t nchunks, uint8_t* __restrict__ out,
                                                  const uint64_t* __restrict__ ooffs, int64_t* __restrict__ rets,
@@ -1340,7 +1344,7 @@ __device__ __forceinline__ void huf0_stream_body(const uint8_t* __restrict__ blo
     // phase 3.2 ms of a 3.7 ms launch).  A stream's final partial burst goes out narrow.
     const bool odd1 = (t & 1) != 0, odd2 = (t & 2) != 0;
     const uint32_t part = (uint32_t)t & 3u;
-    uint32_t head = streaming ? (uint32_t)(0u - (uint32_t)(uintptr_t)op) & 63u : 0u;
+    uint32_t head = streaming && !UA ? (uint32_t)(0u - (uint32_t)(uintptr_t)op) & 63u : 0u;
     auto run = [&](auto SH) {
     for (;;) {
         if (__ballot(left > 0) == 0) break;
@@ -1366,7 +1370,32 @@ __device__ __forceinline__ void huf0_stream_body(const uint8_t* __restrict__ blo
         constexpr bool fast_round = false;
         const bool burst = full;
 #endif
-        {
+        bool last_round_done = false;
+        if constexpr (UA && HUF0_SPECULATIVE_TAIL) {
+            // The last round of a wave (no lane has 64 symbols left), small batches: a lane's whole steps of four symbols run as fast
+            // steps too -- a lane past its last whole step takes its cursor back after each -- and ONE masked step behind them decodes
+            // every lane's last 0 .. 3 symbols: 16 fast + 1 masked instead of 16 masked steps (~9 us -> ~5 of a lane's ~75).
+            if (!fast_round) {
+                const uint32_t nfull = streaming ? (uint32_t)lim >> 2 : 0u;
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    group_top(g, P);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int32_t Pk = P;
+                        wb[4 * g + i] = fast_step(SH);
+                        P = (uint32_t)(4 * g + i) < nfull ? P : Pk;
+                    }
+                }
+                group_top(0, P);
+                const uint32_t m = (streaming && P >= -64) ? (uint32_t)lim & 3u : 0u;
+                const uint32_t wl = step(m, SH);
+#pragma unroll
+                for (int k = 0; k < 16; k++) wb[k] = (uint32_t)k == nfull ? wl : wb[k];
+                last_round_done = true;
+            }
+        }
+        if (!last_round_done) {
             const bool all_full = __ballot(streaming && lim < 64) == 0;      // (lanes without a stream just go through the motions)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
@@ -1490,8 +1519,8 @@ __global__ void __launch_bounds__(64) huf0_stream_small_kernel(const uint8_t* __
                                                                uint8_t* __restrict__ out, const uint64_t* __restrict__ ooffs, int64_t* __restrict__ rets,
                                                                const uint8_t* __restrict__ desc, const uint8_t* __restrict__ share)
 {
-    if (share[(uint64_t)blockIdx.x * 16 >> 6] != 0) huf0_stream_body<true, 1, HUF0_SMALL_PLOG, HUF0_SMALL_CAD != 0>(blocks, boffs, nchunks, out, ooffs, rets, desc, share);
-    else huf0_stream_body<false, 1, HUF0_G_PLOG, HUF0_G_CAD != 0>(blocks, boffs, nchunks, out, ooffs, rets, desc, share);
+    if (share[(uint64_t)blockIdx.x * 16 >> 6] != 0) huf0_stream_body<true, 1, HUF0_SMALL_PLOG, HUF0_SMALL_CAD != 0, 3, true>(blocks, boffs, nchunks, out, ooffs, rets, desc, share);
+    else huf0_stream_body<false, 1, HUF0_G_PLOG, HUF0_G_CAD != 0, 3, true>(blocks, boffs, nchunks, out, ooffs, rets, desc, share);
 }
 
 std::string g_err0;

@@ -190,12 +190,12 @@ def test_options_are_validated_without_a_device():
     option or a value out of range is SPRINTZ_E_INVALID (include/sprintz_mi355x.h: the tuning knobs)"""
     from sprintz_amd import _lib
     for opt, good, bad in [(_lib.OPT_NO_FAST, [0, 1], []), (_lib.OPT_CHUNKS_PER_GROUP, [1, 64], [0, 65]), (_lib.OPT_DENSE_MODE, [0, 1], [-1, 2]),
-                           (_lib.OPT_HUF0_BIG_BATCH, [0, 20000], [-1]), (_lib.OPT_SPLIT_LANES, [0, 1], []), (_lib.OPT_ENC_PAIR, [0, 1, 1024], [-1])]:
+                           (_lib.OPT_HUF0_BIG_BATCH, [0, 16385], [-1]), (_lib.OPT_SPLIT_LANES, [0, 1], []), (_lib.OPT_ENC_PAIR, [0, 1, 1024], [-1])]:
         for v in good:
             assert _lib.set_option(opt, v) == 0, (opt, v)
         for v in bad:
             assert _lib.set_option(opt, v) == _lib.E_INVALID, (opt, v)
     assert _lib.set_option(99, 0) == _lib.E_INVALID
-    for opt, v in [(_lib.OPT_NO_FAST, 0), (_lib.OPT_CHUNKS_PER_GROUP, 1), (_lib.OPT_DENSE_MODE, 1), (_lib.OPT_HUF0_BIG_BATCH, 20000),
+    for opt, v in [(_lib.OPT_NO_FAST, 0), (_lib.OPT_CHUNKS_PER_GROUP, 1), (_lib.OPT_DENSE_MODE, 1), (_lib.OPT_HUF0_BIG_BATCH, 16385),
                    (_lib.OPT_SPLIT_LANES, 1), (_lib.OPT_ENC_PAIR, 1)]:
         assert _lib.set_option(opt, v) == 0                  # back to the defaults

@@ -11,14 +11,14 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module", params=["by batch size", "big-batch form"])
 def sz(request):
-    """every test twice: with the stream kernel the batch size picks (below 20 000 chunks: a wave per 16 chunks) and with the bandwidth-sized form forced (2-wave workgroups around one table, 64-byte pieces)"""
+    """every test twice: with the stream kernel the batch size picks (up to 16 384 chunks: a wave per 16 chunks) and with the bandwidth-sized form forced (2-wave workgroups around one table, 64-byte pieces)"""
     import torch
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     import sprintz_amd
     from sprintz_amd import _lib
-    assert _lib.set_option(_lib.OPT_HUF0_BIG_BATCH, 0 if request.param == "big-batch form" else 20000) == 0
+    assert _lib.set_option(_lib.OPT_HUF0_BIG_BATCH, 0 if request.param == "big-batch form" else 16385) == 0
     yield sprintz_amd
-    _lib.set_option(_lib.OPT_HUF0_BIG_BATCH, 20000)
+    _lib.set_option(_lib.OPT_HUF0_BIG_BATCH, 16385)
 
 
 def pack(blocks, plains, align=1):

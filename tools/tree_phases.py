@@ -46,3 +46,4 @@ names = ["offsets + header copy", "FSE_readNCount", "FSE_buildDTable", "weight d
 for k, nm in enumerate(names):
     print(f"{nm:24s} {(int(ts[k + 1]) - int(ts[k])) * 10:7d} ns")
 print(f"{'total':24s} {(int(ts[8]) - int(ts[0])) * 10:7d} ns")
+
