@@ -85,6 +85,12 @@ __device__ __forceinline__ uint32_t encode_wide_body(const EncodeArgs& a, uint32
         wave_lds_sync();
     };
     auto or_bits = [&](uint32_t bp, uint32_t v, uint32_t nb) {      // low nb (<= 32) bits of v at window bit bp
+#ifdef SPRINTZ_ENC_ABL_NO_OR                       // ablation builds (tools/build_variant.sh): what the ORs cost / what their same-dword collisions cost
+        return;
+#endif
+#ifdef SPRINTZ_ENC_ABL_SPREAD_OR
+        bp += (uint32_t)lane_d * 64u;
+#endif
 #ifndef SPRINTZ_ENC_OR_NOZERO
         if (nb == 0) return;
 #endif
