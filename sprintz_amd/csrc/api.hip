@@ -369,7 +369,7 @@ bool decode_lat_fits(int codec, int esz, uint64_t nchunks, uint32_t chunk_len, i
     const bool lowdim = (qs.general || norle) ? false : is_lowdim(esz, D);
     return !norle && !noheader && !qs.col_stride && !decode_ref_quirk(codec, esz, lowdim) && qs.q == kQueryOff && D <= 64 &&
            (uint64_t)chunk_len * esz <= kLatMaxChunkBytes && chunk_len >= 16u * (uint32_t)D && ((uintptr_t)d_out % 16) == 0 &&
-           ((uint64_t)chunk_len * esz) % 16 == 0 &&
+           (nchunks == 1 || ((uint64_t)chunk_len * esz) % 16 == 0) &&      // (a chunk's output starts 16-byte aligned; its end may lie anywhere)
            // (about one round of workgroups on the chip is where it wins: 5 a CU at 8 columns -- measured 33 vs 47 us at 1 250 chunks, 41 vs 47
            //  at 2 048, 59 vs 47 at 3 072; with more columns a chunk has fewer groups to walk and the lane-per-column kernel catches up
            //  sooner: 32 columns 11.6 vs 14.7 at 640 chunks, 19.7 vs 14.8 at 1 250 -- a third of the limit from 17 columns on)
@@ -532,7 +532,8 @@ bool encode_lat_fits(int codec, int esz, uint64_t nchunks, uint32_t chunk_len, i
 {
     const bool norle = codec >= SPRINTZ_CODEC_DELTA_NORLE;
     return !norle && !col_stride && D <= 64 && (uint64_t)chunk_len * esz <= kEncLatMaxChunkBytes &&
-           ((uintptr_t)d_src % 16) == 0 && ((uint64_t)chunk_len * esz) % 16 == 0 && slot_stride % 16 == 0 && ((uintptr_t)d_slots % 16) == 0 &&
+           ((uintptr_t)d_src % 16) == 0 && (nchunks == 1 || ((uint64_t)chunk_len * esz) % 16 == 0) && slot_stride % 16 == 0 && ((uintptr_t)d_slots % 16) == 0 &&
+           // (a chunk is read in 16-byte pieces from a 16-byte aligned start: the last piece may reach past its end, never past the piece that holds its last byte)
            // (the encoder's crossover sits higher than the decoder's -- the lane-per-column encoders take ~100 us (uint16 x 8) / ~175 us (uint8 x 8)
            //  for ANY batch up to ~16 000 chunks: 75 vs 100 us at 3 072 chunks, 105 vs 101 at 4 096; 32 columns: 24 vs 26 at 1 024 -- tools/lat_sweep_enc.py)
            nchunks <= (uint64_t)process().lat_chunks.load(std::memory_order_relaxed) * (D > 16 ? 1u : 3u) / (D > 16 ? 3u : 2u) && !process().no_fast.load(std::memory_order_relaxed);
