@@ -48,7 +48,7 @@ int main(int argc, char** argv)
         std::vector<Job> jobs(nt);
         uint64_t s = 88172645463325252ull;
         for (auto& j : jobs) {
-            j.calls = nt >= 32 ? 400 : 1500;
+            j.calls = getenv("CALLS") ? atoi(getenv("CALLS")) : (nt >= 32 ? 400 : 1500);      // CALLS=1000000: a soak run (watch VmRSS)
             j.raw.resize(kLen + 64); j.back.assign(kLen + 64, 0); j.comp.assign(kLen * 3 / 2 + 64, 0);
             uint16_t v[kD] = {0};
             for (uint32_t r = 0; r < kLen / kD; r++)
@@ -65,6 +65,11 @@ int main(int argc, char** argv)
         for (auto& j : jobs) ok = ok && j.ok;
         printf("%3d threads: %9.0f calls/s  (%.1f us per call per thread)%s\n", nt, 2.0 * nt * jobs[0].calls / dt, dt / (2.0 * jobs[0].calls) * 1e6, ok ? "" : "  ROUND TRIP FAILED");
         pthread_barrier_destroy(&g_go);
+        if (FILE* f = fopen("/proc/self/status", "r")) {             // resident set after the pass: a runtime that never retired the launches would show here
+            char line[256];
+            while (fgets(line, sizeof line, f)) if (!strncmp(line, "VmRSS", 5)) printf("      %s", line);
+            fclose(f);
+        }
     }
     return 0;
 }
