@@ -92,20 +92,42 @@ __device__ uint64_t g_tree_ts[16];
 #endif
 
 // FSE_readNCount (entropy_common.c) on the header copy: norm[0..15] (zeroed by the caller), table log, last symbol, bytes read
-// UNI: every lane of the wave runs it on the same bytes -- the bit fields go through readfirstlane, which puts the whole walk on the scalar unit
+// UNI: every lane of the wave runs it on the same bytes: the description's first 160 bits are fetched once into wave-uniform registers
+// and the walk shifts a 64-bit window along them on the scalar unit (a lone wave pays ~8 cycles an instruction and ~70 for an LDS
+// round trip: the per-field LDS fetch of the lane form made this 5.8 us of the leader's 25)
 template <bool UNI = false>
 __device__ __forceinline__ bool fse_read_ncount(const uint8_t* hb0, uint32_t isize, int16_t* norm, uint32_t& tl_out, uint32_t& max_sv_out, uint32_t& hl_out)
 {
-    auto bits_at = [&](uint32_t bitpos) -> uint32_t {
-        const uint32_t v = hb32(hb0, bitpos);
-        if constexpr (UNI) return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); else return v;
-    };
     // FSE_readNCount: bit 0 of the description is bit 72 of hb (8 lead bytes + the size byte)
     constexpr uint32_t F0 = 72;
     uint32_t bp = 0;
-    int nb = (int)(bits_at(F0 + bp) & 0xf) + 5;
+    auto uni = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    uint32_t d2 = 0, d3 = 0, d4 = 0, have = 64, idx = 2;
+    uint64_t w = 0;
+    if constexpr (UNI) {
+        const uint32_t d0 = uni(hb32(hb0, F0)), d1 = uni(hb32(hb0, F0 + 32u));
+        d2 = uni(hb32(hb0, F0 + 64u)); d3 = uni(hb32(hb0, F0 + 96u)); d4 = uni(hb32(hb0, F0 + 128u));
+        w = ((uint64_t)d1 << 32) | d0;
+    }
+    auto peek = [&]() -> uint32_t {                       // the next 32 bits (UNI: at least 32 of the window's bits are valid)
+        if constexpr (UNI) return (uint32_t)w; else return hb32(hb0, F0 + bp);
+    };
+    auto skip = [&](uint32_t k) {
+        bp += k;
+        if constexpr (UNI) {
+            w >>= k;
+            have -= k;
+            if (have <= 32u) {
+                const uint32_t nx = idx == 2u ? d2 : idx == 3u ? d3 : idx == 4u ? d4 : uni(hb32(hb0, F0 + 32u * idx));
+                w |= (uint64_t)nx << have;
+                have += 32u;
+                idx++;
+            }
+        }
+    };
+    int nb = (int)(peek() & 0xf) + 5;
     if (nb > 6) return false;                                     // tableLog > maxLog (6)
-    bp += 4;
+    skip(4);
     tl_out = (uint32_t)nb;
     int remaining = (1 << nb) + 1, threshold = 1 << nb;
     nb++;
@@ -115,23 +137,23 @@ __device__ __forceinline__ bool fse_read_ncount(const uint8_t* hb0, uint32_t isi
     while (remaining > 1 && charnum <= 255u) {
         if (previous0) {
             uint32_t n0 = charnum;
-            while ((bits_at(F0 + bp) & 0xffffu) == 0xffffu) { n0 += 24; bp += 16; if (bp > bit_end) return false; }
-            while ((bits_at(F0 + bp) & 3u) == 3u) { n0 += 3; bp += 2; if (bp > bit_end) return false; }
-            n0 += bits_at(F0 + bp) & 3u;
-            bp += 2;
+            while ((peek() & 0xffffu) == 0xffffu) { n0 += 24; skip(16); if (bp > bit_end) return false; }
+            while ((peek() & 3u) == 3u) { n0 += 3; skip(2); if (bp > bit_end) return false; }
+            n0 += peek() & 3u;
+            skip(2);
             if (n0 > 255u) return false;
             charnum = n0;                                     // norm is zero there already
         }
-        const uint32_t bits = bits_at(F0 + bp);
+        const uint32_t bits = peek();
         const int max = (2 * threshold - 1) - remaining;
         int count;
         if ((int)(bits & (uint32_t)(threshold - 1)) < max) {
             count = (int)(bits & (uint32_t)(threshold - 1));
-            bp += (uint32_t)(nb - 1);
+            skip((uint32_t)(nb - 1));
         } else {
             count = (int)(bits & (uint32_t)(2 * threshold - 1));
             if (count >= threshold) count -= max;
-            bp += (uint32_t)nb;
+            skip((uint32_t)nb);
         }
         count--;
         remaining -= count < 0 ? -count : count;
@@ -385,7 +407,9 @@ __device__ uint32_t read_weights_wave(const uint8_t* hb, uint32_t n, uint32_t* w
     // FSE_decompress_usingDTable: two interleaved states; the stream ends by running dry.  The table rides in a register (lane u
     // = cell u) and is read with v_readlane; states, window and cursor are wave-uniform, so the chain runs on the scalar unit
     const auto uni = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
-    const uint32_t tabv = (uint32_t)t < size ? (uint32_t)fse[t] : 0u;
+    // (in the register: new_state << 8 | nbits << 4, the symbol in the TOP nibble -- a 64-bit shift of {weights so far : entry} by 4 then appends it)
+    const uint32_t cell = (uint32_t)t < size ? (uint32_t)fse[t] : 0u;
+    const uint32_t tabv = (cell & 0xfff0u) | (cell << 28);
     const uint8_t* const b = h + 1 + hl;
     const uint32_t bn = isize - hl;
     const uint32_t lastb = uni(b[bn - 1]);
@@ -395,39 +419,52 @@ __device__ uint32_t read_weights_wave(const uint8_t* hb, uint32_t n, uint32_t* w
     uint32_t s2 = uni(back_look(b, P, (int)tl)); P -= (int)tl;
     const uint32_t B0 = 8u + 1u + hl;                             // byte offset of the bit stream in hb
     int endk = -1;                                                // the step (= weight index) after which the cursor is negative
-    for (uint32_t trip = 0; trip < 32u; trip++) {                 // eight weights a trip: one dword of nibbles
-        uint64_t win = 0;                                         // the stream's next 64 bits (8 x 6 bits <= the 57 a refill guarantees)
-        if (P > 0) {
-            const uint32_t a = B0 + ((uint32_t)(P - 1) >> 3) - 7u;
+    auto window_at = [&](int Pc) -> uint64_t {                    // the stream's next 64 bits below cursor Pc (8 x 6 bits <= the 57 a refill guarantees)
+        uint64_t win = 0;
+        if (Pc > 0) {
+            const uint32_t a = B0 + ((uint32_t)(Pc - 1) >> 3) - 7u;
             const uint32_t* const q = (const uint32_t*)hb + (a >> 2);
             const uint32_t d0 = uni(q[0]), d1 = uni(q[1]), d2 = uni(q[2]);
             const uint64_t lo = ((((uint64_t)d1 << 32) | d0) >> (8u * (a & 3u))) & 0xffffffffull, hi = ((((uint64_t)d2 << 32) | d1) >> (8u * (a & 3u))) & 0xffffffffull;
-            win = ((hi << 32) | lo) << (7 - ((P - 1) & 7));
-            if (P < 64) win &= ~0ull << (64 - P);                 // nothing before the stream's first bit
+            win = ((hi << 32) | lo) << (7 - ((Pc - 1) & 7));
+            if (Pc < 64) win &= ~0ull << (64 - Pc);               // nothing before the stream's first bit
         }
-        uint32_t pack = 0, neg = 0;
+        return win;
+    };
+    auto take = [&](uint32_t e, uint32_t& st, uint64_t& win, int& Pc) {      // one state's step: ten scalar instructions with the append below
+        const uint32_t nbt = (e >> 4) & 0xfu;
+        st = ((e >> 8) & 0xffu) + (uint32_t)(((win >> 32) << nbt) >> 32);
+        win <<= nbt;
+        Pc -= (int)nbt;
+    };
+    for (uint32_t trip = 0; trip < 32u; trip++) {                 // eight weights a trip: one dword of nibbles
+        const int P0 = P;
+        const uint32_t s10 = s1, s20 = s2;
+        uint64_t win = window_at(P);
+        uint32_t pack = 0;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const uint32_t e1 = (uint32_t)__builtin_amdgcn_readlane((int)tabv, (int)s1), e2 = (uint32_t)__builtin_amdgcn_readlane((int)tabv, (int)s2);
-            uint32_t nbt = (e1 >> 4) & 0xfu;
-            pack |= (e1 & 0xfu) << (8 * r + 4);
-            s1 = (e1 >> 8) + (uint32_t)(((win >> 32) << nbt) >> 32);
-            win <<= nbt;
-            P -= (int)nbt;
-            neg |= (uint32_t)(P >> 31) & (1u << (2 * r));
-            nbt = (e2 >> 4) & 0xfu;
-            pack |= (e2 & 0xfu) << (8 * r);
-            s2 = (e2 >> 8) + (uint32_t)(((win >> 32) << nbt) >> 32);
-            win <<= nbt;
-            P -= (int)nbt;
-            neg |= (uint32_t)(P >> 31) & (1u << (2 * r + 1));
+            pack = (uint32_t)(((((uint64_t)pack << 32) | e1) << 4) >> 32);
+            take(e1, s1, win, P);
+            pack = (uint32_t)(((((uint64_t)pack << 32) | e2) << 4) >> 32);
+            take(e2, s2, win, P);
         }
-        if (neg) {
-            const uint32_t j = (uint32_t)__builtin_ctz(neg);      // steps 0 .. j of this trip are the stream's, step j + 1 is the symbol emitted after it ran dry
+        pack = __builtin_bswap32(pack);                           // weight i of the trip: byte i / 2, an even i in the high nibble
+        if (P < 0) {                                              // the stream ran dry inside this trip: once more, step by step, for where
+            int Pr = P0;
+            uint32_t r1 = s10, r2 = s20, j = 8;
+            uint64_t wr = window_at(P0);
+            for (uint32_t k = 0; k < 8u; k++) {
+                uint32_t& st = (k & 1u) ? r2 : r1;
+                take((uint32_t)__builtin_amdgcn_readlane((int)tabv, (int)st), st, wr, Pr);
+                if (Pr < 0) { j = k; break; }
+            }
+            // steps 0 .. j of this trip are the stream's, step j + 1 is the symbol emitted after it ran dry
             endk = (int)(8u * trip + j);
             if (j == 7u) {
                 wq[trip] = pack;
-                wq[trip + 1] = ((uint32_t)__builtin_amdgcn_readlane((int)tabv, (int)s1) & 0xfu) << 4;
+                wq[trip + 1] = ((uint32_t)__builtin_amdgcn_readlane((int)tabv, (int)s1) >> 28) << 4;
             } else {
                 const uint32_t m = j + 1u;                        // weights 0 .. m of the dword stay
                 const uint32_t keep = (m & 1u) ? ((m >> 1) == 3u ? 0xffffffffu : (1u << (8u * ((m >> 1) + 1u))) - 1u)
@@ -684,15 +721,24 @@ __global__ void __launch_bounds__(64) huf0_tree_wave_kernel(const uint8_t* __res
     __shared__ __attribute__((aligned(16))) uint8_t s_hb[152 + 192 + 8];      // header copy (8 zero bytes in front) | norm, next, fse
     __shared__ __attribute__((aligned(16))) uint32_t s_wq[36];
     __shared__ __attribute__((aligned(16))) uint8_t s_sorted[256];
-    __shared__ uint32_t s_red;
+    __shared__ uint32_t s_cnt[16];                                            // symbols per weight
     const int t = threadIdx.x;
     const uint64_t chunk = (uint64_t)blockIdx.x * 64;
     if (chunk >= nchunks) return;
     TREE_TS(0);
+    // lane t is also chunk t of the segment (does it follow the leader?): its offsets travel with the leader's, its first byte with the
+    // leader's header -- the same two round trips
+    const uint64_t mine_c = chunk + (uint64_t)t;
+    const bool mine_exists = mine_c < nchunks;
+    const uint64_t mb0 = mine_exists ? boffs[mine_c] : 0, mb1 = mine_exists ? boffs[mine_c + 1] : 0;
+    const uint64_t mo0 = mine_exists ? ooffs[mine_c] : 0, mo1 = mine_exists ? ooffs[mine_c + 1] : 0;
     const uint64_t b0 = boffs[chunk], b1 = boffs[chunk + 1], o0 = ooffs[chunk], o1 = ooffs[chunk + 1];
     const uint64_t csize = b1 - b0, dsize = o1 - o0;
     const bool coded = b1 >= b0 && o1 >= o0 && csize > 1 && csize < dsize;      // HUF_decompress's third case
     const uint32_t hcopy = coded ? (uint32_t)(csize < 129 ? csize : 129) : 0u;
+    const uint64_t mcs = mb1 - mb0, mcd = mo1 - mo0;
+    const bool mcoded = t != 0 && mine_exists && coded && mb1 >= mb0 && mcs > 1 && mcs < mcd;      // a coded block, as the leader's is
+    const uint32_t mfirst = mcoded ? (uint32_t)blocks[mb0] : 0u;
     if (t < 38) {
         uint32_t v = 0;
         if (t >= 2) {
@@ -703,19 +749,57 @@ __global__ void __launch_bounds__(64) huf0_tree_wave_kernel(const uint8_t* __res
         }
         ((uint32_t*)s_hb)[t] = v;
     }
-    if (t == 0) s_red = 0;
+    if (t < 16) s_cnt[t] = 0;
     wave_sync();
     TREE_TS(1);
     // lane t is also chunk t of the segment: does it follow the leader?  (what huf0_follow_kernel, huf0_copy_kernel and
     // huf0_share_kernel do for large batches happens here: three launches less where a launch is 2 % of the job)
-    const uint64_t mine_c = chunk + (uint64_t)t;
-    const bool mine_exists = mine_c < nchunks;
     uint8_t fol = 0;
     uint32_t hl = 0, osize = 0;
-    if (t != 0 && mine_exists) fol = follows_leader(blocks, boffs, ooffs, mine_c);
+    // follows_leader(), in two halves: a chunk's own description bytes are REQUESTED now and looked at after the leader's parse --
+    // three dependent global round trips (~4.5 us) that then pass under the parse; the leader's bytes are the header copy in LDS
+    uint64_t fw[16], ftail = 0;
+    uint32_t fhl = 0;
+    bool fcand = false;
+#pragma unroll
+    for (int k = 0; k < 16; k++) fw[k] = 0;
+    if (mcoded) {
+        typedef uint64_t __attribute__((aligned(1))) u64_a1;
+        {
+            const uint8_t* const p = blocks + mb0;
+            const uint32_t h = tree_desc_bytes(mfirst);
+            if (h < mcs && h < csize) {
+                fcand = true;
+                fhl = h;
+                if (h >= 8) {
+#pragma unroll
+                    for (int k = 0; k < 16; k++)
+                        if (8u * (uint32_t)k + 8u <= h) fw[k] = *(const u64_a1*)(p + 8 * k);
+                    ftail = *(const u64_a1*)(p + h - 8);          // the tail, overlapping
+                } else {
+                    for (uint32_t k = 0; k < h; k++) ftail |= (uint64_t)p[k] << (8u * k);
+                }
+            }
+        }
+    }
     if (coded) {                                               // (wave-uniform: the leader's sizes)
         hl = read_weights_wave(s_hb, hcopy, s_wq, s_hb + 152, osize, t);
         if (hl >= csize) hl = 0;
+    }
+    if (fcand) {
+        const uint8_t* const lead = s_hb + 8;                  // the leader's block from its first byte (read_weights_wave leaves the copy alone)
+        uint64_t diff = 0;
+        if (fhl >= 8) {
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if (8u * (uint32_t)k + 8u <= fhl) diff |= fw[k] ^ *(const uint64_t*)(lead + 8 * k);
+            diff |= ftail ^ ((uint64_t)hb32(s_hb, 8u * fhl) | ((uint64_t)hb32(s_hb, 8u * fhl + 32u) << 32));
+        } else {
+            uint64_t lt = 0;
+            for (uint32_t k = 0; k < fhl; k++) lt |= (uint64_t)lead[k] << (8u * k);
+            diff = ftail ^ lt;
+        }
+        fol = diff == 0 ? 1 : 0;
     }
     if (mine_exists) follow[mine_c] = fol;
     wave_sync();
@@ -729,22 +813,21 @@ __global__ void __launch_bounds__(64) huf0_tree_wave_kernel(const uint8_t* __res
 #pragma unroll
     for (int w = 0; w < 13; w++) cnt[w] = 0;
     if (hl) {
-        uint32_t mine = 0;
-        bool heavy_l = false;
+        // the statistics as an LDS histogram (a lane adds its four symbols' weights; 48 ballots did this before: 3.1 us of the leader's 24)
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const uint32_t sy = 64u * i + (uint32_t)t;
-            const bool valid = sy < osize;
-            const uint32_t w = valid ? weight_of(sy) : 0u;
-            heavy_l |= valid && w >= 12u;
-            mine += valid ? (1u << w) >> 1 : 0u;
-#pragma unroll
-            for (int ww = 0; ww < 12; ww++) cnt[ww] += (uint32_t)__builtin_popcountll(__ballot(valid && w == (uint32_t)ww));
+            if (sy < osize) __hip_atomic_fetch_add(&s_cnt[weight_of(sy)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
-        __hip_atomic_fetch_add(&s_red, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         wave_sync();
-        const uint32_t total = s_red;
-        bool ok = __ballot(heavy_l) == 0 && total != 0;
+        uint32_t total = 0;
+#pragma unroll
+        for (int ww = 0; ww < 12; ww++) {
+            cnt[ww] = s_cnt[ww];
+            total += ww ? cnt[ww] << (ww - 1) : 0u;
+        }
+        const bool heavy = (s_cnt[12] | s_cnt[13] | s_cnt[14] | s_cnt[15]) != 0u;
+        bool ok = !heavy && total != 0;
         uint32_t lw = 0;
         if (ok) {
             tl = (uint32_t)highbit(total) + 1u;
