@@ -143,10 +143,14 @@ int sprintz_mi355x_set_option(int option, int value);
  * exactly the decoded elements (it never over-runs like the reference does).
  * write_size == 0 omits the 8-byte header (sprintz_xff_rle.cpp:119-127).
  * Re-entrant from any number of host threads on disjoint buffers, like the reference (sprintz.h: one call = one thread).
- * Cost of a call (MI355X, 10 KB of uint16 x 8): 32 us decompress / 32 us compress -- memcpy into the calling thread's mapped
- * staging buffer, two launches (stage-in + the one-workgroup-per-chunk kernel, which reads and writes that buffer directly),
- * one event wait, memcpy out; chunks above 16 KB or of more than 64 columns take the batched kernels' lane-per-column form
- * (a chunk's latency then grows with its groups: ~1.2 us each).  The batched API below is the fast path.
+ * Cost of a call (MI355X, 10 KB of uint16 x 8): 25 us either way -- memcpy into the calling thread's mapped staging buffer,
+ * ONE launch (the one-workgroup-per-chunk kernel reads and writes that buffer directly and ends by writing the call's ticket
+ * into a mapped host word), the caller polls that word (no runtime wait), memcpy out; chunks above 16 KB or of more than 64
+ * columns take a staging kernel + the batched kernels' lane-per-column form + a wait (a chunk's latency then grows with its
+ * groups: ~1.2 us each).  A decoder writes what the STREAM says (header counts, run lengths): like the reference's, these
+ * entry points take no destination size, so a damaged stream can announce more samples than the caller's buffer holds --
+ * callers that do not trust their input use the batched API, whose chunk_len bounds every chunk's output.
+ * The batched API below is the fast path.
  * ---------------------------------------------------------------------- */
 int64_t sprintz_mi355x_compress_delta_8b (const uint8_t*  src, uint32_t len, int8_t*  dest, uint16_t ndims, int write_size);
 int64_t sprintz_mi355x_compress_xff_8b   (const uint8_t*  src, uint32_t len, int8_t*  dest, uint16_t ndims, int write_size);

@@ -909,7 +909,9 @@ int wait_flag(Scratch* sc, uint64_t want, bool spin)
     if (spin) {
         for (uint32_t it = 1;; ++it) {
             if (__atomic_load_n(sc->flag, __ATOMIC_ACQUIRE) == want) break;
+#if defined(__x86_64__) || defined(__i386__)
             __builtin_ia32_pause();
+#endif
             if ((it & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
                 HIP_TRY(hipStreamSynchronize(sc->stream));               // a fault surfaces here
                 if (__atomic_load_n(sc->flag, __ATOMIC_ACQUIRE) != want) return fail(SPRINTZ_E_HIP, "the call's completion flag was never written");
