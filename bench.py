@@ -1220,6 +1220,11 @@ def headline_extras(cx, codec, x, comp, offsets, ws, out, nchunks, total_comp, c
         res["single_call_threads"]["native"] = native_threads_leg()
         # ---------------- online.hpp's u16 coders: ONE stream of 64 Mi samples per call, device buffers
         res["online_coders"] = online_leg(cx)
+        # ---------------- real (measured) data: what the image holds without a network
+        try:
+            res["real_data"] = real_data_leg(cx)
+        except Exception as e:      # noqa: BLE001 -- a failing leg must not cost the headline line
+            res["real_data"] = {"failed": repr(e)[:200]}
         # ---------------- PCIe-inclusive: host buffers in and out through the chunked host entry points
         ns = min(nchunks, 16384)
         oh = offsets[: ns + 1].cpu().numpy().astype(np.uint64)
@@ -1264,6 +1269,41 @@ def online_leg(cx):
         assert int(ret[1].item()) == n and torch.equal(back.view(torch.int16), x.view(torch.int16)), name
         out[name] = {"ratio": round(n / max(elems, 1), 4), "pack_ms": round(p_ms, 3), "pack_GBps": round(2 * n / p_ms / 1e6, 1),
                      "unpack_ms": round(u_ms, 3), "unpack_GBps": round(2 * n / u_ms / 1e6, 1)}
+    return out
+
+
+def real_data_leg(cx):
+    """the tabular sets and photographs bundled with scikit-learn (sprintz_amd.datasets.offline_real_datasets), quantised to 8 and 16 bits per
+    variable as python/datasets/compress_bench.py:45-60 does, FIRE codec, 10 KB chunks: ratio per set (round trip checked).  They are
+    small -- 42 MB altogether would be a luxury; these are 6 MB -- so this leg reports ratios, not throughput."""
+    import numpy as np
+    torch, dev = cx.torch, cx.device
+    import sprintz_amd
+    from sprintz_amd import datasets
+    sets = datasets.offline_real_datasets()
+    if not sets:
+        return {"skipped": "scikit-learn's bundled datasets are not importable"}
+    out = {"what": "scikit-learn's bundled tabular sets + photographs (pixel by pixel: 3 variables; scan line by scan line: 1 920), quantised per "
+                   "variable as compress_bench.py:45-60, sprintz_xff, chunks of ~10 KB (at least 64 rows), decode checked; [ratio at 8 bits, ratio at 16 bits]",
+           "sets": {}}
+    raw_total = comp_total = 0
+    for name, mat in sets:
+        pair = []
+        for dt in (np.uint8, np.uint16):
+            q = datasets.quantize(mat, dt)
+            esz, ndims = q.dtype.itemsize, q.shape[1]
+            rows = min(max(64, (10240 // (ndims * esz)) // 8 * 8), max(8, q.shape[0] // 8 * 8))      # ~10 KB of rows, at least 64
+            cd = sprintz_amd.ChunkedCodec("xff", esz, ndims, rows * ndims, device=dev)
+            t = torch.from_numpy(np.ascontiguousarray(q).view(np.int8 if esz == 1 else np.int16)).to(dev).view(cd.dtype)
+            b = cd.compress(t)
+            back = cd.decompress(b)
+            assert torch.equal(back.view(torch.uint8)[: q.nbytes], t.view(torch.uint8).reshape(-1)), (name, str(dt))
+            pair.append(round(q.nbytes / b.total_bytes(), 3))
+            raw_total += q.nbytes
+            comp_total += b.total_bytes()
+        out["sets"][name] = pair
+    out["raw_bytes"] = raw_total
+    out["ratio_overall"] = round(raw_total / comp_total, 3)
     return out
 
 

@@ -54,3 +54,32 @@ def compress_file(path, dtype, ndims, order="c", codec="xff", rows_per_chunk=Non
     cd = ChunkedCodec(codec, esz, ndims, rows_per_chunk * ndims, device=device)
     t = torch.from_numpy(a.view(np.int8 if esz == 1 else np.int16)).to(cd.device).view(cd.dtype)
     return cd, (cd.compress(t) if order == "c" else cd.compress_colmajor(t))
+
+
+def offline_real_datasets():
+    """Real (measured, not generated) data that is present without a network: the tabular sets and the two photographs that ship
+    inside scikit-learn.  -> [(name, float64 matrix [nsamples, nvariables])]; empty if scikit-learn (or Pillow, for the
+    photographs) is not importable.  None of them is a time series -- the paper's archives (UCR, AMPds, MSRC-12, PAMAP, UCI gas:
+    compress_bench.py:80-90 feeds those) are not in the image -- but they are what real quantised measurements look like to the
+    codec: correlated neighbours, plateaus, heavy tails, constant columns.  The photographs are taken twice: pixel by pixel
+    (3 variables: R, G, B down the image) and scan line by scan line (1 920 variables: a row of 640 RGB pixels per sample)."""
+    out = []
+    try:
+        from sklearn import datasets as skd
+    except Exception:                                        # noqa: BLE001 -- no scikit-learn: no real data, the caller says so
+        return out
+    for name in ("load_diabetes", "load_breast_cancer", "load_wine", "load_digits", "load_iris", "load_linnerud"):
+        try:
+            out.append((name[5:], np.asarray(getattr(skd, name)().data, dtype=np.float64)))
+        except Exception:                                    # noqa: BLE001
+            pass
+    try:
+        images = skd.load_sample_images()
+        for fname, im in zip(images.filenames, images.images):
+            base = str(fname).replace("\\", "/").rsplit("/", 1)[-1].rsplit(".", 1)[0]
+            a = np.asarray(im, dtype=np.float64)
+            out.append((base + "_pixels", a.reshape(-1, a.shape[-1])))
+            out.append((base + "_scanlines", a.reshape(a.shape[0], -1)))
+    except Exception:                                        # noqa: BLE001 -- no Pillow
+        pass
+    return out
