@@ -107,3 +107,15 @@ def golden():
         manifest = json.load(f)["cases"]
     arrays = np.load(os.path.join(gdir, "golden_v1.npz"))
     return manifest, arrays
+
+
+@pytest.fixture(scope="session")
+def golden_wide():
+    """the reference's streams at 513 .. 2 047 columns (oracle/gen_golden_wide.py)"""
+    import json
+    import numpy as np
+    gdir = os.path.join(HERE, "golden")
+    with open(os.path.join(gdir, "golden_wide_v1.json")) as f:
+        manifest = json.load(f)["cases"]
+    arrays = np.load(os.path.join(gdir, "golden_wide_v1.npz"))
+    return manifest, arrays

@@ -54,6 +54,24 @@ def test_golden_vectors_single_call(sz, golden):
         assert (dec[data.size:] == dec[-1]).all(), "decoder wrote past the decoded length"
 
 
+def test_golden_vectors_of_513_to_2047_columns(sz, golden_wide):
+    """the reference's own streams at 513 .. 2 047 columns (golden_wide_v1; csrc/any_ndims.hip): the single-call encoder writes them,
+    the decoder inverts them, and so does the batched pair on the same samples as one chunk"""
+    import torch
+    manifest, arrays = golden_wide
+    for m in manifest:
+        data, want = arrays[f"in_{m['idx']}"], arrays[f"out_{m['idx']}"]
+        dest, ret = gpu_compress(sz, m["codec"], data, m["ndims"])
+        assert ret == m["ret"] and np.array_equal(dest[:want.size], want), (m, sz.last_error())
+        dec, dret = gpu_decompress(sz, m["codec"], want, m["esz"], data.size)
+        assert dret == data.size and np.array_equal(dec[:data.size], data.ravel()), m
+        cd = sz.ChunkedCodec(m["codec"], m["esz"], m["ndims"], data.size, device="cuda:0")
+        t = torch.from_numpy(data.ravel().view(np.int8 if m["esz"] == 1 else np.int16)).cuda().view(cd.dtype)
+        b = cd.compress(t)
+        assert int(b.sizes[0]) == want.size and np.array_equal(b.data.cpu().numpy()[: want.size], want), m
+        assert np.array_equal(cd.decompress(b).cpu().numpy().view(data.dtype)[: data.size], data.ravel()), m
+
+
 def test_random_shapes_against_oracle(sz, oracle):
     """both kernel families (decode_path) over random shapes the fixed matrices do not list: every lanes-per-chunk bucket of both
     layouts (1 .. 64 columns, both widths, both codecs), chunk lengths that are and are not whole groups, a ragged last chunk, data

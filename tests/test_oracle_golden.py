@@ -64,3 +64,16 @@ def test_reference_decoder_quirk_is_modelled(oracle, golden):
     assert [c["idx"] for c in cases] == [m["idx"]]
     assert qret == cases[0]["dec_ret"] == m["dec_ret"]
     assert np.array_equal(quirk, refdec[f"refdec_{m['idx']}"])
+
+
+def test_oracle_at_513_to_2047_columns_is_the_reference(oracle, golden_wide):
+    """golden_wide_v1: the compiled reference at widths its own tests never reach (compress_testing.hpp:20-21 stops at 129 columns);
+    the oracle writes the same bytes and inverts them"""
+    manifest, arrays = golden_wide
+    assert {m["ndims"] for m in manifest} == {513, 600, 1000, 2047} and len(manifest) == 16
+    for m in manifest:
+        data, want = arrays[f"in_{m['idx']}"], arrays[f"out_{m['idx']}"]
+        got, ret = oracle.compress(m["codec"], data, m["ndims"])
+        assert ret == m["ret"] and got.size == m["nbytes"] and np.array_equal(got, want), m
+        dec, dret = oracle.decompress(m["codec"], want, m["esz"], data.size)
+        assert dret == data.size and np.array_equal(dec, data.ravel()), m
