@@ -145,7 +145,8 @@ int sprintz_mi355x_set_option(int option, int value);
  * Re-entrant from any number of host threads on disjoint buffers, like the reference (sprintz.h: one call = one thread).
  * Cost of a call (MI355X, 10 KB of uint16 x 8): 25 us either way -- memcpy into the calling thread's mapped staging buffer,
  * ONE launch (the one-workgroup-per-chunk kernel reads and writes that buffer directly and ends by writing the call's ticket
- * into a mapped host word), the caller polls that word (no runtime wait), memcpy out; chunks above 16 KB or of more than 64
+ * into a mapped host word), the caller polls that word (no runtime wait), memcpy out; chunks whose working set does not fit a
+ * workgroup's LDS (above ~40 KB of uint16 / ~24 KB of uint8 to decode, ~34 / ~24 KB to encode) or of more than 64
  * columns take a staging kernel + the batched kernels' lane-per-column form + a wait (a chunk's latency then grows with its
  * groups: ~1.2 us each).  A decoder writes what the STREAM says (header counts, run lengths): like the reference's, these
  * entry points take no destination size, so a damaged stream can announce more samples than the caller's buffer holds --

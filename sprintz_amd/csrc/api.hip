@@ -355,6 +355,20 @@ struct QuerySpec {
     const HostCall* hc = nullptr;
 };
 
+// One chunk's working set of the workgroup-per-chunk kernels (decode_lat.h / encode_lat.h) must fit a workgroup's LDS: up to 16 KB of
+// samples several workgroups share a CU (what the batch limits of SPRINTZ_OPT_LAT_CHUNKS were measured with); larger chunks -- up to
+// ~40 KB of uint16, ~24 KB of uint8: 150 KB of LDS, a workgroup a CU -- only for batches that leave most CUs empty anyway (single calls)
+bool lat_chunk_fits(bool encode, int esz, uint64_t nchunks, uint32_t chunk_len, int D)
+{
+    const uint64_t bytes = (uint64_t)chunk_len * esz;
+    if (bytes <= kLatMaxChunkBytes) return true;
+    if (bytes > (48u << 10) || nchunks > 64) return false;
+    const uint32_t bound = (uint32_t)sprintz_mi355x_compress_bound(esz, chunk_len, (uint16_t)D);
+    if (bound > 60000u) return false;                            // (stream positions travel in 16 bits between the kernels' phases)
+    const uint32_t total = encode ? enc_lat_carve(bound, chunk_len, (uint32_t)D, (uint32_t)esz).total : lat_carve(bound, chunk_len, (uint32_t)D).total;
+    return total <= 150u * 1024u;
+}
+
 bool decode_ref_quirk(int codec, int esz, bool lowdim)
 {
     // (only 16-bit general-layout FIRE streams have the divergence: sprintz_xff_rle.cpp:893-901)
@@ -368,7 +382,7 @@ bool decode_lat_fits(int codec, int esz, uint64_t nchunks, uint32_t chunk_len, i
     const bool norle = codec >= SPRINTZ_CODEC_DELTA_NORLE;
     const bool lowdim = (qs.general || norle) ? false : is_lowdim(esz, D);
     return !norle && !noheader && !qs.col_stride && !decode_ref_quirk(codec, esz, lowdim) && qs.q == kQueryOff && D <= 64 &&
-           (uint64_t)chunk_len * esz <= kLatMaxChunkBytes && chunk_len >= 16u * (uint32_t)D && ((uintptr_t)d_out % 16) == 0 &&
+           lat_chunk_fits(false, esz, nchunks, chunk_len, D) && chunk_len >= 16u * (uint32_t)D && ((uintptr_t)d_out % 16) == 0 &&
            (nchunks == 1 || ((uint64_t)chunk_len * esz) % 16 == 0) &&      // (a chunk's output starts 16-byte aligned; its end may lie anywhere)
            // (about one round of workgroups on the chip is where it wins: 5 a CU at 8 columns -- measured 33 vs 47 us at 1 250 chunks, 41 vs 47
            //  at 2 048, 59 vs 47 at 3 072; with more columns a chunk has fewer groups to walk and the lane-per-column kernel catches up
@@ -531,7 +545,7 @@ struct DenseRequest {
 bool encode_lat_fits(int codec, int esz, uint64_t nchunks, uint32_t chunk_len, int D, uint64_t col_stride, const void* d_src, const void* d_slots, size_t slot_stride)
 {
     const bool norle = codec >= SPRINTZ_CODEC_DELTA_NORLE;
-    return !norle && !col_stride && D <= 64 && (uint64_t)chunk_len * esz <= kEncLatMaxChunkBytes &&
+    return !norle && !col_stride && D <= 64 && lat_chunk_fits(true, esz, nchunks, chunk_len, D) &&
            ((uintptr_t)d_src % 16) == 0 && (nchunks == 1 || ((uint64_t)chunk_len * esz) % 16 == 0) && slot_stride % 16 == 0 && ((uintptr_t)d_slots % 16) == 0 &&
            // (a chunk is read in 16-byte pieces from a 16-byte aligned start: the last piece may reach past its end, never past the piece that holds its last byte)
            // (the encoder's crossover sits higher than the decoder's -- the lane-per-column encoders take ~100 us (uint16 x 8) / ~175 us (uint8 x 8)

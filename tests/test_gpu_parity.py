@@ -72,6 +72,21 @@ def test_golden_vectors_of_513_to_2047_columns(sz, golden_wide):
         assert np.array_equal(cd.decompress(b).cpu().numpy().view(data.dtype)[: data.size], data.ravel()), m
 
 
+@pytest.mark.parametrize("codec,esz,ndims,n", [("xff", 2, 8, 16384), ("xff", 2, 8, 20003), ("delta", 2, 64, 20480), ("xff", 2, 2, 18001), ("delta", 2, 1, 17000),
+                                               ("delta", 1, 8, 24000), ("xff", 1, 16, 22005), ("xff", 1, 1, 20000), ("xff", 1, 3, 23999), ("xff", 2, 33, 19999)])
+def test_single_calls_of_17_to_40_KB(sz, oracle, codec, esz, ndims, n):
+    """single chunks above 16 KB still take the workgroup-per-chunk kernels while one chunk's working set fits a workgroup's LDS
+    (api.hip: lat_chunk_fits): the oracle's bytes, the oracle's samples; flat spans put runs across the larger block counts"""
+    rng = np.random.default_rng(n)
+    for flat in (0, 3):
+        data = gen_walk(rng, n, ndims, esz, 8, flat_every=flat)
+        want, wret = oracle.compress(codec, data, ndims)
+        dest, ret = gpu_compress(sz, codec, data, ndims)
+        assert ret == wret and np.array_equal(dest[:want.size], want), (codec, esz, ndims, n, flat, sz.last_error())
+        dec, dret = gpu_decompress(sz, codec, want, esz, data.size)
+        assert dret == data.size and np.array_equal(dec[:data.size], data.ravel()), (codec, esz, ndims, n, flat)
+
+
 def test_random_shapes_against_oracle(sz, oracle):
     """both kernel families (decode_path) over random shapes the fixed matrices do not list: every lanes-per-chunk bucket of both
     layouts (1 .. 64 columns, both widths, both codecs), chunk lengths that are and are not whole groups, a ragged last chunk, data

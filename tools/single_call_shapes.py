@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 from sprintz_amd import _lib
 from synth import synth_numpy
 for codec, esz, D, n in (("xff", 1, 1, 1024), ("xff", 1, 1, 10240), ("delta", 1, 1, 10240), ("xff", 2, 1, 5120), ("xff", 2, 2, 5120), ("xff", 1, 3, 9999 // 3 * 3),
-                         ("xff", 2, 8, 5120), ("xff", 1, 8, 10240), ("delta", 1, 80, 10240), ("xff", 2, 32, 5120), ("xff", 2, 8, 32768)):
+                         ("xff", 2, 8, 5120), ("xff", 1, 8, 10240), ("delta", 1, 80, 10240), ("xff", 2, 32, 5120), ("xff", 2, 8, 20480), ("xff", 1, 8, 24576), ("xff", 2, 8, 32768)):
     x = synth_numpy("walk", esz, 1, n // D, D, seed=123, step=8 if esz == 2 else 2)
     cdst = np.zeros(n * 3 // 2 + 256, np.int16 if esz == 2 else np.int8)
     dst = np.zeros(n + 64, x.dtype)
