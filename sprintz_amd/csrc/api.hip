@@ -654,8 +654,10 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
         if (pgrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
         if (int rc = arm_dense(pgrid, pgroups)) return rc;
         const bool pfire = codec == SPRINTZ_CODEC_XFF || codec == SPRINTZ_CODEC_XFF_NORLE;
-        e = esz == 1 ? launch_encode_pair_w8(pfire, pdp, D == 2 * pdp, (unsigned)pgrid, (size_t)a.lds_group_stride * pgroups, st, a)
-                     : launch_encode_pair_w16(pfire, pdp, D == 2 * pdp, (unsigned)pgrid, (size_t)a.lds_group_stride * pgroups, st, a);
+        // (experiment knob: extra, unused LDS a workgroup claims -- fewer resident waves; what occupancy is worth to this loop: DESIGN 4.4)
+        static const size_t lds_pad = getenv("SPRINTZ_MI355X_ENC_LDS_PAD") ? (size_t)atol(getenv("SPRINTZ_MI355X_ENC_LDS_PAD")) : 0;
+        e = esz == 1 ? launch_encode_pair_w8(pfire, pdp, D == 2 * pdp, (unsigned)pgrid, (size_t)a.lds_group_stride * pgroups + lds_pad, st, a)
+                     : launch_encode_pair_w16(pfire, pdp, D == 2 * pdp, (unsigned)pgrid, (size_t)a.lds_group_stride * pgroups + lds_pad, st, a);
         if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "encode_wide (pair) kernel launch", e);
         return 0;
     }
