@@ -106,14 +106,15 @@ const char* sprintz_mi355x_last_error(void);     /* thread-local, never NULL; de
  *                                 sprintz_xff_rle.cpp:893-901) -- not lossless on streams whose runs start with a non-zero
  *                                 prediction, but sample-for-sample what sprintz_decompress_xff_16b of the reference returns;
  *                                 env SPRINTZ_MI355X_REF_DECODER_QUIRK
- *   SPRINTZ_OPT_LAT_CHUNKS        batches of at most this many chunks (general layout, 3 .. 64 columns, chunks of at most 16 KB) decode
+ *   SPRINTZ_OPT_LAT_CHUNKS        batches of at most this many chunks (both layouts, 1 .. 64 columns, chunks of at most 16 KB; single calls and batches of
+ *                                 at most 64 chunks up to ~40 KB of uint16 / ~24 KB of uint8: what fits a workgroup's 150 KB of LDS) decode
  *                                 with one workgroup per chunk (csrc/decode_lat.h: a chunk's latency is what counts; a third as many from 17 columns on); default 2048,
  *                                 0 = never (A/B runs, tests); env SPRINTZ_MI355X_LAT_CHUNKS
  *   SPRINTZ_OPT_HOST_WAIT         how a single-call entry point waits for its launches: 0 (default) = spin (hipStreamSynchronize)
  *                                 while at most 4 callers (and at most half of the CPUs this process may use) are inside the library,
  *                                 otherwise sleep and poll a mapped host word that a one-thread kernel at the end of the call writes
  *                                 (no runtime wait: 64 threads on 16 CPUs get 4x the calls per second of either runtime wait; a
- *                                 thread that waits this way gets its timer slack set to 1 us, prctl(PR_SET_TIMERSLACK)); 1 = always
+ *                                 thread that waits this way has its timer slack at 1 us, prctl(PR_SET_TIMERSLACK), for the duration of the wait -- its own value is put back before the call returns); 1 = always
  *                                 spin; 2 = always sleep and poll; env SPRINTZ_MI355X_HOST_WAIT */
 #define SPRINTZ_OPT_NO_FAST 0
 #define SPRINTZ_OPT_CHUNKS_PER_GROUP 1

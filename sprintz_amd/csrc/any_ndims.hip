@@ -371,7 +371,7 @@ template <typename K, typename A>
 hipError_t launch_any(K kernel, unsigned grid, size_t shmem, hipStream_t st, const A& a)
 {
     if (shmem > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        hipError_t e = ensure_max_dynamic_lds(reinterpret_cast<const void*>(kernel));      // once per instantiation and device (launch.h)
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), shmem, st, a);

@@ -361,8 +361,9 @@ struct QuerySpec {
 bool lat_chunk_fits(bool encode, int esz, uint64_t nchunks, uint32_t chunk_len, int D)
 {
     const uint64_t bytes = (uint64_t)chunk_len * esz;
-    if (bytes <= kLatMaxChunkBytes) return true;
-    if (bytes > (48u << 10) || nchunks > 64) return false;
+    if (bytes > (48u << 10) || (bytes > kLatMaxChunkBytes && nchunks > 64)) return false;
+    // the carve and the 16-bit position limit are checked for EVERY size: a shape whose working set does not fit goes to the
+    // lane-per-column kernels instead of failing its launch
     const uint32_t bound = (uint32_t)sprintz_mi355x_compress_bound(esz, chunk_len, (uint16_t)D);
     if (bound > 60000u) return false;                            // (stream positions travel in 16 bits between the kernels' phases)
     const uint32_t total = encode ? enc_lat_carve(bound, chunk_len, (uint32_t)D, (uint32_t)esz).total : lat_carve(bound, chunk_len, (uint32_t)D).total;
@@ -882,10 +883,18 @@ int acquire_scratch(size_t dev_bytes, size_t pin_bytes, Scratch** out)
                 e = hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking);
             }
             if (e != hipSuccess) { delete sc; return fail(SPRINTZ_E_HIP, "hipStreamCreateWithFlags", e); }
+            const char* what = "hipEventCreateWithFlags";
             e = hipEventCreateWithFlags(&sc->done_spin, hipEventDisableTiming);
-            if (e == hipSuccess) e = hipHostMalloc((void**)&sc->flag, 64, hipHostMallocMapped | hipHostMallocCoherent);
-            if (e == hipSuccess) { *sc->flag = 0; e = hipHostGetDevicePointer((void**)&sc->flag_dev, sc->flag, 0); }
-            if (e != hipSuccess) { if (!sc->shared_stream) (void)hipStreamDestroy(sc->stream); delete sc; return fail(SPRINTZ_E_HIP, "hipEventCreateWithFlags", e); }
+            if (e != hipSuccess) sc->done_spin = nullptr;
+            if (e == hipSuccess) { what = "hipHostMalloc (completion flag)"; e = hipHostMalloc((void**)&sc->flag, 64, hipHostMallocMapped | hipHostMallocCoherent); if (e != hipSuccess) sc->flag = nullptr; }
+            if (e == hipSuccess) { *sc->flag = 0; what = "hipHostGetDevicePointer (completion flag)"; e = hipHostGetDevicePointer((void**)&sc->flag_dev, sc->flag, 0); }
+            if (e != hipSuccess) {
+                if (sc->flag) (void)hipHostFree(sc->flag);
+                if (sc->done_spin) (void)hipEventDestroy(sc->done_spin);
+                if (!sc->shared_stream) (void)hipStreamDestroy(sc->stream);
+                delete sc;
+                return fail(SPRINTZ_E_HIP, what, e);
+            }
         }
         t_scratch.s = sc;
     }
@@ -935,8 +944,13 @@ int wait_flag(Scratch* sc, uint64_t want, bool spin)
             }
         }
     } else {
-        static thread_local bool slack_set = false;      // the default 50 us of timer slack would make every 20 us sleep a 75 us one
-        if (!slack_set) { (void)prctl(PR_SET_TIMERSLACK, 1000ul, 0, 0, 0); slack_set = true; }
+        // the default 50 us of timer slack would make every 20 us sleep a 75 us one: 1 us for the duration of THIS wait, the caller's
+        // own value put back before returning (it is the application's thread, not ours)
+        struct SlackGuard {
+            long old;
+            SlackGuard() : old(prctl(PR_GET_TIMERSLACK, 0, 0, 0, 0)) { if (old > 1000) (void)prctl(PR_SET_TIMERSLACK, 1000ul, 0, 0, 0); }
+            ~SlackGuard() { if (old > 1000) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)old, 0, 0, 0); }
+        } slack_guard;
         // first sleep: three quarters of what the thread's last call waited (with many callers a call queues behind the others' for
         // hundreds of microseconds), never under 15 us (no call is shorter); then 5, 10, 20 ... 160 us: 128 threads that each woke
         // every 5 us would spend the container's CPUs on waking up
@@ -1057,7 +1071,7 @@ int64_t compress_host(int codec, int esz, const void* src, uint32_t len, void* d
             rc = encode_launch(codec, esz, sc->pin_dev, len, len, ndims, sc->pin_dev + p_slot, bound, (uint32_t*)(sc->pin_dev + p_meta),
                                (int64_t*)(sc->pin_dev + p_meta + 8), sc->stream, write_size, 0, layout == SPRINTZ_LAYOUT_GENERAL, nullptr, &hc);
             if (rc) return rc;
-            if ((rc = wait_flag(sc, hc.ticket, spin_wait(inside.n)))) return rc;
+            if ((rc = wait_flag(sc, hc.ticket, spin_wait(inside.n)))) { (void)hipStreamSynchronize(sc->stream); *sc->flag = 0; return rc; }   // nothing of this call may still target sc->pin / sc->flag when the scratch is reused
         } else {
             if ((rc = stage_in(sc, 0, 0, src_bytes))) return rc;
             rc = encode_launch(codec, esz, sc->dev, len, len, ndims, sc->pin_dev + p_slot, bound, (uint32_t*)(sc->pin_dev + p_meta),
@@ -1155,7 +1169,7 @@ int64_t decode_host_common(int codec, int esz, const uint8_t* s, uint64_t nbytes
             rc = decode_launch(codec, esz, sc->pin_dev, nullptr, 1, (uint32_t)nelems, ndims, sc->pin_dev + p_out,
                                (int64_t*)(sc->pin_dev + p_ret), sc->stream, noheader, ngroups, remaining, qs);
             if (rc) return rc;
-            if ((rc = wait_flag(sc, hc.ticket, spin_wait(inside.n)))) return rc;
+            if ((rc = wait_flag(sc, hc.ticket, spin_wait(inside.n)))) { (void)hipStreamSynchronize(sc->stream); *sc->flag = 0; return rc; }   // nothing of this call may still target sc->pin / sc->flag when the scratch is reused
         } else {
             if ((rc = stage_in(sc, 0, 0, 16 + nbytes))) return rc;
             rc = decode_launch(codec, esz, sc->dev, (const uint64_t*)sc->dev, 1, (uint32_t)nelems, ndims, sc->pin_dev + p_out,

@@ -2,7 +2,8 @@
 // decode_fast.h's one-lane-per-column mapping (a single drop-in call; one GPU's 1 250-chunk share of BASELINE config 4's
 // 10 000-chunk batches on eight).  Same streams, same samples, same return values as decode_fast.h / decode_kernel.h
 // (sprintz_xff_rle.cpp:569-1179, sprintz_delta_rle.cpp:418-772; the low-dim layouts of sprintz_{delta,xff}_lowdim.cpp as template
-// parameter LOW), headered RLE streams, ndims <= 64, chunks of at most 16 KB.
+// parameter LOW), headered RLE streams, ndims <= 64, chunks of at most 16 KB in batches (several workgroups a CU) and up to what a
+// workgroup's 150 KB of LDS holds (~40 KB of uint16, ~24 KB of uint8) for single calls and batches of at most 64 chunks (api.hip: lat_chunk_fits).
 //
 // decode_fast.h walks a chunk's 40 groups in 40 dependent steps of ~600 wave-instructions each: 50 us a chunk however few
 // chunks there are (a lone wave issues an instruction every 4 .. 8 cycles).  Only two things in the format are serial:
@@ -173,7 +174,9 @@ __global__ void __launch_bounds__(256) decode_lat_kernel(DecodeArgs a, LatCarve 
                 }
                 // every lane writes the same words to the same place (no exec-mask round trip for "lane 0 only")
                 grp[g] = make_uint2(pos | (ob << 16), nob);
-                __hip_atomic_store(&ctl[0], g + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // release: the group's words are ordered before the counter that publishes them (the DS queue keeps one wave's
+                // stores in order anyway; this keeps the COMPILER from sinking the grp store below the counter store)
+                __hip_atomic_store(&ctl[0], g + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 ob = nob;
                 pos = npos;
             }

@@ -26,7 +26,7 @@ hipError_t launch_decode_w16(bool fire, bool lowdim, int cpl, int q, unsigned gr
 // (ds: columns the LDS carve is sized for when that is fewer than dp * cpl -- decode_fast.h, DS; 0 = dp * cpl)
 hipError_t launch_decode_fast_w8(bool fire, int dp, int cpl, bool exact, int q, int ds, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a);
 hipError_t launch_decode_fast_w16(bool fire, int dp, int cpl, bool exact, int q, int ds, unsigned grid, size_t shmem, hipStream_t st, const DecodeArgs& a);
-// small batches: one workgroup per chunk, general layout, 3 .. 64 columns (decode_lat.h); bound_bytes = the longest stream a chunk can have
+// small batches: one workgroup per chunk, both layouts, 1 .. 64 columns (decode_lat.h); bound_bytes = the longest stream a chunk can have
 hipError_t launch_decode_lat(int w, bool fire, int dp, bool lowdim, unsigned grid, uint32_t bound_bytes, hipStream_t st, const DecodeArgs& a);
 hipError_t launch_encode_lat(int w, bool fire, int dp, bool lowdim, unsigned grid, uint32_t bound_bytes, hipStream_t st, const EncodeArgs& a);   // encode_lat.h
 // streams of 513 .. 2047 columns: one workgroup per chunk, <= 8 columns per lane (any_ndims.hip); shmem = the encoder's group window
@@ -49,6 +49,30 @@ hipError_t launch_encode_fast_w8(bool fire, int dp, bool exact, unsigned grid, s
 hipError_t launch_encode_fast_w16(bool fire, int dp, bool exact, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
 hipError_t launch_encode_w8(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
 hipError_t launch_encode_w16(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
+
+// Kernels whose dynamic LDS carve can exceed 48 KB get the 150 KB maximum ONCE per (kernel instantiation, device) instead of a
+// hipFuncSetAttribute on every launch (the single-call hot path; concurrent callers with different sizes raced on the attribute).
+// Lock-free: a small open-addressed set of (kernel, device) keys; a lost race just sets the same value twice.
+inline hipError_t ensure_max_dynamic_lds(const void* kernel)
+{
+    constexpr int kMaxLds = 150 * 1024;
+    static std::atomic<uintptr_t> seen[256];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uintptr_t key = (uintptr_t)kernel * 64u + (uintptr_t)(dev & 63) + 1u;      // != 0
+    for (unsigned h = (unsigned)((key >> 4) * 2654435761u) & 255u, n = 0; n < 256; h = (h + 1) & 255u, n++) {
+        const uintptr_t v = seen[h].load(std::memory_order_acquire);
+        if (v == key) return hipSuccess;
+        if (v == 0) {
+            const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+            if (e != hipSuccess) return e;
+            uintptr_t expect = 0;
+            (void)seen[h].compare_exchange_strong(expect, key, std::memory_order_release);
+            return hipSuccess;
+        }
+    }
+    return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);   // table full (never: a few dozen instantiations)
+}
 
 // records `what` as this thread's last error (sprintz_mi355x_last_error) and returns `code`: every
 // failing return of every translation unit goes through it, so the message is never stale

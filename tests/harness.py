@@ -234,6 +234,32 @@ class Oracle:
                               dest.ctypes.data, stride, sizes.ctypes.data)
         return [dest[c * stride:c * stride + int(sizes[c])].copy() for c in range(nchunks)]
 
+    def compress_chunks_mt(self, codec, data, chunk_len, ndims, threads=None):
+        """every chunk of a large batch on the host's cores (ctypes releases the GIL: plain Python threads, one contiguous
+        chunk range each) -> (dest, stride, sizes): chunk c's stream is dest[c * stride : c * stride + sizes[c]]"""
+        from concurrent.futures import ThreadPoolExecutor
+        data = np.ascontiguousarray(data)
+        esz = data.dtype.itemsize
+        n = data.size
+        nchunks = (n + chunk_len - 1) // chunk_len
+        stride = self.bound(esz, chunk_len, ndims)
+        dest = np.zeros(nchunks * stride + 64, np.uint8)
+        sizes = np.zeros(nchunks, np.uint32)
+        if threads is None:
+            threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        threads = max(1, min(threads, nchunks))
+        edges = [nchunks * t // threads for t in range(threads + 1)]
+
+        def work(t):
+            c0, c1 = edges[t], edges[t + 1]
+            if c1 > c0:
+                e0, e1 = c0 * chunk_len, min(n, c1 * chunk_len)
+                self._compress_chunks(CODECS[codec], esz, data.ctypes.data + e0 * esz, e1 - e0, chunk_len, ndims,
+                                      dest.ctypes.data + c0 * stride, stride, sizes.ctypes.data + 4 * c0)
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(work, range(threads)))
+        return dest, stride, sizes
+
     def decompress_chunks(self, codec, comp, offsets, esz, chunk_len, total_len):
         comp = np.ascontiguousarray(comp, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)

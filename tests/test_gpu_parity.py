@@ -47,7 +47,7 @@ def test_golden_vectors_single_call(sz, golden):
         dest, ret = gpu_compress(sz, m["codec"], data, m["ndims"])
         assert ret == m["ret"], (m, sz.last_error())
         assert np.array_equal(dest[:want.size], want), m
-        assert (dest[want.size + 16:] == 0xAB).all(), "wrote far outside the stream"
+        assert (dest[want.size:] == 0xAB).all(), "wrote outside the stream (the caller's buffer holds exactly the stream afterwards)"
         dec, dret = gpu_decompress(sz, m["codec"], want, m["esz"], data.size)
         assert dret == data.size, (m, sz.last_error())
         assert np.array_equal(dec[:data.size], data), m
@@ -562,13 +562,15 @@ def test_full_size_cfg2_roundtrip_and_size_checksum(sz, oracle):
     assert torch.equal(out.view(torch.int16), x.view(torch.int16))
     sizes = batch.sizes.cpu().numpy()
     offs = batch.offsets.cpu().numpy()
-    sample = np.arange(0, nchunks, 997)
-    xs = x.view(torch.int16).reshape(nchunks, chunk_len)[torch.from_numpy(sample).cuda()].cpu().numpy().view(np.uint16)
     comp = batch.data.cpu().numpy()
-    for j, c in enumerate(sample):
-        want, _ = oracle.compress(codec, xs[j], ndims)
-        assert sizes[c] == want.size
-        assert np.array_equal(comp[offs[c]:offs[c] + sizes[c]], want)
+    # EVERY chunk against the oracle, run over the host's cores (1.34 GB at ~0.3 GB/s a core): all 131 072 sizes, all stream bytes
+    want, stride, wsizes = oracle.compress_chunks_mt(codec, x.cpu().numpy().view(np.uint16), chunk_len, ndims)
+    assert np.array_equal(sizes, wsizes), np.flatnonzero(sizes != wsizes)[:8]
+    assert zlib.crc32(sizes.tobytes()) == zlib.crc32(wsizes.tobytes())
+    for c in range(nchunks):
+        n = int(sizes[c])
+        if not np.array_equal(comp[offs[c]:offs[c] + n], want[c * stride:c * stride + n]):
+            raise AssertionError(f"chunk {c}: stream bytes differ from the oracle's")
     assert 2.0 < x.numel() * 2 / sizes.sum() < 6.0
 
 

@@ -77,3 +77,15 @@ def test_oracle_at_513_to_2047_columns_is_the_reference(oracle, golden_wide):
         assert ret == m["ret"] and got.size == m["nbytes"] and np.array_equal(got, want), m
         dec, dret = oracle.decompress(m["codec"], want, m["esz"], data.size)
         assert dret == data.size and np.array_equal(dec, data.ravel()), m
+
+
+def test_compress_chunks_on_many_threads_is_compress_chunks(oracle):
+    """harness.Oracle.compress_chunks_mt (the full-size GPU tests' all-chunk comparison) == the serial form, ragged last chunk too"""
+    from harness import gen_walk
+    rng = np.random.default_rng(77)
+    data = gen_walk(rng, 37 * 5120 + 1234, 8, 2, 8, flat_every=3)
+    serial = oracle.compress_chunks("xff", data, 5120, 8)
+    for threads in (1, 3, 8):
+        dest, stride, sizes = oracle.compress_chunks_mt("xff", data, 5120, 8, threads=threads)
+        assert sizes.tolist() == [s.size for s in serial]
+        assert all(np.array_equal(dest[c * stride:c * stride + s.size], s) for c, s in enumerate(serial))
