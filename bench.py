@@ -426,15 +426,17 @@ def bench_rowmajor(cx, name, workload, codec, esz, ndims, chunk_len, nchunks_tot
                                                 z_offs.data_ptr(), z_tmp.data_ptr(), st))
 
         zd_tmp = torch.empty(int(_lib.huf0_decode_tmp_bytes(n)), dtype=torch.uint8, device=dev)
+        z_hint = [int(cd.slot_stride)]
 
         def h_dec():
-            _lib.check(_lib.huf0_decompress_batch_ws(z_buf.data_ptr(), z_offs.data_ptr(), n, s_buf.data_ptr(), s_offs.data_ptr(),
-                                                     z_rets.data_ptr(), zd_tmp.data_ptr(), st))
+            _lib.check(_lib.huf0_decompress_batch_hint(z_buf.data_ptr(), z_offs.data_ptr(), n, s_buf.data_ptr(), s_offs.data_ptr(),
+                                                       z_rets.data_ptr(), zd_tmp.data_ptr(), z_hint[0], st))   # (hint: the writer's largest block)
 
         def chain():
             h_dec()
             cd.decompress_into(s_buf, s_offs, n, out)
         h_enc_ms = timer(h_enc, reps)
+        z_hint[0] = int((z_offs[1:] - z_offs[:-1]).max().item())           # what the writer of the blocks knows: its largest block
         h_dec_ms = timer(h_dec, reps)
         chain_ms = timer(chain, reps)
         if not args.no_verify:
@@ -603,8 +605,8 @@ def huf0_private_trees(cx, comp, offs, sizes, n, timer, reps):
     st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
     def h_dec():
-        _lib.check(_lib.huf0_decompress_batch_ws(d_blocks.data_ptr(), d_bo.data_ptr(), nt, d_out.data_ptr(), d_oo.data_ptr(),
-                                                 d_rets.data_ptr(), d_tmp.data_ptr(), st))
+        _lib.check(_lib.huf0_decompress_batch_hint(d_blocks.data_ptr(), d_bo.data_ptr(), nt, d_out.data_ptr(), d_oo.data_ptr(),
+                                                   d_rets.data_ptr(), d_tmp.data_ptr(), int(sz_h.max()), st))
     ms = timer(h_dec, reps)
     if not cx.args.no_verify:
         assert torch.equal(d_rets, torch.from_numpy(np.tile(sz_h, k)).to(dev)), "Huff0 decode (libzstd blocks): a block was rejected"

@@ -46,8 +46,9 @@ extern "C" {
  *      the column-major and run-less codec entry points, the reference's mangled C++ names (sprintz_dropin.hpp)
  *   3  round 3: compress_batch_dense / compress_dense_tmp_bytes, SPRINTZ_OPT_DENSE_MODE, env SPRINTZ_MI355X_RCCL_SONAME
  *   4  round 3: compress_batch_colmajor_dense, SPRINTZ_OPT_SPLIT_LANES, SPRINTZ_OPT_ENC_PAIR
- *   5  round 4: SPRINTZ_OPT_HOST_WAIT, SPRINTZ_OPT_LAT_CHUNKS, SPRINTZ_OPT_HOST_STREAMS, SPRINTZ_OPT_REF_DECODER_QUIRK (the single-call entry points work on a mapped staging buffer: one wait per call) */
-#define SPRINTZ_MI355X_ABI_VERSION 5
+ *   5  round 4: SPRINTZ_OPT_HOST_WAIT, SPRINTZ_OPT_LAT_CHUNKS, SPRINTZ_OPT_HOST_STREAMS, SPRINTZ_OPT_REF_DECODER_QUIRK (the single-call entry points work on a mapped staging buffer: one wait per call)
+ *   6  round 5: huf0_decompress_batch_hint, SPRINTZ_OPT_HUF0_SYNC_CHUNKS */
+#define SPRINTZ_MI355X_ABI_VERSION 6
 
 /* codec ids */
 #define SPRINTZ_CODEC_DELTA 0   /* sprintz_*_delta_*  (sprintz_delta_rle.cpp / sprintz_delta_lowdim.cpp) */
@@ -89,6 +90,10 @@ const char* sprintz_mi355x_last_error(void);     /* thread-local, never NULL; de
  *                                 64-byte stream pieces (the built defaults HUF0_BIG_WG = 2, HUF0_BIG_PLOG = 6) instead of single waves,
  *                                 which are faster while each has a SIMD to itself (16 chunks a wave, 1 024 SIMDs); default 16385,
  *                                 0 = always (tests)
+ *   SPRINTZ_OPT_HUF0_SYNC_CHUNKS  batches of at most this many chunks run the Huff0 reader's stream stage as one wave per chunk with sixteen
+ *                                 self-synchronising decoders per stream (csrc/huf0_sync.h: a stream's ~900-look-up chain becomes three passes
+ *                                 over ~60: what counts while the chip has idle issue slots -- 86 -> 45 us at 1 250 chunks, even at 10 000); default 8192, 0 = never (A/B runs, tests);
+ *                                 env SPRINTZ_MI355X_HUF0_SYNC_CHUNKS
  *   SPRINTZ_OPT_SPLIT_LANES       1 (default) = 8-bit row-major streams of 65 .. 80 columns decode on 32 lanes a chunk (a pair of
  *                                 adjacent columns + one single column per lane, two chunks a wavefront), 0 = on 64 lanes x 2
  *                                 columns like the other shapes up to 128 columns; 0 also sizes the LDS carve of 16-bit streams of
@@ -126,6 +131,7 @@ const char* sprintz_mi355x_last_error(void);     /* thread-local, never NULL; de
 #define SPRINTZ_OPT_LAT_CHUNKS 7
 #define SPRINTZ_OPT_HOST_STREAMS 8
 #define SPRINTZ_OPT_REF_DECODER_QUIRK 9
+#define SPRINTZ_OPT_HUF0_SYNC_CHUNKS 10
 int sprintz_mi355x_set_option(int option, int value);
 
 /* ------------------------------------------------------------------------
@@ -388,6 +394,12 @@ int sprintz_mi355x_huf0_decompress_batch(const void* d_blocks, const uint64_t* d
 size_t sprintz_mi355x_huf0_decode_tmp_bytes(uint64_t nchunks);
 int sprintz_mi355x_huf0_decompress_batch_ws(const void* d_blocks, const uint64_t* d_block_offsets, uint64_t nchunks, void* d_out,
                                             const uint64_t* d_out_offsets, int64_t* d_rets, void* d_tmp, void* hip_stream);
+/* The same with a HINT: max_block_bytes = an upper bound of the batch's block sizes (0 = unknown).  Small batches
+ * (SPRINTZ_OPT_HUF0_SYNC_CHUNKS) keep a chunk's whole block in LDS; the hint sizes that image (up to 16 KB a block; without one 4 KB).
+ * A block above the image -- or above a wrong hint -- is still decoded, from global memory: the hint is never trusted for safety. */
+int sprintz_mi355x_huf0_decompress_batch_hint(const void* d_blocks, const uint64_t* d_block_offsets, uint64_t nchunks, void* d_out,
+                                              const uint64_t* d_out_offsets, int64_t* d_rets, void* d_tmp, uint32_t max_block_bytes,
+                                              void* hip_stream);
 /* The other direction: container (d_dense, d_offsets[nchunks+1], d_sizes[nchunks] = exact stream bytes, as
  * sprintz_mi355x_compact leaves them) -> one Huff0 block per chunk, byte-dense at d_blocks +
  * d_block_offsets[c] (d_block_offsets[nchunks] = total), each one a block HUF_decompress(dst, size of

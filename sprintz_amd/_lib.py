@@ -51,12 +51,12 @@ def _sig(name, restype, *argtypes):
 
 
 abi_version = _sig("sprintz_mi355x_abi_version", _i)
-ABI_REQUIRED = 5
+ABI_REQUIRED = 6
 if abi_version() < ABI_REQUIRED:      # a stale build would otherwise die below with an AttributeError on the first new symbol
     raise ImportError(f"{LIB_PATH} has ABI version {abi_version()}, this binding needs >= {ABI_REQUIRED}: rebuild it "
                       "(`make -C sprintz_amd/csrc`)")
 _last_error = _sig("sprintz_mi355x_last_error", C.c_char_p)
-OPT_NO_FAST, OPT_CHUNKS_PER_GROUP, OPT_DENSE_MODE, OPT_HUF0_BIG_BATCH, OPT_SPLIT_LANES, OPT_ENC_PAIR, OPT_HOST_WAIT, OPT_LAT_CHUNKS, OPT_HOST_STREAMS, OPT_REF_DECODER_QUIRK = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+OPT_NO_FAST, OPT_CHUNKS_PER_GROUP, OPT_DENSE_MODE, OPT_HUF0_BIG_BATCH, OPT_SPLIT_LANES, OPT_ENC_PAIR, OPT_HOST_WAIT, OPT_LAT_CHUNKS, OPT_HOST_STREAMS, OPT_REF_DECODER_QUIRK, OPT_HUF0_SYNC_CHUNKS = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 set_option = _sig("sprintz_mi355x_set_option", _i, _i, _i)
 
 # (1) drop-in single-call API, host pointers
@@ -98,6 +98,7 @@ huf0_compress_batch = _sig("sprintz_mi355x_huf0_compress_batch", _i, _vp, _vp, _
 huf0_decompress_batch = _sig("sprintz_mi355x_huf0_decompress_batch", _i, _vp, _vp, _u64, _vp, _vp, _vp, _vp)
 huf0_decode_tmp_bytes = _sig("sprintz_mi355x_huf0_decode_tmp_bytes", _sz, _u64)
 huf0_decompress_batch_ws = _sig("sprintz_mi355x_huf0_decompress_batch_ws", _i, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp)
+huf0_decompress_batch_hint = _sig("sprintz_mi355x_huf0_decompress_batch_hint", _i, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _u32, _vp)
 huf_decompress_batch = _sig("sprintz_mi355x_huf_decompress_batch", _i, _vp, _vp, _vp, _u64, _u32, _vp, _u64, _vp, _vp, _vp, _vp, _vp)
 
 # (4) query on compressed data (query.hpp:23-29; sprintz_delta.h:95-98; sprintz_xff.h:90-93)
@@ -169,7 +170,7 @@ EXPORTED_SYMBOLS = [
     "sprintz_mi355x_layout_bases", "sprintz_mi355x_comm_destroy",
     "sprintz_mi355x_huf_tmp_bytes", "sprintz_mi355x_huf_bound",
     "sprintz_mi355x_huf_compress_batch", "sprintz_mi355x_huf_decompress_batch", "sprintz_mi355x_huf0_decompress_batch",
-    "sprintz_mi355x_huf0_decode_tmp_bytes", "sprintz_mi355x_huf0_decompress_batch_ws",
+    "sprintz_mi355x_huf0_decode_tmp_bytes", "sprintz_mi355x_huf0_decompress_batch_ws", "sprintz_mi355x_huf0_decompress_batch_hint",
     "sprintz_mi355x_huf0_tmp_bytes", "sprintz_mi355x_huf0_bound", "sprintz_mi355x_huf0_compress_batch",
     "sprintz_mi355x_query_batch", "sprintz_mi355x_query_reduce",
     "sprintz_mi355x_query_delta_8b", "sprintz_mi355x_query_xff_8b",

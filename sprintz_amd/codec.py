@@ -548,11 +548,13 @@ def huf0_compress(batch):
     return blocks, boffs
 
 
-def huf0_decompress(blocks, block_offsets, out_offsets, rets=None, out=None):
+def huf0_decompress(blocks, block_offsets, out_offsets, rets=None, out=None, max_block_bytes=0):
     """Genuine Huff0 blocks (HUF_compress's output, one per chunk; torch uint8 tensor + int64 offsets
     [nchunks+1]) -> the bytes they encode, chunk c at out_offsets[c] (int64 [nchunks+1], device).
     `blocks` must be 16-byte aligned and carry 16 readable bytes past the last block.  Returns the uint8 output tensor
-    (READ_SLACK bytes longer than out_offsets[-1], ready for ChunkedCodec.decompress_into)."""
+    (READ_SLACK bytes longer than out_offsets[-1], ready for ChunkedCodec.decompress_into).
+    max_block_bytes: an upper bound of the blocks' sizes if the caller has one (a chunk's compress_bound, say) -- small
+    batches size their LDS image of a block by it (sprintz_mi355x_huf0_decompress_batch_hint); 0 = unknown."""
     import torch
     dev = blocks.device
     n = block_offsets.numel() - 1
@@ -560,8 +562,13 @@ def huf0_decompress(blocks, block_offsets, out_offsets, rets=None, out=None):
         out = torch.zeros(int(out_offsets[-1].item()) + _lib.READ_SLACK, dtype=torch.uint8, device=dev)
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     with torch.cuda.device(dev):
-        _lib.check(_lib.huf0_decompress_batch(blocks.data_ptr(), block_offsets.data_ptr(), n, out.data_ptr(), out_offsets.data_ptr(),
-                                              rets.data_ptr() if rets is not None else None, stream))
+        if max_block_bytes:
+            tmp = torch.empty(int(_lib.huf0_decode_tmp_bytes(n)), dtype=torch.uint8, device=dev)
+            _lib.check(_lib.huf0_decompress_batch_hint(blocks.data_ptr(), block_offsets.data_ptr(), n, out.data_ptr(), out_offsets.data_ptr(),
+                                                       rets.data_ptr() if rets is not None else None, tmp.data_ptr(), int(max_block_bytes), stream))
+        else:
+            _lib.check(_lib.huf0_decompress_batch(blocks.data_ptr(), block_offsets.data_ptr(), n, out.data_ptr(), out_offsets.data_ptr(),
+                                                  rets.data_ptr() if rets is not None else None, stream))
     return out
 
 

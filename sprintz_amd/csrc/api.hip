@@ -1385,6 +1385,11 @@ int sprintz_mi355x_set_option(int option, int value)
         sprintz::huf0_big_batch() = value;
         return 0;
     }
+    if (option == SPRINTZ_OPT_HUF0_SYNC_CHUNKS) {
+        if (value < 0) return fail(SPRINTZ_E_INVALID, "the batch size must not be negative");
+        sprintz::huf0_sync_chunks() = value;
+        return 0;
+    }
     if (option == SPRINTZ_OPT_SPLIT_LANES) { process().split_lanes = value ? 1 : 0; return 0; }
     if (option == SPRINTZ_OPT_ENC_PAIR) {
         if (value < 0) return fail(SPRINTZ_E_INVALID, "the batch size must not be negative");

@@ -23,6 +23,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include "lds_attr.h"
+
+#include <cstdlib>
 #include <string>
 #include <atomic>
 #include <type_traits>
@@ -36,6 +39,12 @@ std::atomic<long long>& huf0_big_batch()
     // one more than 16 chunks x the chip's 1 024 SIMDs: while every wave of the single-wave form has a SIMD to itself that form is the faster one
     // (tools/huf0_threshold.py: 16 384 chunks 127 vs 136 us, 17 000 chunks 188 vs 137)
     static std::atomic<long long> v{16385};
+    return v;
+}
+// chunks up to which the stream stage runs as one wave per chunk with sixteen self-synchronising decoders per stream (huf0_sync.h; SPRINTZ_OPT_HUF0_SYNC_CHUNKS; 0 = never)
+std::atomic<long long>& huf0_sync_chunks()
+{
+    static std::atomic<long long> v{[] { const char* e = getenv("SPRINTZ_MI355X_HUF0_SYNC_CHUNKS"); return e ? (atoll(e) < 0 ? 0ll : atoll(e)) : 8192ll; }()};
     return v;
 }
 }  // namespace sprintz
@@ -1598,13 +1607,19 @@ huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restric
 
 // small batches: both single-wave forms in ONE launch, a wave takes the one its segment's share flag names (where a launch is 2 - 3 %
 // of the job, a second one in which every wave reads its flag and leaves is not free)
+// (skip_shared: the one-tree segments have been taken by huf0_sync_kernel)
 __global__ void __launch_bounds__(64) huf0_stream_small_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restrict__ boffs, uint64_t nchunks,
                                                                uint8_t* __restrict__ out, const uint64_t* __restrict__ ooffs, int64_t* __restrict__ rets,
-                                                               const uint8_t* __restrict__ desc, const uint8_t* __restrict__ share)
+                                                               const uint8_t* __restrict__ desc, const uint8_t* __restrict__ share, int skip_shared)
 {
-    if (share[(uint64_t)blockIdx.x * 16 >> 6] != 0) huf0_stream_body<true, 1, HUF0_SMALL_PLOG, HUF0_SMALL_CAD != 0, 3, true>(blocks, boffs, nchunks, out, ooffs, rets, desc, share);
+    if (share[(uint64_t)blockIdx.x * 16 >> 6] != 0) {
+        if (skip_shared) return;
+        huf0_stream_body<true, 1, HUF0_SMALL_PLOG, HUF0_SMALL_CAD != 0, 3, true>(blocks, boffs, nchunks, out, ooffs, rets, desc, share);
+    }
     else huf0_stream_body<false, 1, HUF0_G_PLOG, HUF0_G_CAD != 0, 3, true>(blocks, boffs, nchunks, out, ooffs, rets, desc, share);
 }
+
+#include "huf0_sync.h"
 
 std::string g_err0;
 
@@ -1620,6 +1635,12 @@ size_t sprintz_mi355x_huf0_decode_tmp_bytes(uint64_t nchunks)
 
 int sprintz_mi355x_huf0_decompress_batch_ws(const void* d_blocks, const uint64_t* d_block_offsets, uint64_t nchunks, void* d_out,
                                             const uint64_t* d_out_offsets, int64_t* d_rets, void* d_tmp, void* hip_stream)
+{
+    return sprintz_mi355x_huf0_decompress_batch_hint(d_blocks, d_block_offsets, nchunks, d_out, d_out_offsets, d_rets, d_tmp, 0, hip_stream);
+}
+
+int sprintz_mi355x_huf0_decompress_batch_hint(const void* d_blocks, const uint64_t* d_block_offsets, uint64_t nchunks, void* d_out,
+                                              const uint64_t* d_out_offsets, int64_t* d_rets, void* d_tmp, uint32_t max_block_bytes, void* hip_stream)
 {
     if (!d_blocks || !d_block_offsets || !d_out || !d_out_offsets || ((uintptr_t)d_blocks & 15) || (nchunks && (!d_tmp || ((uintptr_t)d_tmp & 15))))
         return sprintz::set_error(SPRINTZ_E_INVALID, "Huff0 stage: invalid argument (null pointer, alignment or size)");
@@ -1662,9 +1683,26 @@ int sprintz_mi355x_huf0_decompress_batch_ws(const void* d_blocks, const uint64_t
                            (uint8_t*)d_out, d_out_offsets, d_rets, (const uint8_t*)desc, (const uint8_t*)share);
         hipLaunchKernelGGL((huf0_stream_kernel<false, 1, HUF0_G_PLOG, HUF0_G_CAD != 0>), dim3((unsigned)grid2), dim3(64), 0, st, blk, d_block_offsets, nchunks,
                            (uint8_t*)d_out, d_out_offsets, d_rets, (const uint8_t*)desc, (const uint8_t*)share);
+    } else if (nchunks <= (uint64_t)sprintz::huf0_sync_chunks().load(std::memory_order_relaxed)) {
+        // small batches: a wave per chunk, sixteen self-synchronising decoders per stream (huf0_sync.h), one launch for both kinds of segment.
+        // The block image a wave keeps in LDS is sized by the caller's hint (the largest block of the batch; a block above the image is read
+        // from global memory by the same code)
+        constexpr int kWpb = 4;
+        const uint32_t want = max_block_bytes ? max_block_bytes : 4096u;
+        const uint32_t img = ((want < 16384u ? want : 16384u) + 16u + 63u) & ~63u;
+        const size_t lds = sync_lds_bytes(kWpb, img);
+        // chunks a wave takes one after the other (experiments; tools/huf0_sync_ab.sh: 1 / 2 / 4 -> 43.8 / 60.0 / 91.5 us at 625 chunks, 106 / 99.5 / 119 at
+        // 10 000, 152 at 16 384 whatever it is -- the form is bound by its instructions there: 2 400 a chunk against 630 of the single-pass kernel)
+        static const int cpw_env = [] { const char* e = getenv("SPRINTZ_MI355X_HUF0_SYNC_CPW"); return e ? atoi(e) : 0; }();
+        const uint32_t cpw = cpw_env > 0 ? (uint32_t)cpw_env : 1u;
+        if (lds > 48 * 1024 && sprintz::ensure_max_dynamic_lds(reinterpret_cast<const void*>(huf0_sync_kernel<kWpb>)) != hipSuccess)
+            return sprintz::set_error(SPRINTZ_E_HIP, "Huff0 stage: hipFuncSetAttribute failed");
+        const uint64_t per_wg = (uint64_t)kWpb * cpw;
+        hipLaunchKernelGGL(huf0_sync_kernel<kWpb>, dim3((unsigned)((nchunks + per_wg - 1) / per_wg)), dim3(64 * kWpb), lds, st, blk, d_block_offsets, nchunks,
+                           (uint8_t*)d_out, d_out_offsets, d_rets, (const uint8_t*)desc, (const uint8_t*)share, img, cpw);
     } else {
         hipLaunchKernelGGL(huf0_stream_small_kernel, dim3((unsigned)grid2), dim3(64), 0, st, blk, d_block_offsets, nchunks,
-                           (uint8_t*)d_out, d_out_offsets, d_rets, (const uint8_t*)desc, (const uint8_t*)share);
+                           (uint8_t*)d_out, d_out_offsets, d_rets, (const uint8_t*)desc, (const uint8_t*)share, 0);
     }
     return hipGetLastError() == hipSuccess ? 0 : sprintz::set_error(SPRINTZ_E_HIP, "Huff0 stage: a HIP call or kernel launch failed");
 }

@@ -7,6 +7,7 @@
 
 #include <atomic>
 
+#include "lds_attr.h"
 #include "decode_kernel.h"
 #include "decode_fast.h"
 #include "decode_uni.h"
@@ -50,30 +51,6 @@ hipError_t launch_encode_fast_w16(bool fire, int dp, bool exact, unsigned grid, 
 hipError_t launch_encode_w8(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
 hipError_t launch_encode_w16(bool fire, bool lowdim, int cpl, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
 
-// Kernels whose dynamic LDS carve can exceed 48 KB get the 150 KB maximum ONCE per (kernel instantiation, device) instead of a
-// hipFuncSetAttribute on every launch (the single-call hot path; concurrent callers with different sizes raced on the attribute).
-// Lock-free: a small open-addressed set of (kernel, device) keys; a lost race just sets the same value twice.
-inline hipError_t ensure_max_dynamic_lds(const void* kernel)
-{
-    constexpr int kMaxLds = 150 * 1024;
-    static std::atomic<uintptr_t> seen[256];
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const uintptr_t key = (uintptr_t)kernel * 64u + (uintptr_t)(dev & 63) + 1u;      // != 0
-    for (unsigned h = (unsigned)((key >> 4) * 2654435761u) & 255u, n = 0; n < 256; h = (h + 1) & 255u, n++) {
-        const uintptr_t v = seen[h].load(std::memory_order_acquire);
-        if (v == key) return hipSuccess;
-        if (v == 0) {
-            const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
-            if (e != hipSuccess) return e;
-            uintptr_t expect = 0;
-            (void)seen[h].compare_exchange_strong(expect, key, std::memory_order_release);
-            return hipSuccess;
-        }
-    }
-    return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);   // table full (never: a few dozen instantiations)
-}
-
 // records `what` as this thread's last error (sprintz_mi355x_last_error) and returns `code`: every
 // failing return of every translation unit goes through it, so the message is never stale
 int set_error(int code, const char* what);
@@ -83,6 +60,7 @@ int set_error(int code, const char* what);
 struct HostScratch { hipStream_t stream; uint8_t* dev; uint8_t* pin; };
 int host_scratch(size_t dev_bytes, size_t pin_bytes, HostScratch* out);
 bool have_device();                       // probed once per process
+std::atomic<long long>& huf0_sync_chunks(); // huf0.hip: batch size up to which the stream stage runs as a wave per chunk with self-synchronising decoders (huf0_sync.h)
 std::atomic<long long>& huf0_big_batch(); // huf0.hip: batch size from which the one-table stream kernel runs as workgroups of HUF0_BIG_WG (2) waves
 
 hipError_t launch_size_scan(const uint32_t* d_sizes, uint64_t n, uint32_t align, uint64_t* d_offsets, void* d_tmp, hipStream_t st);

@@ -9,16 +9,26 @@ from harness import DTYPES
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["by batch size", "big-batch form"])
+@pytest.fixture(scope="module", params=["sync form", "sync form, hinted", "single-wave form", "big-batch form"])
 def sz(request):
-    """every test twice: with the stream kernel the batch size picks (up to 16 384 chunks: a wave per 16 chunks) and with the bandwidth-sized form forced (2-wave workgroups around one table, 64-byte pieces)"""
+    """every test on every stream kernel: the one-wave-per-chunk form with self-synchronising decoders (huf0_sync.h: what batches up to
+    8 192 chunks get; without a size hint its blocks above 4 KB are read from global memory, with one they sit in LDS), the single-wave form
+    it replaced there (a wave per 16 chunks), and the bandwidth-sized form forced (2-wave workgroups around one table, 64-byte pieces)"""
+    import functools
+    import types
     import torch
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     import sprintz_amd
     from sprintz_amd import _lib
     assert _lib.set_option(_lib.OPT_HUF0_BIG_BATCH, 0 if request.param == "big-batch form" else 16385) == 0
-    yield sprintz_amd
+    assert _lib.set_option(_lib.OPT_HUF0_SYNC_CHUNKS, (1 << 30) if request.param.startswith("sync") else 0) == 0
+    mod = sprintz_amd
+    if request.param == "sync form, hinted":                  # the same module with the hint filled in
+        mod = types.SimpleNamespace(**{k: getattr(sprintz_amd, k) for k in dir(sprintz_amd) if not k.startswith("__")})
+        mod.huf0_decompress = functools.partial(sprintz_amd.huf0_decompress, max_block_bytes=16384)
+    yield mod
     _lib.set_option(_lib.OPT_HUF0_BIG_BATCH, 16385)
+    _lib.set_option(_lib.OPT_HUF0_SYNC_CHUNKS, 8192)
 
 
 def pack(blocks, plains, align=1):
