@@ -38,6 +38,9 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
 CPU_SAMPLE_BYTES = 1342177280   # raw bytes of the all-core CPU legs' sample (the headline batch of one GPU: 131 072 x 10 KB)
 METRIC = "decompress MB/s (and ratio) uint16 rowmajor 8-col, 1/2/4/8 MI355X vs CPU ref"
+# the decode kernel each configuration's batch runs on (names as rocprofv3 prints them: profiles/*_kernel_stats.csv)
+DECODE_KERNELS = {"cfg1": "decode_uni_kernel<8, false, 1, 0>", "cfg3_1k": "verbatim_decode_kernel", "cfg3_10k": "decode_fast_kernel<8, false, 32, 3, false, 0, false, 80>",
+                  "cfg4": "decode_fast_kernel<16, true, 8, 1, true, 0, false, 0>"}
 ALL_CONFIGS = ["cfg1", "cfg3_1k", "cfg3_10k", "cfg4_10000", "cfg4_80000", "cfg4_800000", "cfg5", "cfg5_8m"]
 
 
@@ -349,7 +352,7 @@ def chain_traffic(name, algo_bytes, world):
     t, label = load_traffic("chain:" + name)
     if not t:
         return {}
-    return {"traffic": t, "traffic_ratio_measured": round(t / algo_bytes, 3), "traffic_source": label}
+    return {"traffic": t, "traffic_ratio_measured": round(t / algo_bytes, 3), "traffic_measured_in_this_run": False, "traffic_source": label}
 
 
 # ------------------------------------------------------------------------------------------ per-config legs
@@ -402,7 +405,7 @@ def bench_rowmajor(cx, name, workload, codec, esz, ndims, chunk_len, nchunks_tot
            "raw_bytes": raw, "ratio": round(raw / stream_bytes, 4),
            "decompress_ms": round(dec_ms, 4), "decompress_MBps": round(raw / dec_ms / 1e3, 1),
            "compress_ms": round(enc_ms, 4), "compress_MBps": round(raw / enc_ms / 1e3, 1),
-           "roofline": roofline(algo, dec_ms, "sprintz decode kernel of this shape (profiles/: per-config kernel stats)"),
+           "roofline": roofline(algo, dec_ms, DECODE_KERNELS.get(name, DECODE_KERNELS.get(name.split("_")[0], "decode_fast_kernel<16, true, 8, 1, true, 0, false, 0>"))),
            "compress_roofline": roofline(raw + total + 12 * n, enc_ms, "sprintz_mi355x_compress_batch_dense (one launch where the fast encoder takes the shape; else encode + scan + copy)",
                                          {"algorithmic": "raw samples in + dense container out + sizes/offsets (SURVEY 8d)",
                                           "traffic_ratio_by_design": round((raw + stream_bytes + 2 * total + 12 * n) / (raw + total + 12 * n), 3),
@@ -541,6 +544,35 @@ def bench_cfg5(cx, nrows_all=1 << 20, name="cfg5"):
     cd._ws = {}
     torch.cuda.empty_cache()
     return res
+
+
+def strong_scaling_prediction(cx, per):
+    """{config: {"chunks": [n at 1, 2, 4, 8 ranks], "decode_ms": [...], "speedup": [...]}}: one rank's share of a fixed-size job measured on THIS
+    GPU (rank 0's contiguous range; no collective is on the decode path) -- max-over-ranks time of an N-GPU run is this, if the GPUs are alike"""
+    args = cx.args
+    out = {}
+    saved = (args.no_cpu_baseline, args.config_reps)
+    args.no_cpu_baseline, args.config_reps = True, max(10, args.config_reps)
+    try:
+        for e in per:
+            nm = e.get("name")
+            if nm not in ("cfg4_10000", "cfg4_80000", "cfg5") or "error" in e:
+                continue
+            chunks, ms = [e["chunks"]], [e["decompress_ms"]]
+            for N in (2, 4, 8):
+                share = e["chunks"] // N
+                if nm == "cfg5":
+                    r = bench_cfg5(cx, nrows_all=share * 160, name=nm)
+                else:
+                    r = bench_rowmajor(cx, nm, "share", "xff", 2, 8, 5120, share, "walk", 8, huff0=True, strong=True)
+                r.pop("_local", None)
+                chunks.append(share)
+                ms.append(r["decompress_ms"])
+            out[nm] = {"chunks": chunks, "decode_ms": [round(v, 4) for v in ms], "speedup": [round(ms[0] / v, 2) for v in ms]}
+    finally:
+        args.no_cpu_baseline, args.config_reps = saved
+    out["ranks"] = [1, 2, 4, 8]
+    return out
 
 
 def run_config(cx, name):
@@ -869,6 +901,7 @@ def main():
         "kernel_ms": round(kernel_ms, 4),
         "roofline": {"bound": "hbm", "achieved": round(algo_bytes / (kernel_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(algo_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "traffic_measured_in_this_run": False,      # (PMC passes are separate rocprofv3 runs: the figure is the committed profile's, labelled below; null if none matches)
                      "traffic_source": traffic_label, "algorithmic_bytes_per_launch": algo_bytes,
                      "kernel": "decode_fast_kernel<16,FIRE,8,1,EXACT>"},
         "container_bytes_all_ranks": layout.total_bytes, "rank_bases": layout.bases[:8], "rccl_ranks_seen": gather.ranks_seen,
@@ -909,6 +942,10 @@ def main():
                 raise
             per.append({"name": nm, "error": f"{type(e).__name__}: {e}"})
     result["per_config"] = per
+    # ---------------- what ONE GPU takes for one rank's share of the strong-scaled configurations at 2 / 4 / 8 ranks: the prediction a
+    # measured N-GPU run is to be read against (cfg4 at BASELINE's 10 000 chunks is three serial latencies: 8 GPUs cannot buy 8x)
+    if world == 1 and names and not args.no_extras:
+        result["strong_scaling_prediction"] = strong_scaling_prediction(cx, per)
 
     # ---------------- the last collective is behind us: the ranks part, and ONLY THEN does rank 0 spend its minute of CPU legs
     # (no rank waits inside RCCL while another one times the host)
@@ -1253,8 +1290,8 @@ def online_leg(cx):
     n = 64 << 20
     x = synth_torch("walk", 2, 1, n, 1, dev, seed=123, step=8)
     st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    out = {"samples": n, "what": "sprintz_mi355x_online_{pack,unpack}_device on one uint16 stream (walk, steps in [-8, 8]); not tuned (DESIGN.md 4.9)"}
-    for name, kind in (("dynamic_delta", 0), ("zigzag", 2), ("sprintzpack_zigzag", 4)):
+    out = {"samples": n, "what": "sprintz_mi355x_online_{pack,unpack}_device on one uint16 stream (walk, steps in [-8, 8]); *_frac: (samples + container bytes) / time over 8 TB/s"}
+    for name, kind in (("dynamic_delta", 0), ("zigzag", 2), ("sprintzpack", 3), ("sprintzpack_zigzag", 4)):
         dest = torch.zeros(int(_lib.online_bound(kind, n)) + 64, dtype=torch.uint8, device=dev)
         tmp = torch.zeros(int(_lib.online_tmp_bytes(kind, n)) + 64, dtype=torch.uint8, device=dev)
         back = torch.empty(n, dtype=torch.uint16, device=dev)
@@ -1269,8 +1306,10 @@ def online_leg(cx):
         elems = int(ret[0].item())
         u_ms = timed(unpack, 5, 1)
         assert int(ret[1].item()) == n and torch.equal(back.view(torch.int16), x.view(torch.int16)), name
+        moved = 2 * n + 2 * elems                      # algorithmic bytes either way: the samples + the container
         out[name] = {"ratio": round(n / max(elems, 1), 4), "pack_ms": round(p_ms, 3), "pack_GBps": round(2 * n / p_ms / 1e6, 1),
-                     "unpack_ms": round(u_ms, 3), "unpack_GBps": round(2 * n / u_ms / 1e6, 1)}
+                     "unpack_ms": round(u_ms, 3), "unpack_GBps": round(2 * n / u_ms / 1e6, 1),
+                     "pack_frac": round(moved / (p_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "unpack_frac": round(moved / (u_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     return out
 
 

@@ -7,17 +7,18 @@
 // compiled reference).  One call codes ONE stream of any length; the reference walks it serially, here:
 //   * encoders are block-parallel: a block's predictor choice / bit width is a pure function of the input (both of the
 //     reference's predictors are trained on the true values, so neither depends on earlier choices);
-//   * sprintzpack's byte offsets are an exclusive scan of the per-block widths (launch_size_scan, api.hip);
+//   * sprintzpack's byte offsets are an exclusive scan of the per-block widths: inside a tile of 1 024 blocks, the tiles' sums scanned by one workgroup;
 //   * the dynamic-delta DECODER is a scan too: a block maps the running state (x, d) = (last value, last difference)
 //     affinely -- delta: (x + A, e7); double delta: (x + 8 d + C, d + A) with A = sum e, C = sum (8 - i) e_i -- and such
 //     maps compose associatively as (m, a, tx, td): x' = x + m d + tx, d' = a d + td, everything modulo 2^16.
-//     Three launches: tile summaries (256 blocks = 2048 samples per workgroup), one workgroup scanning the tiles,
+//     Three launches: tile summaries (1 024 blocks = 8 192 samples a workgroup), one workgroup scanning the tiles,
 //     and the decode proper with every thread's incoming state.
 #include "../../include/sprintz_mi355x.h"
 
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "launch.h"
@@ -26,7 +27,16 @@ using namespace sprintz;
 
 namespace {
 
-constexpr int kT = 256;                                   // threads per workgroup = blocks of 8 samples per tile
+constexpr int kT = 256;                                   // threads per workgroup
+constexpr int kBPT = 4;                                   // blocks of 8 samples a thread takes (consecutive: 64 bytes of input)
+constexpr int kTile = kT * kBPT;                          // blocks per workgroup = per scan tile (8 192 samples)
+
+typedef uint16_t __attribute__((aligned(1), may_alias)) u16_a1;
+typedef uint32_t __attribute__((aligned(1), may_alias)) u32_a1;
+typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+typedef v4 __attribute__((aligned(2), may_alias)) v4a2;  // 8 samples at any SAMPLE boundary: one 16-byte request (the containers' bodies start 4 or 6 bytes in)
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t zz16(uint32_t x)      // zigzag_encode_16b of the int16 in the low half (bitpack.h:312)
 {
@@ -34,27 +44,71 @@ __device__ __forceinline__ uint32_t zz16(uint32_t x)      // zigzag_encode_16b o
     return ((uint32_t)(v << 1) ^ (uint32_t)(v >> 15)) & 0xffffu;
 }
 __device__ __forceinline__ uint32_t unzz16(uint32_t z) { return ((z >> 1) ^ (0u - (z & 1u))) & 0xffffu; }   // bitpack.h:315
-
-typedef uint16_t __attribute__((aligned(1), may_alias)) u16_a1;
-typedef uint32_t __attribute__((aligned(1), may_alias)) u32_a1;
+// the same on both halves of a dword (v_pk_* instructions)
+__device__ __forceinline__ uint32_t zz16x2(uint32_t w)
+{
+    const s16x2 v = __builtin_bit_cast(s16x2, w);
+    return __builtin_bit_cast(uint32_t, (s16x2)((v << 1) ^ (v >> 15)));
+}
+__device__ __forceinline__ uint32_t unzz16x2(uint32_t w)
+{
+    const u16x2 z = __builtin_bit_cast(u16x2, w);
+    const u16x2 one = {1, 1}, zero = {0, 0};
+    return __builtin_bit_cast(uint32_t, (u16x2)((z >> 1) ^ (zero - (z & one))));
+}
 
 __device__ __forceinline__ uint32_t ld16(const uint8_t* p) { return *(const u16_a1*)p; }
 __device__ __forceinline__ void st16(uint8_t* p, uint32_t v) { *(u16_a1*)p = (uint16_t)v; }
+__device__ __forceinline__ uint32_t half_of(const v4& q, int i) { const uint32_t d = (i >> 1) == 0 ? q.x : (i >> 1) == 1 ? q.y : (i >> 1) == 2 ? q.z : q.w; return (i & 1) ? d >> 16 : d & 0xffffu; }
+
+// sum over the workgroup (every thread gets it); sh: kT / 64 words
+__device__ __forceinline__ uint32_t workgroup_sum(uint32_t v, uint32_t* sh)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint32_t s = 0;
+#pragma unroll
+    for (int w = 0; w < kT / 64; w++) s += sh[w];
+    __syncthreads();
+    return s;
+}
+// exclusive prefix sum over the workgroup; sh: kT / 64 words
+__device__ __forceinline__ uint32_t workgroup_excl(uint32_t v, uint32_t* sh)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)inc, d); if (lane >= d) inc += u; }
+    if (lane == 63) sh[w] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+#pragma unroll
+    for (int k = 0; k < kT / 64; k++) base += k < w ? sh[k] : 0u;
+    __syncthreads();
+    return base + inc - v;
+}
 
 // ---------------------------------------------------------------- zigzag
+// src / dst: the first SAMPLE on both sides (one of them 4 bytes into its buffer); 8 samples = one 16-byte request a thread
 __global__ void __launch_bounds__(kT) zigzag_kernel(const uint8_t* src, uint8_t* dst, uint32_t len, int decode, int64_t* ret)
 {
-    // src/dst are byte pointers to the first SAMPLE on both sides (2-byte aligned); 8 samples a thread
     const uint64_t i0 = ((uint64_t)blockIdx.x * kT + threadIdx.x) * 8;
-    for (int i = 0; i < 8; i++) {
-        const uint64_t i1 = i0 + i;
-        if (i1 < len) st16(dst + 2 * i1, decode ? unzz16(ld16(src + 2 * i1)) : zz16(ld16(src + 2 * i1)));
+    if (i0 + 8 <= len) {
+        v4 q = *(const v4a2*)(src + 2 * i0);
+        if (decode) { q.x = unzz16x2(q.x); q.y = unzz16x2(q.y); q.z = unzz16x2(q.z); q.w = unzz16x2(q.w); }
+        else { q.x = zz16x2(q.x); q.y = zz16x2(q.y); q.z = zz16x2(q.z); q.w = zz16x2(q.w); }
+        *(v4a2*)(dst + 2 * i0) = q;
+    } else {
+        for (uint64_t i1 = i0; i1 < len; i1++) st16(dst + 2 * i1, decode ? unzz16(ld16(src + 2 * i1)) : zz16(ld16(src + 2 * i1)));
     }
     if (i0 == 0 && ret) *ret = decode ? (int64_t)len : 2 + (int64_t)len;
 }
 
 // ---------------------------------------------------------------- dynamic delta, encoder
-// thread = block b of 8 samples (elements 1 + 8 b ... 8 + 8 b); x: the samples; out: the container's sample area
+// thread = block b of 8 samples (elements 1 + 8 b ... 8 + 8 b): one 16-byte request for them (2 bytes off the 16-byte grid), one
+// 4-byte request for the two samples in front, one 16-byte store.  x: the samples; out: the container's sample area
 __global__ void __launch_bounds__(kT) dyndelta_encode_kernel(const uint16_t* x, uint32_t len, uint8_t* out, uint8_t* choices,
                                                              uint32_t choice_bytes, int alt, int64_t* ret)
 {
@@ -63,11 +117,14 @@ __global__ void __launch_bounds__(kT) dyndelta_encode_kernel(const uint16_t* x, 
     int choice = 0;
     if (b < nblocks) {
         const uint32_t at0 = 1 + 8 * b;
-        uint32_t p1 = x[at0 - 1], p2 = at0 >= 2 ? x[at0 - 2] : x[0];
+        const v4 q = *(const v4a2*)(x + at0);
+        uint32_t p1, p2;
+        if (b) { const uint32_t w = *(const u32_a1*)(x + at0 - 2); p2 = w & 0xffffu; p1 = w >> 16; }
+        else { p1 = x[0]; p2 = x[0]; }
         uint32_t z0[8], z1[8], m0 = 0, m1 = 0, s0 = 0, s1 = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const uint32_t v = x[at0 + i];
+            const uint32_t v = half_of(q, i);
             z0[i] = zz16(v - p1);                                  // delta                       online.hpp: DeltaPredictor_u16
             z1[i] = zz16(v - (2 * p1 - p2));                       // double delta                online.hpp: DoubleDeltaPredictor_u16
             p2 = p1;
@@ -79,8 +136,12 @@ __global__ void __launch_bounds__(kT) dyndelta_encode_kernel(const uint16_t* x, 
             s1 += (uint32_t)(16 - __clz((int)z1[i])) & 0xffu;
         }
         choice = alt ? (m0 <= m1 ? 0 : 1) : (s0 <= s1 ? 0 : 1);    // loss0 <= loss1 keeps delta (:119)
-#pragma unroll
-        for (int i = 0; i < 8; i++) st16(out + 2 * (uint64_t)(at0 + i), choice ? z1[i] : z0[i]);
+        v4 o;
+        o.x = (choice ? z1[0] : z0[0]) | ((choice ? z1[1] : z0[1]) << 16);
+        o.y = (choice ? z1[2] : z0[2]) | ((choice ? z1[3] : z0[3]) << 16);
+        o.z = (choice ? z1[4] : z0[4]) | ((choice ? z1[5] : z0[5]) << 16);
+        o.w = (choice ? z1[6] : z0[6]) | ((choice ? z1[7] : z0[7]) << 16);
+        *(v4a2*)(out + 2 * (uint64_t)at0) = o;
     }
     // one choice bit per block, LSB first: a wavefront's 64 bits leave as 8 bytes
     const uint64_t bits = __ballot(choice != 0);
@@ -108,193 +169,358 @@ __device__ __forceinline__ uint64_t pack_aff(const Aff& f) { return (uint64_t)f.
 __device__ __forceinline__ Aff unpack_aff(uint64_t v) { return Aff{(uint32_t)v & 0xffffu, (uint32_t)(v >> 16) & 1u, (uint32_t)(v >> 32) & 0xffffu, (uint32_t)(v >> 48)}; }
 constexpr uint64_t kIdentity = (uint64_t)1 << 16;         // m = 0, a = 1, tx = td = 0
 
-// block b's map from its 8 zigzagged errors; e[] receives the errors
+// block b's map from its 8 zigzagged errors (one 16-byte request); e[] receives the errors
 __device__ __forceinline__ Aff block_map(const uint8_t* in, const uint8_t* choices, uint32_t b, uint32_t (&e)[8], int& choice)
 {
     choice = (choices[b / 8] >> (b % 8)) & 1;
+    v4 q = *(const v4a2*)(in + 2 * (uint64_t)(1 + 8 * b));
+    q.x = unzz16x2(q.x); q.y = unzz16x2(q.y); q.z = unzz16x2(q.z); q.w = unzz16x2(q.w);
     uint32_t A = 0, C = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        e[i] = unzz16(ld16(in + 2 * (uint64_t)(1 + 8 * b + i)));
+        e[i] = half_of(q, i);
         A += e[i];
         C += (uint32_t)(8 - i) * e[i];
     }
     return choice ? Aff{8u, 1u, C & 0xffffu, A & 0xffffu} : Aff{0u, 0u, A & 0xffffu, e[7]};
 }
 
-// inclusive scan of one map per thread over the workgroup (composition is not commutative: left operand = earlier)
-__device__ Aff workgroup_scan(Aff mine, Aff& total, uint64_t* sh)
+__device__ __forceinline__ uint64_t shfl_up64(uint64_t v, int d)
 {
-    const int t = threadIdx.x;
-    sh[t] = pack_aff(mine);
-    __syncthreads();
-    for (int off = 1; off < kT; off <<= 1) {
-        uint64_t prev = kIdentity;
-        if (t >= off) prev = sh[t - off];
-        __syncthreads();
-        if (t >= off) sh[t] = pack_aff(compose(unpack_aff(prev), unpack_aff(sh[t])));
-        __syncthreads();
+    return ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(v >> 32), d) << 32) | (uint32_t)__shfl_up((int)(uint32_t)v, d);
+}
+// scan of one map per thread over the workgroup (composition is not commutative: left operand = earlier).  Returns the composition of
+// the threads BEFORE this one; total = all of them.  sh: kT / 64 words of 64 bits
+__device__ __forceinline__ Aff workgroup_scan_excl(const Aff& mine, Aff& total, uint64_t* sh)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint64_t inc = pack_aff(mine);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t prev = shfl_up64(inc, d);
+        if (lane >= d) inc = pack_aff(compose(unpack_aff(prev), unpack_aff(inc)));
     }
-    total = unpack_aff(sh[kT - 1]);
-    return unpack_aff(sh[t]);
+    uint64_t before = shfl_up64(inc, 1);
+    if (lane == 0) before = kIdentity;
+    if (lane == 63) sh[w] = inc;
+    __syncthreads();
+    Aff base = unpack_aff(kIdentity), all = unpack_aff(kIdentity);
+#pragma unroll
+    for (int k = 0; k < kT / 64; k++) {
+        const Aff wk = unpack_aff(sh[k]);
+        if (k < w) base = compose(base, wk);
+        all = compose(all, wk);
+    }
+    __syncthreads();
+    total = all;
+    return compose(base, unpack_aff(before));
 }
 
+// Three launches: tile summaries (a tile = kTile blocks, a thread kBPT consecutive ones, their maps composed in order), one workgroup
+// scanning the tiles, and the decode proper with every thread's incoming state.  (Round 5 also built the ONE-launch form -- the state in
+// front of a tile from a chained scan over tiles, decoupled look-back as in compact_tail.h -- and measured it slower: 0.166 against
+// 0.129 ms for 64 Mi samples, 0.131 with the look-back cut out.  With 8 192 tiles resident at once the first cohort's look-backs are a
+// chain of ~24 dependent device-scope round trips; a 60 us kernel has nothing to hide that behind.  Same finding for sprintzpack below.)
 __global__ void __launch_bounds__(kT) dyndelta_tile_kernel(const uint8_t* in, const uint8_t* choices, uint32_t nblocks, uint64_t* tiles)
 {
-    __shared__ uint64_t sh[kT];
-    const uint32_t b = blockIdx.x * kT + threadIdx.x;
+    __shared__ uint64_t sh[kT / 64];
+    const uint32_t b0 = (blockIdx.x * kT + threadIdx.x) * kBPT;
     Aff f = unpack_aff(kIdentity);
-    if (b < nblocks) { uint32_t e[8]; int c; f = block_map(in, choices, b, e, c); }
+#pragma unroll
+    for (int j = 0; j < kBPT; j++)
+        if (b0 + j < nblocks) { uint32_t e[8]; int c; f = compose(f, block_map(in, choices, b0 + j, e, c)); }
     Aff total;
-    (void)workgroup_scan(f, total, sh);
+    (void)workgroup_scan_excl(f, total, sh);
     if (threadIdx.x == 0) tiles[blockIdx.x] = pack_aff(total);
 }
 
-// one workgroup: tiles[i] <- composition of tiles[0 .. i-1] (exclusive)
+// one workgroup: tiles[i] <- composition of tiles[0 .. i-1] (exclusive).  The tiles pass through LDS in slabs of kT * kSlab (read
+// and written coalesced; a thread's kSlab consecutive ones are then LDS reads -- as dependent global loads they were 20 us of the call)
+constexpr int kSlab = 16;
 __global__ void __launch_bounds__(kT) dyndelta_tilescan_kernel(uint64_t* tiles, uint32_t ntiles)
 {
-    __shared__ uint64_t sh[kT];
-    const uint32_t per = (ntiles + kT - 1) / kT, lo = threadIdx.x * per, hi = lo + per < ntiles ? lo + per : ntiles;
-    Aff mine = unpack_aff(kIdentity);
-    for (uint32_t i = lo; i < hi; i++) mine = compose(mine, unpack_aff(tiles[i]));
-    Aff total;
-    const Aff incl = workgroup_scan(mine, total, sh);
-    __syncthreads();
-    // exclusive prefix of this thread's run = inclusive of the previous thread
-    Aff run = threadIdx.x == 0 ? unpack_aff(kIdentity) : unpack_aff(sh[threadIdx.x - 1]);
-    (void)incl;
-    for (uint32_t i = lo; i < hi; i++) {
-        const Aff t = unpack_aff(tiles[i]);
-        tiles[i] = pack_aff(run);
-        run = compose(run, t);
+    __shared__ uint64_t slab[kT * kSlab];
+    __shared__ uint64_t sh[kT / 64];
+    Aff carry = unpack_aff(kIdentity);
+    for (uint32_t base = 0; base < ntiles; base += kT * kSlab) {
+        for (int k = 0; k < kSlab; k++) {
+            const uint32_t i = base + k * kT + threadIdx.x;
+            slab[k * kT + threadIdx.x] = i < ntiles ? tiles[i] : kIdentity;
+        }
+        __syncthreads();
+        Aff mine = unpack_aff(kIdentity);
+        for (int k = 0; k < kSlab; k++) mine = compose(mine, unpack_aff(slab[threadIdx.x * kSlab + k]));
+        Aff total;
+        Aff run = compose(carry, workgroup_scan_excl(mine, total, sh));
+        for (int k = 0; k < kSlab; k++) {
+            const Aff t = unpack_aff(slab[threadIdx.x * kSlab + k]);
+            slab[threadIdx.x * kSlab + k] = pack_aff(run);
+            run = compose(run, t);
+        }
+        carry = compose(carry, total);
+        __syncthreads();
+        for (int k = 0; k < kSlab; k++) {
+            const uint32_t i = base + k * kT + threadIdx.x;
+            if (i < ntiles) tiles[i] = slab[k * kT + threadIdx.x];
+        }
+        __syncthreads();
     }
 }
 
 __global__ void __launch_bounds__(kT) dyndelta_decode_kernel(const uint8_t* in, const uint8_t* choices, uint32_t len, uint32_t nblocks,
                                                              const uint64_t* tiles, uint16_t* out, int64_t* ret)
 {
-    __shared__ uint64_t sh[kT];
-    const uint32_t b = blockIdx.x * kT + threadIdx.x;
-    uint32_t e[8];
-    int choice = 0;
+    __shared__ uint64_t sh[kT / 64];
+    const uint32_t b0 = (blockIdx.x * kT + threadIdx.x) * kBPT;
+    uint32_t e[kBPT][8];
+    int choice[kBPT];
     Aff f = unpack_aff(kIdentity);
-    if (b < nblocks) f = block_map(in, choices, b, e, choice);
+#pragma unroll
+    for (int j = 0; j < kBPT; j++) {
+        choice[j] = 0;
+        if (b0 + j < nblocks) f = compose(f, block_map(in, choices, b0 + j, e[j], choice[j]));
+    }
     Aff total;
-    const Aff incl = workgroup_scan(f, total, sh);
-    __syncthreads();
-    // state before this thread's block: (x0, 0) through the tiles before, then the threads before
-    const Aff before_tile = unpack_aff(tiles[blockIdx.x]);
-    const Aff before = threadIdx.x == 0 ? before_tile : compose(before_tile, unpack_aff(sh[threadIdx.x - 1]));
-    (void)incl;
+    const Aff before_wg = workgroup_scan_excl(f, total, sh);
+    // state before this thread's first block: (x0, 0) through the tiles before, then the threads before
+    const Aff before = compose(unpack_aff(tiles[blockIdx.x]), before_wg);
     const uint32_t x0 = ld16(in);
     uint32_t x = (x0 + before.tx) & 0xffffu, d = before.td;       // d starts at 0 (online.hpp: _prev_diff = 0)
-    if (b < nblocks) {
-        uint32_t v[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            d = choice ? (d + e[i]) & 0xffffu : e[i];
-            x = (x + d) & 0xffffu;
-            v[i] = x;
-        }
+    for (int j = 0; j < kBPT; j++) {
+        if (b0 + j < nblocks) {
+            uint32_t v[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) out[1 + 8 * (uint64_t)b + i] = (uint16_t)v[i];
-    }
-    if (b == (nblocks ? nblocks - 1 : 0)) {                       // the owner of the last block walks the < 8 trailing delta errors (:245-251)
-        for (uint32_t at = 1 + 8 * nblocks; at < len; at++) {
-            x = (x + ld16(in + 2 * (uint64_t)at)) & 0xffffu;
-            out[at] = (uint16_t)x;
+            for (int i = 0; i < 8; i++) {
+                d = choice[j] ? (d + e[j][i]) & 0xffffu : e[j][i];
+                x = (x + d) & 0xffffu;
+                v[i] = x;
+            }
+            v4 o;
+            o.x = v[0] | (v[1] << 16); o.y = v[2] | (v[3] << 16); o.z = v[4] | (v[5] << 16); o.w = v[6] | (v[7] << 16);
+            *(v4a2*)(out + 1 + 8 * (uint64_t)(b0 + j)) = o;
+            if (b0 + j == nblocks - 1) {                          // the owner of the last block walks the < 8 trailing delta errors (:245-251)
+                for (uint32_t at = 1 + 8 * nblocks; at < len; at++) {
+                    x = (x + ld16(in + 2 * (uint64_t)at)) & 0xffffu;
+                    out[at] = (uint16_t)x;
+                }
+            }
         }
     }
-    if (b == 0) {
+    if (b0 == 0) {
         out[0] = (uint16_t)x0;
+        if (nblocks == 0) {                                       // fewer than 9 elements: only the trailing deltas
+            uint32_t y = x0;
+            for (uint32_t at = 1; at < len; at++) { y = (y + ld16(in + 2 * (uint64_t)at)) & 0xffffu; out[at] = (uint16_t)y; }
+        }
         if (ret) *ret = len;
     }
 }
 
 // ---------------------------------------------------------------- sprintzpack
-// thread = block of 8 values.  widths[b] = payload bytes of block b (= its bit width); header nibbles two blocks a byte.
-__global__ void __launch_bounds__(kT) pack_width_kernel(const uint16_t* x, uint32_t nblocks, int zig, uint32_t* widths, uint8_t* hdr, uint32_t hdr_bytes)
+// A workgroup takes a TILE of kTile blocks (a thread kBPT consecutive ones).  Three launches either way: the tiles' payload sizes,
+// one workgroup scanning them, and the pack / unpack proper -- which recomputes its blocks' widths (a re-read of the samples / of the
+// header nibbles costs less than round 4's widths array and per-block offsets array written and read back: 12 bytes a block against 16
+// of data).  The one-launch form (a chained scan over tiles, as tried for the dynamic-delta decoder above) measured 0.152 against 0.097 ms.
+__device__ __forceinline__ uint32_t block_width(const v4& q, int zig)
 {
-    const uint32_t b = blockIdx.x * kT + threadIdx.x;
-    uint32_t nb = 0;
-    if (b < nblocks) {
-        const uint4 q = *(const uint4*)(x + 8 * (uint64_t)b);
-        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-        uint32_t all = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t lo = w[k] & 0xffffu, hi = w[k] >> 16;
-            all |= zig ? (zz16(lo) | zz16(hi)) : (lo | hi);
-        }
-        nb = 32u - (uint32_t)__clz((int)all);
-        nb = all == 0 ? 0u : nb;
-        nb += nb == 15u;                                           // bitpack.h:286
-        widths[b] = nb;
-    }
-    // nibble of block b: nb - (nb == 16); the odd lane hands its nibble to the even one (online.cpp:405-412)
-    const uint32_t nib = nb - (nb == 16u);
-    const uint32_t other = (uint32_t)__shfl_down((int)nib, 1);
-    if ((b & 1u) == 0 && b / 2 < hdr_bytes) hdr[b / 2] = (uint8_t)(b < nblocks ? (nib | ((b + 1 < nblocks ? other : 0u) << 4)) : 0u);
+    const uint32_t all = zig ? (zz16x2(q.x) | zz16x2(q.y) | zz16x2(q.z) | zz16x2(q.w)) : (q.x | q.y | q.z | q.w);
+    const uint32_t both = (all | (all >> 16)) & 0xffffu;
+    uint32_t nb = both == 0 ? 0u : 32u - (uint32_t)__clz((int)both);
+    nb += nb == 15u;                                               // bitpack.h:286
+    return nb;
 }
 
-__global__ void __launch_bounds__(kT) pack_write_kernel(const uint16_t* x, uint32_t len, uint32_t nblocks, int zig, const uint32_t* widths,
-                                                        const uint64_t* offsets, uint8_t* payload, uint32_t hdr_elems, int64_t* ret)
+// payload bytes of every tile + the header nibbles (two blocks a byte: nb - (nb == 16), online.cpp:405-412; bytes past the last block: 0)
+__global__ void __launch_bounds__(kT) pack_tile_kernel(const uint16_t* x, uint32_t nblocks, int zig, uint8_t* hdr, uint32_t hdr_bytes, uint32_t* sums)
 {
-    const uint32_t b = blockIdx.x * kT + threadIdx.x;
-    if (b < nblocks) {
-        const uint32_t nb = widths[b];
-        uint8_t* o = payload + offsets[b];
-        unsigned __int128 acc = 0;
+    __shared__ uint32_t sh[kT / 64];
+    const uint32_t gt = blockIdx.x * kT + threadIdx.x, b0 = gt * kBPT;
+    uint32_t sum = 0, nib[kBPT];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            uint32_t v = x[8 * (uint64_t)b + i];
-            v = zig ? zz16(v) : v;
-            acc |= (unsigned __int128)(v & ((1u << nb) - 1u)) << (i * nb);
-        }
-        for (uint32_t k = 0; k < nb; k++) o[k] = (uint8_t)(acc >> (8 * k));
+    for (int j = 0; j < kBPT; j++) {
+        uint32_t nb = 0;
+        if (b0 + j < nblocks) nb = block_width(*(const v4*)(x + 8 * (uint64_t)(b0 + j)), zig);
+        sum += nb;
+        nib[j] = nb - (nb == 16u);
     }
-    if (b == 0) {
-        const uint64_t pos = offsets[nblocks];                    // payload bytes of the full blocks
+#pragma unroll
+    for (int k = 0; k < kBPT / 2; k++)
+        if (gt * (kBPT / 2) + k < hdr_bytes) hdr[gt * (kBPT / 2) + k] = (uint8_t)(nib[2 * k] | (nib[2 * k + 1] << 4));
+    const uint32_t total = workgroup_sum(sum, sh);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(kT) unpack_tile_kernel(const uint8_t* hdr, uint32_t nblocks, uint32_t* sums)
+{
+    __shared__ uint32_t sh[kT / 64];
+    const uint32_t b0 = (blockIdx.x * kT + threadIdx.x) * kBPT;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < kBPT; j++)
+        if (b0 + j < nblocks) { const uint32_t nb = (hdr[(b0 + j) / 2] >> (4 * ((b0 + j) & 1u))) & 15u; sum += nb + (nb == 15u); }   // 15 means 16 (online.cpp:560)
+    const uint32_t total = workgroup_sum(sum, sh);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// one workgroup: offs[i] = sum of sums[0 .. i-1], offs[ntiles] = everything.  The sums pass through LDS in slabs (read coalesced; a
+// thread's consecutive ones are then LDS reads -- as dependent global loads this kernel was 20 us of a 100 us call)
+constexpr int kSumSlab = 32;
+__global__ void __launch_bounds__(kT) tile_offsets_kernel(const uint32_t* sums, uint32_t ntiles, uint64_t* offs)
+{
+    __shared__ uint32_t slab[kT * kSumSlab];
+    __shared__ uint32_t sh[kT / 64];
+    uint64_t carry = 0;
+    for (uint32_t base = 0; base < ntiles; base += kT * kSumSlab) {
+        for (int k = 0; k < kSumSlab; k++) {
+            const uint32_t i = base + k * kT + threadIdx.x;
+            slab[k * kT + threadIdx.x] = i < ntiles ? sums[i] : 0u;
+        }
+        __syncthreads();
+        uint32_t mine = 0;
+        for (int k = 0; k < kSumSlab; k++) mine += slab[threadIdx.x * kSumSlab + k];      // (a slab's payload is < 2^32: 8 192 tiles of <= 16 KB)
+        uint32_t run = workgroup_excl(mine, sh);
+        const uint32_t slab_total = workgroup_sum(mine, sh);
+        for (int k = 0; k < kSumSlab; k++) {
+            const uint32_t v = slab[threadIdx.x * kSumSlab + k];
+            slab[threadIdx.x * kSumSlab + k] = run;
+            run += v;
+        }
+        __syncthreads();
+        for (int k = 0; k < kSumSlab; k++) {
+            const uint32_t i = base + k * kT + threadIdx.x;
+            if (i < ntiles) offs[i] = carry + slab[k * kT + threadIdx.x];
+        }
+        carry += slab_total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) offs[ntiles] = carry;
+}
+
+constexpr uint32_t kPackImage = kTile * 16 + 32;                  // a tile's payload (<= 16 bytes a block) + its misalignment + slack
+
+// The tile's payload is assembled in LDS (fields OR-ed into a zeroed image that starts on the 16-byte line the tile's first byte lies
+// in) and leaves in 16-byte pieces; the first and last partial pieces go out byte by byte (the neighbours' bytes share those lines).
+__global__ void __launch_bounds__(kT) pack_write_kernel(const uint16_t* x, uint32_t len, uint32_t nblocks, int zig, const uint64_t* tile_offs, uint32_t ntiles,
+                                                        uint8_t* payload, uint32_t hdr_elems, int64_t* ret)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t img[kPackImage / 4];
+    __shared__ uint32_t sh[kT / 64];
+    const uint32_t tile = blockIdx.x;
+    const uint32_t t = threadIdx.x, b0 = (tile * kT + t) * kBPT;
+    const uint64_t g0 = tile_offs[tile];
+    const uint32_t tile_bytes = (uint32_t)(tile_offs[tile + 1] - g0);
+    const uint32_t mis = (uint32_t)((uintptr_t)(payload + g0) & 15u);
+    for (uint32_t u = t; u < (mis + tile_bytes + 31u) / 16u; u += kT) ((uint4*)img)[u] = make_uint4(0, 0, 0, 0);
+    v4 q[kBPT];
+    uint32_t nb[kBPT], sum = 0;
+#pragma unroll
+    for (int j = 0; j < kBPT; j++) {
+        nb[j] = 0;
+        q[j] = v4{0, 0, 0, 0};
+        if (b0 + j < nblocks) {
+            q[j] = *(const v4*)(x + 8 * (uint64_t)(b0 + j));
+            nb[j] = block_width(q[j], zig);
+            if (zig) { q[j].x = zz16x2(q[j].x); q[j].y = zz16x2(q[j].y); q[j].z = zz16x2(q[j].z); q[j].w = zz16x2(q[j].w); }
+        }
+        sum += nb[j];
+    }
+    uint32_t at = mis + workgroup_excl(sum, sh);                  // (its barriers also order the zeroing before the ORs)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)img;
+#pragma unroll
+    for (int j = 0; j < kBPT; j++) {
+        const uint32_t n = nb[j];
+        if (n) {
+            // 8 fields of n bits = n bytes: the low four in one 64-bit word, the high four in another, joined 4 n bits up
+            const uint64_t lo = (uint64_t)(q[j].x & 0xffffu) | ((uint64_t)(q[j].x >> 16) << n) | ((uint64_t)(q[j].y & 0xffffu) << (2 * n)) | ((uint64_t)(q[j].y >> 16) << (3 * n));
+            const uint64_t hi = (uint64_t)(q[j].z & 0xffffu) | ((uint64_t)(q[j].z >> 16) << n) | ((uint64_t)(q[j].w & 0xffffu) << (2 * n)) | ((uint64_t)(q[j].w >> 16) << (3 * n));
+            const uint32_t s = 4 * n;                              // 4 .. 64
+            const uint64_t w01 = s < 64 ? lo | (hi << s) : lo;
+            const uint64_t w23 = s < 64 ? hi >> (64 - s) : hi;
+            const uint32_t a[6] = {0u, (uint32_t)w01, (uint32_t)(w01 >> 32), (uint32_t)w23, (uint32_t)(w23 >> 32), 0u};
+            const uint32_t k = at & 3u;                            // byte shift inside the first dword
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                const uint32_t d = k ? __builtin_amdgcn_alignbyte(a[i + 1], a[i], 4u - k) : a[i + 1];
+                if (4u * i < n + k && d)
+                    __hip_atomic_fetch_or((__attribute__((address_space(3))) uint32_t*)(uintptr_t)(lds0 + (at & ~3u) + 4u * i), d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        at += n;
+    }
+    __syncthreads();
+    // image byte i is payload byte (g0 - mis) + i
+    uint8_t* const gbase = payload + g0 - mis;
+    const uint32_t end = mis + tile_bytes;
+    const uint8_t* const ib = (const uint8_t*)img;
+    for (uint32_t u = t * 16u; u < end; u += kT * 16u) {
+        if (u >= mis && u + 16u <= end) *(uint4*)(gbase + u) = *(const uint4*)(ib + u);
+        else for (uint32_t k = u < mis ? mis : u; k < u + 16u && k < end; k++) gbase[k] = ib[k];
+    }
+    if (tile == ntiles - 1 && t == 0) {                           // the last tile knows where the payload of the full blocks ends
+        const uint64_t pos = g0 + tile_bytes;
         uint8_t* o = payload + pos;
         const uint32_t tail = len - 8 * nblocks;
         for (uint32_t k = 0; k < tail; k++) st16(o + 2 * k, x[8 * (uint64_t)nblocks + k]);   // raw, at any byte alignment (:476-478)
-        const uint64_t end = pos + 2 * (uint64_t)tail;
-        if (end & 1) o[2 * tail] = 0;                            // the container is counted in elements: a defined pad byte
-        if (ret) *ret = 2 + (int64_t)hdr_elems + (int64_t)((end + 1) / 2);
+        const uint64_t endb = pos + 2 * (uint64_t)tail;
+        if (endb & 1) o[2 * tail] = 0;                           // the container is counted in elements: a defined pad byte
+        if (ret) *ret = 2 + (int64_t)hdr_elems + (int64_t)((endb + 1) / 2);
     }
 }
 
-__global__ void __launch_bounds__(kT) unpack_width_kernel(const uint8_t* hdr, uint32_t nblocks, uint32_t* widths)
+// the tile's payload -> LDS in 16-byte pieces (from the line its first byte lies in), then every thread takes its blocks from there
+__global__ void __launch_bounds__(kT) unpack_read_kernel(const uint8_t* hdr, const uint8_t* payload, uint32_t len, uint32_t nblocks, int zig,
+                                                         const uint64_t* tile_offs, uint32_t ntiles, uint16_t* out, int64_t* ret)
 {
-    const uint32_t b = blockIdx.x * kT + threadIdx.x;
-    if (b >= nblocks) return;
-    uint32_t nb = (hdr[b / 2] >> (4 * (b & 1u))) & 15u;
-    nb += nb == 15u;                                               // 15 means 16 (online.cpp:560)
-    widths[b] = nb;
-}
-
-__global__ void __launch_bounds__(kT) unpack_read_kernel(const uint8_t* payload, uint32_t len, uint32_t nblocks, int zig, const uint32_t* widths,
-                                                         const uint64_t* offsets, uint16_t* out, int64_t* ret)
-{
-    const uint32_t b = blockIdx.x * kT + threadIdx.x;
-    if (b < nblocks) {
-        const uint32_t nb = widths[b];
-        const uint8_t* in = payload + offsets[b];
-        unsigned __int128 acc = 0;
-        for (uint32_t k = 0; k < nb; k++) acc |= (unsigned __int128)in[k] << (8 * k);
-        uint32_t v[8];
+    __shared__ __attribute__((aligned(16))) uint32_t img[kPackImage / 4 + 4];
+    __shared__ uint32_t sh[kT / 64];
+    const uint32_t tile = blockIdx.x;
+    const uint32_t t = threadIdx.x, b0 = (tile * kT + t) * kBPT;
+    const uint64_t g0 = tile_offs[tile];
+    const uint32_t tile_bytes = (uint32_t)(tile_offs[tile + 1] - g0);
+    const uint32_t mis = (uint32_t)((uintptr_t)(payload + g0) & 15u);
+    const uint8_t* const gbase = payload + g0 - mis;
+    // (the last piece may reach past the payload by < 16 bytes: inside its own 16-byte line)
+    for (uint32_t u = t * 16u; u < mis + tile_bytes; u += kT * 16u) *(uint4*)((uint8_t*)img + u) = *(const uint4*)(gbase + u);
+    uint32_t nb[kBPT], sum = 0;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const uint32_t z = (uint32_t)(acc >> (i * nb)) & ((1u << nb) - 1u);
-            v[i] = zig ? unzz16(z) : z;
-        }
-        uint4 q;
-        q.x = v[0] | (v[1] << 16); q.y = v[2] | (v[3] << 16); q.z = v[4] | (v[5] << 16); q.w = v[6] | (v[7] << 16);
-        *(uint4*)(out + 8 * (uint64_t)b) = q;
+    for (int j = 0; j < kBPT; j++) {
+        nb[j] = 0;
+        if (b0 + j < nblocks) { const uint32_t f = (hdr[(b0 + j) / 2] >> (4 * ((b0 + j) & 1u))) & 15u; nb[j] = f + (f == 15u); }   // 15 means 16 (online.cpp:560)
+        sum += nb[j];
     }
-    if (b == 0) {
-        const uint8_t* in = payload + offsets[nblocks];
-        for (uint32_t at = 8 * nblocks; at < len; at++) out[at] = (uint16_t)ld16(in + 2 * (uint64_t)(at - 8 * nblocks));
+    const uint32_t excl = workgroup_excl(sum, sh);                // (its barriers also order the image's writes before the reads)
+    uint32_t at = mis + excl;
+#pragma unroll
+    for (int j = 0; j < kBPT; j++) {
+        const uint32_t n = nb[j];
+        if (b0 + j < nblocks) {
+            const uint32_t* const p = img + (at >> 2);
+            const uint32_t k = at & 3u;
+            const uint32_t a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4];
+            const uint32_t w0 = __builtin_amdgcn_alignbyte(a1, a0, k), w1 = __builtin_amdgcn_alignbyte(a2, a1, k);
+            const uint32_t w2 = __builtin_amdgcn_alignbyte(a3, a2, k), w3 = __builtin_amdgcn_alignbyte(a4, a3, k);
+            const uint64_t w01 = ((uint64_t)w1 << 32) | w0, w23 = ((uint64_t)w3 << 32) | w2;
+            const uint32_t s = 4 * n;                              // 0 .. 64
+            const uint64_t lo = w01;
+            const uint64_t hi = s == 0 ? 0ull : s < 64 ? (w01 >> s) | (w23 << (64 - s)) : w23;
+            const uint32_t mask = n >= 16 ? 0xffffu : (1u << n) - 1u;
+            uint32_t v[8];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                v[i] = (uint32_t)(lo >> (i * n)) & mask;
+                v[4 + i] = (uint32_t)(hi >> (i * n)) & mask;
+            }
+            v4 o;
+            o.x = v[0] | (v[1] << 16); o.y = v[2] | (v[3] << 16); o.z = v[4] | (v[5] << 16); o.w = v[6] | (v[7] << 16);
+            if (zig) { o.x = unzz16x2(o.x); o.y = unzz16x2(o.y); o.z = unzz16x2(o.z); o.w = unzz16x2(o.w); }
+            *(v4*)(out + 8 * (uint64_t)(b0 + j)) = o;
+        }
+        at += n;
+    }
+    if (tile == ntiles - 1 && t == 0) {
+        const uint8_t* in = payload + g0 + tile_bytes;
+        for (uint32_t k = 8 * nblocks; k < len; k++) out[k] = (uint16_t)ld16(in + 2 * (uint64_t)(k - 8 * nblocks));
         if (ret) *ret = len;
     }
 }
@@ -316,6 +542,8 @@ __global__ void check_len_kernel(const uint8_t* src, uint32_t len, int64_t* ret)
 
 int fail(int code, const char* what) { return sprintz::set_error(code, what); }
 unsigned grid_for(uint64_t items) { return (unsigned)((items + kT - 1) / kT); }
+size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+unsigned tiles_for(uint64_t blocks) { return (unsigned)((blocks + kTile - 1) / kTile); }
 
 uint32_t choice_bytes_of(uint32_t len) { return (((len + 7) / 8) + 7) / 8; }                 // online.cpp:253-258
 uint32_t hdr_bytes_of(uint32_t len) { return (((len + 7) / 8) * 4 + 7) / 8; }                // online.cpp:355-359
@@ -324,7 +552,6 @@ uint32_t hdr_bytes_of(uint32_t len) { return (((len + 7) / 8) * 4 + 7) / 8; }   
 
 namespace {
 constexpr size_t kOnlinePinMax = 4u << 20;     // larger transfers go straight from/to the caller's memory
-size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // `in_bytes` of `in` -> device, run(d_in, d_out, d_ret, d_tmp, stream), then ret elements of 2 bytes -> `out`
 template <typename F>
@@ -369,9 +596,10 @@ size_t sprintz_mi355x_online_bound(int kind, uint32_t len)
 size_t sprintz_mi355x_online_tmp_bytes(int kind, uint32_t len)
 {
     const uint64_t nblocks = len / 8 + 1;
-    if (kind <= SPRINTZ_ONLINE_DYNDELTA_ALT) return (size_t)(((nblocks + kT - 1) / kT + 1) * 8 + 256);
+    const uint64_t ntiles = (nblocks + 4 + kTile - 1) / kTile + 1;
+    if (kind <= SPRINTZ_ONLINE_DYNDELTA_ALT) return (size_t)(ntiles * 8 + 256);               // one composed map a tile
     if (kind == SPRINTZ_ONLINE_ZIGZAG) return 16;
-    return (size_t)(nblocks * 4 + 256 + (nblocks + 1) * 8 + 256 + sprintz_mi355x_compact_tmp_bytes(nblocks) + 256);
+    return (size_t)(up256(ntiles * 4) + (ntiles + 1) * 8 + 256);                               // a payload size and an offset a tile
 }
 
 int sprintz_mi355x_online_pack_device(int kind, const uint16_t* d_src, uint32_t len, void* d_dest, int64_t* d_ret, void* d_tmp, void* hip_stream)
@@ -389,11 +617,14 @@ int sprintz_mi355x_online_pack_device(int kind, const uint16_t* d_src, uint32_t 
         const uint32_t cb = choice_bytes_of(len), celems = (cb + 1) / 2;
         uint8_t* choices = body + 2 * (size_t)len;
         // header, the choice bytes zeroed (bits of blocks that do not exist, the pad byte), and the return value of the short inputs
-        hipLaunchKernelGGL(header_kernel, dim3(1), dim3(256), 0, st, dest, len, choices, celems * 2, d_ret, (int64_t)2 + len + celems, 1);
+        // header; the return value of the short inputs.  The choice bytes (bits of blocks that do not exist and the pad byte included) are
+        // written by the encode launch itself, whose grid reaches 64 blocks = 8 bytes past the last block (round 4 zeroed them here, a
+        // megabyte for 64 Mi samples, with ONE workgroup: a third of the call)
+        hipLaunchKernelGGL(header_kernel, dim3(1), dim3(256), 0, st, dest, len, choices, len >= 2 ? 0u : celems * 2, d_ret, (int64_t)2 + len + celems, 1);
         if (len == 1) (void)hipMemcpyAsync(body, d_src, 2, hipMemcpyDeviceToDevice, st);
         if (len >= 2) {
             const uint32_t nblocks = (len - 1) / 8;
-            hipLaunchKernelGGL(dyndelta_encode_kernel, dim3(grid_for(nblocks ? nblocks : 1)), dim3(kT), 0, st, d_src, len, body, choices, celems * 2,
+            hipLaunchKernelGGL(dyndelta_encode_kernel, dim3(grid_for((uint64_t)nblocks + 64)), dim3(kT), 0, st, d_src, len, body, choices, celems * 2,
                                kind == SPRINTZ_ONLINE_DYNDELTA_ALT ? 1 : 0, d_ret);
         }
     } else {
@@ -401,14 +632,14 @@ int sprintz_mi355x_online_pack_device(int kind, const uint16_t* d_src, uint32_t 
         const uint32_t nblocks = len / 8, hb = hdr_bytes_of(len), helems = (hb + 1) / 2;
         uint8_t* hdr = body;
         uint8_t* payload = body + 2 * (size_t)helems;
-        uint32_t* widths = (uint32_t*)d_tmp;
-        uint64_t* offsets = (uint64_t*)((uint8_t*)d_tmp + (((size_t)nblocks + 1) * 4 + 255) / 256 * 256);
-        void* scan_tmp = (uint8_t*)offsets + (((size_t)nblocks + 2) * 8 + 255) / 256 * 256;
+        const uint32_t ntiles = tiles_for((uint64_t)nblocks + 4);          // (+ 4: the header's pad nibbles are zeroed by the threads behind the last block)
+        uint32_t* sums = (uint32_t*)d_tmp;
+        uint64_t* toffs = (uint64_t*)((uint8_t*)d_tmp + up256((size_t)ntiles * 4));
         hipLaunchKernelGGL(header_kernel, dim3(1), dim3(256), 0, st, dest, len, hdr, nblocks ? 0u : helems * 2, d_ret, (int64_t)2 + helems + len, nblocks ? 0 : 1);
         if (nblocks) {
-            hipLaunchKernelGGL(pack_width_kernel, dim3(grid_for((uint64_t)nblocks + 4)), dim3(kT), 0, st, d_src, nblocks, zig, widths, hdr, helems * 2);
-            if (launch_size_scan(widths, nblocks, 1, offsets, scan_tmp, st) != hipSuccess) return fail(SPRINTZ_E_HIP, "online: size scan launch");
-            hipLaunchKernelGGL(pack_write_kernel, dim3(grid_for(nblocks)), dim3(kT), 0, st, d_src, len, nblocks, zig, widths, offsets, payload, helems, d_ret);
+            hipLaunchKernelGGL(pack_tile_kernel, dim3(ntiles), dim3(kT), 0, st, d_src, nblocks, zig, hdr, helems * 2, sums);
+            hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(kT), 0, st, (const uint32_t*)sums, ntiles, toffs);
+            hipLaunchKernelGGL(pack_write_kernel, dim3(ntiles), dim3(kT), 0, st, d_src, len, nblocks, zig, (const uint64_t*)toffs, ntiles, payload, helems, d_ret);
         } else if (len) {                                           // fewer than 8 values: all of them raw
             (void)hipMemcpyAsync(payload, d_src, (size_t)len * 2, hipMemcpyDeviceToDevice, st);
         }
@@ -429,7 +660,7 @@ int sprintz_mi355x_online_unpack_device(int kind, const void* d_src, uint32_t le
     if (kind == SPRINTZ_ONLINE_ZIGZAG) {
         hipLaunchKernelGGL(zigzag_kernel, dim3(grid_for(((uint64_t)len + 7) / 8)), dim3(kT), 0, st, body, (uint8_t*)d_dest, len, 1, d_ret);
     } else if (kind <= SPRINTZ_ONLINE_DYNDELTA_ALT) {
-        const uint32_t nblocks = (len - 1) / 8, ntiles = grid_for(nblocks ? nblocks : 1);
+        const uint32_t nblocks = (len - 1) / 8, ntiles = tiles_for(nblocks ? nblocks : 1);
         const uint8_t* choices = body + 2 * (size_t)len;
         uint64_t* tiles = (uint64_t*)d_tmp;
         hipLaunchKernelGGL(dyndelta_tile_kernel, dim3(ntiles), dim3(kT), 0, st, body, choices, nblocks, tiles);
@@ -439,17 +670,12 @@ int sprintz_mi355x_online_unpack_device(int kind, const void* d_src, uint32_t le
         const int zig = kind == SPRINTZ_ONLINE_PACK_ZIGZAG;
         const uint32_t nblocks = len / 8, hb = hdr_bytes_of(len), helems = (hb + 1) / 2;
         const uint8_t* payload = body + 2 * (size_t)helems;
-        uint32_t* widths = (uint32_t*)d_tmp;
-        uint64_t* offsets = (uint64_t*)((uint8_t*)d_tmp + (((size_t)nblocks + 1) * 4 + 255) / 256 * 256);
-        void* scan_tmp = (uint8_t*)offsets + (((size_t)nblocks + 2) * 8 + 255) / 256 * 256;
-        if (nblocks) {
-            hipLaunchKernelGGL(unpack_width_kernel, dim3(grid_for(nblocks)), dim3(kT), 0, st, body, nblocks, widths);
-            if (launch_size_scan(widths, nblocks, 1, offsets, scan_tmp, st) != hipSuccess) return fail(SPRINTZ_E_HIP, "online: size scan launch");
-        } else {
-            (void)hipMemsetAsync(offsets, 0, 8, st);
-        }
-        hipLaunchKernelGGL(unpack_read_kernel, dim3(grid_for(nblocks ? nblocks : 1)), dim3(kT), 0, st, payload, len, nblocks, zig, (const uint32_t*)widths,
-                           (const uint64_t*)offsets, d_dest, d_ret);
+        const uint32_t ntiles = tiles_for(nblocks ? nblocks : 1);
+        uint32_t* sums = (uint32_t*)d_tmp;
+        uint64_t* toffs = (uint64_t*)((uint8_t*)d_tmp + up256((size_t)ntiles * 4));
+        hipLaunchKernelGGL(unpack_tile_kernel, dim3(ntiles), dim3(kT), 0, st, body, nblocks, sums);
+        hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(kT), 0, st, (const uint32_t*)sums, ntiles, toffs);
+        hipLaunchKernelGGL(unpack_read_kernel, dim3(ntiles), dim3(kT), 0, st, body, payload, len, nblocks, zig, (const uint64_t*)toffs, ntiles, d_dest, d_ret);
     }
     hipLaunchKernelGGL(check_len_kernel, dim3(1), dim3(1), 0, st, src, len, d_ret);     // the header must agree with the caller
     return hipGetLastError() == hipSuccess ? 0 : fail(SPRINTZ_E_HIP, "online: unpack launch");

@@ -27,7 +27,7 @@ def run_bench(argv, env_extra=None, timeout=240):
     return p
 
 
-@pytest.mark.parametrize("n", [2, 4])
+@pytest.mark.parametrize("n", [2, 4, 8])
 def test_gpus_n_launches_its_own_ranks(n):
     p = run_bench(["--gpus", str(n), "--dry-launch"], {"BENCH_BACKEND": "gloo"})
     assert p.returncode == 0, p.stderr[-2000:]

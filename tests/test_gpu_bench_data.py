@@ -225,3 +225,31 @@ def test_layout_gather_on_two_real_ranks(sz):
     for rank, backend, sizes, bases, err in got:
         assert backend.startswith("rccl-c-abi"), (backend, err)
         assert sizes == [1000, 1017] and bases == [0, 1000]
+
+
+def test_the_line_of_an_8_rank_run_on_one_device():
+    """`python bench.py --gpus 8` as the driver starts it at round end, on the ONE GPU a test box has (BENCH_ONE_DEVICE: eight ranks
+    share the device, gloo carries the layout exchange -- RCCL refuses two ranks on one device): the sharding, the strong-scaled
+    per_config legs, the merge over ranks and the record are the real ones.  The stdout line must stay below the driver's parser
+    limit WITH eight ranks' fields on it, name all eight container bases, and say who gathered the layout."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"BENCH_ONE_DEVICE": "1", "BENCH_BACKEND": "gloo"})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--nchunks", "8192", "--steps", "5", "--warmup", "2",
+                        "--configs", "cfg4_10000,cfg5", "--no-sweep", "--no-extras", "--cpu-seconds", "0.5", "--config-reps", "5", "--ramp-ms", "20"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    assert len(lines[0]) < 10000, len(lines[0])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["config"]["chunks_per_gpu"] == 8192
+    assert len(d["rank_bases"]) == 8 and d["rank_bases"][0] == 0 and all(b > a for a, b in zip(d["rank_bases"], d["rank_bases"][1:]))
+    assert "rccl_ranks_seen" in d and d["container_bytes_all_ranks"] > d["rank_bases"][7]
+    assert d["roofline"]["traffic_measured_in_this_run"] is False
+    summ = d["per_config_summary"]
+    assert set(summ) >= {"fields", "cfg2", "cfg4_10000", "cfg5"} and summ["cfg4_10000"] != "error" and summ["cfg5"] != "error"
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0
