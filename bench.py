@@ -1259,6 +1259,12 @@ def headline_extras(cx, codec, x, comp, offsets, ws, out, nchunks, total_comp, c
         res["single_call_threads"]["native"] = native_threads_leg()
         # ---------------- online.hpp's u16 coders: ONE stream of 64 Mi samples per call, device buffers
         res["online_coders"] = online_leg(cx)
+        # ---------------- the stand-alone transforms (delta.cpp, predict.cpp) and a 1 000-column shape (csrc/any_ndims.hip)
+        try:
+            res["transforms"] = transforms_leg(cx)
+            res["any_ndims"] = any_ndims_leg(cx)
+        except Exception as e:      # noqa: BLE001 -- a failing leg must not cost the headline line
+            res["transforms"] = {"failed": repr(e)[:200]}
         # ---------------- real (measured) data: what the image holds without a network
         try:
             res["real_data"] = real_data_leg(cx)
@@ -1280,6 +1286,53 @@ def headline_extras(cx, codec, x, comp, offsets, ws, out, nchunks, total_comp, c
                                  "what": "sprintz_mi355x_decompress_chunked_host: pageable host buffers in and out (H2D of the streams, kernel, D2H "
                                          "of the samples, allocations included); bounded by the 63 GB/s PCIe Gen5 link -- never `value`"}
     return res
+
+
+def transforms_leg(cx):
+    """delta / double delta / FIRE as stand-alone transforms (delta.cpp:35,533; predict.cpp:57,302) on ONE stream of 64 Mi uint16 samples x 8
+    columns' worth of rows: bytes in = bytes out, so frac = 2 x stream bytes / time over 8 TB/s.  -> {kind: [enc_ms, enc_frac, dec_ms, dec_frac]}"""
+    torch, dev, timed = cx.torch, cx.device, cx.timer
+    import sprintz_amd
+    from synth import synth_torch
+    D, rows = 8, (64 << 20) // 8
+    x = synth_torch("walk", 2, 1, rows, D, dev, seed=123, step=8).reshape(-1)
+    nbytes = x.numel() * 2
+    out = {"samples": x.numel(), "ndims": D, "fields": "enc_ms, enc_frac, dec_ms, dec_frac"}
+    for kind in ("delta", "doubledelta"):
+        y, back = torch.empty_like(x), torch.empty_like(x)
+        te = timed(lambda: sprintz_amd.transform_device(kind, x, D, out=y), 10, 2)
+        td = timed(lambda: sprintz_amd.transform_device(kind, y, D, inverse=True, out=back), 10, 2)
+        assert torch.equal(back.view(torch.int16), x.view(torch.int16)), kind
+        out[kind] = [round(te, 4), round(2 * nbytes / (te * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), round(td, 4), round(2 * nbytes / (td * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)]
+    # FIRE as a transform of ONE stream is a recurrence down every column over the WHOLE stream (the counters never reset): eight lanes of
+    # work for eight columns, however long the stream -- a latency, measured on a sixteenth of the stream and labelled as such
+    xs = x[: x.numel() // 16]
+    y, back = torch.empty_like(xs), torch.empty_like(xs)
+    te = timed(lambda: sprintz_amd.transform_device("xff", xs, D, out=y), 1, 1)
+    td = timed(lambda: sprintz_amd.transform_device("xff", y, D, inverse=True, out=back), 1, 1)
+    assert torch.equal(back.view(torch.int16), xs.view(torch.int16)), "xff"
+    out["xff_serial_4Mi_samples"] = [round(te, 3), round(4 * xs.numel() / (te * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), round(td, 3), round(4 * xs.numel() / (td * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)]
+    return out
+
+
+def any_ndims_leg(cx):
+    """uint16 x 1 000 columns, FIRE, chunks of 16 groups (256 rows = 512 000 bytes), 1 024 chunks = 524 MB: the one-workgroup-per-chunk kernels
+    of csrc/any_ndims.hip (513 .. 65 535 columns).  -> {dec_ms, dec_frac, enc_ms, enc_frac, ratio}"""
+    torch, dev, timed = cx.torch, cx.device, cx.timer
+    import sprintz_amd
+    from synth import synth_torch
+    D, rows, n = 1000, 256, 1024
+    x = synth_torch("walk", 2, n, rows, D, dev, seed=123, step=8).view(torch.int16)
+    cd = sprintz_amd.ChunkedCodec("xff", 2, D, rows * D, device=dev)
+    batch = cd.compress(x)
+    out = torch.empty_like(x)
+    te = timed(lambda: cd.compress(x), 5, 1)
+    td = timed(lambda: cd.decompress(batch, out=out), 5, 1)
+    assert torch.equal(out, x), "any_ndims: GPU decode != input"
+    raw, sb = x.numel() * 2, batch.stream_bytes()
+    return {"workload": "uint16 x 1000 columns, FIRE, 256-row chunks, 1024 chunks", "ratio": round(raw / sb, 4),
+            "dec_ms": round(td, 4), "dec_frac": round((raw + sb) / (td * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "enc_ms": round(te, 4), "enc_frac": round((raw + sb) / (te * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
 
 def online_leg(cx):

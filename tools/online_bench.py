@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py's online_coders leg alone (the 2020 coders of online.cpp on one 128 MiB uint16 stream): python tools/online_bench.py"""
+"""single legs of bench.py's extras: python tools/online_bench.py [online|transforms|any_ndims ...]  (default: online)"""
 import json
 import os
 import sys
@@ -12,4 +12,5 @@ import bench  # noqa: E402
 
 cx = bench.Ctx()
 cx.torch, cx.device, cx.timer = torch, torch.device("cuda", 0), bench.Timer(torch)
-print(json.dumps(bench.online_leg(cx), indent=1))
+for leg in (sys.argv[1:] or ["online"]):
+    print(json.dumps({leg: getattr(bench, leg + "_leg")(cx)}, indent=1))
