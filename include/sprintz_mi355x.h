@@ -47,7 +47,7 @@ extern "C" {
  *   3  round 3: compress_batch_dense / compress_dense_tmp_bytes, SPRINTZ_OPT_DENSE_MODE, env SPRINTZ_MI355X_RCCL_SONAME
  *   4  round 3: compress_batch_colmajor_dense, SPRINTZ_OPT_SPLIT_LANES, SPRINTZ_OPT_ENC_PAIR
  *   5  round 4: SPRINTZ_OPT_HOST_WAIT, SPRINTZ_OPT_LAT_CHUNKS, SPRINTZ_OPT_HOST_STREAMS, SPRINTZ_OPT_REF_DECODER_QUIRK (the single-call entry points work on a mapped staging buffer: one wait per call)
- *   6  round 5: huf0_decompress_batch_hint, SPRINTZ_OPT_HUF0_SYNC_CHUNKS */
+ *   6  round 5: huf0_decompress_batch_hint, SPRINTZ_OPT_HUF0_SYNC_CHUNKS, SPRINTZ_MI355X_MAX_NDIMS 65535 */
 #define SPRINTZ_MI355X_ABI_VERSION 6
 
 /* codec ids */
@@ -67,7 +67,8 @@ extern "C" {
 #define SPRINTZ_E_UNSUPPORTED (-4)  /* ndims above SPRINTZ_MI355X_MAX_NDIMS (or above 512 where only the lane-group kernels exist) */
 #define SPRINTZ_E_CORRUPT    (-5)   /* decoder: stream header disagrees with the arguments */
 
-#define SPRINTZ_MI355X_MAX_NDIMS 2047   /* 513 .. 2047: the four RLE codec pairs, row-major, no query (csrc/any_ndims.hip); everything else <= 512 */
+#define SPRINTZ_MI355X_MAX_NDIMS 65535  /* whatever the stream header's uint16 holds (format.h:36-45).  513 .. 65535: the four RLE codec pairs, row-major,
+                                           no query (csrc/any_ndims.hip: one workgroup per chunk; from 2048 on in column tiles); everything else <= 512 */
 
 /* Extra readable bytes the decoder may touch after the last stream byte and
  * the encoder after the last input element (aligned 8-byte windows; the

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SPRINTZ_MI355X_LIB") or os.path.join(_HERE, "libsprin
 E_INVALID, E_NO_DEVICE, E_HIP, E_UNSUPPORTED, E_CORRUPT = -1, -2, -3, -4, -5
 CODEC_DELTA, CODEC_XFF, CODEC_DELTA_NORLE, CODEC_BITPACK_NORLE, CODEC_XFF_NORLE = 0, 1, 2, 3, 4
 READ_SLACK = 16
-MAX_NDIMS = 2047
+MAX_NDIMS = 65535
 
 
 class SprintzError(RuntimeError):

@@ -428,6 +428,15 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
     if (D > 512) {
         if (norle || cs || qs.q != kQueryOff) return fail(SPRINTZ_E_UNSUPPORTED, "more than 512 columns: the RLE codecs, row-major, without query only");
         if (nchunks > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
+        if (D > 2047) {                                        // column tiles; the FIRE counters in stream-ordered scratch (any_ndims.hip, "big")
+            int32_t* counters = nullptr;
+            const bool fire = codec == SPRINTZ_CODEC_XFF;
+            if (fire && hipMallocAsync((void**)&counters, (size_t)nchunks * (size_t)D * 4, st) != hipSuccess) return fail(SPRINTZ_E_HIP, "hipMallocAsync of the counters' scratch");
+            const hipError_t eb = launch_decode_big(8 * esz, fire, (unsigned)nchunks, st, a, counters);
+            if (counters) (void)hipFreeAsync(counters, st);
+            if (eb != hipSuccess) return fail(SPRINTZ_E_HIP, "decode_big kernel launch", eb);
+            return 0;
+        }
         const hipError_t ea = launch_decode_any(8 * esz, codec == SPRINTZ_CODEC_XFF, (unsigned)nchunks, st, a);
         if (ea != hipSuccess) return fail(SPRINTZ_E_HIP, "decode_any kernel launch", ea);
         return 0;
@@ -585,6 +594,16 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     if (D > 512) {
         if (norle || col_stride) return fail(SPRINTZ_E_UNSUPPORTED, "more than 512 columns: the RLE codecs, row-major only");
         if (nchunks > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
+        if (D > 2047) {                                        // column tiles, fields OR-ed straight into the zeroed slot (any_ndims.hip, "big")
+            if (slot_stride % 16 || ((uintptr_t)d_slots & 15)) return fail(SPRINTZ_E_INVALID, "more than 2047 columns: slots must be 16-byte aligned and a multiple of 16 bytes");
+            int32_t* counters = nullptr;
+            const bool fire = codec == SPRINTZ_CODEC_XFF;
+            if (fire && hipMallocAsync((void**)&counters, (size_t)nchunks * (size_t)D * 4, st) != hipSuccess) return fail(SPRINTZ_E_HIP, "hipMallocAsync of the counters' scratch");
+            const hipError_t eb = launch_encode_big(8 * esz, fire, (unsigned)nchunks, st, a, counters);
+            if (counters) (void)hipFreeAsync(counters, st);
+            if (eb != hipSuccess) return fail(SPRINTZ_E_HIP, "encode_big kernel launch", eb);
+            return 0;
+        }
         a.cap = ((uint32_t)group_bytes_max(esz, D) + 64u + 15u) & ~15u;
         const hipError_t ea = launch_encode_any(8 * esz, codec == SPRINTZ_CODEC_XFF, (unsigned)nchunks, a.cap, st, a);
         if (ea != hipSuccess) return fail(SPRINTZ_E_HIP, "encode_any kernel launch", ea);
@@ -1053,7 +1072,7 @@ int64_t compress_host(int codec, int esz, const void* src, uint32_t len, void* d
     // memcpy into the mapped staging buffer -> stage_in + encoder on the thread's stream, the encoder's slot, size and return
     // value landing straight in the staging buffer -> ONE wait -> memcpy out.  No copy engine, no memset, no second round trip.
     // staging: [source | size, ret (16 B) | slot]      device: [source + read slack]
-    if (codec <= SPRINTZ_CODEC_XFF && src_bytes + 16 + bound + 512 <= kPinMax) {
+    if (codec <= SPRINTZ_CODEC_XFF && ndims <= 2047 && src_bytes + 16 + bound + 512 <= kPinMax) {      // (above 2047 columns the encoder ORs into its slot with device atomics: a slot in HBM)
         const size_t p_meta = round_up(src_bytes + 16, 256), p_slot = p_meta + 16;
         Scratch* sc = nullptr;
         if ((rc = acquire_scratch(round_up(src_bytes, 16) + SPRINTZ_MI355X_READ_SLACK, p_slot + bound, &sc))) return rc;
@@ -1149,7 +1168,7 @@ int64_t decode_host_common(int codec, int esz, const uint8_t* s, uint64_t nbytes
     // ---- the zero-copy call (plain decodes that fit the staging buffer): memcpy the stream into the mapped staging buffer ->
     // stage_in + decoder on the thread's stream, the decoder writing samples and its return value straight into the staging
     // buffer -> ONE wait -> memcpy out.   staging: [offsets[2] | stream | ret (16 B) | out]      device: [offsets[2] | stream + slack]
-    if (!qspec && 16 + nbytes + 512 + 16 + out_bytes <= kPinMax) {
+    if (!qspec && ndims <= 2047 && 16 + nbytes + 512 + 16 + out_bytes <= kPinMax) {      // (above 2047 columns the decoder reads its own output back: an output in HBM)
         const size_t p_ret = round_up(16 + nbytes + 16, 256), p_out = p_ret + 16;
         Scratch* sc = nullptr;
         int rc = acquire_scratch(round_up(16 + nbytes, 16) + SPRINTZ_MI355X_READ_SLACK, p_out + out_bytes, &sc);

@@ -33,6 +33,9 @@ hipError_t launch_encode_lat(int w, bool fire, int dp, bool lowdim, unsigned gri
 // streams of 513 .. 2047 columns: one workgroup per chunk, <= 8 columns per lane (any_ndims.hip); shmem = the encoder's group window
 hipError_t launch_decode_any(int w, bool fire, unsigned grid, hipStream_t st, const DecodeArgs& a);
 hipError_t launch_encode_any(int w, bool fire, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a);
+// streams of 2 048 .. 65 535 columns: the same scheme in column tiles, per-column state behind the rows / in `counters` (nchunks x ndims int32; FIRE only)
+hipError_t launch_decode_big(int w, bool fire, unsigned grid, hipStream_t st, const DecodeArgs& a, int32_t* counters);
+hipError_t launch_encode_big(int w, bool fire, unsigned grid, hipStream_t st, const EncodeArgs& a, int32_t* counters);
 // low-dim streams with 1, 2 or 4 columns (8 bits) / 1 or 2 (16 bits), one lane per chunk (decode_uni.h)
 hipError_t launch_decode_uni_w8(bool fire, int nd, int q, unsigned grid, hipStream_t st, const DecodeArgs& a);
 hipError_t launch_decode_uni_w16(bool fire, int nd, int q, unsigned grid, hipStream_t st, const DecodeArgs& a);

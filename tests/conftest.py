@@ -110,6 +110,18 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden_wide2():
+    """the reference's streams at 2 048 .. 65 535 columns (oracle/gen_golden_wide.py v2): -> (manifest, arrays); a case's input is arrays["in_%d" % m["in_idx"]]"""
+    import json
+    import numpy as np
+    gdir = os.path.join(HERE, "golden")
+    with open(os.path.join(gdir, "golden_wide_v2.json")) as f:
+        manifest = json.load(f)["cases"]
+    arrays = np.load(os.path.join(gdir, "golden_wide_v2.npz"))
+    return manifest, arrays
+
+
+@pytest.fixture(scope="session")
 def golden_wide():
     """the reference's streams at 513 .. 2 047 columns (oracle/gen_golden_wide.py)"""
     import json

@@ -72,6 +72,30 @@ def test_golden_vectors_of_513_to_2047_columns(sz, golden_wide):
         assert np.array_equal(cd.decompress(b).cpu().numpy().view(data.dtype)[: data.size], data.ravel()), m
 
 
+def test_golden_vectors_of_2048_to_65535_columns(sz, golden_wide2):
+    """the reference's streams at 2 048 .. 65 535 columns (golden_wide_v2; the column-tiled kernels of csrc/any_ndims.hip): the single-call
+    encoder writes them -- the 8 192-column ones with their truncated remaining_len included -- and the decoder returns what the
+    reference's decoder returned (the whole input; the decodable prefix at 8 192 columns; at 65 535, where the reference's decoder
+    corrupts its heap, the whole input); the batched pair on the same samples as one chunk"""
+    import torch
+    manifest, arrays = golden_wide2
+    for m in manifest:
+        data, want = arrays[f"in_{m['in_idx']}"], arrays[f"out_{m['idx']}"]
+        dest, ret = gpu_compress(sz, m["codec"], data, m["ndims"])
+        assert ret == m["ret"], (m, ret, sz.last_error())
+        assert np.array_equal(dest[:want.size], want) and (dest[want.size:] == 0xAB).all(), m
+        want_ret = m["ref_dret"] if m["ref_dret"] is not None else data.size
+        dec, dret = gpu_decompress(sz, m["codec"], want, m["esz"], data.size)
+        assert dret == want_ret and np.array_equal(dec[:dret], data.ravel()[:dret]), (m, dret, sz.last_error())
+        if want_ret != data.size:
+            continue                                             # (a chunk whose tail the format cannot hold is not a container member)
+        cd = sz.ChunkedCodec(m["codec"], m["esz"], m["ndims"], data.size, device="cuda:0")
+        t = torch.from_numpy(data.ravel().view(np.int8 if m["esz"] == 1 else np.int16)).cuda().view(cd.dtype)
+        b = cd.compress(t)
+        assert int(b.sizes[0]) == want.size and np.array_equal(b.data.cpu().numpy()[: want.size], want), m
+        assert np.array_equal(cd.decompress(b).cpu().numpy().view(data.dtype)[: data.size], data.ravel()), m
+
+
 @pytest.mark.parametrize("codec,esz,ndims,n", [("xff", 2, 8, 16384), ("xff", 2, 8, 20003), ("delta", 2, 64, 20480), ("xff", 2, 2, 18001), ("delta", 2, 1, 17000),
                                                ("delta", 1, 8, 24000), ("xff", 1, 16, 22005), ("xff", 1, 1, 20000), ("xff", 1, 3, 23999), ("xff", 2, 33, 19999)])
 def test_single_calls_of_17_to_40_KB(sz, oracle, codec, esz, ndims, n):

@@ -79,6 +79,23 @@ def test_oracle_at_513_to_2047_columns_is_the_reference(oracle, golden_wide):
         assert dret == data.size and np.array_equal(dec, data.ravel()), m
 
 
+def test_oracle_at_2048_to_65535_columns_is_the_reference(oracle, golden_wide2):
+    """golden_wide_v2: the header's ndims is a full uint16 (format.h:36-45).  The reference's ENCODER takes every width; the oracle writes its
+    bytes.  Where the reference's decoder could be run (below ~65 521 columns it does not corrupt its heap) the oracle's decoder returns what
+    it returned -- including the 8 192-column streams whose tail does not fit the header's uint16 remaining_len: truncated by the encoder,
+    a decoded prefix for everybody."""
+    manifest, arrays = golden_wide2
+    assert {m["ndims"] for m in manifest} == {2048, 4096, 8192, 65535} and len(manifest) == 16
+    for m in manifest:
+        data, want = arrays[f"in_{m['in_idx']}"], arrays[f"out_{m['idx']}"]
+        got, ret = oracle.compress(m["codec"], data, m["ndims"])
+        assert ret == m["ret"] and got.size == m["nbytes"] and np.array_equal(got, want), m
+        dec, dret = oracle.decompress(m["codec"], want, m["esz"], data.size)
+        want_ret = m["ref_dret"] if m["ref_dret"] is not None else data.size
+        assert dret == want_ret and np.array_equal(dec[:dret], data.ravel()[:dret]), m
+        assert (m["ref_roundtrips"] is False) == (m["ndims"] == 8192), m
+
+
 def test_compress_chunks_on_many_threads_is_compress_chunks(oracle):
     """harness.Oracle.compress_chunks_mt (the full-size GPU tests' all-chunk comparison) == the serial form, ragged last chunk too"""
     from harness import gen_walk
