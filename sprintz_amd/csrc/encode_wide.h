@@ -10,6 +10,11 @@
 #pragma once
 
 #include "encode_fast.h"
+#include "decode_fast.h"      // mad_i16_hi
+
+#ifndef SPRINTZ_ENC_HIGH_HALF
+#define SPRINTZ_ENC_HIGH_HALF 0      // round 5: built, bit-exact, measured 1 % SLOWER on the headline shape (0.684 / 0.671 / 0.675 against 0.671 / 0.667 / 0.659 ms, tools/ab_list.sh): off
+#endif
 
 namespace sprintz {
 
@@ -221,13 +226,54 @@ __device__ __forceinline__ uint32_t encode_wide_body(const EncodeArgs& a, uint32
             load_block(pos_in + blk);
         }
         uint32_t z[CPL][8], nb[CPL], lane_bits = 0;
+#if SPRINTZ_ENC_HIGH_HALF
+        // Round 5, 16-bit pairs (EXACT shapes: rows are whole dwords): the forecast in the HIGH HALF of the registers.  A row's two samples are one
+        // LDS dword; a sample x lives as X = x << 16, so the 16-bit wrap of every difference is the 32-bit subtraction's own (no sign
+        // extension: three v_bfe_i32 a sample less), the prediction's (pd * coef) >> 16 is one v_mad_i32_i16 that takes pd from PD's
+        // high half (op_sel) and a mask, and sign(err) * pd rides the same instruction.  pv / pd hold X and the shifted delta here.
+        constexpr bool kHigh = W == 16 && EXACT && !CM && !SPLIT;
+#else
+        constexpr bool kHigh = false;
+#endif
+        if constexpr (kHigh) {
+            uint32_t dq[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) dq[i] = *(const uint32_t*)(stage + 4u * (uint32_t)lane_d + (uint32_t)i * row_stride * 2u);
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int coef = FIRE ? fire_coef<W, false>(ctr[k]) : 0;
+                int grad = 0;
+                uint32_t mask = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const uint32_t X = k == 0 ? dq[i] << 16 : dq[i] & 0xffff0000u;
+                    const int DELTA = (int)(X - pv[k]);
+                    int ERR;
+                    if constexpr (FIRE) {
+                        const int prod = mad_i16_hi(pd[k], coef, 0);                  // pd * coef, pd = the high half of the shifted delta
+                        ERR = DELTA - (int)((uint32_t)prod & 0xffff0000u);
+                        if (i & 1) grad = mad_i16_hi(pd[k], ERR > 0 ? 1 : (ERR < 0 ? -1 : 0), grad);
+                    } else {
+                        ERR = DELTA;
+                    }
+                    const uint32_t zz = (((uint32_t)ERR >> 15) ^ (uint32_t)(ERR >> 31)) & 0xffffu;
+                    mask |= zz;
+                    z[k][i] = zz;
+                    pv[k] = X;
+                    pd[k] = DELTA;
+                }
+                if constexpr (FIRE) ctr[k] = wrap_counter<W>(ctr[k] + __builtin_amdgcn_sbfe(grad, 2, W - 2));
+                nb[k] = nbits_of<W, false>(mask);
+                lane_bits += nb[k];
+            }
+        }
         uint32_t xp[8];                                    // 8 bits: the pair's two samples of a row come as ONE 16-bit LDS read
         if constexpr (W == 8 && !CM) {                     // (rows are an even number of bytes -- blocks are 16-byte multiples -- and the pair starts on an even column)
 #pragma unroll
             for (int i = 0; i < 8; i++) xp[i] = col_ok[0] ? (uint32_t)*(const uint16_t*)(stage + (uint32_t)genk[0] + i * row_stride) : 0u;
         }
 #pragma unroll
-        for (int k = 0; k < CPL; k++) {
+        for (int k = 0; k < (kHigh ? 0 : CPL); k++) {
             uint32_t x[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) {
