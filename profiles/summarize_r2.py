@@ -31,8 +31,8 @@ OURS = ("sprintz", "huf", "compact_copy", "scan_", "zigzag_kernel", "dyndelta", 
 DOMINANT = {"decode_fast_kernel<16, true, 8": ("headline", 131072, "walk8")}
 # workloads whose decode is a CHAIN of kernels: the chain's HBM bytes = the sum over its kernels of the average bytes per dispatch
 # (every distinct kernel runs once per chain; FETCH_SIZE doubled for all of them: their reads are 16 bytes a lane and contiguous)
-CHAIN_KERNELS = ("huf0_follow", "huf0_copy", "huf0_tree", "huf0_share", "huf0_stream", "decode_fast_kernel", "decode_lat_kernel")
-CHAINS = ("cfg4_10000", "cfg4_80000", "cfg4_800000")
+CHAIN_KERNELS = ("huf0_follow", "huf0_copy", "huf0_tree", "huf0_share", "huf0_stream", "huf0_sync", "decode_fast_kernel", "decode_lat_kernel")
+CHAINS = ("cfg4_1250", "cfg4_10000", "cfg4_80000", "cfg4_800000")
 
 
 def main():
