@@ -216,7 +216,9 @@ __device__ __forceinline__ Aff workgroup_scan_excl(const Aff& mine, Aff& total, 
     return compose(base, unpack_aff(before));
 }
 
-// Three launches: tile summaries (a tile = kTile blocks, a thread kBPT consecutive ones, their maps composed in order), one workgroup
+constexpr int kDdBPT = 8;                                 // blocks a thread of the dynamic-delta decoder takes (128 bytes of errors): half as many tiles to scan as with 4
+constexpr int kDdTile = kT * kDdBPT;
+// Three launches: tile summaries (a tile = kDdTile blocks, a thread kDdBPT consecutive ones, their maps composed in order), one workgroup
 // scanning the tiles, and the decode proper with every thread's incoming state.  (Round 5 also built the ONE-launch form -- the state in
 // front of a tile from a chained scan over tiles, decoupled look-back as in compact_tail.h -- and measured it slower: 0.166 against
 // 0.129 ms for 64 Mi samples, 0.131 with the look-back cut out.  With 8 192 tiles resident at once the first cohort's look-backs are a
@@ -224,10 +226,10 @@ __device__ __forceinline__ Aff workgroup_scan_excl(const Aff& mine, Aff& total, 
 __global__ void __launch_bounds__(kT) dyndelta_tile_kernel(const uint8_t* in, const uint8_t* choices, uint32_t nblocks, uint64_t* tiles)
 {
     __shared__ uint64_t sh[kT / 64];
-    const uint32_t b0 = (blockIdx.x * kT + threadIdx.x) * kBPT;
+    const uint32_t b0 = (blockIdx.x * kT + threadIdx.x) * kDdBPT;
     Aff f = unpack_aff(kIdentity);
 #pragma unroll
-    for (int j = 0; j < kBPT; j++)
+    for (int j = 0; j < kDdBPT; j++)
         if (b0 + j < nblocks) { uint32_t e[8]; int c; f = compose(f, block_map(in, choices, b0 + j, e, c)); }
     Aff total;
     (void)workgroup_scan_excl(f, total, sh);
@@ -271,12 +273,12 @@ __global__ void __launch_bounds__(kT) dyndelta_decode_kernel(const uint8_t* in, 
                                                              const uint64_t* tiles, uint16_t* out, int64_t* ret)
 {
     __shared__ uint64_t sh[kT / 64];
-    const uint32_t b0 = (blockIdx.x * kT + threadIdx.x) * kBPT;
-    uint32_t e[kBPT][8];
-    int choice[kBPT];
+    const uint32_t b0 = (blockIdx.x * kT + threadIdx.x) * kDdBPT;
+    uint32_t e[kDdBPT][8];
+    int choice[kDdBPT];
     Aff f = unpack_aff(kIdentity);
 #pragma unroll
-    for (int j = 0; j < kBPT; j++) {
+    for (int j = 0; j < kDdBPT; j++) {
         choice[j] = 0;
         if (b0 + j < nblocks) f = compose(f, block_map(in, choices, b0 + j, e[j], choice[j]));
     }
@@ -287,7 +289,7 @@ __global__ void __launch_bounds__(kT) dyndelta_decode_kernel(const uint8_t* in, 
     const uint32_t x0 = ld16(in);
     uint32_t x = (x0 + before.tx) & 0xffffu, d = before.td;       // d starts at 0 (online.hpp: _prev_diff = 0)
 #pragma unroll
-    for (int j = 0; j < kBPT; j++) {
+    for (int j = 0; j < kDdBPT; j++) {
         if (b0 + j < nblocks) {
             uint32_t v[8];
 #pragma unroll
@@ -660,7 +662,7 @@ int sprintz_mi355x_online_unpack_device(int kind, const void* d_src, uint32_t le
     if (kind == SPRINTZ_ONLINE_ZIGZAG) {
         hipLaunchKernelGGL(zigzag_kernel, dim3(grid_for(((uint64_t)len + 7) / 8)), dim3(kT), 0, st, body, (uint8_t*)d_dest, len, 1, d_ret);
     } else if (kind <= SPRINTZ_ONLINE_DYNDELTA_ALT) {
-        const uint32_t nblocks = (len - 1) / 8, ntiles = tiles_for(nblocks ? nblocks : 1);
+        const uint32_t nblocks = (len - 1) / 8, ntiles = (uint32_t)(((uint64_t)(nblocks ? nblocks : 1) + kDdTile - 1) / kDdTile);
         const uint8_t* choices = body + 2 * (size_t)len;
         uint64_t* tiles = (uint64_t*)d_tmp;
         hipLaunchKernelGGL(dyndelta_tile_kernel, dim3(ntiles), dim3(kT), 0, st, body, choices, nblocks, tiles);

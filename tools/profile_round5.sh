@@ -12,7 +12,7 @@ OUT=$ROOT/gpurun_out/$1; shift
 WL=${@:-headline cfg1 cfg3_1k cfg3_10k cfg4_1250 cfg4_10000 cfg4_80000 cfg4_800000 cfg5 cfg5_8m}
 mkdir -p $OUT
 # the default bench run first: the record the contract test reads (bench_full.json) and the line the driver would parse
-(timeout 900 python $ROOT/bench.py > $OUT/bench_line.json 2> $OUT/bench_stderr.txt < /dev/null; cp $ROOT/bench_full.json $OUT/bench_full.json 2>/dev/null; echo "bench rc $? $(date +%T)")
+[ -n "$SKIP_BENCH" ] || (timeout 900 python $ROOT/bench.py > $OUT/bench_line.json 2> $OUT/bench_stderr.txt < /dev/null; cp $ROOT/bench_full.json $OUT/bench_full.json 2>/dev/null; echo "bench rc $? $(date +%T)")
 for w in $WL; do
   if [ $w = headline ]; then ARGS="--configs none --no-extras --no-sweep --no-cpu-baseline --steps 20 --warmup 3"; PARGS="--configs none --no-extras --no-sweep --no-cpu-baseline --steps 3 --warmup 1 --ramp-ms 0"
   else ARGS="--only $w --no-cpu-baseline --config-reps 20"; PARGS="--only $w --no-cpu-baseline --config-reps 3"; fi
