@@ -216,7 +216,7 @@ __device__ __forceinline__ Aff workgroup_scan_excl(const Aff& mine, Aff& total, 
     return compose(base, unpack_aff(before));
 }
 
-constexpr int kDdBPT = 8;                                 // blocks a thread of the dynamic-delta decoder takes (128 bytes of errors): half as many tiles to scan as with 4
+constexpr int kDdBPT = 4;                                 // blocks a thread of the dynamic-delta decoder takes (8 measured: 0.222 against 0.135 ms -- 64 more registers of errors a lane)
 constexpr int kDdTile = kT * kDdBPT;
 // Three launches: tile summaries (a tile = kDdTile blocks, a thread kDdBPT consecutive ones, their maps composed in order), one workgroup
 // scanning the tiles, and the decode proper with every thread's incoming state.  (Round 5 also built the ONE-launch form -- the state in
