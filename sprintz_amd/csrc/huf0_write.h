@@ -34,144 +34,257 @@ struct BitW {                           // bytes into LDS, LSB first (bitstream.
     }
 };
 
+// Round 5: the whole wave works.  (Round 4: lane 0 walked the 256 symbols eight times over -- widths, Kraft sum, weight statistics, the
+// decoder table, the state chains' bit writer, the raw form, the canonical code values -- 156 us a launch however few segments, most of
+// it dependent LDS round trips; tools/ktrace: cfg4 at 1 250 chunks.)  Lane t owns symbols 4 t .. 4 t + 3; reductions are wave
+// reductions, histograms and ranks are ballots, the bit writer of the state chains is a prefix sum of the widths + LDS ORs.  What stays
+// serial: the NCount header (<= 13 symbols) and the two state chains (each state is found from the one two weights later).
+__device__ __forceinline__ uint32_t wave_sum32(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max32(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, d); v = o > v ? o : v; }
+    return v;
+}
+
 __global__ void __launch_bounds__(64) huf0_table_kernel(const uint8_t* __restrict__ tables, uint8_t* __restrict__ recs)
 {
-    __shared__ uint8_t lens[256], w[256], f[320], hdr[192], tsym[64], tnb[64], D[256];
+    __shared__ uint8_t lens[256], w[256], hdr[192], tsym[64], tnb[64], D[256];
+    __shared__ __attribute__((aligned(4))) uint8_t f[320];
     __shared__ uint16_t tnew[64], vals[256];
-    __shared__ uint32_t s_hl, s_hlen, s_tl, s_nw, s_ok;
+    __shared__ uint32_t s_hl;
     const int t = threadIdx.x;
     const uint64_t seg = blockIdx.x;
+    const uint64_t lt_mask = t ? (~0ull >> (64 - t)) : 0ull;        // lanes below this one
+    uint32_t ln[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) {
         const int s = 4 * t + e;
-        lens[s] = (uint8_t)((tables[seg * 128 + (s >> 1)] >> (4 * (s & 1))) & 15u);
+        ln[e] = (uint32_t)((tables[seg * 128 + (s >> 1)] >> (4 * (s & 1))) & 15u);
+        lens[s] = (uint8_t)ln[e];
     }
-    if (t == 0) { s_hl = 0; s_hlen = 0; s_tl = 0; s_nw = 0; s_ok = 0; }
+    for (int k = t; k < 80; k += 64) ((uint32_t*)f)[k] = 0;
+    if (t == 0) s_hl = 0;
+    // ---- widths -> weights (HUF_compress: weight = tableLog + 1 - length), the checks of oracle_huf0_compress_batch
+    uint32_t nz_l = 0, tl_l = 0, ms_l = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) if (ln[e]) { nz_l++; tl_l = ln[e] > tl_l ? ln[e] : tl_l; ms_l = (uint32_t)(4 * t + e) + 1u; }
+    const uint32_t nz = wave_sum32(nz_l), tl = wave_max32(tl_l), max_sym1 = wave_max32(ms_l);      // max_sym + 1 (0: none)
+    uint32_t kr_l = 0;
+#pragma unroll
+    for (int e = 0; e < 4; e++) if (ln[e]) kr_l += 1u << (tl - ln[e]);
+    const uint32_t kraft = wave_sum32(kr_l);
+    const bool ok = nz >= 2 && tl <= 11 && kraft == (1u << tl);
+    const uint32_t nw = ok ? max_sym1 - 1u : 0u;
+    uint32_t wt[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const uint32_t s = (uint32_t)(4 * t + e);
+        wt[e] = (ok && s < nw && ln[e]) ? tl + 1u - ln[e] : 0u;
+        w[s] = (uint8_t)wt[e];
+    }
     __syncthreads();
+    // ---- FSE statistics of the weights, NCount, decoder table (fse_write_weights)
+    uint32_t count[16];
     int norm[16];
     uint32_t maxw = 0;
-    if (t == 0) {
-        uint32_t tl = 0, nz = 0, kraft = 0;
-        int max_sym = -1;
-        for (int s = 0; s < 256; s++) if (lens[s]) { nz++; max_sym = s; if (lens[s] > tl) tl = lens[s]; }
-        for (int s = 0; s < 256; s++) if (lens[s]) kraft += 1u << (tl - lens[s]);
-        if (nz >= 2 && tl <= 11 && kraft == (1u << tl)) {
-            const uint32_t nw = (uint32_t)max_sym;
-            for (uint32_t s = 0; s < nw; s++) w[s] = lens[s] ? (uint8_t)(tl + 1 - lens[s]) : 0;
-            s_tl = tl;
-            s_nw = nw;
-            s_ok = 1;
-            // ---- FSE statistics of the weights, NCount, decoder table (fse_write_weights)
-            uint32_t count[16];
-            for (int k = 0; k < 16; k++) { count[k] = 0; norm[k] = 0; }
-            bool fse = nw >= 2;
-            if (fse) {
-                for (uint32_t k = 0; k < nw; k++) { count[w[k]]++; if (w[k] > maxw) maxw = w[k]; }
-                uint32_t present = 0, top = 0;
-                for (uint32_t s = 0; s <= maxw; s++) { present += count[s] != 0; if (count[s] > count[top]) top = s; }
-                int sum = 0;
-                for (uint32_t s = 0; s <= maxw; s++) if (count[s]) { norm[s] = (int)((uint64_t)count[s] * 64u / nw); if (norm[s] < 1) norm[s] = 1; sum += norm[s]; }
-                norm[top] += 64 - sum;
-                if (present < 2 || norm[top] < 1) fse = false;
+    bool fse = ok && nw >= 2;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { count[k] = 0; norm[k] = 0; }
+    if (fse) {                                                         // (wave-uniform)
+#pragma unroll
+        for (int k = 0; k < 13; k++) {
+            uint32_t c = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) c += (uint32_t)__popcll(__ballot((uint32_t)(4 * t + e) < nw && wt[e] == (uint32_t)k));
+            count[k] = c;
+            if (c) maxw = (uint32_t)k;
+        }
+        uint32_t present = 0, top = 0;
+        for (uint32_t s = 0; s <= maxw; s++) { present += count[s] != 0; if (count[s] > count[top]) top = s; }
+        int sum = 0;
+        for (uint32_t s = 0; s <= maxw; s++) if (count[s]) { norm[s] = (int)((uint64_t)count[s] * 64u / nw); if (norm[s] < 1) norm[s] = 1; sum += norm[s]; }
+        norm[top] += 64 - sum;
+        if (present < 2 || norm[top] < 1) fse = false;
+    }
+    uint32_t hl = 0;
+    if (fse) {
+        // the NCount header: <= 13 symbols, every lane the same arithmetic, lane 0 writes
+        uint64_t acc = 0;
+        int nbits = 0;
+        uint32_t nout = 0;
+        auto add = [&](uint32_t v, int nb) {
+            acc |= (uint64_t)v << nbits;
+            nbits += nb;
+            while (nbits >= 8) { if (t == 0) f[nout] = (uint8_t)acc; nout++; acc >>= 8; nbits -= 8; }
+        };
+        add(6 - 5, 4);
+        int remaining = 65, threshold = 64, nb = 7;
+        bool previous0 = false;
+        uint32_t sym = 0;
+        while (sym <= maxw && remaining > 1) {
+            if (previous0) {
+                uint32_t start = sym;
+                while (sym <= maxw && !norm[sym]) sym++;
+                if (sym > maxw) { fse = false; break; }
+                while (sym >= start + 24) { start += 24; add(0xffff, 16); }
+                while (sym >= start + 3) { start += 3; add(3, 2); }
+                add(sym - start, 2);
             }
-            if (fse) {
-                BitW b{f, 0, 0, 0};
-                b.add(6 - 5, 4);
-                int remaining = 65, threshold = 64, nb = 7;
-                bool previous0 = false;
-                uint32_t sym = 0;
-                while (sym <= maxw && remaining > 1) {
-                    if (previous0) {
-                        uint32_t start = sym;
-                        while (sym <= maxw && !norm[sym]) sym++;
-                        if (sym > maxw) { fse = false; break; }
-                        while (sym >= start + 24) { start += 24; b.add(0xffff, 16); }
-                        while (sym >= start + 3) { start += 3; b.add(3, 2); }
-                        b.add(sym - start, 2);
-                    }
-                    int c = norm[sym++];
-                    const int max = (2 * threshold - 1) - remaining;
-                    remaining -= c;
-                    c++;
-                    if (c >= threshold) c += max;
-                    b.add((uint32_t)c, nb - (c < max));
-                    previous0 = c == 1;
-                    if (remaining < 1) { fse = false; break; }
-                    while (remaining < threshold) { nb--; threshold >>= 1; }
-                }
-                if (remaining != 1) fse = false;
-                if (fse) {
-                    s_hl = b.close(false);
-                    uint16_t next[16];
-                    uint32_t pos = 0;
-                    for (uint32_t s = 0; s <= maxw; s++) {
-                        next[s] = (uint16_t)norm[s];
-                        for (int i = 0; i < norm[s]; i++) { tsym[pos] = (uint8_t)s; pos = (pos + 43u) & 63u; }   // step = 32 + 8 + 3
-                    }
-                    for (uint32_t u = 0; u < 64; u++) {
-                        const uint32_t ns = next[tsym[u]]++;
-                        tnb[u] = (uint8_t)(6 - (31 - __clz((int)ns)));
-                        tnew[u] = (uint16_t)((ns << tnb[u]) - 64u);
-                    }
-                }
-            }
+            int c = norm[sym++];
+            const int max = (2 * threshold - 1) - remaining;
+            remaining -= c;
+            c++;
+            if (c >= threshold) c += max;
+            add((uint32_t)c, nb - (c < max));
+            previous0 = c == 1;
+            if (remaining < 1) { fse = false; break; }
+            while (remaining < threshold) { nb--; threshold >>= 1; }
+        }
+        if (remaining != 1) fse = false;
+        if (fse) {
+            if (nbits > 0) { if (t == 0) f[nout] = (uint8_t)acc; nout++; }
+            hl = nout;
+            // the decoder table: step i of the symbol spread (cells (43 i) & 63 in symbol order) belongs to lane i
+            uint32_t c2 = 0, my = 0;
+            for (uint32_t s2 = 0; s2 <= maxw; s2++) { if ((uint32_t)t >= c2 && (uint32_t)t < c2 + (uint32_t)norm[s2]) my = s2; c2 += (uint32_t)norm[s2]; }
+            tsym[(43u * (uint32_t)t) & 63u] = (uint8_t)my;
         }
     }
     __syncthreads();
+    if (fse) {
+        // cell t: its symbol's next state number = norm + (cells of the same symbol below it)
+        const uint32_t my = tsym[t];
+        uint32_t ns = 0;
+        for (uint32_t s2 = 0; s2 <= maxw; s2++) {
+            const uint64_t m = __ballot(my == s2);
+            if (my == s2) ns = (uint32_t)norm[s2] + (uint32_t)__popcll(m & lt_mask);
+        }
+        const uint32_t nbv = 6u - (31u - (uint32_t)__clz((int)ns));
+        tnb[t] = (uint8_t)nbv;
+        tnew[t] = (uint16_t)((ns << nbv) - 64u);
+    }
+    if (t == 0) s_hl = fse ? hl : 0u;
+    __syncthreads();
     // ---- the two state chains, last weight first: D[i] = decoder state when weight i is emitted; every lane
     // tests one table entry, the lowest match wins (= the symbol's smallest state at the chain ends)
-    const uint32_t nw = s_nw, hl = s_hl;
+    hl = s_hl;
     bool chain_ok = hl != 0;
     if (hl != 0) {
         const uint32_t my_sym = tsym[t], lo = tnew[t], hi = (uint32_t)tnew[t] + (1u << tnb[t]);
         uint32_t later[2] = {0, 0};                      // D[i + 2] of either parity
+        uint32_t wi = nw ? w[nw - 1] : 0u;               // (the next weight is requested before this one's ballot)
         for (int i = (int)nw - 1; i >= 0; i--) {
+            const uint32_t wnext = i > 0 ? w[i - 1] : 0u;
             const uint32_t target = later[i & 1];
-            const bool match = my_sym == w[i] && (i + 2 >= (int)nw || (target >= lo && target < hi));
+            const bool match = my_sym == wi && (i + 2 >= (int)nw || (target >= lo && target < hi));
             const uint64_t m = __ballot(match);
             if (m == 0) { chain_ok = false; break; }
             const uint32_t found = (uint32_t)__builtin_ctzll(m);
             later[i & 1] = found;
             if (t == 0) D[i] = (uint8_t)found;
+            wi = wnext;
         }
     }
     __syncthreads();
-    if (t == 0 && s_ok) {
-        uint32_t fs = 0;
-        if (hl != 0 && chain_ok) {
-            BitW sb{f + hl, 0, 0, 0};
-            for (int i = (int)nw - 3; i >= 0; i--) sb.add((uint32_t)D[i + 2] - tnew[D[i]], tnb[D[i]]);
-            sb.add(D[1], 6);
-            sb.add(D[0], 6);
-            fs = hl + sb.close(true);
+    uint32_t fs = 0;
+    if (ok && hl != 0 && chain_ok) {
+        // the chains' bits behind the NCount bytes: items j = 0 .. nw - 3 are weights i = nw - 3 - j (value D[i + 2] - tnew[D[i]], tnb[D[i]]
+        // bits), then D[1] and D[0] (6 bits each), then the end mark; positions = a prefix sum, bits OR-ed into the zeroed buffer
+        const uint32_t nitems = nw >= 2 ? nw - 2u : 0u;
+        uint32_t v[4], nbv[4], mine = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const uint32_t j = (uint32_t)(4 * t + e);
+            v[e] = 0; nbv[e] = 0;
+            if (j < nitems) {
+                const uint32_t i = nitems - 1u - j, d = D[i];
+                v[e] = (uint32_t)D[i + 2] - (uint32_t)tnew[d];
+                nbv[e] = tnb[d];
+            }
+            mine += nbv[e];
         }
-        const uint32_t raw = nw <= 128 ? 1 + (nw + 1) / 2 : 0;
-        uint32_t hlen = 0;
+        uint32_t inc = mine;
+#pragma unroll
+        for (int d2 = 1; d2 < 64; d2 <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)inc, d2); if (t >= d2) inc += u; }
+        const uint32_t total = (uint32_t)__shfl((int)inc, 63);
+        uint32_t at = 8u * hl + inc - mine;
+        auto or_bits = [&](uint32_t bp, uint32_t val, uint32_t nb2) {
+            if (nb2 == 0) return;
+            const uint64_t x = (uint64_t)val << (bp & 31u);
+            uint32_t* const q = (uint32_t*)f + (bp >> 5);
+            atomicOr(q, (uint32_t)x);
+            if ((uint32_t)(x >> 32)) atomicOr(q + 1, (uint32_t)(x >> 32));
+        };
+#pragma unroll
+        for (int e = 0; e < 4; e++) { or_bits(at, v[e] & ((1u << nbv[e]) - 1u), nbv[e]); at += nbv[e]; }
+        if (t == 0) {
+            const uint32_t p = 8u * hl + total;
+            or_bits(p, D[1], 6);
+            or_bits(p + 6, D[0], 6);
+            or_bits(p + 12, 1, 1);                        // BIT_closeCStream's end mark
+        }
+        fs = hl + (total + 13u + 7u) / 8u;
+    }
+    __syncthreads();
+    const uint32_t raw = nw <= 128 ? 1 + (nw + 1) / 2 : 0;
+    uint32_t hlen = 0;
+    if (ok) {
         if (fs > 1 && fs < 128 && (raw == 0 || fs + 1 < raw)) {
-            hdr[0] = (uint8_t)fs;
-            for (uint32_t k = 0; k < fs; k++) hdr[1 + k] = f[k];
+            if (t == 0) hdr[0] = (uint8_t)fs;
+            for (uint32_t k = (uint32_t)t; k < fs; k += 64) hdr[1 + k] = f[k];
             hlen = fs + 1;
         } else if (raw != 0 && nw != 0) {
-            hdr[0] = (uint8_t)(127 + nw);
-            for (uint32_t k = 0; k < nw; k += 2) hdr[1 + k / 2] = (uint8_t)((w[k] << 4) | (k + 1 < nw ? w[k + 1] : 0));
+            if (t == 0) hdr[0] = (uint8_t)(127 + nw);
+            for (uint32_t k = 2u * (uint32_t)t; k < nw; k += 128) hdr[1 + k / 2] = (uint8_t)((w[k] << 4) | (k + 1 < nw ? w[k + 1] : 0));
             hlen = raw;
         }
-        s_hlen = hlen;
         // Huff0's canonical code values (HUF_buildCTable): per length ascending symbols, the longest codes lowest
-        const uint32_t tl = s_tl;
-        uint32_t per[16], start[16];
-        for (int l = 0; l < 16; l++) { per[l] = 0; start[l] = 0; }
-        for (int s = 0; s < 256; s++) per[lens[s]]++;
-        uint32_t min = 0;
-        for (uint32_t l = tl; l > 0; l--) { start[l] = min; min += per[l]; min >>= 1; }
-        for (int s = 0; s < 256; s++) vals[s] = lens[s] ? (uint16_t)start[lens[s]]++ : (uint16_t)0;
+        uint32_t start[16];
+        {
+            uint32_t per[16];
+#pragma unroll
+            for (int l = 0; l < 16; l++) {
+                uint32_t c = 0;
+#pragma unroll
+                for (int e = 0; e < 4; e++) c += (uint32_t)__popcll(__ballot(ln[e] == (uint32_t)l));
+                per[l] = c;
+                start[l] = 0;
+            }
+            uint32_t min = 0;
+            for (uint32_t l = tl; l > 0; l--) { start[l] = min; min += per[l]; min >>= 1; }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) vals[4 * t + e] = 0;
+        for (uint32_t l = 1; l <= tl; l++) {
+            uint64_t m[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) m[e] = __ballot(ln[e] == l);
+            // symbols of this length below 4 t + e: all four of every lower lane's, and this lane's own lower ones
+            uint32_t below = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) below += (uint32_t)__popcll(m[e] & lt_mask);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                if (ln[e] == l) vals[4 * t + e] = (uint16_t)(start[l] + below);
+                below += ln[e] == l ? 1u : 0u;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++) vals[4 * t + e] = 0;
     }
     __syncthreads();
     uint8_t* const rec = recs + seg * kRecBytes;
-    if (t == 0) { ((uint32_t*)rec)[0] = s_hlen; ((uint32_t*)rec)[1] = s_tl; }
-    for (int k = t; k < 160; k += 64) rec[kRecHdr + k] = k < (int)s_hlen ? hdr[k] : (uint8_t)0;
+    if (t == 0) { ((uint32_t*)rec)[0] = hlen; ((uint32_t*)rec)[1] = ok ? tl : 0u; }
+    for (int k = t; k < 160; k += 64) rec[kRecHdr + k] = k < (int)hlen ? hdr[k] : (uint8_t)0;
     for (int k = t; k < 256; k += 64) {
-        ((uint16_t*)(rec + kRecTab))[k] = s_hlen ? vals[k] : (uint16_t)0;
+        ((uint16_t*)(rec + kRecTab))[k] = hlen ? vals[k] : (uint16_t)0;
         rec[kRecTab + 512 + k] = lens[k];
     }
 }
