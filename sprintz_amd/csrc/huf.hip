@@ -90,22 +90,30 @@ __global__ void __launch_bounds__(256) huf_build_kernel(const uint8_t* dense, co
         }
     };
     const int nc = (int)(c1 - c0);
-    for (int cc = 0; cc < nc; cc += 2) {
-        const uint8_t* p0 = dense + s_off[cc];
-        const uint32_t n0 = s_sz[cc], np0 = n0 >> 4;
-        const bool two = cc + 1 < nc;
-        const uint8_t* p1 = dense + s_off[two ? cc + 1 : cc];
-        const uint32_t n1 = two ? s_sz[cc + 1] : 0u, np1 = n1 >> 4;
-        u32x4 x0 = {0, 0, 0, 0}, x1 = {0, 0, 0, 0};
-        const bool h0 = (uint32_t)t < np0, h1 = (uint32_t)t < np1;
-        if (h0) x0 = *(const u32x4_a1*)(p0 + (size_t)t * 16);
-        if (h1) x1 = *(const u32x4_a1*)(p1 + (size_t)t * 16);
-        if (h0) tally(x0);
-        if (h1) tally(x1);
-        for (uint32_t i = t + 256; i < np0; i += 256) { const u32x4 x = *(const u32x4_a1*)(p0 + (size_t)i * 16); tally(x); }
-        for (uint32_t i = t + 256; i < np1; i += 256) { const u32x4 x = *(const u32x4_a1*)(p1 + (size_t)i * 16); tally(x); }
-        for (uint32_t i = (np0 << 4) + t; i < n0; i += 256) atomicAdd(&hw[p0[i]], 1u);
-        for (uint32_t i = (np1 << 4) + t; i < n1; i += 256) atomicAdd(&hw[p1[i]], 1u);
+    // eight chunks' first pieces in flight together (round 4: two -- the loop was 32 dependent memory latencies a segment, ~80 of the
+    // kernel's 110 us; a chunk of the headline shape is < 256 pieces: one trip per thread)
+    constexpr int kU = 8;
+    for (int cc = 0; cc < nc; cc += kU) {
+        u32x4 x[kU];
+        bool h[kU];
+#pragma unroll
+        for (int q = 0; q < kU; q++) {
+            const bool in = cc + q < nc;
+            const uint32_t np = in ? s_sz[cc + q] >> 4 : 0u;
+            h[q] = (uint32_t)t < np;
+            x[q] = u32x4{0, 0, 0, 0};
+            if (h[q]) x[q] = *(const u32x4_a1*)(dense + s_off[cc + q] + (size_t)t * 16);
+        }
+#pragma unroll
+        for (int q = 0; q < kU; q++) if (h[q]) tally(x[q]);
+#pragma unroll 1
+        for (int q = 0; q < kU; q++) {
+            if (cc + q >= nc) break;
+            const uint8_t* const p0 = dense + s_off[cc + q];
+            const uint32_t n0 = s_sz[cc + q], np0 = n0 >> 4;
+            for (uint32_t i = t + 256; i < np0; i += 256) { const u32x4 xx = *(const u32x4_a1*)(p0 + (size_t)i * 16); tally(xx); }
+            for (uint32_t i = (np0 << 4) + t; i < n0; i += 256) atomicAdd(&hw[p0[i]], 1u);
+        }
     }
     __syncthreads();
     hist[t] = hist4[0][t] + hist4[1][t] + hist4[2][t] + hist4[3][t];
@@ -132,15 +140,31 @@ __global__ void __launch_bounds__(256) huf_build_kernel(const uint8_t* dense, co
         if (nz >= 2) {
             // two-queue Huffman (oracle/huf_oracle.c: huf_oracle_lengths)
             for (int i = 0; i < nz; i++) w[i] = lc[i];
+            // (round 5: the two queues' front weights ride in registers, the leaf queue's two ahead -- the walk was six dependent LDS
+            //  reads a merge, 255 merges; the picks and the tree are the same)
             int ql = 0, qi = nz, next = nz;
+            uint32_t lw0 = lc[0], lw1 = nz > 1 ? lc[1] : 0u;         // w[ql], w[ql + 1]
+            uint32_t iw0 = 0, iw1 = 0;                                // w[qi], w[qi + 1] where those exist (qi < next, qi + 1 < next)
             for (int m = 0; m < nz - 1; m++) {
                 int pick[2];
+                uint32_t sum = 0;
                 for (int k = 0; k < 2; k++) {
                     const bool has_l = ql < nz, has_i = qi < next;
-                    if (has_l && (!has_i || w[ql] <= w[qi])) pick[k] = ql++;
-                    else pick[k] = qi++;
+                    if (has_l && (!has_i || lw0 <= iw0)) {
+                        pick[k] = ql++;
+                        sum += lw0;
+                        lw0 = lw1;
+                        lw1 = ql + 1 < nz ? lc[ql + 1] : 0u;
+                    } else {
+                        pick[k] = qi++;
+                        sum += iw0;
+                        iw0 = iw1;
+                        iw1 = qi + 1 < next ? w[qi + 1] : 0u;
+                    }
                 }
-                w[next] = w[pick[0]] + w[pick[1]];
+                w[next] = sum;
+                if (qi == next) iw0 = sum;
+                else if (qi + 1 == next) iw1 = sum;
                 parent[pick[0]] = (uint16_t)next;
                 parent[pick[1]] = (uint16_t)next;
                 next++;
@@ -211,14 +235,17 @@ __global__ void __launch_bounds__(256) huf_build_kernel(const uint8_t* dense, co
         }
     }
     __syncthreads();
-    if (t == 0) {   // first canonical code of every length
-        uint32_t count[LMAX + 2];
-        for (int l = 0; l <= LMAX + 1; l++) count[l] = 0;
-        for (int u = 0; u < 256; u++) count[lens[u]]++;
-        count[0] = 0;
-        uint32_t code = 0;
+    // first canonical code of every length: the symbols per length counted by all threads (round 4: thread 0 walked the 256 lengths
+    // into a dynamically indexed local array)
+    __shared__ uint32_t s_count[LMAX + 2];
+    if (t < LMAX + 2) s_count[t] = 0;
+    __syncthreads();
+    atomicAdd(&s_count[lens[t] <= LMAX + 1 ? lens[t] : LMAX + 1], 1u);
+    __syncthreads();
+    if (t == 0) {
+        uint32_t code = 0, prev = 0;                         // (count[0] does not count)
         first[0] = 0;
-        for (int l = 1; l <= LMAX; l++) { code = (code + count[l - 1]) << 1; first[l] = code; }
+        for (int l = 1; l <= LMAX; l++) { code = (code + prev) << 1; first[l] = code; prev = s_count[l]; }
     }
     __syncthreads();
 
