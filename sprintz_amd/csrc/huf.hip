@@ -30,15 +30,33 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 __attribute__((aligned(4), may_alias)) u32x4_a4;
 typedef u32x4 __attribute__((aligned(1), may_alias)) u32x4_a1;
 
+// wave-wide maximum on the DPP network (quad swaps, the row mirrors, row_bcast15 / 31, lane 63 read back): ~10 dependent vector
+// instructions instead of six ds_bpermute round trips.  (The length-limit repair of huf_build_kernel calls the 64-bit form once per
+// round, up to a few hundred rounds a segment: with __shfl_xor on 64 bits -- twelve LDS-crossbar trips a round -- it was most of the kernel.)
+__device__ __forceinline__ uint32_t wave_max_u32_dpp(uint32_t v)
+{
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false));   // row_half_mirror
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xf, 0xf, false));   // row_mirror: every lane of a row holds the row's
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xa, 0xf, false));   // row_bcast15 into rows 1 and 3
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xc, 0xf, false));   // row_bcast31 into rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint64_t o = __shfl_xor((unsigned long long)v, d);
-        v = o > v ? o : v;
-    }
-    return v;
+    const uint32_t hi = wave_max_u32_dpp((uint32_t)(v >> 32));
+    const uint32_t lo = wave_max_u32_dpp((uint32_t)(v >> 32) == hi ? (uint32_t)v : 0u);
+    return ((uint64_t)hi << 32) | lo;
 }
+
+#ifdef HUF_BUILD_TIMING                         // experiment builds: where a segment's workgroup spends its time (block 0, thread 0; 10 ns ticks)
+__device__ uint64_t g_build_ts[16];
+#define BUILD_TS(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_build_ts[k] = wall_clock64(); } while (0)
+#else
+#define BUILD_TS(k) do {} while (0)
+#endif
 
 // ---------------------------------------------------------------- K1: histogram + code lengths + codes
 // One workgroup per segment.  The histogram and the sort run on all 256 threads, the
@@ -63,6 +81,7 @@ __global__ void __launch_bounds__(256) huf_build_kernel(const uint8_t* dense, co
     const uint64_t seg = blockIdx.x;
     const uint64_t c0 = seg * SEG, c1 = (c0 + SEG < nchunks) ? c0 + SEG : nchunks;
 
+    BUILD_TS(0);
     for (int k = 0; k < 4; k++) hist4[k][t] = 0;
     lens[t] = 0;
     if (t == 0) s_kraft = 0;
@@ -119,6 +138,7 @@ __global__ void __launch_bounds__(256) huf_build_kernel(const uint8_t* dense, co
     hist[t] = hist4[0][t] + hist4[1][t] + hist4[2][t] + hist4[3][t];
     __syncthreads();
 
+    BUILD_TS(1);
     {   // rank sort by (count, symbol)
         const uint32_t cs = hist[t];
         int rank = 0;
@@ -130,6 +150,7 @@ __global__ void __launch_bounds__(256) huf_build_kernel(const uint8_t* dense, co
         lsym[rank] = (uint16_t)t;
     }
     __syncthreads();
+    BUILD_TS(2);
 
     if (t == 0) {
         int z = 0;
@@ -172,6 +193,7 @@ __global__ void __launch_bounds__(256) huf_build_kernel(const uint8_t* dense, co
         }
     }
     __syncthreads();
+    BUILD_TS(3);
     const int z = s_z;
     const int nz = 256 - z;
     if (nz == 1) {
@@ -188,6 +210,7 @@ __global__ void __launch_bounds__(256) huf_build_kernel(const uint8_t* dense, co
             lens[lsym[z + t]] = (uint8_t)myl;
         }
         __syncthreads();
+        BUILD_TS(4);
         if (t < 64 && s_kraft != (1u << LMAX)) {             // wave 0 repairs; 4 leaves per lane
             uint32_t kraft = s_kraft;
             uint32_t cn[4], sy[4], ln[4];
@@ -235,6 +258,7 @@ __global__ void __launch_bounds__(256) huf_build_kernel(const uint8_t* dense, co
         }
     }
     __syncthreads();
+    BUILD_TS(5);
     // first canonical code of every length: the symbols per length counted by all threads (round 4: thread 0 walked the 256 lengths
     // into a dynamically indexed local array)
     __shared__ uint32_t s_count[LMAX + 2];
@@ -261,6 +285,7 @@ __global__ void __launch_bounds__(256) huf_build_kernel(const uint8_t* dense, co
         enc_tables[seg * 256 + t] = e;
     }
     if (t < 128) tables[seg * 128 + t] = (uint8_t)(lens[2 * t] | (lens[2 * t + 1] << 4));
+    BUILD_TS(6);
 }
 
 // sub-stream j of an n-symbol chunk: [a, b)
@@ -918,5 +943,9 @@ int sprintz_mi355x_huf_decompress_batch(const void* d_huf, const uint64_t* d_huf
                        (const uint8_t*)d_tables, nchunks, (uint8_t*)d_dense, (const uint64_t*)d_offsets, dense_capacity, d_rets);
     return hipGetLastError() == hipSuccess ? 0 : sprintz::set_error(SPRINTZ_E_HIP, "Huffman stage: a HIP call or kernel launch failed");
 }
+
+#ifdef HUF_BUILD_TIMING
+int sprintz_mi355x_dbg_build_stamps(uint64_t* out16) { return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_build_ts), 16 * sizeof(uint64_t)); }
+#endif
 
 }  // extern "C"
