@@ -66,7 +66,8 @@ __device__ uint64_t g_build_ts[16];
 __global__ void __launch_bounds__(256) huf_build_kernel(const uint8_t* dense, const uint64_t* offsets, const uint32_t* sizes,
                                                         uint64_t nchunks, uint32_t* enc_tables, uint8_t* tables)
 {
-    __shared__ uint32_t hist4[4][256];
+    constexpr int kHistCopies = 16;                    // (round 4: one per wave -- 64 lanes on <= 256 counters, the hot byte values collide)
+    __shared__ uint32_t hist4[kHistCopies][256];
     __shared__ uint32_t hist[256];
     __shared__ uint32_t lcnt[256];      // leaves sorted by (count, symbol): count
     __shared__ uint16_t lsym[256];      //                                   symbol
@@ -82,11 +83,11 @@ __global__ void __launch_bounds__(256) huf_build_kernel(const uint8_t* dense, co
     const uint64_t c0 = seg * SEG, c1 = (c0 + SEG < nchunks) ? c0 + SEG : nchunks;
 
     BUILD_TS(0);
-    for (int k = 0; k < 4; k++) hist4[k][t] = 0;
+    for (int k = 0; k < kHistCopies; k++) hist4[k][t] = 0;
     lens[t] = 0;
     if (t == 0) s_kraft = 0;
     __syncthreads();
-    uint32_t* const hw = hist4[t >> 6];
+    uint32_t* const hw = hist4[t & (kHistCopies - 1)];
     // chunk geometry once, coalesced; then two chunks' first pieces are in flight together (a
     // chunk of the headline shape is < 256 pieces: one trip per thread, and the loop was two
     // dependent memory latencies per chunk)
@@ -135,7 +136,12 @@ __global__ void __launch_bounds__(256) huf_build_kernel(const uint8_t* dense, co
         }
     }
     __syncthreads();
-    hist[t] = hist4[0][t] + hist4[1][t] + hist4[2][t] + hist4[3][t];
+    {
+        uint32_t hsum = 0;
+#pragma unroll
+        for (int k = 0; k < kHistCopies; k++) hsum += hist4[k][t];
+        hist[t] = hsum;
+    }
     __syncthreads();
 
     BUILD_TS(1);
@@ -152,15 +158,19 @@ __global__ void __launch_bounds__(256) huf_build_kernel(const uint8_t* dense, co
     __syncthreads();
     BUILD_TS(2);
 
+    {   // zero-count symbols sort first: their number, and the leaves' weights into the tree array, by everybody (round 4: thread 0
+        // walked both -- 20 of the merge phase's 57 us)
+        const int zc = __syncthreads_count(hist[t] == 0);
+        if (t == 0) s_z = zc;
+        if (t < 256 - zc) w[t] = lcnt[zc + t];
+        __syncthreads();
+    }
     if (t == 0) {
-        int z = 0;
-        while (z < 256 && lcnt[z] == 0) z++;                 // zero-count symbols sort first
-        s_z = z;
+        const int z = s_z;
         const int nz = 256 - z;
         const uint32_t* lc = lcnt + z;
         if (nz >= 2) {
-            // two-queue Huffman (oracle/huf_oracle.c: huf_oracle_lengths)
-            for (int i = 0; i < nz; i++) w[i] = lc[i];
+            // two-queue Huffman (oracle/huf_oracle.c: huf_oracle_lengths); (branch-free picks measured slower: 75 against 57 us)
             // (round 5: the two queues' front weights ride in registers, the leaf queue's two ahead -- the walk was six dependent LDS
             //  reads a merge, 255 merges; the picks and the tree are the same)
             int ql = 0, qi = nz, next = nz;
