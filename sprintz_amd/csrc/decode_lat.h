@@ -27,6 +27,10 @@
 // It costs about twice the instructions per chunk of decode_fast.h, so it is for batches that leave the chip empty anyway.
 #pragma once
 
+#ifndef SPRINTZ_LAT_POLL_SLEEP
+#define SPRINTZ_LAT_POLL_SLEEP 1          // s_sleep units (64 clocks) between two polls of a hand-off word
+#endif
+
 #include "decode_fast.h"
 
 namespace sprintz {
@@ -197,7 +201,7 @@ __global__ void __launch_bounds__(256) decode_lat_kernel(DecodeArgs a, LatCarve 
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 ad = peek(0);
                 if (fin || ad >= g0 + G) break;
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(SPRINTZ_LAT_POLL_SLEEP);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             if (g0 >= ad) break;                           // (A is done and left nothing for this wave)
@@ -297,7 +301,7 @@ __global__ void __launch_bounds__(256) decode_lat_kernel(DecodeArgs a, LatCarve 
                 }
                 if (ready > b) break;
                 if (fin && gr >= ad) { finished = true; break; }
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(SPRINTZ_LAT_POLL_SLEEP);
             }
             if (finished) break;
             if (b == 0) LAT_DBG(6);
