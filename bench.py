@@ -449,7 +449,7 @@ def bench_rowmajor(cx, name, workload, codec, esz, ndims, chunk_len, nchunks_tot
         algo_chain = hbytes + 8 * n + 8 * n + raw                           # Huff0 blocks in + samples out + both offset tables
         moved_chain = algo_chain + 2 * stream_bytes                         # what the two-stage chain moves: the Sprintz streams out and in again
         res.update({"ratio": round(raw / hbytes, 4), "ratio_sprintz_only": round(raw / stream_bytes, 4),
-                    "entropy_stage": "Huff0 wire format (HUF_compress-compatible blocks, one per chunk)",
+                    "entropy_stage": "Huff0 wire format as of zstd 1.4.8 (HUF_compress-compatible blocks, one per chunk; reader and writer pinned against the system libzstd 1.4.8 -- the Huff0 revision inside the author's lzbench fork is not in the image)",
                     "decompress_ms": round(chain_ms, 4), "decompress_MBps": round(raw / chain_ms / 1e3, 1),
                     "huff0_decode_ms": round(h_dec_ms, 4), "sprintz_decode_ms": round(dec_ms, 4),
                     "compress_ms": round(enc_ms + h_enc_ms, 4), "compress_MBps": round(raw / (enc_ms + h_enc_ms) / 1e3, 1),
