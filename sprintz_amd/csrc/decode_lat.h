@@ -27,6 +27,9 @@
 // It costs about twice the instructions per chunk of decode_fast.h, so it is for batches that leave the chip empty anyway.
 #pragma once
 
+#ifndef SPRINTZ_LAT_ROTATE
+#define SPRINTZ_LAT_ROTATE 0           // round 5: roles rotated by workgroup number measured no different (35.5 vs 35.4 us at 1 250 chunks): off
+#endif
 #ifndef SPRINTZ_LAT_POLL_SLEEP
 #define SPRINTZ_LAT_POLL_SLEEP 1          // s_sleep units (64 clocks) between two polls of a hand-off word
 #endif
@@ -115,7 +118,10 @@ __global__ void __launch_bounds__(256) decode_lat_kernel(DecodeArgs a, LatCarve 
     __syncthreads();
     LAT_STAMP();
 
-    const uint32_t wave = tid >> 6;
+    // the wave's ROLE (A: header walk, B: bit fields, C: recurrence), rotated by the workgroup's number: a workgroup's waves land on
+    // the CU's four SIMDs in order, and with the roles fixed every chunk's recurrence wave -- the longest chain, 33 instructions a
+    // block on 8 of 64 lanes -- sat on the same SIMD of its CU (round 5: 1 250 chunks = 5 workgroups a CU)
+    const uint32_t wave = ((tid >> 6) + (SPRINTZ_LAT_ROTATE ? blockIdx.x : 0u)) & 3u;
     const int lane_d = (int)(tid & (uint32_t)(DP - 1));
     const bool col_ok = lane_d < D;
     const int colk = col_ok ? lane_d : D - 1;              // a lane past the last column stands in for it (uniform code)
@@ -187,7 +193,7 @@ __global__ void __launch_bounds__(256) decode_lat_kernel(DecodeArgs a, LatCarve 
         }
         const uint32_t out_left = a.chunk_len - ob * blk_elems;
         if (!corrupt && (remaining > out_left || pos + remaining * ESZ > send)) corrupt = true;
-        if (tid == 0) { info[0] = corrupt ? 1u : 0u; info[1] = g; info[2] = ob; info[3] = pos; info[4] = remaining; }
+        if ((tid & 63u) == 0) { info[0] = corrupt ? 1u : 0u; info[1] = g; info[2] = ob; info[3] = pos; info[4] = remaining; }
         publish(1, 1u);
         LAT_DBG(0);
     } else if (wave <= NBW) {
