@@ -326,6 +326,7 @@ __device__ __forceinline__ uint32_t encode_wide_body(const EncodeArgs& a, uint32
 
         // ---- RLE state machine (:350-456); group-uniform
         for (;;) {
+#ifndef SPRINTZ_ENC_ABL_NO_RLE                     // ablation build: no run handling at all (right only for data without zero blocks): what the state machine costs
             if (total == 0 && run < 0x7fffu && !a.norle) {
                 run++;
                 pos_in += blk;
@@ -346,6 +347,7 @@ __device__ __forceinline__ uint32_t encode_wide_body(const EncodeArgs& a, uint32
                 if (slot == 2) start_group();
                 continue;
             }
+#endif
             {   // header fields: the lane's two, then four lanes' eight = one 24-bit word (:296)
                 uint32_t f = 0;
 #pragma unroll
