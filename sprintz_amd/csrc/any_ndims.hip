@@ -35,7 +35,7 @@ __device__ __forceinline__ uint32_t wg_scan(uint32_t v, uint32_t& total, uint32_
     return ex + base;
 }
 
-template <int W, bool FIRE>
+template <int W, bool FIRE, int CPL>
 __global__ void __launch_bounds__(256) decode_any_kernel(DecodeArgs a)
 {
     using U = typename Elem<W>::U;
@@ -103,20 +103,20 @@ __global__ void __launch_bounds__(256) decode_any_kernel(DecodeArgs a)
     if (groups_left > a.chunk_len / blk_elems + 2u) corrupt = true;      // a damaged header must not make the loop spin
     if (corrupt) groups_left = 0;
 
-    uint32_t pv[kAnyCpl];
-    int pd[kAnyCpl], ctr[kAnyCpl];
-    uint32_t nbs[2][kAnyCpl];
+    uint32_t pv[CPL];
+    int pd[CPL], ctr[CPL];
+    uint32_t nbs0[CPL], nbs1[CPL];                            // the two slots' widths (one array indexed by the slot went to scratch)
 #pragma unroll
-    for (int k = 0; k < kAnyCpl; k++) { pv[k] = 0; pd[k] = 0; ctr[k] = 0; nbs[0][k] = 0; nbs[1][k] = 0; }
+    for (int k = 0; k < CPL; k++) { pv[k] = 0; pd[k] = 0; ctr[k] = 0; nbs0[k] = 0; nbs1[k] = 0; }
     uint32_t out_elems = 0;
 
     // one block of errors z (zigzagged; run blocks: zeros) -> samples, stored (:993-1150; runs :828-958)
-    auto emit_block = [&](const uint32_t (&z)[8][kAnyCpl], bool run_block) {
+    auto emit_block = [&](const uint32_t (&z)[8][CPL], bool run_block) {
         U* const og = o + out_elems;
         const uint32_t omis = (uint32_t)((uintptr_t)og & 15u);
         U* const ob = (U*)(l_out + omis);                         // (element-aligned: the output's misalignment is a multiple of the element size)
 #pragma unroll
-        for (int k = 0; k < kAnyCpl; k++) {
+        for (int k = 0; k < CPL; k++) {
             const int col = col0 + k;
             if (k >= cpl || col >= D) continue;
             int coef = FIRE ? fire_coef<W, false>(ctr[k]) : 0;
@@ -150,16 +150,16 @@ __global__ void __launch_bounds__(256) decode_any_kernel(DecodeArgs a)
         __syncthreads();
         uint32_t both = 0;
 #pragma unroll
-        for (int k = 0; k < kAnyCpl; k++) {
+        for (int k = 0; k < CPL; k++) {
             const int col = col0 + k;
             uint32_t f0 = 0, f1 = 0;
             if (k < cpl && col < D) {
                 f0 = fetch_bits(hsrc, (uint32_t)col * HB, HB);
                 f1 = fetch_bits(hsrc, (uint32_t)(D + col) * HB, HB);
             }
-            nbs[0][k] = f0 == (uint32_t)(W - 1) ? (uint32_t)W : f0;      // :747-749, :763-765
-            nbs[1][k] = f1 == (uint32_t)(W - 1) ? (uint32_t)W : f1;
-            both += nbs[0][k] | (nbs[1][k] << 16);                        // (a slot's total is at most 2047 * 16 < 2^16)
+            nbs0[k] = f0 == (uint32_t)(W - 1) ? (uint32_t)W : f0;        // :747-749, :763-765
+            nbs1[k] = f1 == (uint32_t)(W - 1) ? (uint32_t)W : f1;
+            both += nbs0[k] | (nbs1[k] << 16);                        // (a slot's total is at most 2047 * 16 < 2^16)
         }
         uint32_t tot_both;
         const uint32_t excl_both = wg_scan(both, tot_both, s4);
@@ -174,11 +174,11 @@ __global__ void __launch_bounds__(256) decode_any_kernel(DecodeArgs a)
                 uint32_t len = b0 & 0x7fu;
                 if (b0 & 0x80u) { len |= load_u8(s + pos + 1) << 7; pos += 2; }
                 else pos += 1;
-                uint32_t zero[8][kAnyCpl];
+                uint32_t zero[8][CPL];
 #pragma unroll
                 for (int i = 0; i < 8; i++)
 #pragma unroll
-                    for (int k = 0; k < kAnyCpl; k++) zero[i][k] = 0;
+                    for (int k = 0; k < CPL; k++) zero[i][k] = 0;
                 for (; len > 0; len--) {
                     if (out_elems + blk_elems > a.chunk_len) { corrupt = true; break; }
                     emit_block(zero, true);
@@ -189,10 +189,10 @@ __global__ void __launch_bounds__(256) decode_any_kernel(DecodeArgs a)
                 uint32_t off = slot ? excl_both >> 16 : excl_both & 0xffffu;
                 const uint8_t* const psrc = l_pay + stage_in(s + pos, row_bits, l_pay);      // (row_bits = the block's 8 rows in BYTES)
                 __syncthreads();
-                uint32_t z[8][kAnyCpl];
+                uint32_t z[8][CPL];
 #pragma unroll
-                for (int k = 0; k < kAnyCpl; k++) {
-                    const uint32_t nb = nbs[slot][k];
+                for (int k = 0; k < CPL; k++) {
+                    const uint32_t nb = slot ? nbs1[k] : nbs0[k];
 #pragma unroll
                     for (int i = 0; i < 8; i++)
                         z[i][k] = (k < cpl && col0 + k < D) ? fetch_bits(psrc, (uint32_t)i * row_bits + off, nb) : 0u;
@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(256) decode_any_kernel(DecodeArgs a)
     if (tid == 0 && a.rets) a.rets[chunk] = corrupt ? kErrCorrupt : (int64_t)out_elems + remaining;
 }
 
-template <int W, bool FIRE>
+template <int W, bool FIRE, int CPL>
 __global__ void __launch_bounds__(256) encode_any_kernel(EncodeArgs a)
 {
     using U = typename Elem<W>::U;
@@ -280,10 +280,10 @@ __global__ void __launch_bounds__(256) encode_any_kernel(EncodeArgs a)
     int64_t pos_in = 0;
     uint32_t ngroups = 0, run = 0, hdr_pos = 0;
     int slot = 0;
-    uint32_t pv[kAnyCpl];
-    int pd[kAnyCpl], ctr[kAnyCpl];
+    uint32_t pv[CPL];
+    int pd[CPL], ctr[CPL];
 #pragma unroll
-    for (int k = 0; k < kAnyCpl; k++) { pv[k] = 0; pd[k] = 0; ctr[k] = 0; }
+    for (int k = 0; k < CPL; k++) { pv[k] = 0; pd[k] = 0; ctr[k] = 0; }
     auto start_group = [&]() {
         ngroups++;
         drain(wl & ~15u);
@@ -298,10 +298,10 @@ __global__ void __launch_bounds__(256) encode_any_kernel(EncodeArgs a)
         // ---- the block at pos_in: forecast, zigzag, widths (:197-298)
         // (round 5 staged the block's 8 rows through LDS with 16-byte requests instead of one 2-byte load a sample: 0.75 against 0.69 ms at
         //  1 000 columns -- the image costs a resident workgroup a CU and the loads were not what the chunk's 32 serial blocks wait for)
-        uint32_t z[8][kAnyCpl], nb[kAnyCpl];
+        uint32_t z[8][CPL], nb[CPL];
         uint32_t lane_bits = 0;
 #pragma unroll
-        for (int k = 0; k < kAnyCpl; k++) {
+        for (int k = 0; k < CPL; k++) {
             const int col = col0 + k;
             nb[k] = 0;
             if (k >= cpl || col >= D) {
@@ -357,7 +357,7 @@ __global__ void __launch_bounds__(256) encode_any_kernel(EncodeArgs a)
             const uint32_t row_bits = ((total + 7u) >> 3) << 3;
             uint32_t off = excl;
 #pragma unroll
-            for (int k = 0; k < kAnyCpl; k++) {
+            for (int k = 0; k < CPL; k++) {
                 const int col = col0 + k;
                 if (k < cpl && col < D) {
                     or_bits(hdr_pos * 8u + (uint32_t)(slot * D + col) * HB, nb[k] == (uint32_t)W ? (uint32_t)(W - 1) : nb[k], HB);      // :296
@@ -747,8 +747,13 @@ hipError_t launch_decode_any(int w, bool fire, unsigned grid, hipStream_t st, co
     // [header image | payload image | block image] (decode_any_kernel): <= 2 KB + 2 x 32 KB at 2 047 uint16 columns
     const uint32_t D = (uint32_t)a.D, esz = (uint32_t)w / 8, hb = w == 8 ? 3u : 4u;
     const size_t shmem = (size_t)(((((2u * D * hb + 7u) >> 3) + 15u) & ~15u) + 32u) + 2u * (size_t)(((8u * D * esz + 15u) & ~15u) + 32u);
-    if (w == 8) return fire ? launch_any(decode_any_kernel<8, true>, grid, shmem, st, a) : launch_any(decode_any_kernel<8, false>, grid, shmem, st, a);
-    return fire ? launch_any(decode_any_kernel<16, true>, grid, shmem, st, a) : launch_any(decode_any_kernel<16, false>, grid, shmem, st, a);
+    // (columns a lane: ceil(D / 256); the kernels are built for <= 4 and <= 8 -- at <= 1 024 columns half the registers: 4 workgroups a CU instead of 3)
+    if (D <= 1024u) {
+        if (w == 8) return fire ? launch_any(decode_any_kernel<8, true, 4>, grid, shmem, st, a) : launch_any(decode_any_kernel<8, false, 4>, grid, shmem, st, a);
+        return fire ? launch_any(decode_any_kernel<16, true, 4>, grid, shmem, st, a) : launch_any(decode_any_kernel<16, false, 4>, grid, shmem, st, a);
+    }
+    if (w == 8) return fire ? launch_any(decode_any_kernel<8, true, 8>, grid, shmem, st, a) : launch_any(decode_any_kernel<8, false, 8>, grid, shmem, st, a);
+    return fire ? launch_any(decode_any_kernel<16, true, 8>, grid, shmem, st, a) : launch_any(decode_any_kernel<16, false, 8>, grid, shmem, st, a);
 }
 // 2 048 .. 65 535 columns; counters: nchunks * ndims int32 of scratch (FIRE codecs only; may be null otherwise)
 hipError_t launch_decode_big(int w, bool fire, unsigned grid, hipStream_t st, const DecodeArgs& a, int32_t* counters)
@@ -765,8 +770,12 @@ hipError_t launch_encode_big(int w, bool fire, unsigned grid, hipStream_t st, co
 }
 hipError_t launch_encode_any(int w, bool fire, unsigned grid, size_t shmem, hipStream_t st, const EncodeArgs& a)
 {
-    if (w == 8) return fire ? launch_any(encode_any_kernel<8, true>, grid, shmem, st, a) : launch_any(encode_any_kernel<8, false>, grid, shmem, st, a);
-    return fire ? launch_any(encode_any_kernel<16, true>, grid, shmem, st, a) : launch_any(encode_any_kernel<16, false>, grid, shmem, st, a);
+    if (a.D <= 1024) {
+        if (w == 8) return fire ? launch_any(encode_any_kernel<8, true, 4>, grid, shmem, st, a) : launch_any(encode_any_kernel<8, false, 4>, grid, shmem, st, a);
+        return fire ? launch_any(encode_any_kernel<16, true, 4>, grid, shmem, st, a) : launch_any(encode_any_kernel<16, false, 4>, grid, shmem, st, a);
+    }
+    if (w == 8) return fire ? launch_any(encode_any_kernel<8, true, 8>, grid, shmem, st, a) : launch_any(encode_any_kernel<8, false, 8>, grid, shmem, st, a);
+    return fire ? launch_any(encode_any_kernel<16, true, 8>, grid, shmem, st, a) : launch_any(encode_any_kernel<16, false, 8>, grid, shmem, st, a);
 }
 
 }  // namespace sprintz
