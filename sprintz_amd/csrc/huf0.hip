@@ -531,11 +531,20 @@ constexpr int ring_stride(int plog) { return 2 * (1 << plog) + 8; }
 #ifndef HUF0_BIG_NS
 #define HUF0_BIG_NS 3                     // ring slots of the big-batch one-table kernel (2: 64-byte pieces only)
 #endif
+#ifndef HUF0_FAST_TAILS
+#define HUF0_FAST_TAILS 1                 // every round that is not a fast one (a wave's first, cut at the output's lines, and its last) runs its whole steps as fast steps + ONE masked step (round 5; before: the unaligned-burst forms' last round only)
+#endif
+#ifndef HUF0_BIG_UA
+#define HUF0_BIG_UA 0                     // the big-batch one-table kernel's bursts start where a stream's output starts (no masked first round) instead of on 64-byte lines
+#endif
 #ifndef HUF0_BIG_WG
 #define HUF0_BIG_WG 2                     // wavefronts a workgroup of the big-batch one-table kernel
 #endif
 #ifndef HUF0_BIG_PLOG
 #define HUF0_BIG_PLOG 6                   // log2 of the stream piece of the big-batch one-table kernel
+#endif
+#ifndef HUF0_CARRY_WINDOW
+#define HUF0_CARRY_WINDOW 1              // the one-table path carries its 64-bit window from step to step (fast_step; round 5)
 #endif
 #ifndef HUF0_CADENCED
 #define HUF0_CADENCED 1                  // the 4-wave one-table kernel refills on a fixed cadence (template parameter CAD)
@@ -1364,8 +1373,63 @@ __device__ __forceinline__ void huf0_stream_body(const uint8_t* __restrict__ blo
     // first bit that 16 steps (<= 16 * 4 * 12 bits) need no masking, no symbol count and no bounds on the piece index.
     // 4 symbols are then ~45 instructions instead of ~130 (the per-symbol `on` masks alone took 40 SGPRs a step).
     constexpr int32_t kFastBits = 64 + 3 * 48;                    // four steps at a time
-    auto fast_step = [&](auto SH) -> uint32_t {
+    // Round 5: the CARRIED window (one-table path, 64-byte pieces on the cadence).  A step used to start by fetching its 64-bit window
+    // from the ring at the cursor's byte -- address arithmetic from P, an LDS round trip, two v_alignbyte and a 64-bit shift, all of it on the
+    // lane's serial chain in front of the first look-up: five dependent LDS round trips per four symbols.  But a step leaves >= 64 - 4 * 12
+    // = 16 valid bits in the window it had, which is all its successor's FIRST look-up needs.  So the window is carried from step to step
+    // (valid while carry_P == P), and what a step fetches from the ring is the 64 bits BELOW its window (from bit P - 65 down), needed only
+    // when the step ends: win' = win << c | below >> (64 - c).  The fetch and its arithmetic leave the chain (four round trips per four
+    // symbols, ~7 dependent VALU instructions a step less); the LDS reads are the same in number.  Reach: the fetch looks 8 bytes further
+    // down than the window did: eight steps take <= 48 bytes, + 7 (window) + 8 = 63 <= the 64 bytes of piece cur_b - 1 that the cadence
+    // keeps resident below the group top's cursor (two slots, refilled every four steps: a piece is requested <= 22 bytes after the cursor entered
+    // the one above it and parked <= 44 bytes in; until then the steps read <= 38.5 + 15 = 54 bytes into that piece).  Lanes that ride along (parked cursor), bits below a stream's first one: garbage that is
+    // never consumed, every address inside the lane's ring as before.
+    constexpr bool kCarry = CAD && PLOG == 6 && HUF0_CARRY_WINDOW;
+    uint64_t carry_pre = 0, carry_fill = 0;                       // the window = carry_pre | carry_fill (the first look-up reads carry_pre alone)
+    int32_t carry_P = -1;                                         // the cursor the carried window belongs to
+    auto ring_bytes = [&](uint32_t top) -> uint64_t {             // CAD, NS == 3: the 8 stream bytes that end with the byte of bit `top` (that byte on top)
+        const uint32_t x = (top >> 3) + s_al;
+        uint32_t o, a;
+        if constexpr (NS == 3) {
+            const uint32_t sb = (int32_t)(x >> kPLog) == cur_b ? cur_s32 : m1_s32;
+            int32_t oo = (int32_t)(sb + (x & (uint32_t)(kPB - 1))) - 7;
+            oo += oo < 0 ? 3 * kPB : 0;
+            o = (uint32_t)oo;
+            a = ring + (o & ~3u);
+        } else {                                                  // two slots: piece k sits in slot k & 1, byte i of the stream at (s_al + i) & 127
+            o = x - 7u;
+            a = ring + (o & (2u * kPB - 4u));
+        }
+        const uint32_t d0 = *(lds_u32c*)(uintptr_t)a, d1 = *(lds_u32c*)(uintptr_t)(a + 4u), d2 = *(lds_u32c*)(uintptr_t)(a + 8u);
+        const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, o & 3u), hi0 = __builtin_amdgcn_alignbyte(d2, d1, o & 3u);
+        return ((uint64_t)hi0 << 32) | lo;
+    };
+    // keep = false (a wave's first and last rounds): the lane goes through the motions and leaves its cursor and its window where they were
+    auto fast_step = [&](auto SH, bool keep = true) -> uint32_t {
         constexpr bool kShared = decltype(SH)::value;
+        if constexpr (kCarry && kShared) {
+            const uint32_t sh = 7u - (((uint32_t)P - 1u) & 7u);   // bits of the window's top byte that are above the cursor
+            const uint64_t below_bytes = ring_bytes((uint32_t)P - 65u);
+            if (__ballot(carry_P != P) != 0) {                    // after a masked step, a parked cursor, a round's first step: fetch it (wave-uniform, rare)
+                carry_pre = ring_bytes((uint32_t)P - 1u) << sh;   // (its low `sh` bits are the top bits of the bytes below)
+                carry_fill = (below_bytes >> 1) >> (63u - sh);
+            }
+            const uint64_t below = below_bytes << sh;             // the stream from bit P - 65 down
+            const uint32_t e0 = *(lds_u16*)(uintptr_t)(ft + (((uint32_t)(carry_pre >> 32) >> look_shift) << 1));
+            uint64_t win = (carry_pre | carry_fill) << (e0 & 63u);
+            const uint32_t e1 = *(lds_u16*)(uintptr_t)(ft + (((uint32_t)(win >> 32) >> look_shift) << 1));
+            win <<= e1 & 63u;
+            const uint32_t e2 = *(lds_u16*)(uintptr_t)(ft + (((uint32_t)(win >> 32) >> look_shift) << 1));
+            win <<= e2 & 63u;
+            const uint32_t e3 = *(lds_u16*)(uintptr_t)(ft + (((uint32_t)(win >> 32) >> look_shift) << 1));
+            const uint32_t c = (e0 + e1 + e2 + e3) & 0xffu;       // 4 .. 48 bits
+            carry_pre = keep ? win << (e3 & 63u) : carry_pre;
+            carry_fill = keep ? below >> ((64u - c) & 63u) : carry_fill;
+            P -= keep ? (int32_t)c : 0;
+            carry_P = P;                                          // (valid either way: the window at the top of the step was this lane's, fetched or carried)
+            const uint32_t w01 = __builtin_amdgcn_perm(e1, e0, 0x0c0c0501u), w23 = __builtin_amdgcn_perm(e3, e2, 0x0c0c0501u);
+            return __builtin_amdgcn_perm(w23, w01, 0x05040100u);
+        }
         const uint32_t pm1 = (uint32_t)P - 1u;
         const uint32_t x = (pm1 >> 3) + s_al;
         uint32_t o, a;
@@ -1457,30 +1521,31 @@ __device__ __forceinline__ void huf0_stream_body(const uint8_t* __restrict__ blo
         const bool fast_round = __ballot(streaming && live && head_lim) == 0 && __ballot(burst) != 0;
         // (a lane that rides along decodes from cursor 0: `x` below is then far above any piece index, so its ring stays as it is)
         const int32_t P0 = P;
-        if (fast_round && !burst) P = 0;
+        if (fast_round && !burst) { P = 0; carry_P = 0; }         // (its carried window is garbage like everything it decodes: no refetch for the riders' sake)
 #else
         constexpr bool fast_round = false;
         const bool burst = full;
 #endif
         bool last_round_done = false;
-        if constexpr (UA && HUF0_SPECULATIVE_TAIL) {
+        if constexpr ((UA || (HUF0_FAST_TAILS && NS == 3)) && HUF0_SPECULATIVE_TAIL) {
             // The last round of a wave (no lane has 64 symbols left), small batches: a lane's whole steps of four symbols run as fast
             // steps too -- a lane past its last whole step takes its cursor back after each -- and ONE masked step behind them decodes
             // every lane's last 0 .. 3 symbols: 16 fast + 1 masked instead of 16 masked steps (~9 us -> ~5 of a lane's ~75).
             if (!fast_round) {
-                const uint32_t nfull = streaming ? (uint32_t)lim >> 2 : 0u;
+                const uint32_t lim64 = lim < 64 ? (uint32_t)lim : 64u;           // (a round that is not a fast one: the wave's last -- and, where the bursts are cut
+                const uint32_t nfull = streaming ? lim64 >> 2 : 0u;               //  at the output's 64-byte lines, its first, in which a lane takes 0 .. 64 symbols)
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     group_top(g, P);
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         const int32_t Pk = P;
-                        wb[4 * g + i] = fast_step(SH);
+                        wb[4 * g + i] = fast_step(SH, (uint32_t)(4 * g + i) < nfull);
                         P = (uint32_t)(4 * g + i) < nfull ? P : Pk;
                     }
                 }
                 group_top(0, P);
-                const uint32_t m = (streaming && P >= -64) ? (uint32_t)lim & 3u : 0u;
+                const uint32_t m = (streaming && P >= -64) ? lim64 & 3u : 0u;
                 const uint32_t wl = step(m, SH);
 #pragma unroll
                 for (int k = 0; k < 16; k++) wb[k] = (uint32_t)k == nfull ? wl : wb[k];
@@ -1597,12 +1662,12 @@ __device__ __forceinline__ void huf0_stream_body(const uint8_t* __restrict__ blo
     }
 }
 
-template <bool SO, int WG = 1, int PLOG = 4, bool CAD = false, int NS = 3>
+template <bool SO, int WG = 1, int PLOG = 4, bool CAD = false, int NS = 3, bool UA = false>
 __global__ void __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(SO ? (CAD && PLOG == 6 ? (NS == 2 ? 4 : 3) : HUF0_SO_WAVES) : HUF0_G_WAVES)))   // (64-byte pieces: the LDS allows 10 waves a CU)
 huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restrict__ boffs, uint64_t nchunks, uint8_t* __restrict__ out,
                    const uint64_t* __restrict__ ooffs, int64_t* __restrict__ rets, const uint8_t* __restrict__ desc, const uint8_t* __restrict__ share)
 {
-    huf0_stream_body<SO, WG, PLOG, CAD, NS>(blocks, boffs, nchunks, out, ooffs, rets, desc, share);
+    huf0_stream_body<SO, WG, PLOG, CAD, NS, UA>(blocks, boffs, nchunks, out, ooffs, rets, desc, share);
 }
 
 // small batches: both single-wave forms in ONE launch, a wave takes the one its segment's share flag names (where a launch is 2 - 3 %
@@ -1678,7 +1743,7 @@ int sprintz_mi355x_huf0_decompress_batch_hint(const void* d_blocks, const uint64
     // the one-table kernel: bandwidth-sized batches as workgroups of HUF0_BIG_WG waves with 2^HUF0_BIG_PLOG-byte stream pieces (built: 2 waves, 64 bytes),
     // then the per-chunk-table kernel for the segments that are not its; small batches: both wave by wave in one launch
     if (nchunks >= (uint64_t)sprintz::huf0_big_batch().load(std::memory_order_relaxed)) {
-        hipLaunchKernelGGL((huf0_stream_kernel<true, HUF0_BIG_WG, HUF0_BIG_PLOG, HUF0_CADENCED != 0, HUF0_BIG_NS>), dim3((unsigned)((nchunks + 16 * HUF0_BIG_WG - 1) / (16 * HUF0_BIG_WG))),
+        hipLaunchKernelGGL((huf0_stream_kernel<true, HUF0_BIG_WG, HUF0_BIG_PLOG, HUF0_CADENCED != 0, HUF0_BIG_NS, HUF0_BIG_UA != 0>), dim3((unsigned)((nchunks + 16 * HUF0_BIG_WG - 1) / (16 * HUF0_BIG_WG))),
                            dim3(64 * HUF0_BIG_WG), 0, st, blk, d_block_offsets, nchunks,
                            (uint8_t*)d_out, d_out_offsets, d_rets, (const uint8_t*)desc, (const uint8_t*)share);
         hipLaunchKernelGGL((huf0_stream_kernel<false, 1, HUF0_G_PLOG, HUF0_G_CAD != 0>), dim3((unsigned)grid2), dim3(64), 0, st, blk, d_block_offsets, nchunks,
