@@ -534,6 +534,15 @@ constexpr int ring_stride(int plog) { return 2 * (1 << plog) + 8; }
 #ifndef HUF0_FAST_TAILS
 #define HUF0_FAST_TAILS 1                 // every round that is not a fast one (a wave's first, cut at the output's lines, and its last) runs its whole steps as fast steps + ONE masked step (round 5; before: the unaligned-burst forms' last round only)
 #endif
+#ifndef HUF0_BIG_QW
+#define HUF0_BIG_QW 1                     // the big-batch one-table kernel: a quad fetches each of its four streams' pieces together (one 64-byte request instead of four of 16 bytes) and its bursts leave as whole 128-byte lines (round 5; tools/probes/huf0_pattern.hip)
+#endif
+#ifndef HUF0_QW_PAIR
+#define HUF0_QW_PAIR 0                    // the quad-wide form pairs its 64-byte bursts into whole 128-byte lines
+#endif
+#ifndef HUF0_QW_WAVES
+#define HUF0_QW_WAVES 3                   // register budget of the quad-wide form as waves a SIMD (3: 168 VGPRs, 18 spilled; 2: 256)
+#endif
 #ifndef HUF0_BIG_UA
 #define HUF0_BIG_UA 0                     // the big-batch one-table kernel's bursts start where a stream's output starts (no masked first round) instead of on 64-byte lines
 #endif
@@ -594,10 +603,13 @@ __global__ void __launch_bounds__(256) huf0_follow_kernel(const uint8_t* __restr
 }
 
 // thread = one 16-byte piece of one follower's descriptor
-__global__ void __launch_bounds__(256) huf0_copy_kernel(uint8_t* __restrict__ desc, const uint8_t* __restrict__ follow, uint64_t nchunks)
+// (a segment that share[] gives to the one-table kernel needs no copies: that kernel reads the LEADER's descriptor -- 256 MB of descriptors
+//  not written at 800 000 chunks)
+__global__ void __launch_bounds__(256) huf0_copy_kernel(uint8_t* __restrict__ desc, const uint8_t* __restrict__ follow, uint64_t nchunks,
+                                                        const uint8_t* __restrict__ share)
 {
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x, c = i / 20, part = i % 20;
-    if (c >= nchunks || !follow[c]) return;
+    if (c >= nchunks || !follow[c] || share[c >> 6]) return;
     const uint64_t L = c & ~(uint64_t)63;
     *(uint4*)(desc + c * kDescStride + 16 * part) = *(const uint4*)(desc + L * kDescStride + 16 * part);
 }
@@ -992,7 +1004,7 @@ __global__ void __launch_bounds__(256) huf0_share_kernel(const uint8_t* __restri
 //     cursor gets there.  136 bytes of ring a lane instead of 200.
 // UA: a stream's 64-byte bursts start where the stream's output starts, not at the next 64-byte line (small batches: the first burst is
 //     then a full one like the others instead of a masked round, ~5 us of a lane's ~80; the lines that straddle cost nothing there)
-template <bool SO, int WG = 1, int PLOG = 4, bool CAD = false, int NS = 3, bool UA = false>
+template <bool SO, int WG = 1, int PLOG = 4, bool CAD = false, int NS = 3, bool UA = false, bool QW = false>
 __device__ __forceinline__ void huf0_stream_body(const uint8_t* __restrict__ blocks, const uint64_t* __restrict__ boffs,
                                                  uint64_t nchunks, uint8_t* __restrict__ out,
                                                  const uint64_t* __restrict__ ooffs, int64_t* __restrict__ rets,
@@ -1001,6 +1013,7 @@ __device__ __forceinline__ void huf0_stream_body(const uint8_t* __restrict__ blo
     static_assert(SO ? (WG == 1 || WG == 2 || WG == 4) : WG == 1, "a workgroup of the one-table kernel stays inside one 64-chunk segment");
     static_assert(!CAD || PLOG == 5 || PLOG == 6, "the cadenced refill: 32-byte pieces every four steps or 64-byte pieces every eight");
     static_assert(NS == 3 || (NS == 2 && CAD && PLOG == 6), "two ring slots: 64-byte pieces");
+    static_assert(!QW || (CAD && NS == 3 && PLOG == 6 && !UA), "quad-wide requests and paired bursts: the cadenced three-slot form with 64-byte pieces and line-aligned bursts");
     constexpr int kThreads = 64 * WG, kChunks = kThreads / 4;
     if ((share[(uint64_t)blockIdx.x * kChunks >> 6] != 0) != SO) return;      // the other instantiation's
     auto sync = [] { if constexpr (SO) __syncthreads(); else wave_sync(); };
@@ -1029,7 +1042,7 @@ __device__ __forceinline__ void huf0_stream_body(const uint8_t* __restrict__ blo
     typedef v4u __attribute__((aligned(16), may_alias)) v4u_a16;
     if constexpr (SO) {                                           // the leader's descriptor stands for all 64
         if (t < 20) {
-            const v4u v = *(const v4u_a16*)(desc + chunk0 * kDescStride + 16u * (uint32_t)t);
+            const v4u v = *(const v4u_a16*)(desc + (chunk0 & ~(uint64_t)63) * kDescStride + 16u * (uint32_t)t);      // (the segment's leader: its followers hold no copies)
             uint32_t* const d = (uint32_t*)(s_c + 16u * (uint32_t)t);
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
@@ -1228,6 +1241,39 @@ __device__ __forceinline__ void huf0_stream_body(const uint8_t* __restrict__ blo
         }
         if (s32 == 0u) *(lds_u64*)(uintptr_t)(ring + 3u * kPB) = (uint64_t)f.q[0].x | ((uint64_t)f.q[0].y << 32);
     };
+    // QW (round 5): the QUAD fetches and parks.  A lane asking for its own 64-byte piece with four 16-byte requests makes a wave's load 64 requests
+    // to 64 different lines, four times over; the memory system takes this kernel's lane-wise requests + 64-byte bursts at 2.2 TB/s -- the probe
+    // tools/probes/huf0_pattern.hip replays the pattern WITHOUT any arithmetic in 2.6 ms, the stage's own time -- and quad-wide requests with
+    // 128-byte bursts at 4.8 TB/s (1.19 ms).  So the four lanes of a quad (= the four streams of a chunk) fetch each of their streams' pieces
+    // together: lane j asks for bytes 16 j .. 16 j + 15 of stream s's piece, s = 0 .. 3 (the offset comes from lane s over the quad's DPP
+    // network) -- one 64-byte request a quad, the same four load instructions -- and writes its 16 bytes into stream s's ring slot itself (LDS is
+    // everybody's: no transpose).  A lane that asks for nothing passes kDrop (the load answers zeros, no traffic) / ~0 (nothing parked).
+    auto quad_bcast = [](uint32_t v, int s) -> uint32_t {
+        return (uint32_t)(s == 0 ? __builtin_amdgcn_mov_dpp((int)v, 0x00, 0xf, 0xf, true) : s == 1 ? __builtin_amdgcn_mov_dpp((int)v, 0x55, 0xf, 0xf, true)
+                          : s == 2 ? __builtin_amdgcn_mov_dpp((int)v, 0xAA, 0xf, 0xf, true) : __builtin_amdgcn_mov_dpp((int)v, 0xFF, 0xf, 0xf, true));
+    };
+    auto quad_fetch = [&](uint32_t vo, Piece& pc) {               // vo: byte offset of this lane's piece in brsrc, or kDrop; pc.q[s] <- bytes 16 j .. of stream s's piece
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const uint32_t v = quad_bcast(vo, s);
+            const auto t0 = __builtin_amdgcn_raw_buffer_load_b128(brsrc, v == kDrop ? kDrop : v + 16u * (uint32_t)j, 0, 0);
+            pc.q[s] = v4u{t0[0], t0[1], t0[2], t0[3]};
+        }
+    };
+    auto quad_park = [&](uint32_t slot32, const Piece& pc) {      // slot32: byte offset of the ring slot this lane's piece goes to, or ~0
+        typedef __attribute__((address_space(3))) uint64_t lds_u64;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const uint32_t d = quad_bcast(slot32, s);
+            if (d != ~0u) {
+                const uint32_t rs = ring + (uint32_t)((s - j) * kRingStride);      // stream s's ring
+                const uint32_t at = rs + d + 16u * (uint32_t)j;
+                *(lds_u64*)(uintptr_t)at = (uint64_t)pc.q[s].x | ((uint64_t)pc.q[s].y << 32);
+                *(lds_u64*)(uintptr_t)(at + 8u) = (uint64_t)pc.q[s].z | ((uint64_t)pc.q[s].w << 32);
+                if (d == 0u && j == 0) *(lds_u64*)(uintptr_t)(rs + 3u * kPB) = (uint64_t)pc.q[s].x | ((uint64_t)pc.q[s].y << 32);   // slot 0's head again behind slot 2
+            }
+        }
+    };
     // the top of every group of four steps.  Preal: the lane's true cursor (a lane that rides along carries a parked one in P)
     // (64-byte pieces: every second group -- eight steps take at most 44 bytes)
     int32_t pend_k = 0;
@@ -1248,6 +1294,7 @@ __device__ __forceinline__ void huf0_stream_body(const uint8_t* __restrict__ blo
             pend_k = k;
         } else if constexpr (CAD) {
             if (g % (kPB / 32) != 0) return;
+            if constexpr (QW) quad_park(pend_on ? pend_s32 : ~0u, pend); else
             if (pend_on) park3(pend_s32, pend);
             const uint32_t xr = ((uint32_t)(Preal > 0 ? Preal - 1 : 0) >> 3) + s_al;
             if (streaming && (int32_t)(xr >> kPLog) < cur_b) {   // at most one boundary per cadence
@@ -1262,6 +1309,7 @@ __device__ __forceinline__ void huf0_stream_body(const uint8_t* __restrict__ blo
             const bool want = streaming && k >= 0 && k + 3 > cur_b;
 #endif
             const uint32_t vo = want ? sp_off + (uint32_t)kPB * (uint32_t)k : kDrop;
+            if constexpr (QW) quad_fetch(vo, pend); else
 #pragma unroll
             for (int i = 0; i < kPL; i++) {
                 const auto t0 = __builtin_amdgcn_raw_buffer_load_b128(brsrc, want ? vo + 16u * i : kDrop, 0, 0);
@@ -1277,6 +1325,18 @@ __device__ __forceinline__ void huf0_stream_body(const uint8_t* __restrict__ blo
         park(cur_b, f0);
         park(cur_b - 1, f1);
         low_k = cur_b - 1;
+        fl = f0;                                                  // (unused in this form)
+    } else if constexpr (CAD && QW) {
+        cur_s32 = (uint32_t)kPB * ((uint32_t)(cur_b < 0 ? 0 : cur_b) % 3u);
+        m1_s32 = slot_below(cur_s32);
+        Piece f0, f1;                                             // (pieces outside the stream are not fetched: what the ring holds there is never consumed by a valid stream)
+        const bool w0 = streaming && cur_b >= 0, w1 = streaming && cur_b >= 1;
+        quad_fetch(w0 ? sp_off + (uint32_t)kPB * (uint32_t)cur_b : kDrop, f0);
+        quad_fetch(w1 ? sp_off + (uint32_t)kPB * (uint32_t)(cur_b - 1) : kDrop, f1);
+        quad_park(w0 ? cur_s32 : ~0u, f0);
+        quad_park(w1 ? m1_s32 : ~0u, f1);
+        low_k = cur_b - 1;
+        low_s32 = m1_s32;
         fl = f0;                                                  // (unused in this form)
     } else if constexpr (CAD) {
         const Piece f0 = load_piece(cur_b), f1 = load_piece(cur_b - 1);
@@ -1501,6 +1561,9 @@ __device__ __forceinline__ void huf0_stream_body(const uint8_t* __restrict__ blo
     const bool odd1 = (t & 1) != 0, odd2 = (t & 2) != 0;
     const uint32_t part = (uint32_t)t & 3u;
     uint32_t head = streaming && !UA ? (uint32_t)(0u - (uint32_t)(uintptr_t)op) & 63u : 0u;
+    uint32_t hold[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};      // QW: stream qq's waiting lower half, this lane's 16 bytes of it
+    bool held = false;                                            // QW: this lane's stream has a lower half waiting, at hold_off
+    uint32_t hold_off = 0;
     auto run = [&](auto SH) {
     for (;;) {
         if (__ballot(left > 0) == 0) break;
@@ -1604,6 +1667,30 @@ __device__ __forceinline__ void huf0_stream_body(const uint8_t* __restrict__ blo
                 const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
                 if (odd2) v[k][d] = recv; else v[k + 2][d] = recv;
             }
+        if constexpr (QW && HUF0_QW_PAIR) {
+            // whole 128-byte lines: a burst that is a line's LOWER half waits in the quad's registers (16 bytes a lane, transposed already) for the
+            // upper half one round later and the two leave back to back; a burst that is an upper half without a lower one waiting (a stream's
+            // first) goes alone, and so does a lower half whose stream has no whole burst left (flushed in the first round its lane rides along,
+            // or behind the loop).  Eight unconditional buffer stores a round, about half of them to a dropped offset.
+            const uint32_t O = (uint32_t)((uint64_t)(uintptr_t)op - out_base);
+            const bool upper = ((uint32_t)(uintptr_t)op & 64u) != 0;
+            const uint32_t offA = held && (!full_out || upper) ? hold_off : kDrop;
+            const uint32_t offB = full_out && upper ? O : kDrop;
+            const bool take = full_out && !upper;
+            typedef __attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t v4s;
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) {
+                const uint32_t a = quad_bcast(offA, qq), b = quad_bcast(offB, qq);
+                const bool tk = quad_bcast((uint32_t)take, qq) != 0;
+                const v4s pa = {hold[qq][0], hold[qq][1], hold[qq][2], hold[qq][3]}, pb = {v[qq][0], v[qq][1], v[qq][2], v[qq][3]};
+                __builtin_amdgcn_raw_buffer_store_b128(pa, orsrc, a == kDrop ? kDrop : a + 16u * part, 0, 2);
+                __builtin_amdgcn_raw_buffer_store_b128(pb, orsrc, b == kDrop ? kDrop : b + 16u * part, 0, 2);
+#pragma unroll
+                for (int d = 0; d < 4; d++) hold[qq][d] = tk ? v[qq][d] : hold[qq][d];
+            }
+            held = take;
+            hold_off = take ? O : hold_off;
+        } else
         if constexpr (CAD) {                                      // four unconditional buffer stores: a lane of the quad without a full line asks for a dropped offset
 #ifdef ABL_CAD_NO_STORE
             const int moff = (int)kDrop;                          // ablation: every line dropped
@@ -1652,6 +1739,16 @@ __device__ __forceinline__ void huf0_stream_body(const uint8_t* __restrict__ blo
     }
     };
     if (shared) run(std::true_type{}); else run(std::false_type{});
+    if constexpr (QW && HUF0_QW_PAIR) {                           // a lower half still waiting when the wave's last round ended
+        const uint32_t offA = held ? hold_off : kDrop;
+        typedef __attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t v4s;
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) {
+            const uint32_t a = quad_bcast(offA, qq);
+            const v4s pa = {hold[qq][0], hold[qq][1], hold[qq][2], hold[qq][3]};
+            __builtin_amdgcn_raw_buffer_store_b128(pa, orsrc, a == kDrop ? kDrop : a + 16u * part, 0, 2);
+        }
+    }
     if (streaming && P != 0) bad = true;                          // every stream ends exactly (BIT_endOfDStream)
     const bool any_bad = __builtin_amdgcn_mov_dpp((int)bad, 0x00, 0xf, 0xf, true) | __builtin_amdgcn_mov_dpp((int)bad, 0x55, 0xf, 0xf, true) |
                          __builtin_amdgcn_mov_dpp((int)bad, 0xAA, 0xf, 0xf, true) | __builtin_amdgcn_mov_dpp((int)bad, 0xFF, 0xf, 0xf, true);
@@ -1662,12 +1759,12 @@ __device__ __forceinline__ void huf0_stream_body(const uint8_t* __restrict__ blo
     }
 }
 
-template <bool SO, int WG = 1, int PLOG = 4, bool CAD = false, int NS = 3, bool UA = false>
-__global__ void __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(SO ? (CAD && PLOG == 6 ? (NS == 2 ? 4 : 3) : HUF0_SO_WAVES) : HUF0_G_WAVES)))   // (64-byte pieces: the LDS allows 10 waves a CU)
+template <bool SO, int WG = 1, int PLOG = 4, bool CAD = false, int NS = 3, bool UA = false, bool QW = false>
+__global__ void __launch_bounds__(64 * WG) __attribute__((amdgpu_waves_per_eu(SO ? (CAD && PLOG == 6 ? (NS == 2 ? 4 : (QW ? HUF0_QW_WAVES : 3)) : HUF0_SO_WAVES) : HUF0_G_WAVES)))   // (64-byte pieces: the LDS allows 10 waves a CU)
 huf0_stream_kernel(const uint8_t* __restrict__ blocks, const uint64_t* __restrict__ boffs, uint64_t nchunks, uint8_t* __restrict__ out,
                    const uint64_t* __restrict__ ooffs, int64_t* __restrict__ rets, const uint8_t* __restrict__ desc, const uint8_t* __restrict__ share)
 {
-    huf0_stream_body<SO, WG, PLOG, CAD, NS, UA>(blocks, boffs, nchunks, out, ooffs, rets, desc, share);
+    huf0_stream_body<SO, WG, PLOG, CAD, NS, UA, QW>(blocks, boffs, nchunks, out, ooffs, rets, desc, share);
 }
 
 // small batches: both single-wave forms in ONE launch, a wave takes the one its segment's share flag names (where a launch is 2 - 3 %
@@ -1735,15 +1832,15 @@ int sprintz_mi355x_huf0_decompress_batch_hint(const void* d_blocks, const uint64
         hipLaunchKernelGGL(huf0_follow_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, st, blk, d_block_offsets, d_out_offsets, nchunks, follow);
         hipLaunchKernelGGL(huf0_tree_kernel<1>, dim3((unsigned)((nleaders + 63) / 64)), dim3(64), 0, st, blk, d_block_offsets, d_out_offsets, nchunks, desc,
                            (const uint8_t*)follow);
-        hipLaunchKernelGGL(huf0_copy_kernel, dim3((unsigned)((nchunks * 20 + 255) / 256)), dim3(256), 0, st, desc, (const uint8_t*)follow, nchunks);
+        hipLaunchKernelGGL(huf0_share_kernel, dim3((unsigned)((nleaders + 255) / 256)), dim3(256), 0, st, (const uint8_t*)desc, (const uint8_t*)follow, nchunks, share);
+        hipLaunchKernelGGL(huf0_copy_kernel, dim3((unsigned)((nchunks * 20 + 255) / 256)), dim3(256), 0, st, desc, (const uint8_t*)follow, nchunks, (const uint8_t*)share);
         hipLaunchKernelGGL(huf0_tree_kernel<2>, dim3((unsigned)grid1), dim3(64), 0, st, blk, d_block_offsets, d_out_offsets, nchunks, desc,
                            (const uint8_t*)follow);
-        hipLaunchKernelGGL(huf0_share_kernel, dim3((unsigned)((nleaders + 255) / 256)), dim3(256), 0, st, (const uint8_t*)desc, (const uint8_t*)follow, nchunks, share);
     }
     // the one-table kernel: bandwidth-sized batches as workgroups of HUF0_BIG_WG waves with 2^HUF0_BIG_PLOG-byte stream pieces (built: 2 waves, 64 bytes),
     // then the per-chunk-table kernel for the segments that are not its; small batches: both wave by wave in one launch
     if (nchunks >= (uint64_t)sprintz::huf0_big_batch().load(std::memory_order_relaxed)) {
-        hipLaunchKernelGGL((huf0_stream_kernel<true, HUF0_BIG_WG, HUF0_BIG_PLOG, HUF0_CADENCED != 0, HUF0_BIG_NS, HUF0_BIG_UA != 0>), dim3((unsigned)((nchunks + 16 * HUF0_BIG_WG - 1) / (16 * HUF0_BIG_WG))),
+        hipLaunchKernelGGL((huf0_stream_kernel<true, HUF0_BIG_WG, HUF0_BIG_PLOG, HUF0_CADENCED != 0, HUF0_BIG_NS, HUF0_BIG_UA != 0, HUF0_BIG_QW != 0>), dim3((unsigned)((nchunks + 16 * HUF0_BIG_WG - 1) / (16 * HUF0_BIG_WG))),
                            dim3(64 * HUF0_BIG_WG), 0, st, blk, d_block_offsets, nchunks,
                            (uint8_t*)d_out, d_out_offsets, d_rets, (const uint8_t*)desc, (const uint8_t*)share);
         hipLaunchKernelGGL((huf0_stream_kernel<false, 1, HUF0_G_PLOG, HUF0_G_CAD != 0>), dim3((unsigned)grid2), dim3(64), 0, st, blk, d_block_offsets, nchunks,

@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(6
         if (c0 >= nchunks) break;                                 // (workgroup-uniform)
         const bool sh = share[c0 >> 6] != 0;
         if (sh && step) continue;
-        const uint64_t tchunk = sh ? c0 : c0 + step;              // whose descriptor the table is built from
+        const uint64_t tchunk = sh ? (c0 & ~(uint64_t)63) : c0 + step;      // whose descriptor the table is built from (one tree: the leader's -- large batches leave its followers without copies)
         if (tchunk >= nchunks) continue;
         const bool mine = sh || wv == (int)step;                  // (wave-uniform)
         const uint64_t chunk = sh ? c0 + (uint64_t)wv : tchunk;
