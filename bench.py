@@ -1310,6 +1310,18 @@ def transforms_leg(cx):
         td = timed(lambda: sprintz_amd.transform_device(kind, y, D, inverse=True, out=back), 10, 2)
         assert torch.equal(back.view(torch.int16), x.view(torch.int16)), kind
         out[kind] = [round(te, 4), round(2 * nbytes / (te * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), round(td, 4), round(2 * nbytes / (td * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)]
+    # the same two on a stream eight times as long (1 GiB): at 128 MiB a pass is 40 - 130 us and the decode's three launches are a sixth of it
+    xl = x.repeat(8)
+    big = {}
+    for kind in ("delta", "doubledelta"):
+        y, back = torch.empty_like(xl), torch.empty_like(xl)
+        te = timed(lambda: sprintz_amd.transform_device(kind, xl, D, out=y), 4, 1)
+        td = timed(lambda: sprintz_amd.transform_device(kind, y, D, inverse=True, out=back), 4, 1)
+        assert torch.equal(back.view(torch.int16), xl.view(torch.int16)), kind
+        big[kind] = [round(te, 4), round(16 * nbytes / (te * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), round(td, 4), round(16 * nbytes / (td * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)]
+        del y, back
+    out["at_512Mi_samples"] = big
+    del xl
     # FIRE as a transform of ONE stream is a recurrence down every column over the WHOLE stream (the counters never reset): eight lanes of
     # work for eight columns, however long the stream -- a latency, measured on a sixteenth of the stream and labelled as such
     xs = x[: x.numel() // 16]
@@ -1342,7 +1354,8 @@ def any_ndims_leg(cx):
 
 
 def online_leg(cx):
-    """dynamic delta / zigzag / sprintzpack over one 128 MiB uint16 walk: GB/s of samples, pack and unpack, round trip checked"""
+    """dynamic delta / zigzag / sprintzpack over one 128 MiB uint16 walk: GB/s of samples, pack and unpack, round trip checked; and the fractions
+    again on a stream eight times as long (1 GiB: `frac_at_512Mi_samples` = [pack, unpack])"""
     torch, dev, timed = cx.torch, cx.device, cx.timer
     from sprintz_amd import _lib
     from synth import synth_torch
@@ -1350,6 +1363,23 @@ def online_leg(cx):
     x = synth_torch("walk", 2, 1, n, 1, dev, seed=123, step=8)
     st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     out = {"samples": n, "what": "sprintz_mi355x_online_{pack,unpack}_device on one uint16 stream (walk, steps in [-8, 8]); *_frac: (samples + container bytes) / time over 8 TB/s"}
+    big = {}
+    nl = 8 * n
+    xl = x.reshape(-1).repeat(8)
+    for name, kind in (("dynamic_delta", 0), ("zigzag", 2), ("sprintzpack", 3)):
+        dest = torch.zeros(int(_lib.online_bound(kind, nl)) + 64, dtype=torch.uint8, device=dev)
+        tmp = torch.zeros(int(_lib.online_tmp_bytes(kind, nl)) + 64, dtype=torch.uint8, device=dev)
+        back = torch.empty(nl, dtype=torch.uint16, device=dev)
+        ret = torch.zeros(2, dtype=torch.int64, device=dev)
+        p_ms = timed(lambda: _lib.check(_lib.online_pack_device(kind, xl.data_ptr(), nl, dest.data_ptr(), ret.data_ptr(), tmp.data_ptr(), st)), 3, 1)
+        elems = int(ret[0].item())
+        u_ms = timed(lambda: _lib.check(_lib.online_unpack_device(kind, dest.data_ptr(), nl, back.data_ptr(), ret.data_ptr() + 8, tmp.data_ptr(), st)), 3, 1)
+        assert int(ret[1].item()) == nl and torch.equal(back.view(torch.int16), xl.view(torch.int16)), name
+        moved = 2 * nl + 2 * elems
+        big[name] = [round(moved / (p_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), round(moved / (u_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)]
+        del dest, tmp, back
+    out["frac_at_512Mi_samples"] = big
+    del xl
     for name, kind in (("dynamic_delta", 0), ("zigzag", 2), ("sprintzpack", 3), ("sprintzpack_zigzag", 4)):
         dest = torch.zeros(int(_lib.online_bound(kind, n)) + 64, dtype=torch.uint8, device=dev)
         tmp = torch.zeros(int(_lib.online_tmp_bytes(kind, n)) + 64, dtype=torch.uint8, device=dev)
