@@ -555,6 +555,9 @@ constexpr int ring_stride(int plog) { return 2 * (1 << plog) + 8; }
 #ifndef HUF0_CARRY_WINDOW
 #define HUF0_CARRY_WINDOW 1              // the one-table path carries its 64-bit window from step to step (fast_step; round 5)
 #endif
+#ifndef HUF0_CARRY_RINGPOS
+#define HUF0_CARRY_RINGPOS 1             // ... and where the bits below it sit in the three-slot ring (a bit position modulo 8 * 192)
+#endif
 #ifndef HUF0_CADENCED
 #define HUF0_CADENCED 1                  // the 4-wave one-table kernel refills on a fixed cadence (template parameter CAD)
 #endif
@@ -1464,15 +1467,43 @@ __device__ __forceinline__ void huf0_stream_body(const uint8_t* __restrict__ blo
         const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, o & 3u), hi0 = __builtin_amdgcn_alignbyte(d2, d1, o & 3u);
         return ((uint64_t)hi0 << 32) | lo;
     };
+    uint32_t carry_rb7 = 0;                                       // ring bit position of the bits below the carried window (fast_step)
+    auto ring_at = [&](uint32_t y) -> uint64_t {                  // the 8 bytes at ring offsets y .. y + 7 (y < 192: past slot 2 sits the copy of slot 0's head)
+        const uint32_t a = ring + (y & ~3u);
+        const uint32_t d0 = *(lds_u32c*)(uintptr_t)a, d1 = *(lds_u32c*)(uintptr_t)(a + 4u), d2 = *(lds_u32c*)(uintptr_t)(a + 8u);
+        const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, y & 3u), hi0 = __builtin_amdgcn_alignbyte(d2, d1, y & 3u);
+        return ((uint64_t)hi0 << 32) | lo;
+    };
     // keep = false (a wave's first and last rounds): the lane goes through the motions and leaves its cursor and its window where they were
     auto fast_step = [&](auto SH, bool keep = true) -> uint32_t {
         constexpr bool kShared = decltype(SH)::value;
         if constexpr (kCarry && kShared) {
-            const uint32_t sh = 7u - (((uint32_t)P - 1u) & 7u);   // bits of the window's top byte that are above the cursor
-            const uint64_t below_bytes = ring_bytes((uint32_t)P - 65u);
-            if (__ballot(carry_P != P) != 0) {                    // after a masked step, a parked cursor, a round's first step: fetch it (wave-uniform, rare)
-                carry_pre = ring_bytes((uint32_t)P - 1u) << sh;   // (its low `sh` bits are the top bits of the bytes below)
-                carry_fill = (below_bytes >> 1) >> (63u - sh);
+            uint32_t sh;                                          // bits of the window's top byte that are above the cursor
+            uint64_t below_bytes;
+            if constexpr (NS == 3 && HUF0_CARRY_RINGPOS) {
+                // Where the bits below sit in the ring is carried along as well: a piece k lives in slot k mod 3, so byte x of the stream (counted
+                // from piece 0) is at ring offset x mod 192 -- no slot to look up, and a step that takes c bits moves the position by exactly c
+                // bits modulo 8 * 192.  carry_rb7 = 8 * ((x - 7) mod 192) + bit, x the byte of bit P - 65: 8 instructions a step for address,
+                // alignment and shift count instead of 17 (piece of x, compare with the cursor's, slot select, - 7, wrap, shift count from P).
+                if (__ballot(carry_P != P) != 0) {                // after a masked step, a parked cursor, a round's first step: fetch it (wave-uniform, rare)
+                    const uint32_t top = (uint32_t)P - 65u, x = (top >> 3) + s_al;
+                    const uint32_t sb = (int32_t)(x >> kPLog) == cur_b ? cur_s32 : m1_s32;
+                    int32_t oo = (int32_t)(sb + (x & (uint32_t)(kPB - 1))) - 7;
+                    oo += oo < 0 ? 3 * kPB : 0;
+                    carry_rb7 = 8u * (uint32_t)oo + (top & 7u);
+                    const uint32_t sh0 = 7u - (top & 7u);
+                    carry_pre = ring_bytes((uint32_t)P - 1u) << sh0;
+                    carry_fill = (ring_at((uint32_t)oo) >> 1) >> (63u - sh0);
+                }
+                sh = 7u - (carry_rb7 & 7u);
+                below_bytes = ring_at(carry_rb7 >> 3);
+            } else {
+                sh = 7u - (((uint32_t)P - 1u) & 7u);
+                below_bytes = ring_bytes((uint32_t)P - 65u);
+                if (__ballot(carry_P != P) != 0) {
+                    carry_pre = ring_bytes((uint32_t)P - 1u) << sh;   // (its low `sh` bits are the top bits of the bytes below)
+                    carry_fill = (below_bytes >> 1) >> (63u - sh);
+                }
             }
             const uint64_t below = below_bytes << sh;             // the stream from bit P - 65 down
             const uint32_t e0 = *(lds_u16*)(uintptr_t)(ft + (((uint32_t)(carry_pre >> 32) >> look_shift) << 1));
@@ -1487,6 +1518,10 @@ __device__ __forceinline__ void huf0_stream_body(const uint8_t* __restrict__ blo
             carry_fill = keep ? below >> ((64u - c) & 63u) : carry_fill;
             P -= keep ? (int32_t)c : 0;
             carry_P = P;                                          // (valid either way: the window at the top of the step was this lane's, fetched or carried)
+            if constexpr (NS == 3 && HUF0_CARRY_RINGPOS) {
+                const uint32_t r1 = carry_rb7 - c, r2 = r1 + 8u * 3u * (uint32_t)kPB;      // c bits down, modulo the ring (r1 wraps to a huge number below 0)
+                carry_rb7 = keep ? (r1 < r2 ? r1 : r2) : carry_rb7;
+            }
             const uint32_t w01 = __builtin_amdgcn_perm(e1, e0, 0x0c0c0501u), w23 = __builtin_amdgcn_perm(e3, e2, 0x0c0c0501u);
             return __builtin_amdgcn_perm(w23, w01, 0x05040100u);
         }
@@ -1584,7 +1619,7 @@ __device__ __forceinline__ void huf0_stream_body(const uint8_t* __restrict__ blo
         const bool fast_round = __ballot(streaming && live && head_lim) == 0 && __ballot(burst) != 0;
         // (a lane that rides along decodes from cursor 0: `x` below is then far above any piece index, so its ring stays as it is)
         const int32_t P0 = P;
-        if (fast_round && !burst) { P = 0; carry_P = 0; }         // (its carried window is garbage like everything it decodes: no refetch for the riders' sake)
+        if (fast_round && !burst) { P = 0; carry_P = 0; carry_rb7 = 0; }         // (its carried window is garbage like everything it decodes: no refetch for the riders' sake)
 #else
         constexpr bool fast_round = false;
         const bool burst = full;
