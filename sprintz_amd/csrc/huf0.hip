@@ -1216,7 +1216,9 @@ __device__ __forceinline__ void huf0_stream_body(const uint8_t* __restrict__ blo
     int32_t cur_b = last_piece;                                   // piece of the cursor's byte
     Piece fl;
     // ---- CAD state: the ring holds pieces cur_b .. low_k in slots (piece mod 3); `pend` is the piece requested at the last group top
-    constexpr uint32_t kDrop = 0xfffffff0u;                       // outside every descriptor: a load answers zeros, a store is dropped
+    // outside every descriptor (they end below 0xfffffe00): a load answers zeros, a store is dropped -- and so does kDrop + 16 j, j < 4: the quad's
+    // lanes add their part's offset to a broadcast one without asking whether it is this one (a compare and a select less per request)
+    constexpr uint32_t kDrop = 0xffffff00u;
     auto uniform64 = [](uint64_t v) {
         return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
     };
@@ -1226,8 +1228,8 @@ __device__ __forceinline__ void huf0_stream_body(const uint8_t* __restrict__ blo
     const uint64_t in_span = CAD ? uniform64((((uint64_t)(uintptr_t)blocks + boffs[nchunks]) - in_base + 15) & ~(uint64_t)15) : 0;
     const uint64_t out_base = CAD ? uniform64(((uint64_t)(uintptr_t)out + ooffs[wf]) & ~(uint64_t)15) : 0;
     const uint64_t out_span = CAD ? uniform64(((uint64_t)(uintptr_t)out + ooffs[nchunks]) - out_base) : 0;
-    const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)in_base, 0, (uint32_t)(in_span < 0xffffffffull ? in_span : 0xffffffffull), 0x00020000);
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)out_base, 0, (uint32_t)(out_span < 0xfffffff0ull ? out_span : 0xfffffff0ull), 0x00020000);
+    const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)in_base, 0, (uint32_t)(in_span < 0xfffffe00ull ? in_span : 0xfffffe00ull), 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)out_base, 0, (uint32_t)(out_span < 0xfffffe00ull ? out_span : 0xfffffe00ull), 0x00020000);
     const uint32_t sp_off = CAD && streaming ? (uint32_t)((uint64_t)(uintptr_t)sp_al - in_base) : 0u;
     int32_t low_k = 0;                                            // lowest piece in the ring or in flight
     uint32_t cur_s32 = 0, m1_s32 = 0, low_s32 = 0, pend_s32 = 0;  // byte offset of the ring slot of cur_b / of cur_b - 1 / of low_k / of the piece in flight
@@ -1259,7 +1261,7 @@ __device__ __forceinline__ void huf0_stream_body(const uint8_t* __restrict__ blo
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             const uint32_t v = quad_bcast(vo, s);
-            const auto t0 = __builtin_amdgcn_raw_buffer_load_b128(brsrc, v == kDrop ? kDrop : v + 16u * (uint32_t)j, 0, 0);
+            const auto t0 = __builtin_amdgcn_raw_buffer_load_b128(brsrc, v + 16u * (uint32_t)j, 0, 0);
             pc.q[s] = v4u{t0[0], t0[1], t0[2], t0[3]};
         }
     };
@@ -1718,8 +1720,8 @@ __device__ __forceinline__ void huf0_stream_body(const uint8_t* __restrict__ blo
                 const uint32_t a = quad_bcast(offA, qq), b = quad_bcast(offB, qq);
                 const bool tk = quad_bcast((uint32_t)take, qq) != 0;
                 const v4s pa = {hold[qq][0], hold[qq][1], hold[qq][2], hold[qq][3]}, pb = {v[qq][0], v[qq][1], v[qq][2], v[qq][3]};
-                __builtin_amdgcn_raw_buffer_store_b128(pa, orsrc, a == kDrop ? kDrop : a + 16u * part, 0, 2);
-                __builtin_amdgcn_raw_buffer_store_b128(pb, orsrc, b == kDrop ? kDrop : b + 16u * part, 0, 2);
+                __builtin_amdgcn_raw_buffer_store_b128(pa, orsrc, a + 16u * part, 0, 2);
+                __builtin_amdgcn_raw_buffer_store_b128(pb, orsrc, b + 16u * part, 0, 2);
 #pragma unroll
                 for (int d = 0; d < 4; d++) hold[qq][d] = tk ? v[qq][d] : hold[qq][d];
             }
@@ -1738,7 +1740,7 @@ __device__ __forceinline__ void huf0_stream_body(const uint8_t* __restrict__ blo
                                               : qq == 2 ? __builtin_amdgcn_mov_dpp(moff, 0xAA, 0xf, 0xf, true) : __builtin_amdgcn_mov_dpp(moff, 0xFF, 0xf, 0xf, true));
                 typedef __attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t v4s;
                 const v4s piece = {v[qq][0], v[qq][1], v[qq][2], v[qq][3]};
-                __builtin_amdgcn_raw_buffer_store_b128(piece, orsrc, dof == kDrop ? kDrop : dof + 16u * part, 0, 2);   // aux 2 = nt: streamed out once
+                __builtin_amdgcn_raw_buffer_store_b128(piece, orsrc, dof + 16u * part, 0, 2);   // aux 2 = nt: streamed out once
             }
         } else {
         const uint64_t mine = full_out ? (uint64_t)(uintptr_t)op : 0ull;
@@ -1781,7 +1783,7 @@ __device__ __forceinline__ void huf0_stream_body(const uint8_t* __restrict__ blo
         for (int qq = 0; qq < 4; qq++) {
             const uint32_t a = quad_bcast(offA, qq);
             const v4s pa = {hold[qq][0], hold[qq][1], hold[qq][2], hold[qq][3]};
-            __builtin_amdgcn_raw_buffer_store_b128(pa, orsrc, a == kDrop ? kDrop : a + 16u * part, 0, 2);
+            __builtin_amdgcn_raw_buffer_store_b128(pa, orsrc, a + 16u * part, 0, 2);
         }
     }
     if (streaming && P != 0) bad = true;                          // every stream ends exactly (BIT_endOfDStream)
