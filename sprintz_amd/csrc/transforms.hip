@@ -143,6 +143,52 @@ __global__ void __launch_bounds__(kTB) apply_kernel(Level<U> lo, uint64_t len, u
     }
 }
 
+// ---------------------------------------------------------------- decode: the runs' incoming states in ONE launch
+// The wave-scan path leaves one summary per run (a few thousand of them for a 128 MiB stream); handing every run its incoming state
+// through the generic levels is three reduce and three apply launches of ~4.6 us each -- 28 of the 119 us of a 64 Mi-sample decode
+// (rocprofv3 kernel trace).  One workgroup does it: thread (g, c) composes the runs of its slice g of column c, the slices' compositions
+// meet in LDS, every thread folds the slices before its own and walks its runs again writing their incoming states.
+// Same arithmetic as reduce_kernel / apply_kernel (composition (S1, S2, n) o (S1', S2', n') = (S1 + S1', S2 + n' S1 + S2', n + n')).
+constexpr int kTopT = 1024;
+template <typename U, int KIND>
+__global__ void __launch_bounds__(kTopT) scan_runs_kernel(Level<U> lo, uint32_t D, uint64_t rows0, uint32_t G)
+{
+    __shared__ U sm1[kTopT], sm2[kTopT], smn[kTopT];
+    const uint32_t t = threadIdx.x, g = t / D, c = t - g * D;
+    const bool on = g < G;
+    const uint64_t per = (lo.rows + G - 1) / G, r0 = (uint64_t)g * per, r1 = r0 + per < lo.rows ? r0 + per : lo.rows;
+    auto rows_of = [&](uint64_t r) -> U { const uint64_t first = r * lo.span; return (U)(rows0 - first < lo.span ? rows0 - first : lo.span); };
+    U S1 = 0, S2 = 0, N = 0;
+    if (on)
+        for (uint64_t r = r0; r < r1; r++) {
+            const uint64_t e = r * D + c;
+            const U c1 = lo.s1[e], n = rows_of(r);
+            if (KIND) S2 = (U)(S2 + (U)(n * S1) + lo.s2[e]);
+            S1 = (U)(S1 + c1);
+            N = (U)(N + n);
+        }
+    if (on) { sm1[t] = S1; sm2[t] = S2; smn[t] = N; }
+    __syncthreads();
+    if (!on) return;
+    U x = 0, d = 0;                                    // the state before slice g: the slices before it applied to the zero state
+    for (uint32_t k = 0; k < g; k++) {
+        const uint32_t i = k * D + c;
+        if (KIND) { x = (U)(x + (U)(smn[i] * d) + sm2[i]); d = (U)(d + sm1[i]); }
+        else x = (U)(x + sm1[i]);
+    }
+    for (uint64_t r = r0; r < r1; r++) {
+        const uint64_t e = r * D + c;
+        lo.xin[e] = x;
+        if (KIND) {
+            lo.din[e] = d;
+            x = (U)(x + (U)(rows_of(r) * d) + lo.s2[e]);
+            d = (U)(d + lo.s1[e]);
+        } else {
+            x = (U)(x + lo.s1[e]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- decode, small rows: one wavefront scans a run of rows
 // When a row is a whole number (<= 64) of 16-byte / 4-byte / element-sized pieces, the
 // lanes of a wavefront share a contiguous 4 KB / 1 KB / 256-element load: a lane folds
@@ -470,8 +516,14 @@ int decode_wave(const U* y, uint64_t len, uint32_t D_real, U* dest, uint8_t* tmp
     hipLaunchKernelGGL((wave_scan_kernel<E, KIND, false>), dim3(grid), dim3(kTB), 0, st, (const T*)y, len_e, dv, nruns, (const T*)nullptr,
                        (const T*)nullptr, (T*)s1, (T*)s2, (T*)nullptr);
     const Level<U> base{s1, s2, xi, di, nruns, run_rows};
-    int rc = scan_levels<U, KIND>(base, len, D, rows0, dest, t, st);
-    if (rc) return rc;
+    if (D <= 64 && nruns <= 4096) {                      // (wide rows, or streams long enough that six ~4.6 us launches do not matter: the generic levels --
+                                                         //  with 16 384 runs the one workgroup measured slower than they are: 0.72 against 0.66 ms at 512 Mi samples)
+        const uint32_t Gmax = (uint32_t)kTopT / D, G = (uint32_t)(nruns < Gmax ? nruns : Gmax);
+        hipLaunchKernelGGL((scan_runs_kernel<U, KIND>), dim3(1), dim3(kTopT), 0, st, base, D, rows0, G);
+    } else {
+        int rc = scan_levels<U, KIND>(base, len, D, rows0, dest, t, st);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL((wave_scan_kernel<E, KIND, true>), dim3(grid), dim3(kTB), 0, st, (const T*)y, len_e, dv, nruns, (const T*)xi,
                        (const T*)di, (T*)nullptr, (T*)nullptr, (T*)dest);
     return hipGetLastError() == hipSuccess ? 0 : fail(SPRINTZ_E_HIP, "transform decode launch");
