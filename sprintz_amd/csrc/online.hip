@@ -90,6 +90,14 @@ __device__ __forceinline__ uint32_t workgroup_excl(uint32_t v, uint32_t* sh)
     return base + inc - v;
 }
 
+// what an unpack launch reports: the stream's header (the four bytes in front of its body) must agree with the caller's length -- checked by the
+// thread that writes the return value (round 5: this was a launch of its own behind the decode, and a memset of the return word in front of it)
+__device__ __forceinline__ int64_t checked_len(const uint8_t* body, uint32_t len)
+{
+    const uint32_t have = (uint32_t)body[-4] | ((uint32_t)body[-3] << 8) | ((uint32_t)body[-2] << 16) | ((uint32_t)body[-1] << 24);
+    return have == len ? (int64_t)len : (int64_t)SPRINTZ_E_CORRUPT;
+}
+
 // ---------------------------------------------------------------- zigzag
 // src / dst: the first SAMPLE on both sides (one of them 4 bytes into its buffer); 8 samples = one 16-byte request a thread
 __global__ void __launch_bounds__(kT) zigzag_kernel(const uint8_t* src, uint8_t* dst, uint32_t len, int decode, int64_t* ret)
@@ -103,7 +111,7 @@ __global__ void __launch_bounds__(kT) zigzag_kernel(const uint8_t* src, uint8_t*
     } else {
         for (uint64_t i1 = i0; i1 < len; i1++) st16(dst + 2 * i1, decode ? unzz16(ld16(src + 2 * i1)) : zz16(ld16(src + 2 * i1)));
     }
-    if (i0 == 0 && ret) *ret = decode ? (int64_t)len : 2 + (int64_t)len;
+    if (i0 == 0 && ret) *ret = decode ? checked_len(src, len) : 2 + (int64_t)len;
 }
 
 // ---------------------------------------------------------------- dynamic delta, encoder
@@ -191,6 +199,7 @@ __device__ __forceinline__ uint64_t shfl_up64(uint64_t v, int d)
 }
 // scan of one map per thread over the workgroup (composition is not commutative: left operand = earlier).  Returns the composition of
 // the threads BEFORE this one; total = all of them.  sh: kT / 64 words of 64 bits
+template <int T = kT>
 __device__ __forceinline__ Aff workgroup_scan_excl(const Aff& mine, Aff& total, uint64_t* sh)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -206,7 +215,7 @@ __device__ __forceinline__ Aff workgroup_scan_excl(const Aff& mine, Aff& total, 
     __syncthreads();
     Aff base = unpack_aff(kIdentity), all = unpack_aff(kIdentity);
 #pragma unroll
-    for (int k = 0; k < kT / 64; k++) {
+    for (int k = 0; k < T / 64; k++) {
         const Aff wk = unpack_aff(sh[k]);
         if (k < w) base = compose(base, wk);
         all = compose(all, wk);
@@ -238,9 +247,11 @@ __global__ void __launch_bounds__(kT) dyndelta_tile_kernel(const uint8_t* in, co
 
 // one workgroup: tiles[i] <- composition of tiles[0 .. i-1] (exclusive).  The tiles pass through LDS in slabs of kT * kSlab (read
 // and written coalesced; a thread's kSlab consecutive ones are then LDS reads -- as dependent global loads they were 20 us of the call)
-constexpr int kSlab = 16;
-__global__ void __launch_bounds__(kT) dyndelta_tilescan_kernel(uint64_t* tiles, uint32_t ntiles)
+// (round 5: 1 024 threads x 4 tiles instead of 256 x 16 -- one workgroup's serial phases were 16.5 us of a 130 us unpack)
+constexpr int kSlab = 4, kDdScanT = 1024;
+__global__ void __launch_bounds__(kDdScanT) dyndelta_tilescan_kernel(uint64_t* tiles, uint32_t ntiles)
 {
+    constexpr int kT = kDdScanT;                       // (shadows the file's 256 inside this kernel)
     __shared__ uint64_t slab[kT * kSlab];
     __shared__ uint64_t sh[kT / 64];
     Aff carry = unpack_aff(kIdentity);
@@ -253,7 +264,7 @@ __global__ void __launch_bounds__(kT) dyndelta_tilescan_kernel(uint64_t* tiles, 
         Aff mine = unpack_aff(kIdentity);
         for (int k = 0; k < kSlab; k++) mine = compose(mine, unpack_aff(slab[threadIdx.x * kSlab + k]));
         Aff total;
-        Aff run = compose(carry, workgroup_scan_excl(mine, total, sh));
+        Aff run = compose(carry, workgroup_scan_excl<kT>(mine, total, sh));
         for (int k = 0; k < kSlab; k++) {
             const Aff t = unpack_aff(slab[threadIdx.x * kSlab + k]);
             slab[threadIdx.x * kSlab + k] = pack_aff(run);
@@ -315,7 +326,7 @@ __global__ void __launch_bounds__(kT) dyndelta_decode_kernel(const uint8_t* in, 
             uint32_t y = x0;
             for (uint32_t at = 1; at < len; at++) { y = (y + ld16(in + 2 * (uint64_t)at)) & 0xffffu; out[at] = (uint16_t)y; }
         }
-        if (ret) *ret = len;
+        if (ret) *ret = checked_len(in, len);
     }
 }
 
@@ -366,23 +377,32 @@ __global__ void __launch_bounds__(kT) unpack_tile_kernel(const uint8_t* hdr, uin
 }
 
 // one workgroup: offs[i] = sum of sums[0 .. i-1], offs[ntiles] = everything.  The sums pass through LDS in slabs (read coalesced; a
-// thread's consecutive ones are then LDS reads -- as dependent global loads this kernel was 20 us of a 100 us call)
-constexpr int kSumSlab = 32;
-__global__ void __launch_bounds__(kT) tile_offsets_kernel(const uint32_t* sums, uint32_t ntiles, uint64_t* offs)
+// thread's consecutive ones are then LDS reads -- as dependent global loads this kernel was 20 us of a 100 us call).
+// (Round 5: 1 024 threads x 8 sums instead of 256 x 32 -- the kernel is one workgroup's serial phases, 15.4 us of a 102 us unpack.)
+constexpr int kScanT = 1024, kSumSlab = 8;
+__global__ void __launch_bounds__(kScanT) tile_offsets_kernel(const uint32_t* sums, uint32_t ntiles, uint64_t* offs)
 {
-    __shared__ uint32_t slab[kT * kSumSlab];
-    __shared__ uint32_t sh[kT / 64];
+    __shared__ uint32_t slab[kScanT * kSumSlab];
+    __shared__ uint32_t sh[kScanT / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint64_t carry = 0;
-    for (uint32_t base = 0; base < ntiles; base += kT * kSumSlab) {
+    for (uint32_t base = 0; base < ntiles; base += kScanT * kSumSlab) {
         for (int k = 0; k < kSumSlab; k++) {
-            const uint32_t i = base + k * kT + threadIdx.x;
-            slab[k * kT + threadIdx.x] = i < ntiles ? sums[i] : 0u;
+            const uint32_t i = base + k * kScanT + threadIdx.x;
+            slab[k * kScanT + threadIdx.x] = i < ntiles ? sums[i] : 0u;
         }
         __syncthreads();
         uint32_t mine = 0;
         for (int k = 0; k < kSumSlab; k++) mine += slab[threadIdx.x * kSumSlab + k];      // (a slab's payload is < 2^32: 8 192 tiles of <= 16 KB)
-        uint32_t run = workgroup_excl(mine, sh);
-        const uint32_t slab_total = workgroup_sum(mine, sh);
+        uint32_t inc = mine;                                                              // inclusive scan over the wave, then over the 16 waves
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)inc, d); if (lane >= d) inc += u; }
+        if (lane == 63) sh[w] = inc;
+        __syncthreads();
+        uint32_t wbase = 0, slab_total = 0;
+#pragma unroll
+        for (int k = 0; k < kScanT / 64; k++) { wbase += k < w ? sh[k] : 0u; slab_total += sh[k]; }
+        uint32_t run = wbase + inc - mine;
         for (int k = 0; k < kSumSlab; k++) {
             const uint32_t v = slab[threadIdx.x * kSumSlab + k];
             slab[threadIdx.x * kSumSlab + k] = run;
@@ -390,8 +410,8 @@ __global__ void __launch_bounds__(kT) tile_offsets_kernel(const uint32_t* sums, 
         }
         __syncthreads();
         for (int k = 0; k < kSumSlab; k++) {
-            const uint32_t i = base + k * kT + threadIdx.x;
-            if (i < ntiles) offs[i] = carry + slab[k * kT + threadIdx.x];
+            const uint32_t i = base + k * kScanT + threadIdx.x;
+            if (i < ntiles) offs[i] = carry + slab[k * kScanT + threadIdx.x];
         }
         carry += slab_total;
         __syncthreads();
@@ -523,7 +543,7 @@ __global__ void __launch_bounds__(kT) unpack_read_kernel(const uint8_t* hdr, con
     if (tile == ntiles - 1 && t == 0) {
         const uint8_t* in = payload + g0 + tile_bytes;
         for (uint32_t k = 8 * nblocks; k < len; k++) out[k] = (uint16_t)ld16(in + 2 * (uint64_t)(k - 8 * nblocks));
-        if (ret) *ret = len;
+        if (ret) *ret = checked_len(hdr, len);
     }
 }
 
@@ -640,7 +660,7 @@ int sprintz_mi355x_online_pack_device(int kind, const uint16_t* d_src, uint32_t 
         hipLaunchKernelGGL(header_kernel, dim3(1), dim3(256), 0, st, dest, len, hdr, nblocks ? 0u : helems * 2, d_ret, (int64_t)2 + helems + len, nblocks ? 0 : 1);
         if (nblocks) {
             hipLaunchKernelGGL(pack_tile_kernel, dim3(ntiles), dim3(kT), 0, st, d_src, nblocks, zig, hdr, helems * 2, sums);
-            hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(kT), 0, st, (const uint32_t*)sums, ntiles, toffs);
+            hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(kScanT), 0, st, (const uint32_t*)sums, ntiles, toffs);
             hipLaunchKernelGGL(pack_write_kernel, dim3(ntiles), dim3(kT), 0, st, d_src, len, nblocks, zig, (const uint64_t*)toffs, ntiles, payload, helems, d_ret);
         } else if (len) {                                           // fewer than 8 values: all of them raw
             (void)hipMemcpyAsync(payload, d_src, (size_t)len * 2, hipMemcpyDeviceToDevice, st);
@@ -657,8 +677,11 @@ int sprintz_mi355x_online_unpack_device(int kind, const void* d_src, uint32_t le
     hipStream_t st = (hipStream_t)hip_stream;
     const uint8_t* src = (const uint8_t*)d_src;
     const uint8_t* body = src + 4;
-    if (d_ret) (void)hipMemsetAsync(d_ret, 0, 8, st);
-    if (len == 0) { hipLaunchKernelGGL(check_len_kernel, dim3(1), dim3(1), 0, st, src, len, d_ret); return 0; }
+    if (len == 0) {
+        if (d_ret) (void)hipMemsetAsync(d_ret, 0, 8, st);
+        hipLaunchKernelGGL(check_len_kernel, dim3(1), dim3(1), 0, st, src, len, d_ret);
+        return 0;
+    }
     if (kind == SPRINTZ_ONLINE_ZIGZAG) {
         hipLaunchKernelGGL(zigzag_kernel, dim3(grid_for(((uint64_t)len + 7) / 8)), dim3(kT), 0, st, body, (uint8_t*)d_dest, len, 1, d_ret);
     } else if (kind <= SPRINTZ_ONLINE_DYNDELTA_ALT) {
@@ -666,7 +689,7 @@ int sprintz_mi355x_online_unpack_device(int kind, const void* d_src, uint32_t le
         const uint8_t* choices = body + 2 * (size_t)len;
         uint64_t* tiles = (uint64_t*)d_tmp;
         hipLaunchKernelGGL(dyndelta_tile_kernel, dim3(ntiles), dim3(kT), 0, st, body, choices, nblocks, tiles);
-        hipLaunchKernelGGL(dyndelta_tilescan_kernel, dim3(1), dim3(kT), 0, st, tiles, ntiles);
+        hipLaunchKernelGGL(dyndelta_tilescan_kernel, dim3(1), dim3(kDdScanT), 0, st, tiles, ntiles);
         hipLaunchKernelGGL(dyndelta_decode_kernel, dim3(ntiles), dim3(kT), 0, st, body, choices, len, nblocks, (const uint64_t*)tiles, d_dest, d_ret);
     } else {
         const int zig = kind == SPRINTZ_ONLINE_PACK_ZIGZAG;
@@ -676,10 +699,10 @@ int sprintz_mi355x_online_unpack_device(int kind, const void* d_src, uint32_t le
         uint32_t* sums = (uint32_t*)d_tmp;
         uint64_t* toffs = (uint64_t*)((uint8_t*)d_tmp + up256((size_t)ntiles * 4));
         hipLaunchKernelGGL(unpack_tile_kernel, dim3(ntiles), dim3(kT), 0, st, body, nblocks, sums);
-        hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(kT), 0, st, (const uint32_t*)sums, ntiles, toffs);
+        hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(kScanT), 0, st, (const uint32_t*)sums, ntiles, toffs);
         hipLaunchKernelGGL(unpack_read_kernel, dim3(ntiles), dim3(kT), 0, st, body, payload, len, nblocks, zig, (const uint64_t*)toffs, ntiles, d_dest, d_ret);
     }
-    hipLaunchKernelGGL(check_len_kernel, dim3(1), dim3(1), 0, st, src, len, d_ret);     // the header must agree with the caller
+    // (the header must agree with the caller: checked_len(), by the thread of the last launch that writes the return value)
     return hipGetLastError() == hipSuccess ? 0 : fail(SPRINTZ_E_HIP, "online: unpack launch");
 }
 
