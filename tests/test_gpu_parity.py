@@ -991,7 +991,7 @@ def test_random_shapes(sz, oracle, seed):
     ("delta", 1, 80, 10240, 97), ("xff", 1, 72, 72 * 64, 1031),       # the split mapping's encoder (8 bits, 65 .. 80 columns)
     ("xff", 2, 80, 10240, 205), ("delta", 1, 128, 16384, 66),           # 64 lanes x two columns
     ("xff", 2, 7, 7 * 160, 999),                                         # an odd width at 16 bits: the last lane's pair is half genuine
-    ("delta", 1, 1, 1024, 5000),          # low-dim: no dense tail in that encoder -- the entry point runs the two launches itself
+    ("delta", 1, 1, 1024, 5000), ("xff", 1, 3, 3 * 400, 70001), ("xff", 2, 2, 2048, 513), ("delta", 2, 1, 1000, 255),   # low-dim: no dense tail in that encoder -- the entry point runs the two launches itself (a tail for 256 chunks a workgroup was built in round 5 and measured slower: 0.416 against 0.396 ms on BASELINE config 1)
     ("delta", 1, 80, 1024, 5003), ("xff", 2, 8, 100, 333), ("xff", 2, 128, 2000, 77), ("delta", 1, 5, 77, 1),   # chunks too short for a group: verbatim, written straight into the container
     ("delta", 1, 8, 128, 16384), ("delta", 1, 8, 128, 16385),          # either side of the one-workgroup size scan (the scan + copy side of the comparison)
     ("xff", 2, 4, 4000, 500), ("delta", 2, 3, 3000, 257),              # 3 and 4 uint16 columns: encode_fast.h on 4 lanes a chunk, the one shape of it that arms the tail
