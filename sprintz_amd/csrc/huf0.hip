@@ -543,6 +543,9 @@ constexpr int ring_stride(int plog) { return 2 * (1 << plog) + 8; }
 #ifndef HUF0_QW_WAVES
 #define HUF0_QW_WAVES 3                   // register budget of the quad-wide form as waves a SIMD (3: 168 VGPRs, 18 spilled; 2: 256)
 #endif
+#ifndef HUF0_WAVE_LEADERS
+#define HUF0_WAVE_LEADERS 65536          // segments up to which the leaders' trees are parsed a WAVE each (one kernel that also does the follow test, the copies and the share flags); above: a lane each + four small passes
+#endif
 #ifndef HUF0_BIG_UA
 #define HUF0_BIG_UA 0                     // the big-batch one-table kernel's bursts start where a stream's output starts (no masked first round) instead of on 64-byte lines
 #endif
@@ -925,8 +928,12 @@ __global__ void __launch_bounds__(64) huf0_tree_wave_kernel(const uint8_t* __res
         for (int w = 0; w < 13; w++) v = t == w ? tabw[w] : v;
         *(uint32_t*)(d + 256 + 4 * t) = v;
     }
+    // huf0_share_kernel's verdict for this segment
+    const bool all_follow = __ballot(mine_exists && t != 0 && !fol) == 0;
+    const bool shared_seg = all_follow && nchunks - chunk > 1 && hl != 0 && tl != 0 && tl <= kSharedMaxLog;
     // the followers' copies, a lane each: 16 pieces of sorted symbols from LDS, 4 of table words from the registers
-    if (fol) {
+    // (not in a segment the one-table kernels take: they read the leader's descriptor -- 320 bytes a chunk not written)
+    if (fol && !shared_seg) {
         typedef uint32_t v4u __attribute__((ext_vector_type(4)));
         uint8_t* const dm = desc + mine_c * kDescStride;
 #pragma unroll
@@ -936,9 +943,7 @@ __global__ void __launch_bounds__(64) huf0_tree_wave_kernel(const uint8_t* __res
         *(v4u*)(dm + 288) = v4u{tabw[8], tabw[9], tabw[10], tabw[11]};
         *(v4u*)(dm + 304) = v4u{tabw[12], 0u, 0u, 0u};
     }
-    // huf0_share_kernel's verdict for this segment
-    const bool all_follow = __ballot(mine_exists && t != 0 && !fol) == 0;
-    if (t == 0) share[blockIdx.x] = (all_follow && nchunks - chunk > 1 && hl != 0 && tl != 0 && tl <= kSharedMaxLog) ? 1 : 0;
+    if (t == 0) share[blockIdx.x] = shared_seg ? 1 : 0;
     TREE_TS(8);
     // chunks of this segment that are neither its leader nor followers (a writer with a tree per chunk: all of them) parse their own
     // description, a lane each -- huf0_tree_kernel<2>'s work, here instead of in a launch of its own that finds nothing to do
@@ -1853,11 +1858,13 @@ int sprintz_mi355x_huf0_decompress_batch_hint(const void* d_blocks, const uint64
     uint8_t* const follow = desc + (((size_t)nchunks * kDescStride + 255) & ~(size_t)255);
     uint8_t* const share = follow + ((nchunks + 63) & ~(uint64_t)63);
     const uint8_t* const blk = (const uint8_t*)d_blocks;
-    // Few leaders (<= 4096 segments): ONE kernel, a wave per segment, does the follow test, the leader's tree, the followers'
+    // Up to HUF0_WAVE_LEADERS segments: ONE kernel, a wave per segment, does the follow test, the leader's tree, the followers'
     // copies and the share flag (46 us instead of 112 for the leader's tree at 157 .. 1 250 leaders, and three launches less).
-    // Many: the follow pass, a LANE per leader (0.13 ms at 12 500 leaders; the wave kernel takes 0.22), the copy pass, the
-    // share pass, then huf0_tree_kernel<2> for every chunk that is neither leader nor follower (the wave kernel does those itself).
-    if (nleaders <= 4096) {
+    // Above: the follow pass, a LANE per leader, the share pass, the copy pass, then huf0_tree_kernel<2> for every chunk that is neither
+    // leader nor follower (the wave kernel does those itself).  (Round 4 drew the line at 4 096 segments: the lane-per-leader parse
+    // alone is 0.13 ms at 12 500 leaders where the wave kernel takes 0.22 -- but the wave kernel's 0.22 is the follow pass's 0.08 and the
+    // other passes as well: at 800 000 chunks the whole stage 2.23 against 2.28 - 2.31 ms with it, round 5.)
+    if (nleaders <= HUF0_WAVE_LEADERS) {
         if (nleaders <= 1024) {
             hipLaunchKernelGGL(huf0_tree_wave_kernel<true>, dim3((unsigned)nleaders), dim3(64), 0, st, blk, d_block_offsets, d_out_offsets, nchunks, desc, follow, share);
         } else {
