@@ -209,21 +209,27 @@ __global__ void __launch_bounds__(kScanBlock) scan_one_kernel(const uint32_t* si
         v[k] = i0 + k < n ? (((uint64_t)sizes[i0 + k] + a) & ~a) : 0;
         sum += v[k];
     }
-    sh[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < kScanBlock; off <<= 1) {
-        const uint64_t t = threadIdx.x >= (unsigned)off ? sh[threadIdx.x - off] : 0;
-        __syncthreads();
-        sh[threadIdx.x] += t;
-        __syncthreads();
+    // inclusive scan of the 1 024 partial sums: inside a wavefront with shuffles, over the 16 wavefronts through LDS (round 5: ten
+    // Hillis-Steele rounds of two barriers each were most of this one-workgroup kernel's 9 - 12 us)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint64_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)incl, off, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), off, 64);
+        if ((int)lane >= off) incl += ((uint64_t)hi << 32) | lo;
     }
-    uint64_t run = sh[threadIdx.x] - sum;
+    if (lane == 63) sh[wave] = incl;
+    __syncthreads();
+    uint64_t wbase = 0, total = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kScanBlock / 64; k++) { wbase += k < wave ? sh[k] : 0ull; total += sh[k]; }
+    uint64_t run = wbase + incl - sum;
 #pragma unroll
     for (int k = 0; k < kScanPer; k++) {
         if (i0 + k < n) offsets[i0 + k] = run;
         run += v[k];
     }
-    if (threadIdx.x == kScanBlock - 1) offsets[n] = sh[threadIdx.x];
+    if (threadIdx.x == kScanBlock - 1) offsets[n] = total;
 }
 
 #ifndef SPRINTZ_COPY_SMALL_LOG2
