@@ -65,6 +65,9 @@ def parse():
     p.add_argument("--dry-launch", action="store_true",
                    help="launch check only: bring the N ranks up (self-launching them if need be), all-gather the ranks, print one JSON "
                         "line; needs no GPU (gloo without one)")
+    p.add_argument("--strict-rccl", action="store_true",
+                   help="with --gpus N > 1: abort before any timing if the layout exchange is not the library's own ncclAllGather "
+                        "(csrc/comm.cpp behind the C-ABI); the default reports the fall-back to torch.distributed loudly on stderr and on the line")
     p.add_argument("--rccl", action="store_true",
                    help="with --dry-launch: also run the library's own layout gather (comm.cpp, ncclAllGather behind the C-ABI) over the N "
                         "ranks and check what every rank received -- seconds on a multi-GPU box, needs one GPU per rank")
@@ -710,17 +713,27 @@ def dry_launch(args, world, rank):
         os.dup2(2, 1)
         # the product's own exchange (csrc/comm.cpp: ncclAllGather behind the C-ABI) on a real communicator of `world` ranks:
         # rank r contributes 1000 + r bytes, every rank must see all of them and derive the same bases
-        assert use_gpu and (world == 1 or backend == "nccl"), "--rccl needs one visible GPU per rank (RCCL refuses two ranks on one device)"
+        one_device = bool(os.environ.get("BENCH_ONE_DEVICE")) and torch.cuda.is_available()
+        assert one_device or (use_gpu and (world == 1 or backend == "nccl")), "--rccl needs one visible GPU per rank (or BENCH_ONE_DEVICE=1: the fall-back drill)"
         from sprintz_amd.dist import LayoutGather
-        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        dev = torch.device("cuda", 0 if one_device else int(os.environ.get("LOCAL_RANK", "0")))
         torch.cuda.set_device(dev)
-        g = LayoutGather(dev)
+        # BENCH_ONE_DEVICE=1: the FALL-BACK DRILL -- N ranks on one GPU, gloo bootstrap, the library's communicator attempted all the same:
+        # RCCL refuses a second rank on the device, every rank must say so loudly and take torch.distributed together, the layout must still be right
+        g = LayoutGather(dev, prefer_c_abi="force" if one_device else True)
+        if world > 1 and g.comm is None:
+            print(f"[bench rank {rank}] LAYOUT GATHER FELL BACK from rccl-c-abi (sprintz_mi355x_gather_layout) to {g.backend}; "
+                  f"the C-ABI communicator did not come up: {g.c_abi_error}", file=sys.stderr, flush=True)
+            if args.strict_rccl:
+                raise SystemExit(f"--strict-rccl: rank {rank}: layout gather is not rccl-c-abi ({g.c_abi_error})")
+        if g.comm is None and world > 1 and one_device:
+            g.device, g.all = torch.device("cpu"), torch.zeros(world, dtype=torch.int64)     # gloo carries CPU tensors
         lay = g.layout(1000 + rank)
         want = [1000 + r for r in range(world)]
         assert lay.rank_bytes == want, (lay.rank_bytes, want)
         assert lay.rank_base == [sum(want[:r]) for r in range(world)] and lay.total_bytes == sum(want)
         rccl = {"backend": g.backend, "ranks_seen": g.ranks_seen, "c_abi_error": g.c_abi_error, "rank_bytes": lay.rank_bytes}
-        assert world == 1 or g.comm is not None, f"comm.cpp could not bring RCCL up: {g.c_abi_error}"
+        assert world == 1 or g.comm is not None or one_device, f"comm.cpp could not bring RCCL up: {g.c_abi_error}"
         g.close()
     if world > 1:
         dist.barrier()
@@ -819,6 +832,13 @@ def main():
     offsets = torch.empty(nchunks + 1, dtype=torch.int64, device=device)
     gather = LayoutGather(device)            # RCCL behind the C-ABI when it comes up, torch.distributed otherwise
     timer = cx.timer
+    # ---------------- N > 1: say EARLY and LOUDLY what carries the one exchange of the write path
+    gather_fallback = None
+    if world > 1 and gather.comm is None:
+        gather_fallback = f"{gather.backend}; the C-ABI communicator did not come up: {gather.c_abi_error}"
+        print(f"[bench rank {rank}] LAYOUT GATHER FELL BACK from rccl-c-abi (sprintz_mi355x_gather_layout) to {gather_fallback}", file=sys.stderr, flush=True)
+        if args.strict_rccl:
+            raise SystemExit(f"--strict-rccl: rank {rank}: layout gather is not rccl-c-abi ({gather_fallback})")
 
     def compress_step():                     # encode + container (one launch) -> (N > 1) all-gather of byte counts: the whole write path
         codec.compress_dense(src_padded, x.numel(), ws, dense, offsets)
@@ -835,6 +855,8 @@ def main():
     comp = dense[: total_comp + _lib.READ_SLACK].clone()
     del dense
     layout = gather.layout(total_comp)       # bases of every rank's container in the job-wide one
+    assert gather.ranks_seen == world and len(layout.rank_bytes) == world and all(b > 0 for b in layout.rank_bytes), \
+        f"rank {rank}: the layout exchange saw {gather.ranks_seen} of {world} ranks: {layout.rank_bytes}"
     out = torch.empty(nchunks * chunk_len, dtype=torch.int16, device=device)
     rets = torch.empty(nchunks, dtype=torch.int64, device=device)
 
@@ -870,6 +892,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    wall_ranks = [wall]
+    if world > 1:                                          # every rank's own clock beside the maximum the line is quoted on
+        tw = torch.tensor([wall], dtype=torch.float64, device=device)
+        got = [torch.zeros_like(tw) for _ in range(world)]
+        dist.all_gather(got, tw)
+        wall_ranks = [float(g.item()) for g in got]
     wall = max_over_ranks(wall, device)
     kernel_ms = sum(a.elapsed_time(b) for a, b in evs) / args.steps     # HIP-event average launch duration
 
@@ -898,13 +926,21 @@ def main():
                      "two_launch_ms_this_rank": round(compress_2l_ms, 4), "layout_gather": gather.backend,
                      "roofline_frac": round((nchunks * chunk_bytes + total_comp + 12 * nchunks) / (compress_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                      "roofline_algorithmic": "raw samples in + dense container out + sizes/offsets, this rank"},
+        "ms_per_step_ranks": [round(w / args.steps * 1e3, 4) for w in wall_ranks],
         "kernel_ms": round(kernel_ms, 4),
-        "roofline": {"bound": "hbm", "achieved": round(algo_bytes / (kernel_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(algo_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
+        # `achieved` / `frac`: this rank's algorithmic bytes per launch over the line's own ms_per_step (the wall clock the driver can
+        # re-derive: bytes / ms_per_step / 8 TB/s); the HIP-event average of the same launches beside it as *_kernel_events
+        "roofline": {"bound": "hbm", "achieved": round(algo_bytes / (wall / args.steps) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(algo_bytes / (wall / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                     "achieved_kernel_events": round(algo_bytes / (kernel_ms * 1e-3) / 1e9, 1),
+                     "frac_kernel_events": round(algo_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "traffic_measured_in_this_run": False,      # (PMC passes are separate rocprofv3 runs: the figure is the committed profile's, labelled below; null if none matches)
                      "traffic_source": traffic_label, "algorithmic_bytes_per_launch": algo_bytes,
                      "kernel": "decode_fast_kernel<16,FIRE,8,1,EXACT>"},
         "container_bytes_all_ranks": layout.total_bytes, "rank_bases": layout.bases[:8], "rccl_ranks_seen": gather.ranks_seen,
+        "layout_gather_fallback": gather_fallback,
+        # what the multi-GPU sharding of every configuration has run on so far (a reader of this line alone should know)
+        "configs_8gpu_sharding": "gloo on CPU + 8 ranks on one device only; never on 8 devices" if world == 1 else f"this run: {world} ranks, {gather.backend}",
         "host": {**host_description(), **numa},
     }
 
@@ -987,7 +1023,7 @@ def finish_and_emit(result, emit):
     """per_config_summary (LAST key: a reader who keeps only the tail of the line sees every configuration), the full record to
     bench_full.json + stderr, the compact line to stdout"""
     per = result["per_config"]
-    summ = {"cfg2": [result["kernel_ms"], result["roofline"]["frac"], result["compress"]["ms_per_step_max_rank"], result["compress"]["roofline_frac"],
+    summ = {"cfg2": [result["ms_per_step"], result["roofline"]["frac"], result["compress"]["ms_per_step_max_rank"], result["compress"]["roofline_frac"],
                      result.get("cpu_baseline", {}).get("value"), result.get("cpu_baseline", {}).get("value_1thread")]}
     for e in per[1:]:
         if "error" in e:
@@ -998,6 +1034,13 @@ def finish_and_emit(result, emit):
         summ[e["name"]] = [j.get("decompress_ms_max_rank", e["decompress_ms"]), e["roofline"]["frac"], j.get("compress_ms_max_rank", e["compress_ms"]),
                            e["compress_roofline"]["frac"], cb.get("value"), cb.get("value_1thread")]
     result["per_config_summary"] = {"fields": SUMMARY_FIELDS, **summ}
+    # the driver's record keeps `config`, `roofline` and `cpu_baseline` whole and drops every other extra key: the per-configuration
+    # fractions ride inside `roofline` so that a reader of BENCH_rNN.json's `parsed` alone sees them
+    result["roofline"]["per_config"] = {"fields": "dec_ms, dec_frac, enc_ms, enc_frac (algorithmic bytes / time / 8 TB/s; cfg4: the whole chain)",
+                                        **{k: (v[:4] if isinstance(v, list) else v) for k, v in summ.items()}}
+    result["config"]["multi_gpu_evidence"] = result.get("configs_8gpu_sharding")
+    if result.get("layout_gather_fallback"):
+        result["config"]["layout_gather_fallback"] = result["layout_gather_fallback"]
     full_path = os.path.join(ROOT, "bench_full.json")
     result["full_record"] = "bench_full.json next to bench.py (per_config entries, the prose of every field); also on stderr"
     result["per_config_summary"] = result.pop("per_config_summary")          # stays the last key

@@ -210,7 +210,15 @@ uint64_t sprintz_mi355x_num_chunks(uint64_t total_len, uint32_t chunk_len);
  * d_slots + c*slot_stride (slot_stride >= compress_bound, multiple of 16,
  * d_slots 16-byte aligned); d_sizes[c] receives its exact byte length and
  * d_rets[c] (optional, may be NULL) the reference's element-count return.
- * d_src must be readable for SPRINTZ_MI355X_READ_SLACK bytes past its end. */
+ * d_src must be readable for SPRINTZ_MI355X_READ_SLACK bytes past its end.
+ * More than 2 047 columns: d_slots (and the decoder's d_out) must be ordinary DEVICE memory (hipMalloc) -- those
+ * kernels build the stream with device-scope atomics on the slot and read their own output back; they also take
+ * nchunks * ndims * 4 bytes of stream-ordered scratch (hipMallocAsync) per FIRE launch, so such a launch cannot be
+ * captured into a graph.  From 4 096 columns on a shape whose verbatim tail can exceed the stream header's 16-bit
+ * remaining_len (format.h:40; a chunk of whole blocks: 16 * ndims elements, else 8 * ndims + the ragged rest, or the
+ * whole chunk when it is shorter than a group) is REFUSED with SPRINTZ_E_UNSUPPORTED by every batched entry point: the
+ * reference's single call writes such a stream truncated (it decodes to a prefix), which the drop-in single-call
+ * symbols reproduce and a batch must not. */
 int sprintz_mi355x_compress_batch(int codec, int elem_bytes,
                                   const void* d_src, uint64_t total_len, uint32_t chunk_len, uint16_t ndims,
                                   void* d_slots, size_t slot_stride,

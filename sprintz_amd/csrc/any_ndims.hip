@@ -732,12 +732,7 @@ __global__ void __launch_bounds__(256) encode_big_kernel(EncodeArgs a, int32_t* 
 template <typename K, typename A>
 hipError_t launch_any(K kernel, unsigned grid, size_t shmem, hipStream_t st, const A& a)
 {
-    if (shmem > 48 * 1024) {
-        hipError_t e = ensure_max_dynamic_lds(reinterpret_cast<const void*>(kernel));      // once per instantiation and device (launch.h)
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), shmem, st, a);
-    return hipGetLastError();
+    return launch_with_lds(kernel, grid, 256u, shmem, st, a);      // (> 48 KB: the attribute once per instantiation and device, lds_attr.h)
 }
 
 }  // namespace

@@ -342,6 +342,25 @@ int check_common(int codec, int esz, uint16_t ndims)
     return 0;
 }
 
+// The stream header's remaining_len is a uint16 (format.h:40): from 4 096 columns on a chunk's verbatim tail -- the whole chunk when
+// it is shorter than one group, otherwise at most two blocks (the "<" codecs: sprintz_delta_rle.cpp:226) or one block and the
+// ragged rest -- can exceed 65 535 elements.  The reference's single call then writes a header that decodes to a prefix, and the
+// drop-in symbols reproduce that; a BATCH that silently loses samples is not acceptable, so the batched entry points refuse it.
+int check_batch_tail(uint64_t total_len, uint32_t chunk_len, uint16_t ndims)
+{
+    if (ndims < 4096 || chunk_len == 0) return 0;
+    auto tail_max = [&](uint64_t n) -> uint64_t {
+        const uint64_t blk = 8ull * ndims;
+        if (n < 128 || n < 2 * blk) return n;
+        return n % blk == 0 ? 2 * blk : blk + n % blk;
+    };
+    const uint64_t last = total_len % chunk_len;
+    const bool full = total_len >= chunk_len;
+    if ((full && tail_max(chunk_len) > 0xffffu) || (last && tail_max(last) > 0xffffu))
+        return fail(SPRINTZ_E_UNSUPPORTED, "a chunk's verbatim tail can exceed the stream header's 16-bit remaining_len at this ndims x chunk_len: the batch would decode to a prefix");
+    return 0;
+}
+
 // query-on-compressed options of one decode launch (decode_kernel.h: Q template parameter)
 // a single call served straight from the caller thread's mapped host buffer by ONE launch of a workgroup-per-chunk kernel
 // (decode_lat.h / encode_lat.h): no staging kernel in front, no runtime wait behind -- the kernel's last store is the
@@ -1474,6 +1493,7 @@ int sprintz_mi355x_compress_batch(int codec, int elem_bytes, const void* d_src, 
     if (slot_stride % 16 || (uintptr_t)d_slots % 16) return fail(SPRINTZ_E_INVALID, "slots must be 16-byte aligned/strided");
     if (slot_stride < sprintz_mi355x_compress_bound(elem_bytes, chunk_len, ndims))
         return fail(SPRINTZ_E_INVALID, "slot_stride below sprintz_mi355x_compress_bound");
+    if ((rc = check_batch_tail(total_len, chunk_len, ndims))) return rc;
     if ((rc = ensure_device())) return rc;
     return encode_launch(codec, elem_bytes, d_src, total_len, chunk_len, ndims, d_slots, slot_stride, d_sizes, d_rets,
                          (hipStream_t)hip_stream, 1);
@@ -1499,6 +1519,7 @@ int sprintz_mi355x_compress_batch_dense(int codec, int elem_bytes, const void* d
         return fail(SPRINTZ_E_INVALID, "slots and the container must be 16-byte aligned/strided");
     if (slot_stride < sprintz_mi355x_compress_bound(elem_bytes, chunk_len, ndims))
         return fail(SPRINTZ_E_INVALID, "slot_stride below sprintz_mi355x_compress_bound");
+    if ((rc = check_batch_tail(total_len, chunk_len, ndims))) return rc;
     if ((rc = ensure_device())) return rc;
     hipStream_t st = (hipStream_t)hip_stream;
     const uint64_t nchunks = sprintz_mi355x_num_chunks(total_len, chunk_len);
@@ -1607,6 +1628,7 @@ int64_t sprintz_mi355x_compress_chunked_host(int codec, int elem_bytes, const vo
     int rc = check_common(codec, elem_bytes, ndims);
     if (rc) return rc;
     if (chunk_len == 0) return fail(SPRINTZ_E_INVALID, "chunk_len == 0");
+    if ((rc = check_batch_tail(total_len, chunk_len, ndims))) return rc;
     if ((rc = ensure_device())) return rc;
     const uint64_t nchunks = sprintz_mi355x_num_chunks(total_len, chunk_len);
     if (nchunks == 0) { offsets[0] = 0; return 0; }

@@ -6,12 +6,7 @@ namespace {
 template <typename K>
 hipError_t launch_enc_lat(K kernel, unsigned grid, const EncLatCarve& c, hipStream_t st, const EncodeArgs& a)
 {
-    if (c.total > 48 * 1024) {
-        hipError_t e = ensure_max_dynamic_lds(reinterpret_cast<const void*>(kernel));      // once per instantiation and device (launch.h)
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), c.total, st, a, c);
-    return hipGetLastError();
+    return launch_with_lds(kernel, grid, 256u, c.total, st, a, c);      // (> 48 KB: the attribute once per instantiation and device, lds_attr.h)
 }
 }  // namespace
 #define SPRINTZ_ENC_LAT_CASE(WV, DPV)                                                                     \

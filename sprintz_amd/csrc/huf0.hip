@@ -1897,15 +1897,13 @@ int sprintz_mi355x_huf0_decompress_batch_hint(const void* d_blocks, const uint64
         const uint32_t want = max_block_bytes ? max_block_bytes : 4096u;
         const uint32_t img = ((want < 16384u ? want : 16384u) + 16u + 63u) & ~63u;
         const size_t lds = sync_lds_bytes(kWpb, img);
-        // chunks a wave takes one after the other (experiments; tools/huf0_sync_ab.sh: 1 / 2 / 4 -> 43.8 / 60.0 / 91.5 us at 625 chunks, 106 / 99.5 / 119 at
-        // 10 000, 152 at 16 384 whatever it is -- the form is bound by its instructions there: 2 400 a chunk against 630 of the single-pass kernel)
-        static const int cpw_env = [] { const char* e = getenv("SPRINTZ_MI355X_HUF0_SYNC_CPW"); return e ? atoi(e) : 0; }();
-        const uint32_t cpw = cpw_env > 0 ? (uint32_t)cpw_env : 1u;
-        if (lds > 48 * 1024 && sprintz::ensure_max_dynamic_lds(reinterpret_cast<const void*>(huf0_sync_kernel<kWpb>)) != hipSuccess)
-            return sprintz::set_error(SPRINTZ_E_HIP, "Huff0 stage: hipFuncSetAttribute failed");
+        // (chunks a wave takes one after the other: measured 1 / 2 / 4 -> 43.8 / 60.0 / 91.5 us at 625 chunks, 106 / 99.5 / 119 at 10 000 -- tools/huf0_sync_ab.sh,
+        //  round 5; the environment knob that chose it had no test and is gone: one chunk a wave)
+        const uint32_t cpw = 1u;
         const uint64_t per_wg = (uint64_t)kWpb * cpw;
-        hipLaunchKernelGGL(huf0_sync_kernel<kWpb>, dim3((unsigned)((nchunks + per_wg - 1) / per_wg)), dim3(64 * kWpb), lds, st, blk, d_block_offsets, nchunks,
-                           (uint8_t*)d_out, d_out_offsets, d_rets, (const uint8_t*)desc, (const uint8_t*)share, img, cpw);
+        if (sprintz::launch_with_lds(huf0_sync_kernel<kWpb>, (unsigned)((nchunks + per_wg - 1) / per_wg), 64u * kWpb, lds, st, blk, d_block_offsets, nchunks,
+                                     (uint8_t*)d_out, d_out_offsets, d_rets, (const uint8_t*)desc, (const uint8_t*)share, img, cpw) != hipSuccess)
+            return sprintz::set_error(SPRINTZ_E_HIP, "Huff0 stage: the self-synchronising stream kernel's launch failed");
     } else {
         hipLaunchKernelGGL(huf0_stream_small_kernel, dim3((unsigned)grid2), dim3(64), 0, st, blk, d_block_offsets, nchunks,
                            (uint8_t*)d_out, d_out_offsets, d_rets, (const uint8_t*)desc, (const uint8_t*)share, 0);

@@ -72,7 +72,9 @@ class LayoutGather:
         self.backend = "single-rank" if self.world == 1 else f"torch.distributed/{dist.get_backend()}"
         self.ranks_seen = 1
         self.c_abi_error = None
-        if cuda and prefer_c_abi and (self.world == 1 or dist.get_backend() == "nccl"):
+        # prefer_c_abi == "force": try the library's communicator whatever carries the bootstrap (bench.py --dry-launch --rccl on a
+        # one-device box: the process group is gloo, RCCL then refuses the second rank on the device and the fall-back shows)
+        if cuda and prefer_c_abi and (self.world == 1 or dist.get_backend() == "nccl" or prefer_c_abi == "force"):
             self._init_c_abi()
 
     def _init_c_abi(self):
@@ -83,9 +85,10 @@ class LayoutGather:
         ok = 1
         if self.rank == 0:
             ok = 1 if _lib.comm_unique_id(idbuf) == 0 else 0
-        t = torch.zeros(_lib.COMM_ID_BYTES + 1, dtype=torch.uint8, device=self.device)
+        boot = self.device if (self.world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")   # what the bootstrap's collectives travel on
+        t = torch.zeros(_lib.COMM_ID_BYTES + 1, dtype=torch.uint8, device=boot)
         if self.rank == 0:
-            t[:-1] = torch.frombuffer(bytearray(idbuf), dtype=torch.uint8).to(self.device)
+            t[:-1] = torch.frombuffer(bytearray(idbuf), dtype=torch.uint8).to(boot)
             t[-1] = ok
         if self.world > 1:
             dist.broadcast(t, src=0)
@@ -97,7 +100,7 @@ class LayoutGather:
         comm = C.c_void_p()
         with torch.cuda.device(self.device):
             rc = _lib.comm_init(idb, self.rank, self.world, C.byref(comm))
-        good = torch.tensor([1 if rc == 0 else 0], dtype=torch.int64, device=self.device)
+        good = torch.tensor([1 if rc == 0 else 0], dtype=torch.int64, device=boot)
         if self.world > 1:
             dist.all_reduce(good, op=dist.ReduceOp.MIN)            # all ranks take the same path
         if int(good.item()) == 1:

@@ -27,8 +27,10 @@ def sz(request):
         mod = types.SimpleNamespace(**{k: getattr(sprintz_amd, k) for k in dir(sprintz_amd) if not k.startswith("__")})
         mod.huf0_decompress = functools.partial(sprintz_amd.huf0_decompress, max_block_bytes=16384)
     yield mod
-    _lib.set_option(_lib.OPT_HUF0_BIG_BATCH, 16385)
-    _lib.set_option(_lib.OPT_HUF0_SYNC_CHUNKS, 8192)
+    # back to what the process was configured with (the environment's value, else the library's default), not to a constant
+    import os
+    _lib.set_option(_lib.OPT_HUF0_BIG_BATCH, 16385)            # (no environment knob: the library's constant)
+    _lib.set_option(_lib.OPT_HUF0_SYNC_CHUNKS, int(os.environ.get("SPRINTZ_MI355X_HUF0_SYNC_CHUNKS", 8192)))
 
 
 def pack(blocks, plains, align=1):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of the Huff0 stream stage for small batches: huf0_sync.h (a wave per chunk, sixteen self-synchronising decoders per stream) against
 # the single-wave form it replaces there, over batch sizes (tools/huf0_sync_ab.sh > gpurun_out/huf0_sync_ab.txt)
-# SYNCS: values of SPRINTZ_MI355X_HUF0_SYNC_CHUNKS to compare; CPWS: chunks a wave takes in a row (0 = the library's choice)
+# SYNCS: values of SPRINTZ_MI355X_HUF0_SYNC_CHUNKS to compare; CPWS: (round 5 only: the knob was removed in round 6, one chunk a wave)
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
 for sync in ${SYNCS:-0 1073741824}; do
  for cpw in ${CPWS:-0}; do
