@@ -47,8 +47,9 @@ extern "C" {
  *   3  round 3: compress_batch_dense / compress_dense_tmp_bytes, SPRINTZ_OPT_DENSE_MODE, env SPRINTZ_MI355X_RCCL_SONAME
  *   4  round 3: compress_batch_colmajor_dense, SPRINTZ_OPT_SPLIT_LANES, SPRINTZ_OPT_ENC_PAIR
  *   5  round 4: SPRINTZ_OPT_HOST_WAIT, SPRINTZ_OPT_LAT_CHUNKS, SPRINTZ_OPT_HOST_STREAMS, SPRINTZ_OPT_REF_DECODER_QUIRK (the single-call entry points work on a mapped staging buffer: one wait per call)
- *   6  round 5: huf0_decompress_batch_hint, SPRINTZ_OPT_HUF0_SYNC_CHUNKS, SPRINTZ_MI355X_MAX_NDIMS 65535 */
-#define SPRINTZ_MI355X_ABI_VERSION 6
+ *   6  round 5: huf0_decompress_batch_hint, SPRINTZ_OPT_HUF0_SYNC_CHUNKS, SPRINTZ_MI355X_MAX_NDIMS 65535
+ *   7  round 6: SPRINTZ_OPT_BLK_CHUNKS (block-parallel delta kernels); the batched entry points refuse shapes whose tail outgrows remaining_len */
+#define SPRINTZ_MI355X_ABI_VERSION 7
 
 /* codec ids */
 #define SPRINTZ_CODEC_DELTA 0   /* sprintz_*_delta_*  (sprintz_delta_rle.cpp / sprintz_delta_lowdim.cpp) */
@@ -116,6 +117,9 @@ const char* sprintz_mi355x_last_error(void);     /* thread-local, never NULL; de
  *                                 at most 64 chunks up to ~40 KB of uint16 / ~24 KB of uint8: what fits a workgroup's 150 KB of LDS) decode
  *                                 with one workgroup per chunk (csrc/decode_lat.h: a chunk's latency is what counts; a third as many from 17 columns on); default 2048,
  *                                 0 = never (A/B runs, tests); env SPRINTZ_MI355X_LAT_CHUNKS
+ *   SPRINTZ_OPT_BLK_CHUNKS        batches of at least this many chunks of the DELTA codec take the block-parallel kernels (a thread per block and
+ *                                 16-byte row piece / per 16 rows of a univariate stream; csrc/encode_blk.h, decode_blk.h) where the shape allows;
+ *                                 0 = never, default 2049 (env SPRINTZ_MI355X_BLK_CHUNKS).  Same bytes either way.
  *   SPRINTZ_OPT_HOST_WAIT         how a single-call entry point waits for its launches: 0 (default) = spin (hipStreamSynchronize)
  *                                 while at most 4 callers (and at most half of the CPUs this process may use) are inside the library,
  *                                 otherwise sleep and poll a mapped host word that a one-thread kernel at the end of the call writes
@@ -133,6 +137,7 @@ const char* sprintz_mi355x_last_error(void);     /* thread-local, never NULL; de
 #define SPRINTZ_OPT_HOST_STREAMS 8
 #define SPRINTZ_OPT_REF_DECODER_QUIRK 9
 #define SPRINTZ_OPT_HUF0_SYNC_CHUNKS 10
+#define SPRINTZ_OPT_BLK_CHUNKS 11
 int sprintz_mi355x_set_option(int option, int value);
 
 /* ------------------------------------------------------------------------

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "launch.h"
+#include "encode_blk.h"
 #include "decode_lat.h"
 #include "encode_lat.h"
 
@@ -56,6 +57,7 @@ struct Process {
     std::atomic<int> chunks_per_group{1};   // SPRINTZ_MI355X_CHUNKS_PER_GROUP (decode_fast read-ahead across chunks)
     std::atomic<int> dense_mode{1};         // SPRINTZ_MI355X_DENSE_MODE: how compress_batch_dense builds the container (see SPRINTZ_OPT_DENSE_MODE)
     std::atomic<int> enc_pair{1024};        // SPRINTZ_MI355X_ENC_PAIR: chunks from which row-major streams of 5 .. 64 columns are encoded with two columns per lane (0: never; see SPRINTZ_OPT_ENC_PAIR)
+    std::atomic<int> blk_chunks{2049};      // SPRINTZ_MI355X_BLK_CHUNKS: batches of at least this many chunks take the block-parallel delta kernels (encode_blk.h; 0: never)
     std::atomic<int> lat_chunks{2048};      // SPRINTZ_MI355X_LAT_CHUNKS: batches of at most this many chunks decode with one workgroup per chunk (decode_lat.h; 0: never)
     std::atomic<int> ref_quirk{0};          // SPRINTZ_MI355X_REF_DECODER_QUIRK: decode as the reference DECODER does where it differs from the inverse of its encoder
     std::atomic<int> host_streams{4};       // SPRINTZ_MI355X_HOST_STREAMS: streams the host-pointer calls of all threads share per device (0: one per thread)
@@ -75,6 +77,7 @@ Process& process()
             p.dense_mode = k <= 0 ? 0 : 1;
         }
         if (const char* e = getenv("SPRINTZ_MI355X_LAT_CHUNKS")) p.lat_chunks = atoi(e) < 0 ? 0 : atoi(e);
+        if (const char* e = getenv("SPRINTZ_MI355X_BLK_CHUNKS")) p.blk_chunks = atoi(e) < 0 ? 0 : atoi(e);
         if (const char* e = getenv("SPRINTZ_MI355X_REF_DECODER_QUIRK")) p.ref_quirk = atoi(e) != 0 ? 1 : 0;
         if (const char* e = getenv("SPRINTZ_MI355X_HOST_STREAMS")) p.host_streams = atoi(e) < 0 ? 0 : (atoi(e) > 64 ? 64 : atoi(e));
         if (const char* e = getenv("SPRINTZ_MI355X_HOST_WAIT")) p.host_wait = atoi(e) < 0 || atoi(e) > 2 ? 0 : atoi(e);
@@ -660,6 +663,27 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
         e = launch_encode_lat(8 * esz, codec == SPRINTZ_CODEC_XFF, ldp, lowdim, (unsigned)nchunks, (uint32_t)sprintz_mi355x_compress_bound(esz, chunk_len, ndims), st, a);
         if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "encode_lat kernel launch", e);
         return 0;
+    }
+    // large batches of the DELTA codec, general layout, rows of whole 16-byte pieces: the block-parallel encoder (encode_blk.h) -- a thread
+    // per (block, 16-byte row piece), the RLE state machine as scans; the container, if one was asked for, by the scan + copy passes.
+    // (The container inside this launch -- images flushed straight to their place, found by compact_tail.h's chained scan -- was built and
+    //  measured on BASELINE config 3 at 10 KB, 17 476 workgroups of three chunks: 0.296 ms against 0.267 for the launches in a row.  Taken
+    //  apart: no scan, no tickets 0.177; tickets alone +0.070 (17 476 atomics on one word); the look-back alone +0.089 with 256 predecessors
+    //  a hop, +0.114 with 1 024 -- a workgroup that lives 10 us waits for the slowest of a thousand resident predecessors with 33 KB of LDS
+    //  held.  The tail pays from 64 chunks a workgroup on, as on the lane-per-column kernels.)
+    {
+        const int blk_from = process().blk_chunks.load(std::memory_order_relaxed);
+        if (blk_from > 0 && nchunks >= (uint64_t)blk_from && codec == SPRINTZ_CODEC_DELTA && !lowdim && !col_stride && !hc && write_size &&
+            ((uintptr_t)d_src % 16) == 0 && slot_stride % 16 == 0 && ((uintptr_t)d_slots % 16) == 0 && !process().no_fast.load(std::memory_order_relaxed)) {
+            const BlkEncGeom g = blk_enc_geom((uint32_t)esz, chunk_len, (uint32_t)D, (uint32_t)sprintz_mi355x_compress_bound(esz, chunk_len, ndims));
+            if (g.ok) {
+                const uint64_t bgrid = (nchunks + g.CPW - 1) / g.CPW;
+                if (bgrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
+                e = launch_encode_blk(8 * esz, (unsigned)bgrid, st, a, g);
+                if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "encode_blk kernel launch", e);
+                return 0;
+            }
+        }
     }
     // the container built inside the launch (compact_tail.h): every kernel of encode_fast.h / encode_wide.h carries the tail
     auto arm_dense = [&](uint64_t grid, size_t groups) -> int {
@@ -1438,6 +1462,11 @@ int sprintz_mi355x_set_option(int option, int value)
     if (option == SPRINTZ_OPT_ENC_PAIR) {
         if (value < 0) return fail(SPRINTZ_E_INVALID, "the batch size must not be negative");
         process().enc_pair = value;
+        return 0;
+    }
+    if (option == SPRINTZ_OPT_BLK_CHUNKS) {
+        if (value < 0 || value > (1ll << 30)) return fail(SPRINTZ_E_INVALID, "SPRINTZ_OPT_BLK_CHUNKS must be in 0..2^30");
+        process().blk_chunks = (int)value;
         return 0;
     }
     if (option == SPRINTZ_OPT_LAT_CHUNKS) {

@@ -20,15 +20,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
-@pytest.fixture(params=["lat", "wide"])
+@pytest.fixture(params=["lat", "wide", "blk"])
 def decode_path(request):
-    """the two row-major decoders of the general layout: small batches (by default up to 2 048 chunks) take decode_lat.h (one
-    workgroup per chunk), larger ones decode_fast.h / decode_kernel.h (one lane per column).  The parity modules run every test
-    on both: "lat" sends every eligible batch to the small-batch decoder whatever its size, "wide" switches it off."""
+    """the three families of row-major kernels: small batches (by default up to 2 048 chunks) take decode_lat.h / encode_lat.h (one
+    workgroup per chunk), larger ones decode_fast.h / decode_kernel.h / encode_wide.h (one lane per column or column pair), large
+    batches of the DELTA codec the block-parallel kernels (encode_blk.h, decode_blk.h; SPRINTZ_OPT_BLK_CHUNKS).  The parity modules run
+    every test on all three: "lat" sends every eligible batch to the workgroup-per-chunk kernels whatever its size, "wide" switches both
+    other families off, "blk" sends every eligible batch -- one chunk included -- to the block-parallel kernels."""
     from sprintz_amd import _lib
     _lib.check(_lib.set_option(_lib.OPT_LAT_CHUNKS, (1 << 30) if request.param == "lat" else 0))
+    _lib.check(_lib.set_option(_lib.OPT_BLK_CHUNKS, 1 if request.param == "blk" else 0))
     yield request.param
-    _lib.set_option(_lib.OPT_LAT_CHUNKS, 2048)
+    _lib.set_option(_lib.OPT_LAT_CHUNKS, int(os.environ.get("SPRINTZ_MI355X_LAT_CHUNKS", 2048)))
+    _lib.set_option(_lib.OPT_BLK_CHUNKS, int(os.environ.get("SPRINTZ_MI355X_BLK_CHUNKS", 2049)))
 
 
 @pytest.fixture(scope="session")

@@ -44,7 +44,7 @@ def test_library_exports_every_declared_symbol(lib_path):
 def test_python_binding_matches_header(lib_path):
     from sprintz_amd import _lib
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared_symbols()
-    assert _lib.abi_version() == 6
+    assert _lib.abi_version() == 7
 
 
 def test_no_cpu_fallback(lib_path):

@@ -1,0 +1,118 @@
+"""GPU tests (-m gpu) of the BLOCK-PARALLEL delta kernels (csrc/encode_blk.h, decode_blk.h; SPRINTZ_OPT_BLK_CHUNKS): every
+shape family they take, batched through the C-ABI, against the oracle -- stream bytes, sizes, return values, samples.  The
+general parity modules run on these kernels too (tests/conftest.py: decode_path "blk"); here the shapes are chosen to sit
+ON the new kernels (the module asserts that the option is honoured by comparing with the lane-per-column kernels' bytes)."""
+import numpy as np
+import pytest
+
+from harness import DTYPES, gen_walk
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sz():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import sprintz_amd
+    return sprintz_amd
+
+
+@pytest.fixture(params=["blk", "old"])
+def path(request):
+    """every test on the block-parallel kernels and, as a control, on the kernels they replace (same bytes)"""
+    import os
+    from sprintz_amd import _lib
+    _lib.check(_lib.set_option(_lib.OPT_LAT_CHUNKS, 0))
+    _lib.check(_lib.set_option(_lib.OPT_BLK_CHUNKS, 1 if request.param == "blk" else 0))
+    yield request.param
+    _lib.set_option(_lib.OPT_LAT_CHUNKS, int(os.environ.get("SPRINTZ_MI355X_LAT_CHUNKS", 2048)))
+    _lib.set_option(_lib.OPT_BLK_CHUNKS, int(os.environ.get("SPRINTZ_MI355X_BLK_CHUNKS", 2049)))
+
+
+def make_data(kind, rng, n, ndims, esz):
+    if kind == "walk":
+        return gen_walk(rng, n, ndims, esz, 3)
+    if kind == "walk_flat":                                   # flat spans: runs inside and across groups, runs that end a chunk
+        return gen_walk(rng, n, ndims, esz, 5, flat_every=2)
+    if kind == "zeros":
+        return np.zeros(n, DTYPES[esz])
+    if kind == "const_cols":                                  # all-zero deltas after the first row: one long run per chunk
+        return np.tile(rng.integers(0, 1 << (8 * esz), ndims).astype(DTYPES[esz]), (n + ndims - 1) // ndims)[:n]
+    if kind == "noise":                                       # every width at its maximum
+        return rng.integers(0, 1 << (8 * esz), n).astype(DTYPES[esz])
+    if kind == "mixed":                                       # per column a different step size: every width 0 .. W in one row
+        rows = (n + ndims - 1) // ndims
+        amp = (1 << (rng.integers(0, 8 * esz + 1, ndims))) >> 1
+        steps = rng.integers(-1, 2, (rows, ndims)) * amp[None, :]
+        steps[(np.arange(rows) // 24) % 3 == 1] = 0
+        return np.mod(np.cumsum(steps, axis=0), 1 << (8 * esz)).astype(DTYPES[esz]).ravel()[:n]
+    raise ValueError(kind)
+
+
+SHAPES = [
+    # esz, ndims, chunk_len (elements), nchunks, ragged last chunk (elements short of a full one)
+    (1, 80, 10240, 37, 0),            # BASELINE config 3 at 10 KB
+    (1, 80, 10240, 5, 3000),
+    (1, 16, 2048, 64, 0),
+    (1, 16, 16 * 16 * 3 + 32, 19, 48),  # chunk not a whole number of blocks
+    (1, 32, 4096, 33, 0),
+    (1, 48, 48 * 40, 21, 0),
+    (1, 64, 8192, 17, 64 * 5),
+    (1, 96, 96 * 24, 13, 0),
+    (1, 128, 128 * 16, 11, 0),        # exactly one group a chunk
+    (1, 256, 256 * 16 * 2, 6, 0),
+    (2, 8, 5120, 70, 0),              # the headline shape on the delta codec
+    (2, 8, 5120, 9, 1000),
+    (2, 8, 8 * 16 * 2 + 8, 40, 0),
+    (2, 16, 4096, 21, 0),
+    (2, 24, 24 * 56, 15, 24 * 3),
+    (2, 40, 40 * 128, 9, 0),
+    (2, 64, 64 * 32, 9, 0),
+    (2, 80, 80 * 64, 7, 0),
+    (2, 128, 128 * 16, 5, 0),
+]
+
+
+@pytest.mark.parametrize("kind", ["walk", "walk_flat", "zeros", "const_cols", "noise", "mixed"])
+@pytest.mark.parametrize("esz,ndims,chunk_len,nchunks,short", SHAPES)
+def test_delta_batches_match_the_oracle(sz, oracle, path, kind, esz, ndims, chunk_len, nchunks, short):
+    import torch
+    rng = np.random.default_rng(1000 * ndims + chunk_len + esz)
+    n = nchunks * chunk_len - short
+    data = make_data(kind, rng, n, ndims, esz)
+    cd = sz.ChunkedCodec("delta", esz, ndims, chunk_len, device="cuda:0")
+    t = torch.from_numpy(data.view(np.int8 if esz == 1 else np.int16)).cuda().view(cd.dtype)
+    batch = cd.compress(t)
+    sizes, offs, comp = batch.sizes.cpu().numpy(), batch.offsets.cpu().numpy(), batch.data.cpu().numpy()
+    for c in range(nchunks):
+        want, wret = oracle.compress("delta", data[c * chunk_len:(c + 1) * chunk_len], ndims)
+        assert sizes[c] == want.size, (path, kind, c, int(sizes[c]), want.size)
+        got = comp[offs[c]:offs[c] + sizes[c]]
+        if not np.array_equal(got, want):
+            bad = np.flatnonzero(got != want)
+            raise AssertionError((path, kind, "chunk", c, "first differing stream bytes", bad[:6].tolist(), "of", want.size,
+                                  got[bad[:6]].tolist(), want[bad[:6]].tolist()))
+    rets = torch.empty(nchunks, dtype=torch.int64, device="cuda:0")
+    out = cd.decompress(batch, rets=rets).cpu().numpy().view(DTYPES[esz])
+    assert np.array_equal(out[:n], data), (path, kind)
+    r = rets.cpu().numpy()
+    assert (r[:-1] == chunk_len).all() and r[-1] == chunk_len - short, (path, kind, r[-3:])
+
+
+@pytest.mark.parametrize("esz,ndims,chunk_len", [(1, 80, 10240), (2, 8, 5120), (1, 16, 1024)])
+def test_a_large_batch_takes_the_new_kernels_by_default(sz, oracle, esz, ndims, chunk_len):
+    """default options, more chunks than SPRINTZ_OPT_BLK_CHUNKS' default: bytes against the oracle on every chunk"""
+    import torch
+    nchunks = 5000
+    rng = np.random.default_rng(7)
+    data = gen_walk(rng, nchunks * chunk_len, ndims, esz, 4, flat_every=5)
+    cd = sz.ChunkedCodec("delta", esz, ndims, chunk_len, device="cuda:0")
+    t = torch.from_numpy(data.view(np.int8 if esz == 1 else np.int16)).cuda().view(cd.dtype)
+    batch = cd.compress(t)
+    sizes, offs, comp = batch.sizes.cpu().numpy(), batch.offsets.cpu().numpy(), batch.data.cpu().numpy()
+    want, stride, wsizes = oracle.compress_chunks_mt("delta", data, chunk_len, ndims)
+    assert np.array_equal(sizes, wsizes)
+    for c in range(nchunks):
+        assert np.array_equal(comp[offs[c]:offs[c] + sizes[c]], want[c * stride:c * stride + sizes[c]]), c
+    assert np.array_equal(cd.decompress(batch).cpu().numpy().view(DTYPES[esz]), data)
