@@ -56,7 +56,7 @@ if abi_version() < ABI_REQUIRED:      # a stale build would otherwise die below 
     raise ImportError(f"{LIB_PATH} has ABI version {abi_version()}, this binding needs >= {ABI_REQUIRED}: rebuild it "
                       "(`make -C sprintz_amd/csrc`)")
 _last_error = _sig("sprintz_mi355x_last_error", C.c_char_p)
-OPT_NO_FAST, OPT_CHUNKS_PER_GROUP, OPT_DENSE_MODE, OPT_HUF0_BIG_BATCH, OPT_SPLIT_LANES, OPT_ENC_PAIR, OPT_HOST_WAIT, OPT_LAT_CHUNKS, OPT_HOST_STREAMS, OPT_REF_DECODER_QUIRK, OPT_HUF0_SYNC_CHUNKS, OPT_BLK_CHUNKS = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
+OPT_NO_FAST, OPT_CHUNKS_PER_GROUP, OPT_DENSE_MODE, OPT_HUF0_BIG_BATCH, OPT_SPLIT_LANES, OPT_ENC_PAIR, OPT_HOST_WAIT, OPT_LAT_CHUNKS, OPT_HOST_STREAMS, OPT_REF_DECODER_QUIRK, OPT_HUF0_SYNC_CHUNKS, OPT_BLK_CHUNKS, OPT_BLK_KERNELS = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
 set_option = _sig("sprintz_mi355x_set_option", _i, _i, _i)
 
 # (1) drop-in single-call API, host pointers

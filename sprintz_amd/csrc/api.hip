@@ -23,6 +23,7 @@
 
 #include "launch.h"
 #include "encode_blk.h"
+#include "decode_blk.h"
 #include "decode_lat.h"
 #include "encode_lat.h"
 
@@ -57,6 +58,7 @@ struct Process {
     std::atomic<int> chunks_per_group{1};   // SPRINTZ_MI355X_CHUNKS_PER_GROUP (decode_fast read-ahead across chunks)
     std::atomic<int> dense_mode{1};         // SPRINTZ_MI355X_DENSE_MODE: how compress_batch_dense builds the container (see SPRINTZ_OPT_DENSE_MODE)
     std::atomic<int> enc_pair{1024};        // SPRINTZ_MI355X_ENC_PAIR: chunks from which row-major streams of 5 .. 64 columns are encoded with two columns per lane (0: never; see SPRINTZ_OPT_ENC_PAIR)
+    std::atomic<int> blk_kernels{1};        // SPRINTZ_MI355X_BLK_KERNELS: which block-parallel kernels large delta batches take: bit 0 encode_blk (general layout), bit 1 decode_blk, bit 2 encode_blk_uni (univariate low-dim)
     std::atomic<int> blk_chunks{2049};      // SPRINTZ_MI355X_BLK_CHUNKS: batches of at least this many chunks take the block-parallel delta kernels (encode_blk.h; 0: never)
     std::atomic<int> lat_chunks{2048};      // SPRINTZ_MI355X_LAT_CHUNKS: batches of at most this many chunks decode with one workgroup per chunk (decode_lat.h; 0: never)
     std::atomic<int> ref_quirk{0};          // SPRINTZ_MI355X_REF_DECODER_QUIRK: decode as the reference DECODER does where it differs from the inverse of its encoder
@@ -78,6 +80,7 @@ Process& process()
         }
         if (const char* e = getenv("SPRINTZ_MI355X_LAT_CHUNKS")) p.lat_chunks = atoi(e) < 0 ? 0 : atoi(e);
         if (const char* e = getenv("SPRINTZ_MI355X_BLK_CHUNKS")) p.blk_chunks = atoi(e) < 0 ? 0 : atoi(e);
+        if (const char* e = getenv("SPRINTZ_MI355X_BLK_KERNELS")) p.blk_kernels = atoi(e) & 7;
         if (const char* e = getenv("SPRINTZ_MI355X_REF_DECODER_QUIRK")) p.ref_quirk = atoi(e) != 0 ? 1 : 0;
         if (const char* e = getenv("SPRINTZ_MI355X_HOST_STREAMS")) p.host_streams = atoi(e) < 0 ? 0 : (atoi(e) > 64 ? 64 : atoi(e));
         if (const char* e = getenv("SPRINTZ_MI355X_HOST_WAIT")) p.host_wait = atoi(e) < 0 || atoi(e) > 2 ? 0 : atoi(e);
@@ -530,6 +533,21 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
         if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "decode_lat kernel launch", e);
         return 0;
     }
+    // large batches of the DELTA codec, general layout, rows of whole 16-byte pieces: the block-parallel decoder (decode_blk.h)
+    {
+        const int blk_from = process().blk_chunks.load(std::memory_order_relaxed);
+        if (blk_from > 0 && (process().blk_kernels.load(std::memory_order_relaxed) & 2) && nchunks >= (uint64_t)blk_from && codec == SPRINTZ_CODEC_DELTA && !lowdim && !noheader && !cs && qs.q == kQueryOff && !qs.hc &&
+            ((uintptr_t)d_out % 16) == 0 && !process().no_fast.load(std::memory_order_relaxed)) {
+            const BlkDecGeom g = blk_dec_geom((uint32_t)esz, chunk_len, (uint32_t)D, (uint32_t)sprintz_mi355x_compress_bound(esz, chunk_len, ndims));
+            if (g.ok) {
+                const uint64_t bgrid = (nchunks + g.CPW - 1) / g.CPW;
+                if (bgrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
+                e = launch_decode_blk(8 * esz, (unsigned)bgrid, st, a, g);
+                if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "decode_blk kernel launch", e);
+                return 0;
+            }
+        }
+    }
     if (fast) {
         a.log2DP = 0;
         while ((1 << a.log2DP) < fdp) a.log2DP++;
@@ -673,7 +691,8 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     //  held.  The tail pays from 64 chunks a workgroup on, as on the lane-per-column kernels.)
     {
         const int blk_from = process().blk_chunks.load(std::memory_order_relaxed);
-        if (blk_from > 0 && nchunks >= (uint64_t)blk_from && codec == SPRINTZ_CODEC_DELTA && !lowdim && !col_stride && !hc && write_size &&
+        const int blk_which = process().blk_kernels.load(std::memory_order_relaxed);
+        if (blk_from > 0 && (blk_which & 1) && nchunks >= (uint64_t)blk_from && codec == SPRINTZ_CODEC_DELTA && !lowdim && !col_stride && !hc && write_size &&
             ((uintptr_t)d_src % 16) == 0 && slot_stride % 16 == 0 && ((uintptr_t)d_slots % 16) == 0 && !process().no_fast.load(std::memory_order_relaxed)) {
             const BlkEncGeom g = blk_enc_geom((uint32_t)esz, chunk_len, (uint32_t)D, (uint32_t)sprintz_mi355x_compress_bound(esz, chunk_len, ndims));
             if (g.ok) {
@@ -681,6 +700,18 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
                 if (bgrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
                 e = launch_encode_blk(8 * esz, (unsigned)bgrid, st, a, g);
                 if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "encode_blk kernel launch", e);
+                return 0;
+            }
+        }
+        // the same for univariate streams of the low-dim layout (BASELINE config 1): a thread per 16 bytes of the series
+        if (blk_from > 0 && (blk_which & 4) && nchunks >= (uint64_t)blk_from && codec == SPRINTZ_CODEC_DELTA && lowdim && D == 1 && !col_stride && !hc && write_size &&
+            ((uintptr_t)d_src % 16) == 0 && slot_stride % 16 == 0 && ((uintptr_t)d_slots % 16) == 0 && !process().no_fast.load(std::memory_order_relaxed)) {
+            const BlkEncGeom g = blk_enc_uni_geom((uint32_t)esz, chunk_len, (uint32_t)sprintz_mi355x_compress_bound(esz, chunk_len, ndims));
+            if (g.ok) {
+                const uint64_t bgrid = (nchunks + g.CPW - 1) / g.CPW;
+                if (bgrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
+                e = launch_encode_blk_uni(8 * esz, (unsigned)bgrid, st, a, g);
+                if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "encode_blk_uni kernel launch", e);
                 return 0;
             }
         }
@@ -1462,6 +1493,11 @@ int sprintz_mi355x_set_option(int option, int value)
     if (option == SPRINTZ_OPT_ENC_PAIR) {
         if (value < 0) return fail(SPRINTZ_E_INVALID, "the batch size must not be negative");
         process().enc_pair = value;
+        return 0;
+    }
+    if (option == SPRINTZ_OPT_BLK_KERNELS) {
+        if (value < 0 || value > 7) return fail(SPRINTZ_E_INVALID, "SPRINTZ_OPT_BLK_KERNELS is a mask of bits 0 .. 2");
+        process().blk_kernels = value;
         return 0;
     }
     if (option == SPRINTZ_OPT_BLK_CHUNKS) {

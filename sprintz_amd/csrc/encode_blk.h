@@ -422,6 +422,179 @@ __global__ void __launch_bounds__(256) encode_blk_kernel(EncodeArgs a, BlkEncGeo
     }
 }
 
+// ---- the same scheme for UNIVARIATE streams of the low-dim layout (compress_rowmajor_delta_rle_lowdim, ndims == 1:
+// sprintz_delta_lowdim.cpp:39-384; BASELINE config 1): a task is 16 bytes of the series = two blocks of uint8 / one of uint16; a
+// block's payload is its 8 fields back to back = nbits BYTES, its header field the 3 / 4 bits of its slot; widths are
+// rounded W - 1 -> W only (:207-208).  g: P = 1, T = tasks a chunk, NBC = blocks a chunk (blk_enc_uni_geom).
+inline BlkEncGeom blk_enc_uni_geom(uint32_t esz, uint32_t chunk_len, uint32_t bound_bytes)
+{
+    BlkEncGeom g{};
+    if (((uint64_t)chunk_len * esz) % 16u || chunk_len < 16u) return g;
+    g.P = 1;
+    g.NBC = chunk_len / 8u;
+    g.T = chunk_len * esz / 16u;
+    if (g.T == 0 || g.T > 256u) return g;
+    g.GW = g.NBC > 32u ? 64u : g.NBC > 16u ? 32u : 16u;
+    const uint32_t by_tasks = 256u / g.T, by_walk = 4u * (64u / g.GW);
+    g.img_cap = (bound_bytes + 16u + 15u) & ~15u;
+    auto al = [](uint32_t x) { return (x + 15u) & ~15u; };
+    uint32_t cpw = by_tasks < by_walk ? by_tasks : by_walk;
+    for (; cpw >= 1; cpw--) {
+        g.CPW = cpw;
+        g.o_psum = cpw * g.img_cap;                      // (unused: one column)
+        g.o_rbits = g.o_psum;
+        g.o_wofs = g.o_rbits + al(cpw * g.NBC * 4u);
+        g.o_info = g.o_wofs + al(cpw * g.NBC * 8u);
+        g.total = g.o_info + cpw * 16u;
+        if (g.total <= 64u * 1024u) break;
+    }
+    g.ok = cpw >= 1 ? 1u : 0u;
+    return g;
+}
+
+template <int W>
+__global__ void __launch_bounds__(256) encode_blk_uni_kernel(EncodeArgs a, BlkEncGeom g)
+{
+    constexpr int HB = Elem<W>::HB;
+    constexpr int ESZ = W / 8;
+    constexpr int BPT = 2 / ESZ;                 // blocks per task: 16 bytes = 2 x 8 uint8 / 1 x 8 uint16
+    constexpr int DPB = 4 / BPT;                 // dwords per block
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t ci = tid / g.T, k = tid - ci * g.T;
+    const bool in_wg = ci < g.CPW;
+    const uint64_t chunk = (uint64_t)blockIdx.x * g.CPW + ci;
+    const bool exists = in_wg && chunk < a.nchunks;
+    const uint64_t first = chunk * (uint64_t)a.chunk_len;
+    const uint32_t n = exists ? (uint32_t)((a.total_len - first < a.chunk_len) ? (a.total_len - first) : a.chunk_len) : 0u;
+    const uint32_t NB = n / 8u;                  // whole blocks this chunk holds
+    const uint32_t b0 = k * BPT;                 // the task's first block
+    const bool task = exists && b0 < NB;         // (its second block may lie past the last whole one: checked per block)
+    const uint32_t cix = in_wg ? ci : 0u;
+    uint8_t* const img = smem + cix * g.img_cap;
+    const uint32_t img_a = lds_addr(img);
+    uint32_t* const rbits = (uint32_t*)(smem + g.o_rbits) + cix * g.NBC;
+    uint2* const wofs = (uint2*)(smem + g.o_wofs) + cix * g.NBC;
+    uint32_t* const info = (uint32_t*)(smem + g.o_info) + cix * 4u;
+    const uint8_t* const csrc = (const uint8_t*)a.src + first * ESZ;
+
+    // ---- A: 16 bytes of the series and the sample in front of them (0 at the chunk's start: state resets per chunk)
+    v4 x = v4{0u, 0u, 0u, 0u};
+    uint32_t prev = 0;
+    if (task) {
+        x = *(const v4*)(csrc + 16u * k);                                // (the chunk's last piece may reach past it: inside SPRINTZ_MI355X_READ_SLACK)
+        if (k != 0) prev = ESZ == 1 ? (uint32_t)csrc[16u * k - 1u] << 24 : (uint32_t)((const uint16_t*)csrc)[8u * k - 1u] << 16;
+    }
+    for (uint32_t i = tid; i < (g.CPW * g.img_cap) >> 4; i += 256u) ((uint4*)smem)[i] = make_uint4(0, 0, 0, 0);
+
+    uint32_t z[4];
+    {
+        uint32_t before = prev;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t xs = __builtin_amdgcn_alignbyte(x[j], before, 4 - ESZ);       // the series shifted by one sample
+            z[j] = zz_delta<W>(x[j], xs);
+            before = x[j];
+        }
+    }
+    uint32_t nbk[BPT];
+#pragma unroll
+    for (int q = 0; q < BPT; q++) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int d = 0; d < DPB; d++) m |= z[q * DPB + d];
+        m |= m >> 16;
+        if constexpr (W == 8) m |= m >> 8;
+        m &= Elem<W>::MASK;
+        nbk[q] = nbits_of<W, true>(m);                                   // W - 1 -> W only
+        if (task && b0 + (uint32_t)q < NB) { rbits[b0 + q] = nbk[q]; wofs[b0 + q] = make_uint2(0xffffffffu, 0u); }
+    }
+    __syncthreads();
+
+    // ---- B: the RLE / group state machine (payload bytes of a block = its width: one column)
+    {
+        const uint32_t wave = tid >> 6, lane = tid & 63u;
+        const uint32_t cpwave = 64u / g.GW;
+        if (wave * cpwave < g.CPW) {
+            const uint32_t wc = wave * cpwave + lane / g.GW, lg = lane & (g.GW - 1u);
+            const bool wlive = wc < g.CPW && (uint64_t)blockIdx.x * g.CPW + wc < a.nchunks;
+            const uint32_t wcx = wc < g.CPW ? wc : 0u;
+            const uint64_t wfirst = ((uint64_t)blockIdx.x * g.CPW + wc) * (uint64_t)a.chunk_len;
+            const uint32_t wn = wlive ? (uint32_t)((a.total_len - wfirst < a.chunk_len) ? (a.total_len - wfirst) : a.chunk_len) : 0u;
+            const uint32_t hdr_bytes = (2u * HB + 7u) >> 3;
+            const uint32_t* const wr = (const uint32_t*)(smem + g.o_rbits) + wcx * g.NBC;
+            uint2* const ww = (uint2*)(smem + g.o_wofs) + wcx * g.NBC;
+            uint8_t* const wi = smem + wcx * g.img_cap;
+            uint32_t* const wf = (uint32_t*)(smem + g.o_info) + wcx * 4u;
+            const uint32_t base_wl = a.write_size ? 8u : 0u;
+            if (g.GW == 16u) rle_walk_scan<16, true, false>(lg, wlive, wn, 8u, wn / 8u, hdr_bytes, HB, base_wl, wr, ww, wi, wf);
+            else if (g.GW == 32u) rle_walk_scan<32, true, false>(lg, wlive, wn, 8u, wn / 8u, hdr_bytes, HB, base_wl, wr, ww, wi, wf);
+            else rle_walk_scan<64, true, false>(lg, wlive, wn, 8u, wn / 8u, hdr_bytes, HB, base_wl, wr, ww, wi, wf);
+        }
+    }
+    __syncthreads();
+    const uint32_t ngroups = info[0], pos_in = info[1], wl = info[2];
+    const uint32_t remaining = n - pos_in;
+
+    // ---- C: a block's header field and its 8 fields, nbits bytes, into the image (sprintz_delta_lowdim.cpp:306-357)
+    if (task) {
+#pragma unroll
+        for (int q = 0; q < BPT; q++) {
+            if (b0 + (uint32_t)q >= NB) continue;
+            const uint2 wo = wofs[b0 + q];
+            if (wo.x == 0xffffffffu) continue;
+            const uint32_t nb = nbk[q];
+            img_or32(img_a, wo.y, nb == (uint32_t)W ? (uint32_t)(W - 1) : nb);
+            if constexpr (W == 8) {
+                const uint32_t za = z[2 * q], zb = z[2 * q + 1];
+                const uint32_t lo = (za & 0xffu) | (((za >> 8) & 0xffu) << nb) | (((za >> 16) & 0xffu) << (2u * nb)) | ((za >> 24) << (3u * nb));
+                const uint32_t hi = (zb & 0xffu) | (((zb >> 8) & 0xffu) << nb) | (((zb >> 16) & 0xffu) << (2u * nb)) | ((zb >> 24) << (3u * nb));
+                img_or64(img_a, wo.x * 8u, (uint64_t)lo | ((uint64_t)hi << (4u * nb)));           // 4 nb <= 32
+            } else {
+                // fields 0 .. 3 (<= 64 bits) and 4 .. 7, 4 nb bits further on
+                uint64_t v[2];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const uint32_t za = z[2 * h], zb = z[2 * h + 1];
+                    const uint64_t p0 = (uint64_t)(za & 0xffffu) | ((uint64_t)(za >> 16) << nb);   // <= 32 bits
+                    const uint64_t p1 = (uint64_t)(zb & 0xffffu) | ((uint64_t)(zb >> 16) << nb);
+                    v[h] = p0 | (p1 << (2u * nb));                                               // 2 nb <= 32
+                }
+                img_or64(img_a, wo.x * 8u, v[0]);
+                img_or64(img_a, wo.x * 8u + 4u * nb, v[1]);
+            }
+        }
+    }
+    if (exists) {                                                            // the verbatim tail (:553), dwords OR-ed in at the image's byte phase
+        const uint32_t tb = remaining * ESZ;
+        const uint8_t* const tp = csrc + (size_t)pos_in * ESZ;               // pos_in is whole blocks: 8 / 16-byte aligned
+        for (uint32_t i = k; i < (tb + 3u) >> 2; i += g.T) {
+            uint32_t v = ((const uint32_t*)tp)[i];
+            const uint32_t left = tb - 4u * i;
+            if (left < 4u) v &= (1u << (8u * left)) - 1u;
+            img_or32(img_a, (wl + 4u * i) * 8u, v);
+        }
+    }
+    __syncthreads();
+    if (exists && k == 0 && a.write_size) {
+        ((uint32_t*)img)[0] = ngroups;
+        ((uint32_t*)img)[1] = (remaining & 0xffffu) | (1u << 16);
+    }
+    __syncthreads();
+    if (exists) {
+        const uint32_t total_bytes = wl + remaining * ESZ;
+        uint8_t* const gdst = a.slots + chunk * a.slot_stride;
+        for (uint32_t i = k; i < (total_bytes + 15u) >> 4; i += g.T) ((uint4*)gdst)[i] = ((const uint4*)img)[i];
+        if (k == 0) {
+            a.sizes[chunk] = total_bytes;
+            if (a.rets) a.rets[chunk] = (int64_t)(total_bytes / ESZ);
+        }
+    }
+}
+
 hipError_t launch_encode_blk(int w, unsigned grid, hipStream_t st, const EncodeArgs& a, const BlkEncGeom& g);
+hipError_t launch_encode_blk_uni(int w, unsigned grid, hipStream_t st, const EncodeArgs& a, const BlkEncGeom& g);
 
 }  // namespace sprintz

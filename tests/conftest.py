@@ -30,9 +30,11 @@ def decode_path(request):
     from sprintz_amd import _lib
     _lib.check(_lib.set_option(_lib.OPT_LAT_CHUNKS, (1 << 30) if request.param == "lat" else 0))
     _lib.check(_lib.set_option(_lib.OPT_BLK_CHUNKS, 1 if request.param == "blk" else 0))
+    _lib.check(_lib.set_option(_lib.OPT_BLK_KERNELS, 7))            # every block-parallel kernel, whatever the default mask is
     yield request.param
     _lib.set_option(_lib.OPT_LAT_CHUNKS, int(os.environ.get("SPRINTZ_MI355X_LAT_CHUNKS", 2048)))
     _lib.set_option(_lib.OPT_BLK_CHUNKS, int(os.environ.get("SPRINTZ_MI355X_BLK_CHUNKS", 2049)))
+    _lib.set_option(_lib.OPT_BLK_KERNELS, int(os.environ.get("SPRINTZ_MI355X_BLK_KERNELS", 1)))
 
 
 @pytest.fixture(scope="session")

@@ -25,9 +25,11 @@ def path(request):
     from sprintz_amd import _lib
     _lib.check(_lib.set_option(_lib.OPT_LAT_CHUNKS, 0))
     _lib.check(_lib.set_option(_lib.OPT_BLK_CHUNKS, 1 if request.param == "blk" else 0))
+    _lib.check(_lib.set_option(_lib.OPT_BLK_KERNELS, 7))            # every block-parallel kernel, whatever the default mask is
     yield request.param
     _lib.set_option(_lib.OPT_LAT_CHUNKS, int(os.environ.get("SPRINTZ_MI355X_LAT_CHUNKS", 2048)))
     _lib.set_option(_lib.OPT_BLK_CHUNKS, int(os.environ.get("SPRINTZ_MI355X_BLK_CHUNKS", 2049)))
+    _lib.set_option(_lib.OPT_BLK_KERNELS, int(os.environ.get("SPRINTZ_MI355X_BLK_KERNELS", 1)))
 
 
 def make_data(kind, rng, n, ndims, esz):
@@ -71,6 +73,16 @@ SHAPES = [
     (2, 64, 64 * 32, 9, 0),
     (2, 80, 80 * 64, 7, 0),
     (2, 128, 128 * 16, 5, 0),
+    # univariate streams of the low-dim layout (encode_blk_uni_kernel)
+    (1, 1, 1024, 300, 0),             # BASELINE config 1
+    (1, 1, 1024, 67, 500),
+    (1, 1, 4096, 40, 16),
+    (1, 1, 272, 90, 0),
+    (1, 1, 128, 90, 0),               # the shortest coded chunk
+    (1, 1, 112, 33, 0),               # below 128 elements: verbatim
+    (2, 1, 512, 150, 0),
+    (2, 1, 2048, 40, 200),
+    (2, 1, 200, 77, 0),
 ]
 
 
@@ -100,7 +112,7 @@ def test_delta_batches_match_the_oracle(sz, oracle, path, kind, esz, ndims, chun
     assert (r[:-1] == chunk_len).all() and r[-1] == chunk_len - short, (path, kind, r[-3:])
 
 
-@pytest.mark.parametrize("esz,ndims,chunk_len", [(1, 80, 10240), (2, 8, 5120), (1, 16, 1024)])
+@pytest.mark.parametrize("esz,ndims,chunk_len", [(1, 80, 10240), (2, 8, 5120), (1, 16, 1024), (1, 1, 1024), (2, 1, 1024)])
 def test_a_large_batch_takes_the_new_kernels_by_default(sz, oracle, esz, ndims, chunk_len):
     """default options, more chunks than SPRINTZ_OPT_BLK_CHUNKS' default: bytes against the oracle on every chunk"""
     import torch
