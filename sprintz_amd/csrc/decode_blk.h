@@ -27,6 +27,7 @@ struct BlkDecGeom {
     uint32_t P, NBC, T, CPW;
     uint32_t img_cap;                                    // bytes of one chunk's stream image (multiple of 16)
     uint32_t o_desc, o_psum, o_csum, o_info, total;      // LDS carve (bytes)
+    uint32_t invT, invP;                                 // ceil(2^16 / T), ceil(2^16 / P): n / d == (n * inv) >> 16 for n < 256, d <= 256
     uint32_t ok;
 };
 
@@ -35,7 +36,7 @@ inline BlkDecGeom blk_dec_geom(uint32_t esz, uint32_t chunk_len, uint32_t D, uin
     BlkDecGeom g{};
     const uint32_t rowbytes = D * esz, hb = esz == 1 ? 3u : 4u;
     if (rowbytes % 16u || ((uint64_t)chunk_len * esz) % 16u || chunk_len < 32u * D) return g;      // (>= 4 blocks: the scan's lanes are tasks)
-    if (2u * D * hb > 512u) return g;                    // a group header is at most 16 dwords: one per lane of the walk
+    if (2u * D > 16u * (hb == 3u ? 10u : 8u)) return g;  // a group header's 2 D fields over the walk's 16 lanes: 10 x 3 / 8 x 4 bits each (80 / 64 columns)
     g.P = rowbytes / 16u;
     g.NBC = chunk_len / (8u * D);
     g.T = g.NBC * g.P;
@@ -53,6 +54,8 @@ inline BlkDecGeom blk_dec_geom(uint32_t esz, uint32_t chunk_len, uint32_t D, uin
         g.total = g.o_info + cpw * 16u;
         if (g.total <= 64u * 1024u) break;
     }
+    g.invT = (65536u + g.T - 1u) / g.T;
+    g.invP = (65536u + g.P - 1u) / g.P;
     g.ok = cpw >= 1 ? 1u : 0u;
     return g;
 }
@@ -97,8 +100,8 @@ __global__ void __launch_bounds__(256) decode_blk_kernel(DecodeArgs a, BlkDecGeo
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t ci = tid / g.T, k = tid - ci * g.T;
-    const uint32_t b = k / g.P, p = k - b * g.P;
+    const uint32_t ci = (tid * g.invT) >> 16, k = tid - ci * g.T;
+    const uint32_t b = (k * g.invP) >> 16, p = k - b * g.P;
     const bool in_wg = ci < g.CPW;
     const uint64_t chunk = (uint64_t)blockIdx.x * g.CPW + ci;
     const bool exists = in_wg && chunk < a.nchunks;
@@ -141,7 +144,7 @@ __global__ void __launch_bounds__(256) decode_blk_kernel(DecodeArgs a, BlkDecGeo
             const uint32_t wimg = lds_addr(smem + wcx * g.img_cap) + wphase;  // LDS byte address of the stream's first byte
             uint2* const wdesc = (uint2*)(smem + g.o_desc) + wcx * g.NBC;
             uint32_t* const winfo = (uint32_t*)(smem + g.o_info) + wcx * 4u;
-            const uint32_t hdr_bytes = (2u * D * HB + 7u) >> 3, hdr_dw = (hdr_bytes + 3u) >> 2;
+            const uint32_t hdr_bytes = (2u * D * HB + 7u) >> 3;
 
             bool corrupt = !wlive || !wfits || wslen < 8u;
             uint32_t groups_left = 0, remaining = 0, pos = 8u, bout = 0;
@@ -153,70 +156,89 @@ __global__ void __launch_bounds__(256) decode_blk_kernel(DecodeArgs a, BlkDecGeo
                 corrupt = (w1 >> 16) != D || groups_left > a.chunk_len / blk + 2u;
             }
             if (corrupt) groups_left = 0;
-            // first field this lane owns: the first whose lowest bit lies in header dword lg
-            const uint32_t k0 = (32u * lg + (uint32_t)HB - 1u) / (uint32_t)HB, r0 = k0 * HB - 32u * lg;
+            // A group header is 2 D fields of HB bits.  Lane lg of the chunk's 16 takes FPL of them -- 10 x 3 / 8 x 4 bits: one 32-bit window at a bit
+            // address -- the first n0 of which belong to slot 0; both slots' width sums are population counts of the window's bit planes
+            // (width = field, + 1 where the field is all ones: W - 1 means W, :747-749), then four DPP adds over the 16 lanes.
+            constexpr uint32_t FPL = HB == 3 ? 10u : 8u;
+            const uint32_t f_lo = FPL * lg;
+            const uint32_t fv = 2u * D > f_lo ? (2u * D - f_lo < FPL ? 2u * D - f_lo : FPL) : 0u;      // fields of this lane that exist
+            const uint32_t n0 = D > f_lo ? (D - f_lo < fv ? D - f_lo : fv) : 0u;                        // ... that belong to slot 0
+            const uint32_t maskv = fv * HB >= 32u ? 0xffffffffu : (1u << (fv * HB)) - 1u;
+            const uint32_t mask0 = n0 * HB >= 32u ? 0xffffffffu : (1u << (n0 * HB)) - 1u;
+            const uint32_t mask1 = maskv & ~mask0;
+            constexpr uint32_t PL = HB == 3 ? 0x09249249u : 0x11111111u;                                // bit 0 of every field
+            auto width_sum = [&](uint32_t y) -> uint32_t {
+                const uint32_t p0 = y & PL, p1 = (y >> 1) & PL, p2 = (y >> 2) & PL;
+                if constexpr (HB == 3) {
+                    return (uint32_t)__builtin_popcount(p0) + (uint32_t)__builtin_popcount(p0 & p1 & p2) + 2u * (uint32_t)__builtin_popcount(p1) + 4u * (uint32_t)__builtin_popcount(p2);
+                } else {
+                    const uint32_t p3 = (y >> 3) & PL;
+                    return (uint32_t)__builtin_popcount(p0) + (uint32_t)__builtin_popcount(p0 & p1 & p2 & p3) + 2u * (uint32_t)__builtin_popcount(p1) +
+                           4u * (uint32_t)__builtin_popcount(p2) + 8u * (uint32_t)__builtin_popcount(p3);
+                }
+            };
+            const uint32_t slot_bits = D * HB;
             while (__ballot(groups_left != 0u) != 0ull) {
                 const bool act = groups_left != 0u;
                 // (lanes of a chunk that is done run along on position 0 of their own image: every read stays inside the carve)
                 const uint32_t hpos = act ? pos : 0u;
-                bool bad = act && hdr_bytes > wslen - hpos;
-                uint32_t x = 0;
-                if (lg < hdr_dw && !bad) x = lds_rd32(wimg + hpos + 4u * lg);
-                const uint32_t nx = dpp<DPP_ROW_SHL(1)>(0u, x);               // the dword after mine (lane 15: 0)
-                const uint32_t ylo = r0 ? __builtin_amdgcn_alignbit(nx, x, r0) : x, yhi = nx >> r0;
-                uint32_t s0 = 0, s1 = 0;
-                constexpr int NF = (32 + HB - 1) / HB;                        // fields that can start in one dword: 11 / 8
-#pragma unroll
-                for (int i = 0; i < NF; i++) {
-                    const uint32_t kf = k0 + (uint32_t)i;
-                    uint32_t f;
-                    if (HB * i + HB <= 32) f = (ylo >> (HB * i)) & FM;
-                    else f = ((ylo >> (HB * i)) | (yhi << (32 - HB * i))) & FM;
-                    const bool mine = (uint32_t)(HB * i) + r0 < 32u && kf < 2u * D;
-                    const uint32_t wdt = mine ? f + ((f + 1u) >> HB) : 0u;    // field -> width: W - 1 means W (:747-749)
-                    s0 += kf < D ? wdt : 0u;
-                    s1 += kf < D ? 0u : wdt;
+                const bool hdr_ok = hdr_bytes <= wslen - hpos || !act;
+                uint32_t y = 0;
+                {
+                    typedef __attribute__((address_space(3))) const uint32_t lds_cw;
+                    const uint32_t A = (wimg + hpos) * 8u + f_lo * HB;
+                    lds_cw* q = (lds_cw*)(uintptr_t)((A >> 3) & ~3u);
+                    y = __builtin_amdgcn_alignbit(q[1], q[0], A & 31u);
                 }
-                uint32_t both = s0 | (s1 << 16);                              // (<= 16 * 80 a slot: no carry between the halves)
+                uint32_t both = width_sum(y & mask0) | (width_sum(y & mask1) << 16);   // (<= 80 x 8 / 64 x 16 a slot: no carry between the halves)
                 both += dpp<DPP_QUAD_PERM(1, 0, 3, 2)>(0u, both);
                 both += dpp<DPP_QUAD_PERM(2, 3, 0, 1)>(0u, both);
                 both += dpp<DPP_ROW_HALF_MIRROR>(0u, both);
                 both += dpp<DPP_ROW_MIRROR>(0u, both);
-                uint32_t cur = hpos + hdr_bytes;
-#pragma unroll
-                for (int slot = 0; slot < 2; slot++) {
-                    const uint32_t S = slot ? both >> 16 : both & 0xffffu;
-                    if (S == 0u) {                                            // RUN slot: length in blocks, 1 or 2 bytes (:829-833)
-                        bool short_of = false;
-                        if (!bad && wslen - cur < 2u) short_of = wslen == cur || (lds_rd8(wimg + cur) & 0x80u) != 0u;
-                        bad = bad || short_of;
-                        const uint32_t b0 = bad ? 0u : lds_rd8(wimg + cur);
-                        uint32_t len = b0 & 0x7fu;
-                        if (b0 & 0x80u) { len |= (bad ? 0u : lds_rd8(wimg + cur + 1u)) << 7; cur += 2u; }
-                        else cur += 1u;
-                        if (act && !bad && len != 0u) {
-                            if (bout + len > g.NBC) bad = true;
-                            else {
-                                for (uint32_t q = bout + lg; q < bout + len; q += 16u) wdesc[q] = make_uint2(kBlkZero, 0u);
-                                bout += len;
-                            }
-                        }
-                    } else {                                                  // packed block: 8 rows of ceil(S / 8) bytes
-                        const uint32_t pay = ((S + 7u) >> 3) << 3;
-                        if (act && !bad) {
-                            if (pay > wslen - cur || bout >= g.NBC) bad = true;
-                            else {
-                                if (lg == 0) wdesc[bout] = make_uint2(cur, hpos * 8u + (uint32_t)slot * D * HB);
-                                bout += 1u;
-                                cur += pay;
-                            }
-                        }
-                    }
-                }
-                if (act) {
-                    pos = cur;
+                const uint32_t S0 = both & 0xffffu, S1 = both >> 16;
+                const uint32_t pay0 = ((S0 + 7u) >> 3) << 3, pay1 = ((S1 + 7u) >> 3) << 3;
+                // the common group: two packed blocks that fit the stream and the chunk
+                const bool fast = act && hdr_ok && S0 != 0u && S1 != 0u && hdr_bytes + pay0 + pay1 <= wslen - hpos && bout + 2u <= g.NBC;
+                if (fast) {
+                    if (lg < 2u) wdesc[bout + lg] = make_uint2(hpos + hdr_bytes + (lg ? pay0 : 0u), hpos * 8u + (lg ? slot_bits : 0u));
+                    bout += 2u;
+                    pos = hpos + hdr_bytes + pay0 + pay1;
                     groups_left -= 1u;
-                    if (bad) { corrupt = true; groups_left = 0u; }
+                }
+                if (__ballot(act && !fast) != 0ull) {            // a run, a padding slot, the chunk's end, damage: slot by slot
+                    if (act && !fast) {
+                        bool bad = !hdr_ok;
+                        uint32_t cur = hpos + hdr_bytes;
+#pragma unroll
+                        for (int slot = 0; slot < 2; slot++) {
+                            const uint32_t S = slot ? S1 : S0;
+                            if (S == 0u) {                                            // RUN slot: length in blocks, 1 or 2 bytes (:829-833)
+                                if (!bad && wslen - cur < 2u) bad = wslen == cur || (lds_rd8(wimg + cur) & 0x80u) != 0u;
+                                const uint32_t b0 = bad ? 0u : lds_rd8(wimg + cur);
+                                uint32_t len = b0 & 0x7fu;
+                                if (b0 & 0x80u) { len |= lds_rd8(wimg + cur + 1u) << 7; cur += 2u; }
+                                else cur += 1u;
+                                if (!bad && len != 0u) {
+                                    if (bout + len > g.NBC) bad = true;
+                                    else {
+                                        for (uint32_t q = bout + lg; q < bout + len; q += 16u) wdesc[q] = make_uint2(kBlkZero, 0u);
+                                        bout += len;
+                                    }
+                                }
+                            } else if (!bad) {                                        // packed block: 8 rows of ceil(S / 8) bytes
+                                const uint32_t pay = slot ? pay1 : pay0;
+                                if (pay > wslen - cur || bout >= g.NBC) bad = true;
+                                else {
+                                    if (lg == 0) wdesc[bout] = make_uint2(cur, hpos * 8u + (uint32_t)slot * slot_bits);
+                                    bout += 1u;
+                                    cur += pay;
+                                }
+                            }
+                        }
+                        pos = cur;
+                        groups_left -= 1u;
+                        if (bad) { corrupt = true; groups_left = 0u; }
+                    }
                 }
             }
             // the verbatim tail must fit both ways (:1171)
@@ -333,13 +355,18 @@ __global__ void __launch_bounds__(256) decode_blk_kernel(DecodeArgs a, BlkDecGeo
     if (task) {
         const v4 cy = csum[k];
         uint8_t* const o = (uint8_t*)a.out + ((uint64_t)chunk * a.chunk_len + (uint64_t)b * blk) * ESZ + p * 16u;
+        // (the carry is the same for the 8 rows: its two halves of the carry-isolated byte add are split once)
+        uint32_t cl[4], ch[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { cl[j] = cy[j] & 0x7f7f7f7fu; ch[j] = cy[j] & 0x80808080u; }
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             v4 v;
-            v.x = lanes_add<W>(acc[r][0], cy.x);
-            v.y = lanes_add<W>(acc[r][1], cy.y);
-            v.z = lanes_add<W>(acc[r][2], cy.z);
-            v.w = lanes_add<W>(acc[r][3], cy.w);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if constexpr (W == 8) v[j] = ((acc[r][j] & 0x7f7f7f7fu) + cl[j]) ^ ((acc[r][j] & 0x80808080u) ^ ch[j]);
+                else v[j] = lanes_add<W>(acc[r][j], cy[j]);
+            }
             __builtin_nontemporal_store(v, (v4*)(o + (size_t)r * rowbytes));
         }
     }

@@ -434,6 +434,8 @@ inline BlkEncGeom blk_enc_uni_geom(uint32_t esz, uint32_t chunk_len, uint32_t bo
     g.NBC = chunk_len / 8u;
     g.T = chunk_len * esz / 16u;
     if (g.T == 0 || g.T > 256u) return g;
+    // (BASELINE config 1, 128 blocks a chunk: 0.565 ms with 64 lanes a chunk in the walk, 0.661 with 16 -- four chunks a walking wavefront, eight
+    //  blocks a lane: the walk's price is its passes over a lane's blocks, not its wave-wide scans; the lane-per-chunk kernel takes 0.399)
     g.GW = g.NBC > 32u ? 64u : g.NBC > 16u ? 32u : 16u;
     const uint32_t by_tasks = 256u / g.T, by_walk = 4u * (64u / g.GW);
     g.img_cap = (bound_bytes + 16u + 15u) & ~15u;
