@@ -800,6 +800,9 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     if (lowdim && (D <= 2 || esz == 1) && !col_stride && !process().no_fast.load(std::memory_order_relaxed)) {
         const uint64_t ugrid = (nchunks + 255) / 256;
         if (ugrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
+        // (round 6: the container inside THIS launch was built too -- 256 chunks a workgroup, 2 048 workgroups on BASELINE config 1, a short chain --
+        //  and measured: 0.405 ms with a lane-parallel copy (a piece's chunk found by bisection), 0.49 - 0.51 chunk by chunk, against 0.3945 for
+        //  encode + scan + copy in a row: streams of ~440 bytes re-read from their slots cost the workgroup what the copy pass costs.  Not kept.)
         e = esz == 1 ? launch_encode_uni_w8(codec == SPRINTZ_CODEC_XFF, D, (unsigned)ugrid, st, a)
                      : launch_encode_uni_w16(codec == SPRINTZ_CODEC_XFF, D, (unsigned)ugrid, st, a);
         if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "encode_uni kernel launch", e);
