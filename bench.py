@@ -41,6 +41,9 @@ METRIC = "decompress MB/s (and ratio) uint16 rowmajor 8-col, 1/2/4/8 MI355X vs C
 # the decode kernel each configuration's batch runs on (names as rocprofv3 prints them: profiles/*_kernel_stats.csv)
 DECODE_KERNELS = {"cfg1": "decode_uni_kernel<8, false, 1, 0>", "cfg3_1k": "verbatim_decode_kernel", "cfg3_10k": "decode_fast_kernel<8, false, 32, 3, false, 0, false, 80>",
                   "cfg4": "decode_fast_kernel<16, true, 8, 1, true, 0, false, 0>"}
+# ... and the kernels its compress call runs (round 6: large delta batches of the general layout take the block-parallel encoder, csrc/encode_blk.h)
+ENCODE_KERNELS = {"cfg1": "encode_uni_kernel<8, false, 1> + scan_* + compact_copy_kernel", "cfg3_1k": "verbatim_dense_kernel",
+                  "cfg3_10k": "encode_blk_kernel<8> + scan_* + compact_copy_kernel", "cfg4": "encode_wide_kernel<16, true, true, false, 4, false> (container inside the launch)"}
 ALL_CONFIGS = ["cfg1", "cfg3_1k", "cfg3_10k", "cfg4_10000", "cfg4_80000", "cfg4_800000", "cfg5", "cfg5_8m"]
 
 
@@ -409,10 +412,26 @@ def bench_rowmajor(cx, name, workload, codec, esz, ndims, chunk_len, nchunks_tot
            "decompress_ms": round(dec_ms, 4), "decompress_MBps": round(raw / dec_ms / 1e3, 1),
            "compress_ms": round(enc_ms, 4), "compress_MBps": round(raw / enc_ms / 1e3, 1),
            "roofline": roofline(algo, dec_ms, DECODE_KERNELS.get(name, DECODE_KERNELS.get(name.split("_")[0], "decode_fast_kernel<16, true, 8, 1, true, 0, false, 0>"))),
-           "compress_roofline": roofline(raw + total + 12 * n, enc_ms, "sprintz_mi355x_compress_batch_dense (one launch where the fast encoder takes the shape; else encode + scan + copy)",
+           "compress_roofline": roofline(raw + total + 12 * n, enc_ms, "sprintz_mi355x_compress_batch_dense: " + ENCODE_KERNELS.get(name, ENCODE_KERNELS.get(name.split("_")[0], "encode + scan + copy")),
                                          {"algorithmic": "raw samples in + dense container out + sizes/offsets (SURVEY 8d)",
                                           "traffic_ratio_by_design": round((raw + stream_bytes + 2 * total + 12 * n) / (raw + total + 12 * n), 3),
                                           "traffic_note": "the encoder writes slots, the compaction pass re-reads them and writes the dense container"})}
+    if codec == "delta" and name in ("cfg1", "cfg3_10k") and not args.no_extras:
+        # ---- round 6: the block-parallel delta kernels beside the lane-per-column / lane-per-chunk ones, same batch, same process
+        # (SPRINTZ_OPT_BLK_KERNELS: 1 general-layout encoder, 2 general-layout decoder, 4 univariate encoder; the default mask is what won)
+        ab = {"fields": "ms; *_blk: block-parallel kernel (csrc/encode_blk.h, decode_blk.h), *_lane: the kernel it would replace; compress = the whole compress_batch_dense call"}
+        try:
+            for label, mask in (("lane", 0), ("blk", 7)):
+                _lib.check(_lib.set_option(_lib.OPT_BLK_KERNELS, mask))
+                ab["compress_" + label] = round(timer(enc, reps), 4)
+                cd.decompress_into(comp, offs, n, out, rets)
+                torch.cuda.synchronize()
+                assert torch.equal(out, x), f"{name}: decode != input on the {label} kernels"
+                ab["decompress_" + label] = round(timer(lambda: cd.decompress_into(comp, offs, n, out), reps), 4)
+        finally:
+            _lib.set_option(_lib.OPT_BLK_KERNELS, int(os.environ.get("SPRINTZ_MI355X_BLK_KERNELS", 1)))
+        ab["default_mask"] = int(os.environ.get("SPRINTZ_MI355X_BLK_KERNELS", 1))
+        res["block_parallel_ab"] = ab
     if n * chunk_len * esz < (64 << 20):
         res["note"] = ("launch-bound: %d chunks keep %d of the chip's 1024 SIMDs' worth of wavefronts busy; the time is one kernel's "
                        "end-to-end latency, not a bandwidth" % (n, min(1024, max(1, n * ndims // 64))))
