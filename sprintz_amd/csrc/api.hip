@@ -367,6 +367,15 @@ int check_batch_tail(uint64_t total_len, uint32_t chunk_len, uint16_t ndims)
     return 0;
 }
 
+// more than 2 047 columns: the column-tiled kernels build the stream with device-scope atomics on the slot and read their own output back
+// (any_ndims.hip, "big"): that needs ordinary device memory -- a mapped host or managed buffer is refused instead of producing a damaged stream
+bool is_plain_device_memory(const void* p)
+{
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return at.type == hipMemoryTypeDevice;
+}
+
 // query-on-compressed options of one decode launch (decode_kernel.h: Q template parameter)
 // a single call served straight from the caller thread's mapped host buffer by ONE launch of a workgroup-per-chunk kernel
 // (decode_lat.h / encode_lat.h): no staging kernel in front, no runtime wait behind -- the kernel's last store is the
@@ -460,9 +469,11 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
         if (norle || cs || qs.q != kQueryOff) return fail(SPRINTZ_E_UNSUPPORTED, "more than 512 columns: the RLE codecs, row-major, without query only");
         if (nchunks > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
         if (D > 2047) {                                        // column tiles; the FIRE counters in stream-ordered scratch (any_ndims.hip, "big")
+            if (!is_plain_device_memory(d_out)) return fail(SPRINTZ_E_INVALID, "more than 2047 columns: the output must be device memory (hipMalloc), not mapped host or managed memory");
             int32_t* counters = nullptr;
             const bool fire = codec == SPRINTZ_CODEC_XFF;
-            if (fire && hipMallocAsync((void**)&counters, (size_t)nchunks * (size_t)D * 4, st) != hipSuccess) return fail(SPRINTZ_E_HIP, "hipMallocAsync of the counters' scratch");
+            if (fire && (uint64_t)nchunks * (uint64_t)D * 4 > (1ull << 30)) return fail(SPRINTZ_E_UNSUPPORTED, "more than 2047 columns, FIRE: the counters' scratch (nchunks x ndims x 4 bytes) is limited to 1 GiB a launch: split the batch");
+            if (fire && hipMallocAsync((void**)&counters, (size_t)nchunks * (size_t)D * 4, st) != hipSuccess) return fail(SPRINTZ_E_HIP, "hipMallocAsync of the counters' scratch (not available during stream capture)");
             const hipError_t eb = launch_decode_big(8 * esz, fire, (unsigned)nchunks, st, a, counters);
             if (counters) (void)hipFreeAsync(counters, st);
             if (eb != hipSuccess) return fail(SPRINTZ_E_HIP, "decode_big kernel launch", eb);
@@ -642,9 +653,11 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
         if (nchunks > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
         if (D > 2047) {                                        // column tiles, fields OR-ed straight into the zeroed slot (any_ndims.hip, "big")
             if (slot_stride % 16 || ((uintptr_t)d_slots & 15)) return fail(SPRINTZ_E_INVALID, "more than 2047 columns: slots must be 16-byte aligned and a multiple of 16 bytes");
+            if (!is_plain_device_memory(d_slots)) return fail(SPRINTZ_E_INVALID, "more than 2047 columns: the slots must be device memory (hipMalloc), not mapped host or managed memory");
             int32_t* counters = nullptr;
             const bool fire = codec == SPRINTZ_CODEC_XFF;
-            if (fire && hipMallocAsync((void**)&counters, (size_t)nchunks * (size_t)D * 4, st) != hipSuccess) return fail(SPRINTZ_E_HIP, "hipMallocAsync of the counters' scratch");
+            if (fire && (uint64_t)nchunks * (uint64_t)D * 4 > (1ull << 30)) return fail(SPRINTZ_E_UNSUPPORTED, "more than 2047 columns, FIRE: the counters' scratch (nchunks x ndims x 4 bytes) is limited to 1 GiB a launch: split the batch");
+            if (fire && hipMallocAsync((void**)&counters, (size_t)nchunks * (size_t)D * 4, st) != hipSuccess) return fail(SPRINTZ_E_HIP, "hipMallocAsync of the counters' scratch (not available during stream capture)");
             const hipError_t eb = launch_encode_big(8 * esz, fire, (unsigned)nchunks, st, a, counters);
             if (counters) (void)hipFreeAsync(counters, st);
             if (eb != hipSuccess) return fail(SPRINTZ_E_HIP, "encode_big kernel launch", eb);
