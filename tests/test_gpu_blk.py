@@ -128,3 +128,24 @@ def test_a_large_batch_takes_the_new_kernels_by_default(sz, oracle, esz, ndims, 
     for c in range(nchunks):
         assert np.array_equal(comp[offs[c]:offs[c] + sizes[c]], want[c * stride:c * stride + sizes[c]]), c
     assert np.array_equal(cd.decompress(batch).cpu().numpy().view(DTYPES[esz]), data)
+
+
+@pytest.mark.parametrize("esz,ndims,chunk_len,nchunks", [(1, 80, 10240, 23), (2, 8, 5120, 41), (1, 16, 2048, 50), (2, 40, 40 * 64, 17)])
+def test_byte_dense_containers(sz, oracle, path, esz, ndims, chunk_len, nchunks):
+    """a container whose streams start at ANY byte (sprintz_mi355x_compact with align = 1): the block-parallel decoder stages a stream from the
+    16-byte piece that holds its first byte and carries the phase through every bit address"""
+    import torch
+    rng = np.random.default_rng(31)
+    data = gen_walk(rng, nchunks * chunk_len, ndims, esz, 6, flat_every=3)
+    cd = sz.ChunkedCodec("delta", esz, ndims, chunk_len, device="cuda:0", align=1)
+    t = torch.from_numpy(data.view(np.int8 if esz == 1 else np.int16)).cuda().view(cd.dtype)
+    batch = cd.compress(t)
+    offs, sizes, comp = batch.offsets.cpu().numpy(), batch.sizes.cpu().numpy(), batch.data.cpu().numpy()
+    assert (np.diff(offs) == sizes).all() and (offs % 16 != 0).any()
+    for c in range(nchunks):
+        want, _ = oracle.compress("delta", data[c * chunk_len:(c + 1) * chunk_len], ndims)
+        assert np.array_equal(comp[offs[c]:offs[c + 1]], want), (path, c)
+    rets = torch.empty(nchunks, dtype=torch.int64, device="cuda:0")
+    out = cd.decompress(batch, rets=rets).cpu().numpy().view(DTYPES[esz])
+    assert np.array_equal(out, data), path
+    assert (rets.cpu().numpy() == chunk_len).all()
