@@ -120,9 +120,10 @@ const char* sprintz_mi355x_last_error(void);     /* thread-local, never NULL; de
  *   SPRINTZ_OPT_BLK_CHUNKS        batches of at least this many chunks of the DELTA codec take the block-parallel kernels (a thread per block and
  *                                 16-byte row piece / per 16 rows of a univariate stream; csrc/encode_blk.h, decode_blk.h) where the shape allows;
  *                                 0 = never, default 2049 (env SPRINTZ_MI355X_BLK_CHUNKS).  Same bytes either way.
- *   SPRINTZ_OPT_BLK_KERNELS       which of the block-parallel kernels such batches take, a mask: 1 = the general-layout encoder, 2 = the
- *                                 general-layout decoder, 4 = the univariate low-dim encoder; default: the ones that measured faster than the
- *                                 lane-per-column kernels on BASELINE's configurations (env SPRINTZ_MI355X_BLK_KERNELS); 7 in the tests
+ *   SPRINTZ_OPT_BLK_KERNELS       which of the round-6 delta kernels such batches take, a mask: 1 = the block-parallel general-layout encoder, 2 = the
+ *                                 block-parallel general-layout decoder, 4 = the block-parallel univariate low-dim encoder, 8 = the piece-sequential
+ *                                 general-layout decoder (csrc/decode_row.h; wins over 2); default: the ones that measured faster than the
+ *                                 lane-per-column kernels on BASELINE's configurations (env SPRINTZ_MI355X_BLK_KERNELS)
  *   SPRINTZ_OPT_HOST_WAIT         how a single-call entry point waits for its launches: 0 (default) = spin (hipStreamSynchronize)
  *                                 while at most 4 callers (and at most half of the CPUs this process may use) are inside the library,
  *                                 otherwise sleep and poll a mapped host word that a one-thread kernel at the end of the call writes

@@ -24,6 +24,7 @@
 #include "launch.h"
 #include "encode_blk.h"
 #include "decode_blk.h"
+#include "decode_row.h"
 #include "decode_lat.h"
 #include "encode_lat.h"
 
@@ -80,7 +81,7 @@ Process& process()
         }
         if (const char* e = getenv("SPRINTZ_MI355X_LAT_CHUNKS")) p.lat_chunks = atoi(e) < 0 ? 0 : atoi(e);
         if (const char* e = getenv("SPRINTZ_MI355X_BLK_CHUNKS")) p.blk_chunks = atoi(e) < 0 ? 0 : atoi(e);
-        if (const char* e = getenv("SPRINTZ_MI355X_BLK_KERNELS")) p.blk_kernels = atoi(e) & 7;
+        if (const char* e = getenv("SPRINTZ_MI355X_BLK_KERNELS")) p.blk_kernels = atoi(e) & 15;
         if (const char* e = getenv("SPRINTZ_MI355X_REF_DECODER_QUIRK")) p.ref_quirk = atoi(e) != 0 ? 1 : 0;
         if (const char* e = getenv("SPRINTZ_MI355X_HOST_STREAMS")) p.host_streams = atoi(e) < 0 ? 0 : (atoi(e) > 64 ? 64 : atoi(e));
         if (const char* e = getenv("SPRINTZ_MI355X_HOST_WAIT")) p.host_wait = atoi(e) < 0 || atoi(e) > 2 ? 0 : atoi(e);
@@ -544,7 +545,24 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
         if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "decode_lat kernel launch", e);
         return 0;
     }
-    // large batches of the DELTA codec, general layout, rows of whole 16-byte pieces: the block-parallel decoder (decode_blk.h)
+    // large batches of the DELTA codec, general layout, rows of whole dwords: a lane per dword-wide column group, blocks in order (decode_row.h)
+    {
+        const int blk_from = process().blk_chunks.load(std::memory_order_relaxed);
+        if (blk_from > 0 && (process().blk_kernels.load(std::memory_order_relaxed) & 8) && nchunks >= (uint64_t)blk_from && codec == SPRINTZ_CODEC_DELTA && !lowdim && !noheader && !cs &&
+            qs.q == kQueryOff && !qs.hc && ((uintptr_t)d_out % 4) == 0 && ((uintptr_t)d_comp % 4) == 0 && !process().no_fast.load(std::memory_order_relaxed)) {
+            const RowDecGeom g = row_dec_geom((uint32_t)esz, chunk_len, (uint32_t)D);
+            // (32-bit offsets inside the kernel: the output and -- whatever the streams' lengths -- the container below 4 GB)
+            const bool below_4g = (uint64_t)nchunks * chunk_len * esz < 0xf0000000ull && (uint64_t)nchunks * sprintz_mi355x_compress_bound(esz, chunk_len, ndims) < 0xf0000000ull;
+            if (g.ok && below_4g) {
+                const uint64_t rgrid = (nchunks + 4ull * g.G - 1) / (4ull * g.G);
+                if (rgrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
+                e = launch_decode_row(8 * esz, (unsigned)rgrid, st, a, g);
+                if (e != hipSuccess) return fail(SPRINTZ_E_HIP, "decode_row kernel launch", e);
+                return 0;
+            }
+        }
+    }
+    // ... or the block-parallel decoder (decode_blk.h)
     {
         const int blk_from = process().blk_chunks.load(std::memory_order_relaxed);
         if (blk_from > 0 && (process().blk_kernels.load(std::memory_order_relaxed) & 2) && nchunks >= (uint64_t)blk_from && codec == SPRINTZ_CODEC_DELTA && !lowdim && !noheader && !cs && qs.q == kQueryOff && !qs.hc &&
@@ -1512,7 +1530,7 @@ int sprintz_mi355x_set_option(int option, int value)
         return 0;
     }
     if (option == SPRINTZ_OPT_BLK_KERNELS) {
-        if (value < 0 || value > 7) return fail(SPRINTZ_E_INVALID, "SPRINTZ_OPT_BLK_KERNELS is a mask of bits 0 .. 2");
+        if (value < 0 || value > 15) return fail(SPRINTZ_E_INVALID, "SPRINTZ_OPT_BLK_KERNELS is a mask of bits 0 .. 3");
         process().blk_kernels = value;
         return 0;
     }

@@ -18,14 +18,15 @@ def sz():
     return sprintz_amd
 
 
-@pytest.fixture(params=["blk", "old"])
+@pytest.fixture(params=["blk", "row", "old"])
 def path(request):
-    """every test on the block-parallel kernels and, as a control, on the kernels they replace (same bytes)"""
+    """every test on the block-parallel kernels ("blk": encode_blk + decode_blk + encode_blk_uni; "row": encode_blk + the piece-sequential
+    decoder decode_row.h) and, as a control, on the kernels they replace (same bytes)"""
     import os
     from sprintz_amd import _lib
     _lib.check(_lib.set_option(_lib.OPT_LAT_CHUNKS, 0))
-    _lib.check(_lib.set_option(_lib.OPT_BLK_CHUNKS, 1 if request.param == "blk" else 0))
-    _lib.check(_lib.set_option(_lib.OPT_BLK_KERNELS, 7))            # every block-parallel kernel, whatever the default mask is
+    _lib.check(_lib.set_option(_lib.OPT_BLK_CHUNKS, 0 if request.param == "old" else 1))
+    _lib.check(_lib.set_option(_lib.OPT_BLK_KERNELS, 9 if request.param == "row" else 7))
     yield request.param
     _lib.set_option(_lib.OPT_LAT_CHUNKS, int(os.environ.get("SPRINTZ_MI355X_LAT_CHUNKS", 2048)))
     _lib.set_option(_lib.OPT_BLK_CHUNKS, int(os.environ.get("SPRINTZ_MI355X_BLK_CHUNKS", 2049)))
@@ -73,6 +74,13 @@ SHAPES = [
     (2, 64, 64 * 32, 9, 0),
     (2, 80, 80 * 64, 7, 0),
     (2, 128, 128 * 16, 5, 0),
+    # rows of whole dwords that are not whole 16-byte pieces: the column-group-sequential decoder alone (decode_row.h)
+    (1, 12, 12 * 40, 50, 0),
+    (1, 20, 20 * 64, 31, 20 * 7),
+    (1, 8, 1024, 90, 0),
+    (2, 6, 6 * 80, 41, 0),
+    (2, 10, 10 * 48, 33, 0),
+    (2, 4, 2048, 60, 0),
     # univariate streams of the low-dim layout (encode_blk_uni_kernel)
     (1, 1, 1024, 300, 0),             # BASELINE config 1
     (1, 1, 1024, 67, 500),
@@ -149,3 +157,39 @@ def test_byte_dense_containers(sz, oracle, path, esz, ndims, chunk_len, nchunks)
     out = cd.decompress(batch, rets=rets).cpu().numpy().view(DTYPES[esz])
     assert np.array_equal(out, data), path
     assert (rets.cpu().numpy() == chunk_len).all()
+
+
+@pytest.mark.parametrize("esz,ndims,chunk_len,nchunks", [(1, 80, 10240, 40), (2, 8, 5120, 64), (1, 16, 2048, 70), (2, 40, 40 * 64, 24)])
+def test_damaged_streams_stay_inside_their_chunk(sz, path, esz, ndims, chunk_len, nchunks):
+    """bit-flipped / zeroed / all-ones / header-damaged streams through the new decoders: they terminate, write nothing outside their
+    chunk's slot and report SPRINTZ_E_CORRUPT or a count within the chunk"""
+    import torch
+    rng = np.random.default_rng(77)
+    data = gen_walk(rng, nchunks * chunk_len, ndims, esz, 8, flat_every=4)
+    cd = sz.ChunkedCodec("delta", esz, ndims, chunk_len, device="cuda:0")
+    batch = cd.compress(torch.from_numpy(data.view(np.int8 if esz == 1 else np.int16)).cuda().view(cd.dtype))
+    comp0 = batch.data.cpu().numpy().copy()
+    offs = batch.offsets.cpu().numpy()
+    for trial in range(7):
+        comp = comp0.copy()
+        if trial == 0:
+            for c in range(nchunks):
+                comp[offs[c]:offs[c] + 4] = 0xFF
+        elif trial == 1:
+            comp[:] = 0
+        elif trial == 2:
+            comp[:] = 0xFF
+        elif trial == 3:                                     # truncated: every stream's tail zeroed
+            for c in range(nchunks):
+                comp[(offs[c] + offs[c + 1]) // 2:offs[c + 1]] = 0
+        else:
+            idx = rng.integers(0, comp.size, comp.size // 50)
+            comp[idx] ^= rng.integers(1, 256, idx.size).astype(np.uint8)
+        guard = 4096
+        out = torch.full((nchunks * chunk_len + guard,), 0x5A, dtype=torch.int16 if esz == 2 else torch.int8, device="cuda:0")
+        rets = torch.zeros(nchunks, dtype=torch.int64, device="cuda:0")
+        cd.decompress_into(torch.from_numpy(comp).cuda(), batch.offsets, nchunks, out, rets)
+        torch.cuda.synchronize()
+        r = rets.cpu().numpy()
+        assert ((r == sz._lib.E_CORRUPT) | ((r >= 0) & (r <= chunk_len))).all(), (path, trial, r[:8])
+        assert (out[nchunks * chunk_len:].cpu().numpy() == 0x5A).all(), (path, trial)
