@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
 CPU_SAMPLE_BYTES = 1342177280   # raw bytes of the all-core CPU legs' sample (the headline batch of one GPU: 131 072 x 10 KB)
 METRIC = "decompress MB/s (and ratio) uint16 rowmajor 8-col, 1/2/4/8 MI355X vs CPU ref"
 # the decode kernel each configuration's batch runs on (names as rocprofv3 prints them: profiles/*_kernel_stats.csv)
-DECODE_KERNELS = {"cfg1": "decode_uni_kernel<8, false, 1, 0>", "cfg3_1k": "verbatim_decode_kernel", "cfg3_10k": "decode_fast_kernel<8, false, 32, 3, false, 0, false, 80>",
+DECODE_KERNELS = {"cfg1": "decode_uni_kernel<8, false, 1, 0>", "cfg3_1k": "verbatim_decode_kernel", "cfg3_10k": "decode_row_kernel<8>",
                   "cfg4": "decode_fast_kernel<16, true, 8, 1, true, 0, false, 0>"}
 # ... and the kernels its compress call runs (round 6: large delta batches of the general layout take the block-parallel encoder, csrc/encode_blk.h)
 ENCODE_KERNELS = {"cfg1": "encode_uni_kernel<8, false, 1> + scan_* + compact_copy_kernel", "cfg3_1k": "verbatim_dense_kernel",
@@ -432,14 +432,15 @@ def bench_rowmajor(cx, name, workload, codec, esz, ndims, chunk_len, nchunks_tot
     if codec == "delta" and name in ("cfg1", "cfg3_10k") and not args.no_extras:
         # ---- round 6: the block-parallel delta kernels beside the lane-per-column / lane-per-chunk ones, same batch, same process
         # (SPRINTZ_OPT_BLK_KERNELS: 1 general-layout encoder, 2 general-layout decoder, 4 univariate encoder; the default mask is what won)
-        ab = {"fields": "ms; *_blk: block-parallel kernel (csrc/encode_blk.h, decode_blk.h), *_lane: the kernel it would replace; compress = the whole compress_batch_dense call"}
+        ab = {"fields": "ms; *_lane: the lane-per-column / lane-per-chunk kernels of rounds 1 - 5; *_blk: the block-parallel kernels (csrc/encode_blk.h, decode_blk.h); "
+                        "*_row: encode_blk + the column-group-sequential decoder (csrc/decode_row.h; general layout only); compress = the whole compress_batch_dense call"}
         dense2 = torch.empty(n * cd.slot_stride + _lib.READ_SLACK, dtype=torch.uint8, device=dev)
         offs2 = torch.empty(n + 1, dtype=torch.int64, device=dev)
 
         def enc2():
             cd.compress_dense(src, x.numel(), ws, dense2, offs2)
         try:
-            for label, mask in (("lane", 0), ("blk", 7)):
+            for label, mask in (("lane", 0), ("blk", 7), ("row", 9)):
                 _lib.check(_lib.set_option(_lib.OPT_BLK_KERNELS, mask))
                 ab["compress_" + label] = round(timer(enc2, reps, ramp_ms=ramp), 4)
                 cd.decompress_into(comp, offs, n, out, rets)
@@ -447,8 +448,8 @@ def bench_rowmajor(cx, name, workload, codec, esz, ndims, chunk_len, nchunks_tot
                 assert torch.equal(out, x), f"{name}: decode != input on the {label} kernels"
                 ab["decompress_" + label] = round(timer(lambda: cd.decompress_into(comp, offs, n, out), reps, ramp_ms=ramp), 4)
         finally:
-            _lib.set_option(_lib.OPT_BLK_KERNELS, int(os.environ.get("SPRINTZ_MI355X_BLK_KERNELS", 1)))
-        ab["default_mask"] = int(os.environ.get("SPRINTZ_MI355X_BLK_KERNELS", 1))
+            _lib.set_option(_lib.OPT_BLK_KERNELS, int(os.environ.get("SPRINTZ_MI355X_BLK_KERNELS", 9)))
+        ab["default_mask"] = int(os.environ.get("SPRINTZ_MI355X_BLK_KERNELS", 9))
         res["block_parallel_ab"] = ab
         del dense2, offs2
     if n * chunk_len * esz < (64 << 20):

@@ -59,7 +59,7 @@ struct Process {
     std::atomic<int> chunks_per_group{1};   // SPRINTZ_MI355X_CHUNKS_PER_GROUP (decode_fast read-ahead across chunks)
     std::atomic<int> dense_mode{1};         // SPRINTZ_MI355X_DENSE_MODE: how compress_batch_dense builds the container (see SPRINTZ_OPT_DENSE_MODE)
     std::atomic<int> enc_pair{1024};        // SPRINTZ_MI355X_ENC_PAIR: chunks from which row-major streams of 5 .. 64 columns are encoded with two columns per lane (0: never; see SPRINTZ_OPT_ENC_PAIR)
-    std::atomic<int> blk_kernels{1};        // SPRINTZ_MI355X_BLK_KERNELS: which block-parallel kernels large delta batches take: bit 0 encode_blk (general layout), bit 1 decode_blk, bit 2 encode_blk_uni (univariate low-dim)
+    std::atomic<int> blk_kernels{9};        // SPRINTZ_MI355X_BLK_KERNELS: which of round 6's delta kernels large batches take: bit 0 encode_blk (general layout), bit 1 decode_blk, bit 2 encode_blk_uni (univariate low-dim), bit 3 decode_row (wins over bit 1)
     std::atomic<int> blk_chunks{2049};      // SPRINTZ_MI355X_BLK_CHUNKS: batches of at least this many chunks take the block-parallel delta kernels (encode_blk.h; 0: never)
     std::atomic<int> lat_chunks{2048};      // SPRINTZ_MI355X_LAT_CHUNKS: batches of at most this many chunks decode with one workgroup per chunk (decode_lat.h; 0: never)
     std::atomic<int> ref_quirk{0};          // SPRINTZ_MI355X_REF_DECODER_QUIRK: decode as the reference DECODER does where it differs from the inverse of its encoder

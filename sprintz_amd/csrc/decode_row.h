@@ -109,30 +109,34 @@ __global__ void __launch_bounds__(256) decode_row_kernel(DecodeArgs a, RowDecGeo
     // request a row instead of 64 scattered 8-byte ones (the first form of this kernel was bound by the texture addresser: TA busy 87 % of
     // the launch) -- and every lane picks the pair its fields start in from the lane that holds it (ds_bpermute: my fields start Bp bits
     // into the row, never behind my own dword).  cb: the block's first byte in the stream; R: bytes a row.
-    auto load_rows = [&](Win2 (&wv)[8], uint32_t cb, uint32_t R, uint32_t Bp) {
-        Win2 raw[8];
+    auto load_rows = [&](Win2 (&raw)[8], uint32_t& phases, uint32_t cb, uint32_t R) {
+        uint32_t A = off + cb;
+        phases = 0;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const uint32_t A = off + cb + (uint32_t)r * R;
-            const uint32_t* q = (const uint32_t*)(a.comp + ((A & ~3u) + 4u * u));
-            raw[r].lo = 0u;
-            raw[r].hi = 0u;
-            if (4u * u < (A & 3u) + R) {                                 // (only the dwords the row lies in, and the one behind its last: nothing is read past the stream + its slack)
-                raw[r].lo = q[0];
-                raw[r].hi = q[1];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const uint32_t X = (((off + cb + (uint32_t)r * R) & 3u) << 3) + Bp;
-            const int src = (int)((seg0 + (X >> 5)) << 2);
-            wv[r].lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)raw[r].lo);
-            wv[r].hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)raw[r].hi);
+            // (only the dwords the row lies in, and the one behind its last: a lane past the row's end reads the row's last pair again --
+            //  nothing is read past the stream + its slack, and no lane leaves the instruction)
+            const uint32_t ph = A & 3u, last_dw = (ph + R - 1u) & ~3u;
+            const uint32_t mine4 = 4u * u < last_dw ? 4u * u : last_dw;
+            const uint32_t* q = (const uint32_t*)(a.comp + ((A & ~3u) + mine4));
+            raw[r].lo = q[0];
+            raw[r].hi = q[1];
+            phases |= ph << (2 * r);                                     // the rows' byte phases, two bits each
+            A += R;
         }
     };
     const bool quads = (g.U & 3u) == 0u;         // rows of whole 16-byte pieces: a quad of lanes transposes 4 rows x 4 dwords and stores 16 bytes a lane
     const bool odd1 = (lane & 1u) != 0u, odd2 = (lane & 2u) != 0u;
-    auto decode_rows = [&](const Win2 (&wv)[8], const uint32_t (&nb4)[FPD], uint32_t cb, uint32_t R, uint32_t Bp, uint32_t ob) {
+    auto decode_rows = [&](const Win2 (&raw)[8], uint32_t phases, uint32_t Bp, const uint32_t (&nb4)[FPD], uint32_t ob) {
+        Win2 wv[8];
+        uint32_t X[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {                                    // bit offset of my fields in the row's aligned dwords; the pair they start in, from its lane
+            X[r] = (((phases >> (2 * r)) & 3u) << 3) + Bp;
+            const int src = (int)((seg0 + (X[r] >> 5)) << 2);
+            wv[r].lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)raw[r].lo);
+            wv[r].hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)raw[r].hi);
+        }
         uint32_t fs[FPD], fs1[FPD], wm[FPD], w1[FPD];
         uint32_t acc = 0;
 #pragma unroll
@@ -146,8 +150,7 @@ __global__ void __launch_bounds__(256) decode_row_kernel(DecodeArgs a, RowDecGeo
         uint32_t rows[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const uint32_t X = (((off + cb + (uint32_t)r * R) & 3u) << 3) + Bp;
-            const uint32_t t = __builtin_amdgcn_alignbit(wv[r].hi, wv[r].lo, X & 31u);
+            const uint32_t t = __builtin_amdgcn_alignbit(wv[r].hi, wv[r].lo, X[r]);     // (the shift's low 5 bits count)
             uint32_t row = 0;
 #pragma unroll
             for (int f = 0; f < FPD; f++) {
@@ -238,16 +241,17 @@ __global__ void __launch_bounds__(256) decode_row_kernel(DecodeArgs a, RowDecGeo
                 const uint32_t c0 = hpos + hdr_bytes, c1 = c0 + pay0, npos = c1 + pay1;
                 const uint32_t B0 = before & 0xffffu, B1 = before >> 16;
                 Win2 wa[8], wb[8];
-                load_rows(wa, c0, pay0 >> 3, B0);
-                load_rows(wb, c1, pay1 >> 3, B1);
+                uint32_t pa, pb;
+                load_rows(wa, pa, c0, pay0 >> 3);
+                load_rows(wb, pb, c1, pay1 >> 3);
                 if (groups_left > 1u && hdr_bytes <= slen - npos) {
                     pre0 = gwin_load(a.comp, off, npos * 8u + u * (uint32_t)(FPD * HB));
                     pre1 = gwin_load(a.comp, off, npos * 8u + u * (uint32_t)(FPD * HB) + D * HB);
                     pre_pos = npos;
                 }
                 const uint32_t ob = o + out_blocks * blk * ESZ;
-                decode_rows(wa, nbs[0], c0, pay0 >> 3, B0, ob);
-                decode_rows(wb, nbs[1], c1, pay1 >> 3, B1, ob + blk * ESZ);
+                decode_rows(wa, pa, B0, nbs[0], ob);
+                decode_rows(wb, pb, B1, nbs[1], ob + blk * ESZ);
                 out_blocks += 2u;
                 pos = npos;
                 groups_left -= 1u;
@@ -284,9 +288,10 @@ __global__ void __launch_bounds__(256) decode_row_kernel(DecodeArgs a, RowDecGeo
                         if (pay > slen - cur || out_blocks >= max_blocks) bad = true;
                         else {
                             Win2 wv[8];
-                            load_rows(wv, cur, pay >> 3, Bp);
-                            if (sl == 0) decode_rows(wv, nbs[0], cur, pay >> 3, Bp, o + out_blocks * blk * ESZ);
-                            else decode_rows(wv, nbs[1], cur, pay >> 3, Bp, o + out_blocks * blk * ESZ);
+                            uint32_t pv;
+                            load_rows(wv, pv, cur, pay >> 3);
+                            if (sl == 0) decode_rows(wv, pv, Bp, nbs[0], o + out_blocks * blk * ESZ);
+                            else decode_rows(wv, pv, Bp, nbs[1], o + out_blocks * blk * ESZ);
                             out_blocks += 1u;
                             cur += pay;
                         }

@@ -30,7 +30,7 @@ def path(request):
     yield request.param
     _lib.set_option(_lib.OPT_LAT_CHUNKS, int(os.environ.get("SPRINTZ_MI355X_LAT_CHUNKS", 2048)))
     _lib.set_option(_lib.OPT_BLK_CHUNKS, int(os.environ.get("SPRINTZ_MI355X_BLK_CHUNKS", 2049)))
-    _lib.set_option(_lib.OPT_BLK_KERNELS, int(os.environ.get("SPRINTZ_MI355X_BLK_KERNELS", 1)))
+    _lib.set_option(_lib.OPT_BLK_KERNELS, int(os.environ.get("SPRINTZ_MI355X_BLK_KERNELS", 9)))
 
 
 def make_data(kind, rng, n, ndims, esz):
