@@ -89,7 +89,8 @@ __global__ void __launch_bounds__(256) decode_row_kernel(DecodeArgs a, RowDecGeo
     const uint32_t o = (uint32_t)chunk * a.chunk_len * ESZ + u * 4u;      // byte offset of my dword of the chunk's first row (the output is below 4 GB too)
 
     // ---- 8-byte stream header (format.h:48-62)
-    bool corrupt = !exists || slen < 8u;
+    // (offsets are the caller's data: a stream that does not lie inside the first 4 GB of the container is never touched)
+    bool corrupt = !exists || slen < 8u || off64 + slen64 >= 0xfffffff0ull;
     uint32_t groups_left = 0, remaining = 0;
     if (!corrupt) {
         const uint32_t w0 = gbits32(a.comp, off, 0), w1 = gbits32(a.comp, off, 32);
