@@ -113,16 +113,15 @@ __global__ void __launch_bounds__(256) decode_row_kernel(DecodeArgs a, RowDecGeo
     auto load_rows = [&](Win2 (&raw)[8], uint32_t& phases, uint32_t cb, uint32_t R) {
         uint32_t A = off + cb;
         phases = 0;
+        // (a lane past the row's end reads the row's last dwords again -- no lane leaves the instruction, and nothing is read more than
+        //  11 bytes past a row, i.e. past the stream + its 16 bytes of slack: the clamp is the block's, whatever a row's byte phase)
+        const uint32_t cap4 = (R + 3u) & ~3u, mine4 = 4u * u < cap4 ? 4u * u : cap4;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            // (only the dwords the row lies in, and the one behind its last: a lane past the row's end reads the row's last pair again --
-            //  nothing is read past the stream + its slack, and no lane leaves the instruction)
-            const uint32_t ph = A & 3u, last_dw = (ph + R - 1u) & ~3u;
-            const uint32_t mine4 = 4u * u < last_dw ? 4u * u : last_dw;
             const uint32_t* q = (const uint32_t*)(a.comp + ((A & ~3u) + mine4));
             raw[r].lo = q[0];
             raw[r].hi = q[1];
-            phases |= ph << (2 * r);                                     // the rows' byte phases, two bits each
+            phases |= (A & 3u) << (2 * r);                               // the rows' byte phases, two bits each
             A += R;
         }
     };
