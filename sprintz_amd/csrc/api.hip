@@ -719,7 +719,10 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     //  measured on BASELINE config 3 at 10 KB, 17 476 workgroups of three chunks: 0.296 ms against 0.267 for the launches in a row.  Taken
     //  apart: no scan, no tickets 0.177; tickets alone +0.070 (17 476 atomics on one word); the look-back alone +0.089 with 256 predecessors
     //  a hop, +0.114 with 1 024 -- a workgroup that lives 10 us waits for the slowest of a thousand resident predecessors with 33 KB of LDS
-    //  held.  The tail pays from 64 chunks a workgroup on, as on the lane-per-column kernels.)
+    //  held.  The tail pays from 64 chunks a workgroup on, as on the lane-per-column kernels.
+    //  Second form: a workgroup takes 16 / 32 / 64 chunks in passes of three and ends with compact_tail.h's dense_tail (slot -> container copy, one
+    //  chained-scan step per workgroup): 0.352 / 0.369 / 0.432 ms against 0.280 on the same box -- the looped kernel needs 149 registers (3 waves a
+    //  SIMD instead of 4) and 820 - 3 277 workgroups are one to three cohorts: the tails do not hide behind anybody's encoding.)
     {
         const int blk_from = process().blk_chunks.load(std::memory_order_relaxed);
         const int blk_which = process().blk_kernels.load(std::memory_order_relaxed);
