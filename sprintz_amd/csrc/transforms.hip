@@ -26,6 +26,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <type_traits>
@@ -198,7 +199,13 @@ __global__ void __launch_bounds__(kTopT) scan_runs_kernel(Level<U> lo, uint32_t 
 // finishes its rows, stores, and the last lane's state is carried into the next load.  A run of kRunLoads loads per wavefront is one "row"
 // of level 1; the levels above it reuse reduce_kernel / apply_kernel on the summaries, which
 // have the layout of the stream's rows (packed lanes ARE elements).
-constexpr int kRunLoads = 16;
+#ifndef TR_RUN_LOADS
+#define TR_RUN_LOADS 16
+#endif
+#ifndef TR_PREFETCH
+#define TR_PREFETCH 1                      // the next load of a run is requested before this one is folded (one more load in flight a wave)
+#endif
+constexpr int kRunLoads = TR_RUN_LOADS;
 constexpr int kRowsPerLane = 4;
 
 // LDS hand-off between lanes of one wavefront (DS ops of a wave execute in issue order)
@@ -315,26 +322,38 @@ __global__ void __launch_bounds__(kTB) wave_scan_kernel(const typename E::T* y, 
     T* const xb = xbuf[threadIdx.x >> 6];
     const bool via_lds = dv < 3;                          // (1 or 2: powers of two, 64 pieces per row-step, which the hand-over is laid out for)
     const uint64_t e0 = run * (uint64_t)kRunLoads * PL * K;
+    // load j's pieces as this lane requests them: piece m * 64 + lane of the load (LDS hand-over) or the lane's own K rows
+    auto fetch = [&](int j, T (&v)[K]) {
+        const uint64_t eb = e0 + (uint64_t)j * PL * K;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const uint64_t e = via_lds ? eb + (uint64_t)k * 64 + lane : eb + (uint64_t)r * K * dv + (uint64_t)c + (uint64_t)k * dv;
+            v[k] = ((via_lds || act) && j < kRunLoads && e < len_e) ? y[e] : E::zero();
+        }
+    };
+    T nx[K];
+    if (TR_PREFETCH) fetch(0, nx);
     for (int j = 0; j < kRunLoads; j++) {
         const uint64_t eb = e0 + (uint64_t)j * PL * K;  // first piece of this load
         if (eb >= len_e) break;                         // wave-uniform
         const uint64_t el = eb + (uint64_t)r * K * dv + (uint64_t)c;   // this lane's first piece; its rows are dv pieces apart
         T yk[K];
+        if (TR_PREFETCH) {
+#pragma unroll
+            for (int k = 0; k < K; k++) yk[k] = nx[k];
+            fetch(j + 1, nx);                           // (past the run's or the stream's end: zeros, no request)
+        } else fetch(j, yk);
         T s1 = E::zero(), s2 = E::zero();               // summary of the lane's K rows
         const uint32_t pl = (uint32_t)r * K * dv + (uint32_t)c;      // this lane's first piece within the load
         if (via_lds) {
 #pragma unroll
-            for (int m = 0; m < K; m++) {
-                const uint64_t e = eb + (uint64_t)m * 64 + lane;
-                xb[swz((uint32_t)m * 64 + lane)] = e < len_e ? y[e] : E::zero();
-            }
+            for (int m = 0; m < K; m++) xb[swz((uint32_t)m * 64 + lane)] = yk[m];
             wave_sync();
+#pragma unroll
+            for (int k = 0; k < K; k++) yk[k] = xb[swz(pl + (uint32_t)k * dv)];
         }
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            const uint64_t e = el + (uint64_t)k * dv;
-            if (via_lds) yk[k] = xb[swz(pl + (uint32_t)k * dv)];
-            else yk[k] = (act && e < len_e) ? y[e] : E::zero();
             if constexpr (E::M > 1) {                   // a piece of M rows: (S1, S2, n) o (S1', S2', M)
                 const T p1 = E::prefix(yk[k]);
                 if (KIND) s2 = E::add(E::add(s2, E::mul(s1, (uint32_t)E::M)), E::last(E::prefix(p1)));
@@ -408,10 +427,386 @@ __global__ void __launch_bounds__(kTB) wave_scan_kernel(const typename E::T* y, 
     }
 }
 
+
+// ---------------------------------------------------------------- decode in ONE pass over the stream (round 6; VERDICT r5 "next" 8)
+// The two wave_scan launches read the stream twice (summaries, then the store pass): 3 bytes moved for every 2 of the job, and both passes
+// run at the memory system's rate (prefetching the next load, runs of 4 / 8 / 16 loads: nothing, tools/tr_ab.sh).  Here a workgroup keeps its
+// TILE (kChainWaves waves x kChainLoads loads of 64 x kRowsPerLane pieces: 128 KB at 16-byte pieces) in registers between the two: it folds the
+// tile, publishes the tile's summary, gets the state ENTERING the tile from a chained scan over the tiles before it (decoupled look-back:
+// tiles are taken in ticket order, a tile waits only for lower tickets -- which are running), publishes the state leaving it, and finishes
+// and stores its rows.
+// What makes the look-back cheap here where four forms of it lost in the encoders: the tiles are large (a few hundred in flight
+// on the chip) and the workgroup looks back with ALL its waves at once -- wave w takes the 64 / dv tiles at distance w * 64 / dv + .. (a
+// lane per tile and column piece), composes them from its nearest published STATE on with a shuffle tree, the waves' partial results meet in
+// LDS -- so that one step covers 512 / dv predecessors: every tile older than the ones in flight has its state out, one step finds it.
+// The composition is the one at the top of this file; a published state (x, d) is the summary (S1, S2) = (d, x) of everything before it.
+// Column pieces are independent scans: each finds its own nearest state.
+#ifndef TR_CHAIN_LOADS
+#define TR_CHAIN_LOADS 4
+#endif
+#ifndef TR_CHAIN_WAVES
+#define TR_CHAIN_WAVES 8
+#endif
+constexpr int kChainWaves = TR_CHAIN_WAVES, kChainT = 64 * kChainWaves, kChainLoads = TR_CHAIN_LOADS, kChainMaxDv = 8;
+
+// What crosses workgroups: 64-bit words of 32 data bits under a 32-bit tag (0: not there yet -- the scratch is zeroed before the launch),
+// written and read with relaxed agent-scope atomics, summary and state in arrays of their own.  A word is there or not, whole: no flag beside
+// the data, no fence, no wait between a tile's data and its flag.  (The first form had a flag per tile behind an agent-scope release fence,
+// which writes the XCD's whole L2 back -- the tile's own output sits dirty in it -- and readers behind an acquire, which invalidates it:
+// 0.167 ms where the two-pass decode takes 0.092.  With the data in atomics and an s_waitcnt in front of the flag: 0.094, of which a tile
+// spent 1.6 us of its 19.7 publishing and 4.0 looking back through two dependent round trips, tools/chain_phases.py.)
+template <typename T> struct ChainWs {
+    static constexpr int kWords = sizeof(T) == 16 ? 4 : 1;
+    uint32_t* ticket;
+    uint64_t* agg1; uint64_t* agg2;          // a tile's summary, dv pieces of kWords words each
+    uint64_t* inc1; uint64_t* inc2;          // the state leaving a tile
+};
+template <typename T> __device__ __forceinline__ void chain_put(uint64_t* base, uint64_t i, const T& v)
+{
+    constexpr int NW = ChainWs<T>::kWords;
+    uint32_t d[NW];
+    if constexpr (sizeof(T) == 16) __builtin_memcpy(d, &v, 16);
+    else d[0] = (uint32_t)v;
+#pragma unroll
+    for (int k = 0; k < NW; k++) __hip_atomic_store(base + i * NW + k, (1ull << 32) | d[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T> __device__ __forceinline__ bool chain_try(uint64_t* base, uint64_t i, T& v)
+{
+    constexpr int NW = ChainWs<T>::kWords;
+    uint64_t w[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) w[k] = __hip_atomic_load(base + i * NW + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t d[NW];
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < NW; k++) { ok = ok && (w[k] >> 32) != 0ull; d[k] = (uint32_t)w[k]; }
+    if constexpr (sizeof(T) == 16) __builtin_memcpy(&v, d, 16);
+    else v = (T)d[0];
+    return ok;
+}
+
+// one piece a row (dv == 1): the scans across the lanes as DPP moves (row_shr 1 / 2 / 4 / 8, row_bcast 15 / 31: lanes without a source read 0, the
+// identity) instead of ds_bpermute round trips
+template <int CTRL, int RM> __device__ __forceinline__ uint32_t dpp0(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, RM, 0xf, false); }
+template <typename T, int CTRL, int RM> __device__ __forceinline__ T dpp_t(const T& v)
+{
+    if constexpr (sizeof(T) == 16) {
+        T r;
+#pragma unroll
+        for (int k = 0; k < 4; k++) r.v[k] = dpp0<CTRL, RM>(v.v[k]);
+        return r;
+    } else {
+        return (T)dpp0<CTRL, RM>((uint32_t)v);
+    }
+}
+template <typename T> __device__ __forceinline__ T lane63_t(const T& v)
+{
+    if constexpr (sizeof(T) == 16) {
+        T r;
+#pragma unroll
+        for (int k = 0; k < 4; k++) r.v[k] = (uint32_t)__builtin_amdgcn_readlane((int)v.v[k], 63);
+        return r;
+    } else {
+        return (T)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
+    }
+}
+
+#ifdef TR_CHAIN_TIMING                         // experiment builds: where a tile's time goes (thread 0 of every tile < 4096; 10 ns ticks)
+__device__ uint64_t g_chain_ts[4096][8];
+#define CHAIN_TS(k) do { if (threadIdx.x == 0 && tile < 4096u) g_chain_ts[tile][k] = wall_clock64(); } while (0)
+#else
+#define CHAIN_TS(k) do {} while (0)
+#endif
+#ifndef TR_CHAIN_EU0
+#define TR_CHAIN_EU0 2                      // waves a SIMD the compiler is asked to leave room for: delta / double delta
+#endif
+#ifndef TR_CHAIN_EU1
+#define TR_CHAIN_EU1 2
+#endif
+template <typename E, int KIND>
+__global__ void __launch_bounds__(kChainT) __attribute__((amdgpu_waves_per_eu(KIND ? TR_CHAIN_EU1 : TR_CHAIN_EU0))) chain_scan_kernel(const typename E::T* y, uint64_t len_e, uint32_t dv, ChainWs<typename E::T> ws,
+                                                             typename E::T* dest)
+{
+    typedef typename E::T T;
+    constexpr int K = kRowsPerLane, J = kChainLoads;
+    __shared__ T xbuf[kChainWaves][64 * K];
+    __shared__ T sm1[kChainWaves][kChainMaxDv], sm2[kChainWaves][kChainMaxDv];
+    __shared__ uint32_t smn[kChainWaves][kChainMaxDv], sminc[kChainWaves][kChainMaxDv], s_ticket;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) s_ticket = __hip_atomic_fetch_add(ws.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const uint32_t tile = s_ticket;
+    CHAIN_TS(0);
+    const int rpw = 64 / (int)dv, r = lane / (int)dv, c = lane - r * (int)dv;
+    const bool act = r < rpw;
+    const uint32_t PL = (uint32_t)rpw * dv;
+    const bool via_lds = dv < 3;
+    T* const xb = xbuf[w];
+    const uint32_t nL = (uint32_t)(rpw * K * E::M), nW = (uint32_t)J * nL, nT = (uint32_t)kChainWaves * nW;      // rows a load / a wave / a tile
+    const uint32_t nR = (uint32_t)(r * K * E::M);                            // rows of a load in front of this lane's
+    const uint64_t e0 = ((uint64_t)tile * kChainWaves + (uint64_t)w) * (uint64_t)J * PL * K;
+    const uint32_t pl = (uint32_t)r * K * dv + (uint32_t)c;                  // this lane's first piece within a load
+    const int last = (rpw - 1) * (int)dv + c;                                // the lane holding a load's last rows of this column piece
+    const int prev = lane - (int)dv < 0 ? lane : lane - (int)dv;
+
+    // ---- the tile: every load of the wave requested at once, then (1 or 2 pieces a row) handed over in LDS to the lanes that fold them
+    T yk[J][K];
+#pragma unroll
+    for (int j = 0; j < J; j++) {
+        const uint64_t eb = e0 + (uint64_t)j * PL * K;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const uint64_t e = via_lds ? eb + (uint64_t)k * 64 + lane : eb + (uint64_t)pl + (uint64_t)k * dv;
+            yk[j][k] = ((via_lds || act) && e < len_e) ? y[e] : E::zero();
+        }
+    }
+    if (via_lds) {
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+#pragma unroll
+            for (int m = 0; m < K; m++) xb[swz((uint32_t)m * 64 + lane)] = yk[j][m];
+            wave_sync();
+#pragma unroll
+            for (int k = 0; k < K; k++) yk[j][k] = xb[swz(pl + (uint32_t)k * dv)];
+            wave_sync();
+        }
+    }
+    CHAIN_TS(1);
+    // (S1, S2, n) o (S1', S2', n'): `o` the older operand, (a, n) the newer one, result in a
+    auto compose = [&](const T& o1, const T& o2, uint32_t on, T& a1, T& a2, uint32_t& an) {
+        if (KIND) a2 = E::add(E::add(o2, E::mul(o1, an)), a2);
+        a1 = E::add(o1, a1);
+        an += on;
+    };
+
+    // ---- the lanes' summaries of every load, the J scans across the lanes side by side (a scan step is a dependent LDS round trip: one after
+    // the other they were 3.3 of a tile's 19.7 us), then (q1, q2)[j] = the summary of the wave's rows in front of this lane's rows of load j
+    T q1[J], q2[J], W1, W2;
+    {
+        T i1[J], i2[J];
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            T s1 = E::zero(), s2 = E::zero();
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                if constexpr (E::M > 1) {                   // a piece of M rows: (S1, S2, n) o (S1', S2', M)
+                    const T p1 = E::prefix(yk[j][k]);
+                    if (KIND) s2 = E::add(E::add(s2, E::mul(s1, (uint32_t)E::M)), E::last(E::prefix(p1)));
+                    s1 = E::add(s1, E::last(p1));
+                } else {
+                    s1 = E::add(s1, yk[j][k]);
+                    if (KIND) s2 = E::add(s2, s1);
+                }
+            }
+            i1[j] = s1;
+            i2[j] = s2;
+        }
+        const bool dpp_scan = dv == 1u;
+        if (dpp_scan) {
+            // (the left operand's S1 is multiplied by the rows of the RIGHT one: 2^st lanes' where a lane has a source; in the two broadcast
+            //  steps what the lane has gathered so far -- its place in the row of 16, of 32)
+#define CHAIN_DPP_STEP(CTRL, RM, NR)                                                                                          \
+            _Pragma("unroll") for (int j = 0; j < J; j++) {                                                                   \
+                const T l1 = dpp_t<T, CTRL, RM>(i1[j]);                                                                       \
+                if (KIND) { const T l2 = dpp_t<T, CTRL, RM>(i2[j]); i2[j] = E::add(E::add(l2, E::mul(l1, (uint32_t)(NR))), i2[j]); } \
+                i1[j] = E::add(l1, i1[j]);                                                                                    \
+            }
+            CHAIN_DPP_STEP(0x111, 0xf, K * E::M)
+            CHAIN_DPP_STEP(0x112, 0xf, 2 * K * E::M)
+            CHAIN_DPP_STEP(0x114, 0xf, 4 * K * E::M)
+            CHAIN_DPP_STEP(0x118, 0xf, 8 * K * E::M)
+            CHAIN_DPP_STEP(0x142, 0xa, ((lane & 15) + 1) * K * E::M)
+            CHAIN_DPP_STEP(0x143, 0xc, ((lane & 31) + 1) * K * E::M)
+#undef CHAIN_DPP_STEP
+        } else
+        for (int st = 0; (1 << st) < rpw; st++) {
+            const int src = lane - (int)(dv << st);
+            const bool on = r >= (1 << st);
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                const T l1 = E::shfl(i1[j], src < 0 ? lane : src);
+                if (KIND) {
+                    const T l2 = E::shfl(i2[j], src < 0 ? lane : src);
+                    if (on) i2[j] = E::add(E::add(l2, E::mul(l1, (uint32_t)(K * E::M) << st)), i2[j]);
+                }
+                if (on) i1[j] = E::add(l1, i1[j]);
+            }
+        }
+        T e1 = E::zero(), e2 = E::zero();                   // the loads before j
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            T p1, p2 = E::zero(), t1, t2 = E::zero();
+            if (dpp_scan) {                                 // wave_shr:1; lane 63
+                p1 = dpp_t<T, 0x138, 0xf>(i1[j]);
+                t1 = lane63_t<T>(i1[j]);
+                if (KIND) { p2 = dpp_t<T, 0x138, 0xf>(i2[j]); t2 = lane63_t<T>(i2[j]); }
+            } else {
+                p1 = E::shfl(i1[j], prev);
+                t1 = E::shfl(i1[j], last);
+                if (KIND) { p2 = E::shfl(i2[j], prev); t2 = E::shfl(i2[j], last); }
+            }
+            q1[j] = e1;
+            q2[j] = e2;
+            if (r > 0) {
+                q1[j] = E::add(e1, p1);
+                if (KIND) q2[j] = E::add(E::add(e2, E::mul(e1, nR)), p2);
+            }
+            if (KIND) e2 = E::add(E::add(e2, E::mul(e1, nL)), t2);
+            e1 = E::add(e1, t1);
+        }
+        W1 = e1;
+        W2 = e2;
+    }
+    CHAIN_TS(2);
+    if (lane < (int)dv) { sm1[w][lane] = W1; if (KIND) sm2[w][lane] = W2; }
+    __syncthreads();
+    T B1 = E::zero(), B2 = E::zero(), T1 = E::zero(), T2 = E::zero();     // the waves before mine; the whole tile
+    {
+        uint32_t bn = 0, tn = 0;
+#pragma unroll
+        for (int k = kChainWaves - 1; k >= 0; k--) {                      // newest first: compose(older, acc)
+            const T a1 = sm1[k][c], a2 = KIND ? sm2[k][c] : E::zero();
+            compose(a1, a2, nW, T1, T2, tn);
+            if (k < w) compose(a1, a2, nW, B1, B2, bn);
+        }
+    }
+    __syncthreads();                                                      // (sm1 / sm2 are the look-back's from here on)
+    const uint64_t mine = (uint64_t)tile * dv + (uint64_t)c;
+    if (w == 0 && lane < (int)dv) {
+        chain_put<T>(tile == 0 ? ws.inc1 : ws.agg1, mine, T1);
+        if (KIND) chain_put<T>(tile == 0 ? ws.inc2 : ws.agg2, mine, T2);
+    }
+    CHAIN_TS(3);
+
+    // ---- the state entering the tile: (A1, A2) = everything before it
+    T A1 = E::zero(), A2 = E::zero();
+    uint32_t An = 0;
+    if (tile != 0) {
+        uint64_t colmask = 0;                                             // the lanes of my column piece
+        for (int rr = 0; rr < rpw; rr++) colmask |= 1ull << (rr * (int)dv + c);
+        bool done = false;                                                // my column piece has found its nearest state
+        int64_t base = (int64_t)tile - 1;
+        for (;;) {
+            const int64_t p = base - ((int64_t)w * rpw + r);               // this lane's tile
+            uint32_t f = 2u;                                               // before tile 0: the zero state; a column that is done: nothing
+            T v1 = E::zero(), v2 = E::zero();
+            if (act && p >= 0 && !done) {
+                const uint64_t at = (uint64_t)p * dv + (uint64_t)c;
+                for (;;) {                                                 // its holder is running (tickets): this ends
+                    // (state and summary asked for together: one round trip whichever is there)
+                    T a = E::zero(), b = E::zero(), g = E::zero(), h = E::zero();
+                    bool oki = chain_try<T>(ws.inc1, at, a), oka = chain_try<T>(ws.agg1, at, g);
+                    if (KIND) { oki = chain_try<T>(ws.inc2, at, b) && oki; oka = chain_try<T>(ws.agg2, at, h) && oka; }
+                    if (oki) { f = 2u; v1 = a; v2 = b; break; }
+                    if (oka) { f = 1u; v1 = g; v2 = h; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            const uint64_t inc_lanes = __ballot(act && f == 2u) & colmask;
+            const int first_r = inc_lanes ? (int)__builtin_ctzll(inc_lanes) / (int)dv : rpw;      // the nearest tile of my window that has its state out
+            const bool use = act && r <= first_r && p >= 0 && !done;
+            if (!use) { v1 = E::zero(); v2 = E::zero(); }
+            uint32_t vn = use ? nT : 0u;
+            for (int st = 0; (1 << st) < rpw; st++) {                      // lane r <- (lane r + 2^st: older) o (lane r)
+                const int src = lane + (int)(dv << st);
+                const bool ok = r + (1 << st) < rpw;
+                const T o1 = E::shfl(v1, ok ? src : lane), o2 = KIND ? E::shfl(v2, ok ? src : lane) : E::zero();
+                const uint32_t on = (uint32_t)__shfl((int)vn, ok ? src : lane);
+                if (ok) compose(o1, o2, on, v1, v2, vn);
+            }
+            if (lane < (int)dv) { sm1[w][lane] = v1; if (KIND) sm2[w][lane] = v2; smn[w][lane] = vn; sminc[w][lane] = inc_lanes != 0ull ? 1u : 0u; }
+            __syncthreads();
+            T P1 = E::zero(), P2 = E::zero();
+            uint32_t Pn = 0;
+            bool found = false;
+            for (int k = 0; k < kChainWaves && !found; k++) {              // wave 0's window is the nearest
+                compose(sm1[k][c], KIND ? sm2[k][c] : E::zero(), smn[k][c], P1, P2, Pn);
+                found = sminc[k][c] != 0u;
+            }
+            if (!done) compose(P1, P2, Pn, A1, A2, An);
+            done = done || found;
+            if (__syncthreads_and(done ? 1 : 0)) break;
+            base -= (int64_t)kChainWaves * rpw;
+        }
+        // the state leaving the tile
+        if (w == 0 && lane < (int)dv) {
+            T I1 = T1, I2 = T2;
+            uint32_t In = nT;
+            compose(A1, A2, An, I1, I2, In);
+            chain_put<T>(ws.inc1, mine, I1);
+            if (KIND) chain_put<T>(ws.inc2, mine, I2);
+        }
+    }
+    CHAIN_TS(4);
+
+    // ---- my wave's rows: the state entering the tile, advanced over the waves before mine, then over the wave's rows in front of each lane's
+    {
+        uint32_t bn = (uint32_t)w * nW;
+        compose(A1, A2, An, B1, B2, bn);
+        const T x = KIND ? B2 : B1, d = KIND ? B1 : E::zero();
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const uint64_t eb = e0 + (uint64_t)j * PL * K;
+            T xl, dl = E::zero();
+            if (KIND) { xl = E::add(E::add(x, E::mul(d, (uint32_t)j * nL + nR)), q2[j]); dl = E::add(d, q1[j]); }
+            else xl = E::add(x, q1[j]);
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                T outv;
+                if constexpr (E::M > 1) {                   // the rows inside the piece: x + (j + 1) d + prefix^2(y), d + prefix(y)
+                    const T g1 = E::prefix(yk[j][k]);
+                    if (KIND) {
+                        const T g2 = E::prefix(g1);
+                        outv = E::add(E::add(xl, E::prefix(dl)), g2);
+                        xl = E::add(E::add(xl, E::mul(dl, (uint32_t)E::M)), E::last(g2));
+                        dl = E::add(dl, E::last(g1));
+                    } else {
+                        outv = E::add(xl, g1);
+                        xl = E::add(xl, E::last(g1));
+                    }
+                } else {
+                    if (KIND) { dl = E::add(dl, yk[j][k]); xl = E::add(xl, dl); }
+                    else xl = E::add(xl, yk[j][k]);
+                    outv = xl;
+                }
+                const uint64_t e = eb + (uint64_t)pl + (uint64_t)k * dv;
+                if (via_lds) xb[swz(pl + (uint32_t)k * dv)] = outv;
+                else if (act && e < len_e) dest[e] = outv;
+            }
+            if (via_lds) {
+                wave_sync();
+#pragma unroll
+                for (int m = 0; m < K; m++) {
+                    const uint64_t e = eb + (uint64_t)m * 64 + lane;
+                    if (e < len_e) dest[e] = xb[swz((uint32_t)m * 64 + lane)];
+                }
+                wave_sync();
+            }
+        }
+    }
+    CHAIN_TS(5);
+}
+
 }  // namespace
 namespace sprintz { int set_error(int code, const char* what); }   // api.hip: the library's one error sink
 namespace {
 int fail(int code, const char* what) { return sprintz::set_error(code, what); }
+
+#ifndef TR_CHAIN_MIN_TILES
+#define TR_CHAIN_MIN_TILES 8
+#endif
+// scratch of the one-pass decode: the ticket + two (delta) or four arrays of dv x 1 or 4 tagged 64-bit words per tile.  A tile is >= 8 waves
+// x 2 loads x 56 pieces x 4 rows, dv <= 8: below 12 % of the stream for 1-byte pieces (unaligned streams), 1.5 % for 16-byte ones
+size_t chain_tmp_bound(uint64_t stream_bytes) { return (size_t)(stream_bytes / 8) + 8192; }
+// SPRINTZ_MI355X_TRANSFORM_CHAIN: 0 = the two-pass decode always; n > 0 = the one-pass decode from n tiles on (default TR_CHAIN_MIN_TILES;
+// 1 lets the tests drive the chained scan with small streams)
+uint64_t chain_min_tiles()
+{
+    const char* e = getenv("SPRINTZ_MI355X_TRANSFORM_CHAIN");
+    if (!e || !e[0]) return TR_CHAIN_MIN_TILES;
+    const long v = strtol(e, nullptr, 10);
+    return v <= 0 ? ~0ull : (uint64_t)v;
+}
 
 struct Plan {
     std::vector<uint64_t> rows;      // rows[k] = runs at level k (rows[0] = input rows)
@@ -501,6 +896,24 @@ int decode_wave(const U* y, uint64_t len, uint32_t D_real, U* dest, uint8_t* tmp
     const uint64_t run_rows = (uint64_t)kRunLoads * kRowsPerLane * (64 / dv) * E::M;
     const uint64_t nruns = (rows0 + run_rows - 1) / run_rows;
     const unsigned grid = (unsigned)((nruns * 64 + kTB - 1) / kTB);
+    // ---- streams of at least TR_CHAIN_MIN_TILES tiles, rows of at most kChainMaxDv pieces: one pass (chain_scan_kernel)
+    if (dv <= (uint32_t)kChainMaxDv) {
+        const uint64_t tile_e = (uint64_t)kChainWaves * kChainLoads * (uint64_t)((64 / dv) * dv) * kRowsPerLane;
+        const uint64_t ntiles = (len_e + tile_e - 1) / tile_e;
+        auto up = [](size_t v, size_t a) { return (v + a - 1) & ~(a - 1); };
+        const size_t arr = up((size_t)ntiles * dv * ChainWs<T>::kWords * 8, 256), need = 256 + (KIND ? 4 : 2) * arr;
+        if (ntiles >= chain_min_tiles() && ntiles < 0x7fffffffull && need <= chain_tmp_bound(len * sizeof(U))) {
+            ChainWs<T> ws;
+            ws.ticket = (uint32_t*)tmp;
+            ws.agg1 = (uint64_t*)(tmp + 256);
+            ws.inc1 = (uint64_t*)(tmp + 256 + arr);
+            ws.agg2 = KIND ? (uint64_t*)(tmp + 256 + 2 * arr) : nullptr;
+            ws.inc2 = KIND ? (uint64_t*)(tmp + 256 + 3 * arr) : nullptr;
+            if (hipMemsetAsync(tmp, 0, need, st) != hipSuccess) return fail(SPRINTZ_E_HIP, "transform decode: hipMemsetAsync of the tiles' words");
+            hipLaunchKernelGGL((chain_scan_kernel<E, KIND>), dim3((unsigned)ntiles), dim3(kChainT), 0, st, (const T*)y, len_e, dv, ws, (T*)dest);
+            return hipGetLastError() == hipSuccess ? 0 : fail(SPRINTZ_E_HIP, "transform decode launch");
+        }
+    }
     if (nruns == 1) {
         hipLaunchKernelGGL((wave_scan_kernel<E, KIND, true>), dim3(grid), dim3(kTB), 0, st, (const T*)y, len_e, dv, nruns,
                            (const T*)nullptr, (const T*)nullptr, (T*)nullptr, (T*)nullptr, (T*)dest);
@@ -693,7 +1106,7 @@ size_t sprintz_mi355x_transform_tmp_bytes(int kind, int elem_bytes, uint64_t len
 {
     if (ndims == 0 || (elem_bytes != 1 && elem_bytes != 2)) return 0;
     if (kind == SPRINTZ_TRANSFORM_XFF) return 64;              // no scratch: a lane per column
-    return make_plan(kind, elem_bytes, len, ndims).tmp_bytes + 64;
+    return make_plan(kind, elem_bytes, len, ndims).tmp_bytes + chain_tmp_bound(len * (uint64_t)elem_bytes) + 64;
 }
 
 int sprintz_mi355x_transform_encode_device(int kind, int elem_bytes, const void* d_src, uint64_t len, uint16_t ndims, void* d_dest,
@@ -714,6 +1127,10 @@ int sprintz_mi355x_transform_encode_device(int kind, int elem_bytes, const void*
     return kind ? encode_device<uint16_t, 1>((const uint16_t*)d_src, len, ndims, (uint16_t*)d_dest, st)
                 : encode_device<uint16_t, 0>((const uint16_t*)d_src, len, ndims, (uint16_t*)d_dest, st);
 }
+
+#ifdef TR_CHAIN_TIMING
+int sprintz_mi355x_dbg_chain_stamps(uint64_t* out, uint32_t ntiles) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_ts), (size_t)ntiles * 8 * sizeof(uint64_t)); }
+#endif
 
 int sprintz_mi355x_transform_decode_device(int kind, int elem_bytes, const void* d_src, uint64_t len, uint16_t ndims, void* d_dest,
                                            void* d_tmp, void* hip_stream)

@@ -49,9 +49,13 @@ def test_reference_containers_single_call(sz, golden_transforms):
                                          (2, 1, 8 * 700_001), (2, 2, 2 * 4_000_004), (2, 4, 4 * 600_002), (1, 1, 16), (2, 1, 65536 * 8 + 8),
                                          # piece counts that are not powers of two: 5, 3, 9, 37 pieces a row
                                          (1, 80, 80 * 300_001), (2, 24, 24 * 200_003), (1, 144, 144 * 70_001), (2, 296, 296 * 30_011), (2, 40, 40 * 17)])
-def test_long_streams_on_device(sz, oracle, kind, esz, ndims, n):
-    """one stream of millions of rows: element-wise encode, scan decode (3 to 6 levels)"""
+@pytest.mark.parametrize("chain", ["default", "1", "0"])
+def test_long_streams_on_device(sz, oracle, kind, esz, ndims, n, chain, monkeypatch):
+    """one stream of millions of rows: element-wise encode, scan decode -- the one-pass chained scan over tiles (default from 8 tiles on; "1":
+    from the first tile on, so that the short streams take it too) and the two-pass form with its 3 to 6 levels ("0")"""
     import torch
+    if chain != "default":
+        monkeypatch.setenv("SPRINTZ_MI355X_TRANSFORM_CHAIN", chain)
     g = torch.Generator(device="cuda")
     g.manual_seed(n % 1000)
     x = torch.randint(0, 1 << (8 * esz), (n,), generator=g, device="cuda", dtype=torch.int32).to(torch.uint8 if esz == 1 else torch.uint16)
