@@ -444,6 +444,9 @@ __global__ void __launch_bounds__(kTB) wave_scan_kernel(const typename E::T* y, 
 #ifndef TR_CHAIN_LOADS
 #define TR_CHAIN_LOADS 4
 #endif
+#ifndef TR_CHAIN_PREFETCH
+#define TR_CHAIN_PREFETCH 1
+#endif
 #ifndef TR_CHAIN_WAVES
 #define TR_CHAIN_WAVES 8
 #endif
@@ -525,7 +528,7 @@ __device__ uint64_t g_chain_ts[4096][8];
 #endif
 template <typename E, int KIND>
 __global__ void __launch_bounds__(kChainT) __attribute__((amdgpu_waves_per_eu(KIND ? TR_CHAIN_EU1 : TR_CHAIN_EU0))) chain_scan_kernel(const typename E::T* y, uint64_t len_e, uint32_t dv, ChainWs<typename E::T> ws,
-                                                             typename E::T* dest)
+                                                             typename E::T* dest, uint32_t ntiles)
 {
     typedef typename E::T T;
     constexpr int K = kRowsPerLane, J = kChainLoads;
@@ -535,8 +538,8 @@ __global__ void __launch_bounds__(kChainT) __attribute__((amdgpu_waves_per_eu(KI
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) s_ticket = __hip_atomic_fetch_add(ws.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    const uint32_t tile = s_ticket;
-    CHAIN_TS(0);
+    uint32_t tile = s_ticket;
+    __syncthreads();
     const int rpw = 64 / (int)dv, r = lane / (int)dv, c = lane - r * (int)dv;
     const bool act = r < rpw;
     const uint32_t PL = (uint32_t)rpw * dv;
@@ -544,22 +547,43 @@ __global__ void __launch_bounds__(kChainT) __attribute__((amdgpu_waves_per_eu(KI
     T* const xb = xbuf[w];
     const uint32_t nL = (uint32_t)(rpw * K * E::M), nW = (uint32_t)J * nL, nT = (uint32_t)kChainWaves * nW;      // rows a load / a wave / a tile
     const uint32_t nR = (uint32_t)(r * K * E::M);                            // rows of a load in front of this lane's
-    const uint64_t e0 = ((uint64_t)tile * kChainWaves + (uint64_t)w) * (uint64_t)J * PL * K;
     const uint32_t pl = (uint32_t)r * K * dv + (uint32_t)c;                  // this lane's first piece within a load
     const int last = (rpw - 1) * (int)dv + c;                                // the lane holding a load's last rows of this column piece
     const int prev = lane - (int)dv < 0 ? lane : lane - (int)dv;
 
-    // ---- the tile: every load of the wave requested at once, then (1 or 2 pieces a row) handed over in LDS to the lanes that fold them
+    // A workgroup takes tiles until there are none (one workgroup a CU: the tile's registers).  Delta: it asks for its NEXT tile's loads before it
+    // looks back for this one -- the memory system, idle while a lone workgroup folds, publishes and looks back (7 of a tile's 13.6 us,
+    // tools/chain_phases.py), has the next tile to fetch meanwhile: 0.0716 -> 0.0654 ms at 64 Mi samples.  It is not the whole of the idle time that
+    // comes back: this hardware counts a wave's loads in order, so the look-back's polls wait for every load requested before them (look-back
+    // 4.5 -> 6.9 us, the wait for the tile 3.8 -> 1.2); requested at the tile's top instead, two tickets ahead, the top waits for the tile before's
+    // stores: 0.0729 ms (0.470 against 0.491 at 512 Mi).  Double delta has no registers left for a second tile (spills: 0.089 -> 0.118 ms): no prefetch.
+    constexpr bool PF = KIND == 0 && TR_CHAIN_PREFETCH;
+    T nk[J][K];
+    auto request = [&](uint32_t t) {                                       // every load of the wave's part of tile t, as the lanes request them
+        const uint64_t f0 = ((uint64_t)t * kChainWaves + (uint64_t)w) * (uint64_t)J * PL * K;
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const uint64_t eb = f0 + (uint64_t)j * PL * K;
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const uint64_t e = via_lds ? eb + (uint64_t)k * 64 + lane : eb + (uint64_t)pl + (uint64_t)k * dv;
+                nk[j][k] = ((via_lds || act) && e < len_e) ? y[e] : E::zero();
+            }
+        }
+    };
+    if (PF) request(tile);
+    while (tile < ntiles) {
+    CHAIN_TS(0);
+    if (tid == 0) s_ticket = __hip_atomic_fetch_add(ws.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next tile (read behind the first barrier below)
+    if (!PF) request(tile);
+    const uint64_t e0 = ((uint64_t)tile * kChainWaves + (uint64_t)w) * (uint64_t)J * PL * K;
+
+    // ---- the tile: (1 or 2 pieces a row) handed over in LDS to the lanes that fold them
     T yk[J][K];
 #pragma unroll
-    for (int j = 0; j < J; j++) {
-        const uint64_t eb = e0 + (uint64_t)j * PL * K;
+    for (int j = 0; j < J; j++)
 #pragma unroll
-        for (int k = 0; k < K; k++) {
-            const uint64_t e = via_lds ? eb + (uint64_t)k * 64 + lane : eb + (uint64_t)pl + (uint64_t)k * dv;
-            yk[j][k] = ((via_lds || act) && e < len_e) ? y[e] : E::zero();
-        }
-    }
+        for (int k = 0; k < K; k++) yk[j][k] = nk[j][k];
     if (via_lds) {
 #pragma unroll
         for (int j = 0; j < J; j++) {
@@ -660,6 +684,7 @@ __global__ void __launch_bounds__(kChainT) __attribute__((amdgpu_waves_per_eu(KI
     CHAIN_TS(2);
     if (lane < (int)dv) { sm1[w][lane] = W1; if (KIND) sm2[w][lane] = W2; }
     __syncthreads();
+    const uint32_t next = s_ticket;
     T B1 = E::zero(), B2 = E::zero(), T1 = E::zero(), T2 = E::zero();     // the waves before mine; the whole tile
     {
         uint32_t bn = 0, tn = 0;
@@ -677,6 +702,7 @@ __global__ void __launch_bounds__(kChainT) __attribute__((amdgpu_waves_per_eu(KI
         if (KIND) chain_put<T>(tile == 0 ? ws.inc2 : ws.agg2, mine, T2);
     }
     CHAIN_TS(3);
+    if (PF && next < ntiles) request(next);
 
     // ---- the state entering the tile: (A1, A2) = everything before it
     T A1 = E::zero(), A2 = E::zero();
@@ -785,6 +811,8 @@ __global__ void __launch_bounds__(kChainT) __attribute__((amdgpu_waves_per_eu(KI
         }
     }
     CHAIN_TS(5);
+    tile = next;
+    }
 }
 
 }  // namespace
@@ -792,12 +820,25 @@ namespace sprintz { int set_error(int code, const char* what); }   // api.hip: t
 namespace {
 int fail(int code, const char* what) { return sprintz::set_error(code, what); }
 
+#ifndef TR_CHAIN_WGS_PER_CU
+#define TR_CHAIN_WGS_PER_CU 1
+#endif
 #ifndef TR_CHAIN_MIN_TILES
 #define TR_CHAIN_MIN_TILES 8
 #endif
 // scratch of the one-pass decode: the ticket + two (delta) or four arrays of dv x 1 or 4 tagged 64-bit words per tile.  A tile is >= 8 waves
 // x 2 loads x 56 pieces x 4 rows, dv <= 8: below 12 % of the stream for 1-byte pieces (unaligned streams), 1.5 % for 16-byte ones
 size_t chain_tmp_bound(uint64_t stream_bytes) { return (size_t)(stream_bytes / 8) + 8192; }
+// workgroups of the one-pass decode: one per CU (each takes tiles until there are none)
+int chain_resident_wgs()
+{
+    static const int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        return cus * TR_CHAIN_WGS_PER_CU;
+    }();
+    return n;
+}
 // SPRINTZ_MI355X_TRANSFORM_CHAIN: 0 = the two-pass decode always; n > 0 = the one-pass decode from n tiles on (default TR_CHAIN_MIN_TILES;
 // 1 lets the tests drive the chained scan with small streams)
 uint64_t chain_min_tiles()
@@ -910,7 +951,8 @@ int decode_wave(const U* y, uint64_t len, uint32_t D_real, U* dest, uint8_t* tmp
             ws.agg2 = KIND ? (uint64_t*)(tmp + 256 + 2 * arr) : nullptr;
             ws.inc2 = KIND ? (uint64_t*)(tmp + 256 + 3 * arr) : nullptr;
             if (hipMemsetAsync(tmp, 0, need, st) != hipSuccess) return fail(SPRINTZ_E_HIP, "transform decode: hipMemsetAsync of the tiles' words");
-            hipLaunchKernelGGL((chain_scan_kernel<E, KIND>), dim3((unsigned)ntiles), dim3(kChainT), 0, st, (const T*)y, len_e, dv, ws, (T*)dest);
+            const uint64_t wgs = ntiles < (uint64_t)chain_resident_wgs() ? ntiles : (uint64_t)chain_resident_wgs();
+            hipLaunchKernelGGL((chain_scan_kernel<E, KIND>), dim3((unsigned)wgs), dim3(kChainT), 0, st, (const T*)y, len_e, dv, ws, (T*)dest, (uint32_t)ntiles);
             return hipGetLastError() == hipSuccess ? 0 : fail(SPRINTZ_E_HIP, "transform decode launch");
         }
     }
