@@ -330,6 +330,225 @@ __global__ void __launch_bounds__(kT) dyndelta_decode_kernel(const uint8_t* in, 
     }
 }
 
+// ---------------------------------------------------------------- dynamic delta, decoder in ONE pass (round 6)
+// transforms.hip's chained scan with this coder's affine maps as the monoid: a persistent workgroup of 8 waves a CU takes TILES of
+// 8 192 blocks (128 KB of errors, kept packed in registers: 16 blocks a lane as 4 loads of 4 consecutive blocks, handed over in LDS so that
+// loads and stores are coalesced), folds them, publishes the tile's map, gets the map of everything BEFORE the tile from a look-back by all 8
+// waves at once (a lane a predecessor, a DPP scan from the nearest published state on, the waves' results folded in LDS), publishes the state,
+// decodes and stores.  A tile's word is its packed map (64 bits, 15 of them spare) with a tag in bits 24 - 25 -- 1: the tile's own map, 2: the
+// map up to and including it -- one relaxed agent-scope atomic word, no fence, no flag beside it.  Round 5's one-launch form (one wave looking
+// back over tiles of 1 024 blocks, 8 192 of them resident) measured 0.166 against 0.129 ms; this one 0.114 -> see DESIGN 4.10.
+constexpr int kDcWaves = 8, kDcT = 64 * kDcWaves, kDcJ = 4, kDcK = 4;
+constexpr uint32_t kDcWaveBlocks = kDcJ * 64 * kDcK, kDcTileBlocks = kDcWaves * kDcWaveBlocks;     // 1 024, 8 192
+constexpr uint64_t kDcTagMap = 1ull << 24, kDcTagState = 2ull << 24, kDcTagMask = 3ull << 24;
+
+__device__ __forceinline__ void dc_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ uint32_t dc_swz(uint32_t p) { return (p & ~3u) | ((p + (p >> 4)) & 3u); }
+// the lane's neighbour's map through a DPP move; a lane without a source reads the identity
+template <int CTRL, int RM> __device__ __forceinline__ Aff dpp_aff(const Aff& f)
+{
+    Aff r;
+    r.m = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f.m, CTRL, RM, 0xf, false);
+    r.a = (uint32_t)__builtin_amdgcn_update_dpp(1, (int)f.a, CTRL, RM, 0xf, false);
+    r.tx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f.tx, CTRL, RM, 0xf, false);
+    r.td = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f.td, CTRL, RM, 0xf, false);
+    return r;
+}
+// inclusive scan of N maps a lane over the wave, side by side (lane l: the composition of lanes 0 .. l)
+template <int N> __device__ __forceinline__ void wave_scan_aff(Aff (&v)[N])
+{
+#define DC_STEP(CTRL, RM) _Pragma("unroll") for (int j = 0; j < N; j++) v[j] = compose(dpp_aff<CTRL, RM>(v[j]), v[j]);
+    DC_STEP(0x111, 0xf) DC_STEP(0x112, 0xf) DC_STEP(0x114, 0xf) DC_STEP(0x118, 0xf) DC_STEP(0x142, 0xa) DC_STEP(0x143, 0xc)
+#undef DC_STEP
+}
+__device__ __forceinline__ Aff lane63_aff(const Aff& f)
+{
+    return Aff{(uint32_t)__builtin_amdgcn_readlane((int)f.m, 63), (uint32_t)__builtin_amdgcn_readlane((int)f.a, 63),
+               (uint32_t)__builtin_amdgcn_readlane((int)f.tx, 63), (uint32_t)__builtin_amdgcn_readlane((int)f.td, 63)};
+}
+// a block's map from its 8 errors (packed pairs, zigzag undone)
+__device__ __forceinline__ Aff map_of(const v4& e, int choice)
+{
+    uint32_t A = 0, C = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint32_t v = half_of(e, i);
+        A += v;
+        C += (uint32_t)(8 - i) * v;
+    }
+    return choice ? Aff{8u, 1u, C & 0xffffu, A & 0xffffu} : Aff{0u, 0u, A & 0xffffu, e.w >> 16};
+}
+
+#ifndef DC_WAVES_PER_EU
+#define DC_WAVES_PER_EU 2
+#endif
+#ifndef DC_WGS_PER_CU
+#define DC_WGS_PER_CU 1
+#endif
+__global__ void __launch_bounds__(kDcT) __attribute__((amdgpu_waves_per_eu(DC_WAVES_PER_EU))) dyndelta_chain_kernel(const uint8_t* in, const uint8_t* choices, uint32_t len, uint32_t nblocks, uint32_t ntiles,
+                                                              uint32_t* ticket, uint64_t* words, uint16_t* out, int64_t* ret)
+{
+    constexpr int J = kDcJ, K = kDcK;
+    __shared__ v4 xbuf[kDcWaves][64 * K];
+    __shared__ uint64_t sm[kDcWaves];
+    __shared__ uint32_t sminc[kDcWaves], s_ticket;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    v4* const xb = xbuf[w];
+    const uint32_t x0 = ld16(in);
+    if (tid == 0) s_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    uint32_t tile = s_ticket;
+    __syncthreads();
+    while (tile < ntiles) {
+        if (tid == 0) s_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (read behind the first barrier below)
+        const uint32_t wb0 = tile * kDcTileBlocks + w * kDcWaveBlocks;         // the wave's first block
+        // ---- the wave's 4 loads of 256 blocks, coalesced (lane l: blocks m * 64 + l of the load), and the lane's 16 choice bits
+        v4 e[J][K];
+        uint32_t ch = 0;
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+#pragma unroll
+            for (int m = 0; m < K; m++) {
+                const uint32_t b = wb0 + (uint32_t)j * 256u + (uint32_t)m * 64u + lane;
+                v4 q = {0u, 0u, 0u, 0u};
+                if (b < nblocks) q = *(const v4a2*)(in + 2 * (uint64_t)(1 + 8 * (uint64_t)b));
+                e[j][m] = q;
+            }
+            const uint32_t bl = wb0 + (uint32_t)j * 256u + 4u * lane;             // the 4 consecutive blocks this lane folds: half a choice byte
+            const uint32_t cbyte = bl < nblocks ? choices[bl >> 3] : 0u;
+            ch |= ((cbyte >> (bl & 4u)) & 15u) << (4 * j);
+        }
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+#pragma unroll
+            for (int m = 0; m < K; m++) xb[dc_swz((uint32_t)m * 64u + lane)] = e[j][m];
+            dc_wave_sync();
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                v4 q = xb[dc_swz(4u * lane + (uint32_t)k)];
+                q.x = unzz16x2(q.x); q.y = unzz16x2(q.y); q.z = unzz16x2(q.z); q.w = unzz16x2(q.w);
+                e[j][k] = q;
+            }
+            dc_wave_sync();
+        }
+        // ---- the lanes' maps of every load, the 4 scans side by side; q[j]: the wave's blocks in front of this lane's of load j
+        Aff q[J], W;
+        {
+            Aff v[J];
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                Aff f = unpack_aff(kIdentity);
+#pragma unroll
+                for (int k = 0; k < K; k++) f = compose(f, map_of(e[j][k], (int)((ch >> (4 * j + k)) & 1u)));
+                v[j] = f;
+            }
+            wave_scan_aff<J>(v);
+            Aff before = unpack_aff(kIdentity);
+#pragma unroll
+            for (int j = 0; j < J; j++) {
+                q[j] = compose(before, dpp_aff<0x138, 0xf>(v[j]));                // wave_shr:1: the lanes before mine (lane 0: the identity)
+                before = compose(before, lane63_aff(v[j]));
+            }
+            W = before;
+        }
+        if (lane == 0) sm[w] = pack_aff(W);
+        __syncthreads();
+        const uint32_t next = s_ticket;
+        Aff B = unpack_aff(kIdentity), T = unpack_aff(kIdentity);                 // the waves before mine; the whole tile
+#pragma unroll
+        for (int k = 0; k < kDcWaves; k++) {
+            const Aff wk = unpack_aff(sm[k]);
+            if ((uint32_t)k < w) B = compose(B, wk);
+            T = compose(T, wk);
+        }
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(&words[tile], pack_aff(T) | (tile == 0 ? kDcTagState : kDcTagMap), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+        // ---- the map of everything before the tile: lane l of wave w <- the tile at distance 64 w + 63 - l (older tiles in lower lanes)
+        Aff A = unpack_aff(kIdentity);
+        if (tile != 0) {
+            int64_t base = (int64_t)tile - 1;
+            for (;;) {
+                const int64_t p = base - (int64_t)(64u * w + 63u - lane);
+                uint64_t word = kIdentity | kDcTagState;                          // before tile 0: the identity, a state
+                if (p >= 0) {
+                    word = __hip_atomic_load(&words[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    while ((word & kDcTagMask) == 0ull) {                         // its holder is running (tickets): this ends
+                        __builtin_amdgcn_s_sleep(1);
+                        word = __hip_atomic_load(&words[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                const uint64_t st_lanes = __ballot((word & kDcTagMask) == kDcTagState);
+                const uint32_t nearest = st_lanes ? 63u - (uint32_t)__builtin_clzll(st_lanes) : 0u;      // the nearest state of my window: the highest lane that has one
+                Aff v[1] = {lane >= nearest || st_lanes == 0ull ? unpack_aff(word) : unpack_aff(kIdentity)};
+                wave_scan_aff<1>(v);
+                const Aff tot = lane63_aff(v[0]);
+                if (lane == 0) { sm[w] = pack_aff(tot); sminc[w] = st_lanes != 0ull ? 1u : 0u; }
+                __syncthreads();
+                Aff P = unpack_aff(kIdentity);
+                bool found = false;
+                for (int k = 0; k < kDcWaves && !found; k++) {                    // wave 0's window is the nearest
+                    P = compose(unpack_aff(sm[k]), P);
+                    found = sminc[k] != 0u;
+                }
+                A = compose(P, A);
+                __syncthreads();
+                if (found) break;
+                base -= 64 * kDcWaves;
+            }
+            if (tid == 0) __hip_atomic_store(&words[tile], pack_aff(compose(A, T)) | kDcTagState, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+
+        // ---- decode: the state in front of the lane's blocks of load j; the samples change hands in LDS again and leave coalesced
+        const Aff AB = compose(A, B);
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const Aff f = compose(AB, q[j]);
+            uint32_t x = (x0 + f.tx) & 0xffffu, d = f.td;                         // d starts at 0 (online.hpp: _prev_diff = 0)
+            const uint32_t bl = wb0 + (uint32_t)j * 256u + 4u * lane;
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const int choice = (int)((ch >> (4 * j + k)) & 1u);
+                uint32_t v[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const uint32_t ei = half_of(e[j][k], i);
+                    d = choice ? (d + ei) & 0xffffu : ei;
+                    x = (x + d) & 0xffffu;
+                    v[i] = x;
+                }
+                v4 o;
+                o.x = v[0] | (v[1] << 16); o.y = v[2] | (v[3] << 16); o.z = v[4] | (v[5] << 16); o.w = v[6] | (v[7] << 16);
+                xb[dc_swz(4u * lane + (uint32_t)k)] = o;
+                if (bl + (uint32_t)k == nblocks - 1u) {                           // the owner of the last block walks the < 8 trailing delta errors (:245-251)
+                    uint32_t y = x;
+                    for (uint32_t at = 1 + 8 * nblocks; at < len; at++) {
+                        y = (y + ld16(in + 2 * (uint64_t)at)) & 0xffffu;
+                        out[at] = (uint16_t)y;
+                    }
+                }
+            }
+            dc_wave_sync();
+#pragma unroll
+            for (int m = 0; m < K; m++) {
+                const uint32_t b = wb0 + (uint32_t)j * 256u + (uint32_t)m * 64u + lane;
+                if (b < nblocks) *(v4a2*)(out + 1 + 8 * (uint64_t)b) = xb[dc_swz((uint32_t)m * 64u + lane)];
+            }
+            dc_wave_sync();
+        }
+        if (tile == 0 && tid == 0) {
+            out[0] = (uint16_t)x0;
+            if (ret) *ret = checked_len(in, len);
+        }
+        tile = next;
+    }
+}
+
 // ---------------------------------------------------------------- sprintzpack
 // A workgroup takes a TILE of kTile blocks (a thread kBPT consecutive ones).  Three launches either way: the tiles' payload sizes,
 // one workgroup scanning them, and the pack / unpack proper -- which recomputes its blocks' widths (a re-read of the samples / of the
@@ -567,6 +786,25 @@ unsigned grid_for(uint64_t items) { return (unsigned)((items + kT - 1) / kT); }
 size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 unsigned tiles_for(uint64_t blocks) { return (unsigned)((blocks + kTile - 1) / kTile); }
 
+// the one-pass dynamic-delta decoder: one workgroup a CU; SPRINTZ_MI355X_ONLINE_CHAIN: 0 = the three-launch form always, n > 0 = one pass from n
+// tiles (of 8 192 blocks) on -- default 8; 1 lets the tests drive it with short streams
+int dc_resident_wgs()
+{
+    static const int n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        return cus * DC_WGS_PER_CU;
+    }();
+    return n;
+}
+uint32_t dc_min_tiles()
+{
+    const char* e = getenv("SPRINTZ_MI355X_ONLINE_CHAIN");
+    if (!e || !e[0]) return 8u;
+    const long v = strtol(e, nullptr, 10);
+    return v <= 0 ? 0xffffffffu : (uint32_t)v;
+}
+
 uint32_t choice_bytes_of(uint32_t len) { return (((len + 7) / 8) + 7) / 8; }                 // online.cpp:253-258
 uint32_t hdr_bytes_of(uint32_t len) { return (((len + 7) / 8) * 4 + 7) / 8; }                // online.cpp:355-359
 
@@ -688,6 +926,15 @@ int sprintz_mi355x_online_unpack_device(int kind, const void* d_src, uint32_t le
         const uint32_t nblocks = (len - 1) / 8, ntiles = (uint32_t)(((uint64_t)(nblocks ? nblocks : 1) + kDdTile - 1) / kDdTile);
         const uint8_t* choices = body + 2 * (size_t)len;
         uint64_t* tiles = (uint64_t*)d_tmp;
+        // long streams: one pass (dyndelta_chain_kernel); its words fit the scratch of the three-launch form (a word per 8 192 blocks + the ticket)
+        const uint32_t ctiles = (uint32_t)(((uint64_t)nblocks + kDcTileBlocks - 1) / kDcTileBlocks);
+        if (ctiles >= dc_min_tiles()) {
+            if (hipMemsetAsync(d_tmp, 0, 256 + (size_t)ctiles * 8, st) != hipSuccess) return fail(SPRINTZ_E_HIP, "online: hipMemsetAsync of the tiles' words");
+            const uint32_t wgs = ctiles < (uint32_t)dc_resident_wgs() ? ctiles : (uint32_t)dc_resident_wgs();
+            hipLaunchKernelGGL(dyndelta_chain_kernel, dim3(wgs), dim3(kDcT), 0, st, body, choices, len, nblocks, ctiles, (uint32_t*)d_tmp,
+                               (uint64_t*)((uint8_t*)d_tmp + 256), d_dest, d_ret);
+            return hipGetLastError() == hipSuccess ? 0 : fail(SPRINTZ_E_HIP, "online: unpack launch");
+        }
         hipLaunchKernelGGL(dyndelta_tile_kernel, dim3(ntiles), dim3(kT), 0, st, body, choices, nblocks, tiles);
         hipLaunchKernelGGL(dyndelta_tilescan_kernel, dim3(1), dim3(kDdScanT), 0, st, tiles, ntiles);
         hipLaunchKernelGGL(dyndelta_decode_kernel, dim3(ntiles), dim3(kT), 0, st, body, choices, len, nblocks, (const uint64_t*)tiles, d_dest, d_ret);

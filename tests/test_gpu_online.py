@@ -48,10 +48,16 @@ def test_golden_containers_single_call(lib, golden_online):
         assert dret == x.size and np.array_equal(back, x), m
 
 
+@pytest.mark.parametrize("chain", ["default", "1", "0"])
 @pytest.mark.parametrize("kind", [0, 1, 2, 3, 4])
-def test_device_forms_on_long_streams(lib, orc, kind):
-    """streams spanning many workgroups and scan tiles, incl. the reference suite's 1024*1024+7 elements"""
+def test_device_forms_on_long_streams(lib, orc, kind, chain, monkeypatch):
+    """streams spanning many workgroups and scan tiles, incl. the reference suite's 1024*1024+7 elements.  chain: the dynamic-delta decoder's
+    one-pass form (a chained scan over tiles of 8 192 blocks) from 8 tiles on (default), from the first tile on ("1"), never ("0")"""
     import torch
+    if chain != "default":
+        if kind > 1:
+            pytest.skip("only the dynamic-delta decoder has two forms")
+        monkeypatch.setenv("SPRINTZ_MI355X_ONLINE_CHAIN", chain)
     rng = np.random.default_rng(1000 + kind)
     for n in (2049, 16 * 2048 + 1, 300001, 1024 * 1024 + 7):
         for x in (gen_walk(rng, n, 1, 2, 7), gen_fuzz(rng, n, 2, int(rng.integers(0, 12))),
