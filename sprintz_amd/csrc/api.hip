@@ -722,7 +722,11 @@ int encode_launch(int codec, int esz, const void* d_src, uint64_t total_len, uin
     //  held.  The tail pays from 64 chunks a workgroup on, as on the lane-per-column kernels.
     //  Second form: a workgroup takes 16 / 32 / 64 chunks in passes of three and ends with compact_tail.h's dense_tail (slot -> container copy, one
     //  chained-scan step per workgroup): 0.352 / 0.369 / 0.432 ms against 0.280 on the same box -- the looped kernel needs 149 registers (3 waves a
-    //  SIMD instead of 4) and 820 - 3 277 workgroups are one to three cohorts: the tails do not hide behind anybody's encoding.)
+    //  SIMD instead of 4) and 820 - 3 277 workgroups are one to three cohorts: the tails do not hide behind anybody's encoding.
+    //  Third form, priced before it was built: encoders that never wait -- they flush to their slots with write-through (sc0 sc1) stores, wait for
+    //  them and add their size to their block's word; the block's last finisher finds the block's place (a look-back over a few hundred blocks) and
+    //  copies it.  The encoder's side alone (the stores, the s_waitcnt, one atomic a chunk; no placement at all) measured 0.302 against 0.270 ms for
+    //  the whole compress call: a third of the 0.098 ms the scan + copy launches cost is gone before the placers' copies and the last block's tail.)
     {
         const int blk_from = process().blk_chunks.load(std::memory_order_relaxed);
         const int blk_which = process().blk_kernels.load(std::memory_order_relaxed);
