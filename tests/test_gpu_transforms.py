@@ -92,3 +92,26 @@ def test_xff_long_streams_on_device(sz, oracle, esz, ndims, n):
     assert np.array_equal(y.cpu().numpy().view(DTYPES[esz]), want[6:].view(DTYPES[esz]))
     back = sz.transform_device("xff", y, ndims, inverse=True)
     assert torch.equal(back, xd)
+
+
+def test_one_pass_decoders_on_two_streams_at_once(sz):
+    """the one-pass decoders' workgroups wait for each other (a chained scan over tiles, tiles taken by ticket): two decodes in flight at once on
+    two streams -- neither launch has the chip to itself, a waiting tile's predecessors are still held by running workgroups -- must both finish"""
+    import torch
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    n = 8 * (4 << 20)                                                   # 64 MB of uint16 x 8 columns: 512 tiles, two rounds of the persistent grid
+    xs = [torch.randint(0, 1 << 16, (n,), generator=g, device="cuda", dtype=torch.int32).to(torch.uint16) for _ in range(2)]
+    ys = [sz.transform_device("delta", xs[0], 8), sz.transform_device("doubledelta", xs[1], 8)]
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    torch.cuda.synchronize()
+    outs = [[], []]
+    for it in range(6):
+        for k, kind in enumerate(("delta", "doubledelta")):
+            with torch.cuda.stream(streams[k]):
+                outs[k].append(sz.transform_device(kind, ys[k], 8, inverse=True))
+    torch.cuda.synchronize()
+    for k in range(2):
+        for o in outs[k]:
+            assert torch.equal(o, xs[k])
