@@ -122,7 +122,8 @@ const char* sprintz_mi355x_last_error(void);     /* thread-local, never NULL; de
  *                                 0 = never, default 2049 (env SPRINTZ_MI355X_BLK_CHUNKS).  Same bytes either way.
  *   SPRINTZ_OPT_BLK_KERNELS       which of the round-6 delta kernels such batches take, a mask: 1 = the block-parallel general-layout encoder, 2 = the
  *                                 block-parallel general-layout decoder, 4 = the block-parallel univariate low-dim encoder, 8 = the piece-sequential
- *                                 general-layout decoder (csrc/decode_row.h; wins over 2); default 9: the ones that measured faster than the
+ *                                 general-layout decoder (csrc/decode_row.h; wins over 2) on the shapes it measured faster on (8-bit rows of at
+ *                                 least 32 columns), 16 = ... on every shape it fits (tests); default 9: the ones that measured faster than the
  *                                 lane-per-column kernels on BASELINE's configurations (env SPRINTZ_MI355X_BLK_KERNELS)
  *   SPRINTZ_OPT_HOST_WAIT         how a single-call entry point waits for its launches: 0 (default) = spin (hipStreamSynchronize)
  *                                 while at most 4 callers (and at most half of the CPUs this process may use) are inside the library,

@@ -59,7 +59,7 @@ struct Process {
     std::atomic<int> chunks_per_group{1};   // SPRINTZ_MI355X_CHUNKS_PER_GROUP (decode_fast read-ahead across chunks)
     std::atomic<int> dense_mode{1};         // SPRINTZ_MI355X_DENSE_MODE: how compress_batch_dense builds the container (see SPRINTZ_OPT_DENSE_MODE)
     std::atomic<int> enc_pair{1024};        // SPRINTZ_MI355X_ENC_PAIR: chunks from which row-major streams of 5 .. 64 columns are encoded with two columns per lane (0: never; see SPRINTZ_OPT_ENC_PAIR)
-    std::atomic<int> blk_kernels{9};        // SPRINTZ_MI355X_BLK_KERNELS: which of round 6's delta kernels large batches take: bit 0 encode_blk (general layout), bit 1 decode_blk, bit 2 encode_blk_uni (univariate low-dim), bit 3 decode_row (wins over bit 1)
+    std::atomic<int> blk_kernels{9};        // SPRINTZ_MI355X_BLK_KERNELS: which of round 6's delta kernels large batches take: bit 0 encode_blk (general layout), bit 1 decode_blk, bit 2 encode_blk_uni (univariate low-dim), bit 3 decode_row (wins over bit 1) on the shapes it wins on, bit 4 decode_row on every shape it fits
     std::atomic<int> blk_chunks{2049};      // SPRINTZ_MI355X_BLK_CHUNKS: batches of at least this many chunks take the block-parallel delta kernels (encode_blk.h; 0: never)
     std::atomic<int> lat_chunks{2048};      // SPRINTZ_MI355X_LAT_CHUNKS: batches of at most this many chunks decode with one workgroup per chunk (decode_lat.h; 0: never)
     std::atomic<int> ref_quirk{0};          // SPRINTZ_MI355X_REF_DECODER_QUIRK: decode as the reference DECODER does where it differs from the inverse of its encoder
@@ -81,7 +81,7 @@ Process& process()
         }
         if (const char* e = getenv("SPRINTZ_MI355X_LAT_CHUNKS")) p.lat_chunks = atoi(e) < 0 ? 0 : atoi(e);
         if (const char* e = getenv("SPRINTZ_MI355X_BLK_CHUNKS")) p.blk_chunks = atoi(e) < 0 ? 0 : atoi(e);
-        if (const char* e = getenv("SPRINTZ_MI355X_BLK_KERNELS")) p.blk_kernels = atoi(e) & 15;
+        if (const char* e = getenv("SPRINTZ_MI355X_BLK_KERNELS")) p.blk_kernels = atoi(e) & 31;
         if (const char* e = getenv("SPRINTZ_MI355X_REF_DECODER_QUIRK")) p.ref_quirk = atoi(e) != 0 ? 1 : 0;
         if (const char* e = getenv("SPRINTZ_MI355X_HOST_STREAMS")) p.host_streams = atoi(e) < 0 ? 0 : (atoi(e) > 64 ? 64 : atoi(e));
         if (const char* e = getenv("SPRINTZ_MI355X_HOST_WAIT")) p.host_wait = atoi(e) < 0 || atoi(e) > 2 ? 0 : atoi(e);
@@ -551,9 +551,14 @@ int decode_launch(int codec, int esz, const void* d_comp, const uint64_t* d_offs
         if (blk_from > 0 && (process().blk_kernels.load(std::memory_order_relaxed) & 8) && nchunks >= (uint64_t)blk_from && codec == SPRINTZ_CODEC_DELTA && !lowdim && !noheader && !cs &&
             qs.q == kQueryOff && !qs.hc && ((uintptr_t)d_out % 4) == 0 && ((uintptr_t)d_comp % 4) == 0 && !process().no_fast.load(std::memory_order_relaxed)) {
             const RowDecGeom g = row_dec_geom((uint32_t)esz, chunk_len, (uint32_t)D);
+            // where it wins (tools/blk_shapes.py, profiles/r6_blk_shapes.txt; 10 KB chunks, ms against the lane-per-column kernels): 8-bit rows of 32 / 48 / 64 / 80 /
+            // 128 / 256 columns 0.153 / 0.202 / 0.121 / 0.132 / 0.136 / 0.187 against 0.172 / 0.237 / 0.184 / 0.172 / 0.155 / 0.539; where it does not: 16 8-bit columns
+            // (4 lanes a chunk) 0.233 against 0.182, and 16-bit elements -- two fields a dword carry the same per-row work as four -- 8 / 16 / 24 / 128 columns 0.129 /
+            // 0.103 / 0.171 / 0.186 against 0.114 / 0.096 / 0.136 / 0.132 (32 and 64 columns level).  Mask bit 4 takes every shape the kernel fits (tests).
+            const bool wins = (esz == 1 && g.U >= 8u) || (process().blk_kernels.load(std::memory_order_relaxed) & 16);
             // (32-bit offsets inside the kernel: the output and -- whatever the streams' lengths -- the container below 4 GB)
             const bool below_4g = (uint64_t)nchunks * chunk_len * esz < 0xf0000000ull && (uint64_t)nchunks * sprintz_mi355x_compress_bound(esz, chunk_len, ndims) < 0xf0000000ull;
-            if (g.ok && below_4g) {
+            if (g.ok && below_4g && wins) {
                 const uint64_t rgrid = (nchunks + 4ull * g.G - 1) / (4ull * g.G);
                 if (rgrid > 0x7fffffffull) return fail(SPRINTZ_E_INVALID, "too many chunks for one launch");
                 e = launch_decode_row(8 * esz, (unsigned)rgrid, st, a, g);
@@ -1537,7 +1542,7 @@ int sprintz_mi355x_set_option(int option, int value)
         return 0;
     }
     if (option == SPRINTZ_OPT_BLK_KERNELS) {
-        if (value < 0 || value > 15) return fail(SPRINTZ_E_INVALID, "SPRINTZ_OPT_BLK_KERNELS is a mask of bits 0 .. 3");
+        if (value < 0 || value > 31) return fail(SPRINTZ_E_INVALID, "SPRINTZ_OPT_BLK_KERNELS is a mask of bits 0 .. 4");
         process().blk_kernels = value;
         return 0;
     }

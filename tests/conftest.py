@@ -30,7 +30,7 @@ def decode_path(request):
     from sprintz_amd import _lib
     _lib.check(_lib.set_option(_lib.OPT_LAT_CHUNKS, (1 << 30) if request.param == "lat" else 0))
     _lib.check(_lib.set_option(_lib.OPT_BLK_CHUNKS, 1 if request.param == "blk" else 0))
-    _lib.check(_lib.set_option(_lib.OPT_BLK_KERNELS, 15))           # every new kernel, whatever the default mask is (the decoder: decode_row.h; decode_blk.h has tests/test_gpu_blk.py)
+    _lib.check(_lib.set_option(_lib.OPT_BLK_KERNELS, 31))           # every new kernel, whatever the default mask is (the decoder: decode_row.h; decode_blk.h has tests/test_gpu_blk.py)
     yield request.param
     _lib.set_option(_lib.OPT_LAT_CHUNKS, int(os.environ.get("SPRINTZ_MI355X_LAT_CHUNKS", 2048)))
     _lib.set_option(_lib.OPT_BLK_CHUNKS, int(os.environ.get("SPRINTZ_MI355X_BLK_CHUNKS", 2049)))

@@ -26,7 +26,7 @@ def path(request):
     from sprintz_amd import _lib
     _lib.check(_lib.set_option(_lib.OPT_LAT_CHUNKS, 0))
     _lib.check(_lib.set_option(_lib.OPT_BLK_CHUNKS, 0 if request.param == "old" else 1))
-    _lib.check(_lib.set_option(_lib.OPT_BLK_KERNELS, 9 if request.param == "row" else 7))
+    _lib.check(_lib.set_option(_lib.OPT_BLK_KERNELS, 25 if request.param == "row" else 7))
     yield request.param
     _lib.set_option(_lib.OPT_LAT_CHUNKS, int(os.environ.get("SPRINTZ_MI355X_LAT_CHUNKS", 2048)))
     _lib.set_option(_lib.OPT_BLK_CHUNKS, int(os.environ.get("SPRINTZ_MI355X_BLK_CHUNKS", 2049)))
