@@ -443,7 +443,7 @@ int sprintz_mi355x_huf0_compress_batch(const void* d_dense, const uint64_t* d_of
  * wrapping at the element width: delta y[r] = x[r] - x[r-1]; double delta
  * y[r] = x[r] - 2 x[r-1] + x[r-2].  One call transforms ONE stream of any
  * length; the decode is a scan over its rows (transforms.hip): one pass -- a chained scan
- * over 128 KB tiles on persistent workgroups -- for 16-bit streams of at least 8 tiles whose
+ * over 128 KB tiles on persistent workgroups -- for 16-bit streams whose
  * rows are at most 8 pieces of 16 / 4 / element bytes, two passes otherwise (env
  * SPRINTZ_MI355X_TRANSFORM_CHAIN: 0 = two passes always, n = one pass from n tiles on;
  * A/B runs, tests).  The scratch is zeroed by the call (hipMemsetAsync on the stream).
@@ -484,7 +484,7 @@ const char* sprintz_mi355x_transform_last_error(void);
  * Return values are ELEMENTS like the reference's.  Device forms: d_src / d_dest 16-byte aligned,
  * d_dest of sprintz_mi355x_online_bound() bytes, d_tmp of sprintz_mi355x_online_tmp_bytes(); *d_ret (device) receives the
  * return value -- for unpack, SPRINTZ_E_CORRUPT if the container's length field differs from `len`.
- * The dynamic-delta decoder takes streams of at least 8 tiles (of 8 192 blocks) in one pass -- a chained scan of the blocks' affine
+ * The dynamic-delta decoder takes streams of at least 128 tiles (of 8 192 blocks: 16 MB) in one pass -- a chained scan of the blocks' affine
  * maps on persistent workgroups -- and shorter ones in three launches (env SPRINTZ_MI355X_ONLINE_CHAIN: 0 = three launches always,
  * n = one pass from n tiles on; A/B runs, tests).
  * ---------------------------------------------------------------------- */

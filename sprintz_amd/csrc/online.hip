@@ -787,7 +787,7 @@ size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 unsigned tiles_for(uint64_t blocks) { return (unsigned)((blocks + kTile - 1) / kTile); }
 
 // the one-pass dynamic-delta decoder: one workgroup a CU; SPRINTZ_MI355X_ONLINE_CHAIN: 0 = the three-launch form always, n > 0 = one pass from n
-// tiles (of 8 192 blocks) on -- default 8; 1 lets the tests drive it with short streams
+// tiles (of 8 192 blocks) on -- default 128; 1 lets the tests drive it with short streams
 int dc_resident_wgs()
 {
     static const int n = [] {
@@ -800,7 +800,7 @@ int dc_resident_wgs()
 uint32_t dc_min_tiles()
 {
     const char* e = getenv("SPRINTZ_MI355X_ONLINE_CHAIN");
-    if (!e || !e[0]) return 8u;
+    if (!e || !e[0]) return 128u;            // (16 MB of samples: 25.1 against 26.3 us there, 17 - 19 against 15 below, 94 against 114 at 128 MB -- tools/chain_sizes.py)
     const long v = strtol(e, nullptr, 10);
     return v <= 0 ? 0xffffffffu : (uint32_t)v;
 }

@@ -824,7 +824,7 @@ int fail(int code, const char* what) { return sprintz::set_error(code, what); }
 #define TR_CHAIN_WGS_PER_CU 1
 #endif
 #ifndef TR_CHAIN_MIN_TILES
-#define TR_CHAIN_MIN_TILES 8
+#define TR_CHAIN_MIN_TILES 1                  // (from the first tile on: 9.6 against 13.7 us at 32 KB, 13 against 52 at 0.5 MB, 64 against 90 at 128 MB -- tools/chain_sizes.py)
 #endif
 // scratch of the one-pass decode: the ticket + two (delta) or four arrays of dv x 1 or 4 tagged 64-bit words per tile.  A tile is >= 8 waves
 // x 2 loads x 56 pieces x 4 rows, dv <= 8: below 12 % of the stream for 1-byte pieces (unaligned streams), 1.5 % for 16-byte ones

@@ -52,7 +52,7 @@ def test_golden_containers_single_call(lib, golden_online):
 @pytest.mark.parametrize("kind", [0, 1, 2, 3, 4])
 def test_device_forms_on_long_streams(lib, orc, kind, chain, monkeypatch):
     """streams spanning many workgroups and scan tiles, incl. the reference suite's 1024*1024+7 elements.  chain: the dynamic-delta decoder's
-    one-pass form (a chained scan over tiles of 8 192 blocks) from 8 tiles on (default), from the first tile on ("1"), never ("0")"""
+    one-pass form (a chained scan over tiles of 8 192 blocks) from 128 tiles on (default), from the first tile on ("1"), never ("0")"""
     import torch
     if chain != "default":
         if kind > 1:

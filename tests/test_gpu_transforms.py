@@ -51,7 +51,7 @@ def test_reference_containers_single_call(sz, golden_transforms):
                                          (1, 80, 80 * 300_001), (2, 24, 24 * 200_003), (1, 144, 144 * 70_001), (2, 296, 296 * 30_011), (2, 40, 40 * 17)])
 @pytest.mark.parametrize("chain", ["default", "1", "0"])
 def test_long_streams_on_device(sz, oracle, kind, esz, ndims, n, chain, monkeypatch):
-    """one stream of millions of rows: element-wise encode, scan decode -- the one-pass chained scan over tiles (default from 8 tiles on; "1":
+    """one stream of millions of rows: element-wise encode, scan decode -- the one-pass chained scan over tiles (default: every 16-bit stream; "1":
     from the first tile on, so that the short streams take it too) and the two-pass form with its 3 to 6 levels ("0")"""
     import torch
     if chain != "default":
