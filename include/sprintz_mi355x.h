@@ -444,7 +444,7 @@ int sprintz_mi355x_huf0_compress_batch(const void* d_dense, const uint64_t* d_of
  * y[r] = x[r] - 2 x[r-1] + x[r-2].  One call transforms ONE stream of any
  * length; the decode is a scan over its rows (transforms.hip): one pass -- a chained scan
  * over 128 KB tiles on persistent workgroups -- for 16-bit streams whose
- * rows are at most 8 pieces of 16 / 4 / element bytes, two passes otherwise (env
+ * rows are 1 .. 8 whole 16-byte pieces (or 2 / 4 / 8 bytes), two passes otherwise (env
  * SPRINTZ_MI355X_TRANSFORM_CHAIN: 0 = two passes always, n = one pass from n tiles on;
  * A/B runs, tests).  The scratch is zeroed by the call (hipMemsetAsync on the stream).
  * SPRINTZ_TRANSFORM_XFF is the FIRE forecaster with no packing (errors out), with

@@ -940,8 +940,10 @@ int decode_wave(const U* y, uint64_t len, uint32_t D_real, U* dest, uint8_t* tmp
     // ---- streams of at least TR_CHAIN_MIN_TILES tiles, rows of at most kChainMaxDv pieces: one pass (chain_scan_kernel)
     // (16-bit elements only: at 8 bits the packed arithmetic is five instructions an add where v_pk_add_u16 is one, the tile's fold and walk
     //  run on one workgroup a CU, and the form measured SLOWER than the two passes on every column count -- tools/transforms_shapes.py:
-    //  delta 0.126 - 0.167 against 0.103 - 0.143 ms on 128 MiB, double delta 0.28 - 0.48 against 0.15 - 0.26; at 16 bits 0.063 - 0.074 against 0.090 - 0.124)
-    if constexpr (sizeof(U) == 2)
+    //  delta 0.126 - 0.167 against 0.103 - 0.143 ms on 128 MiB, double delta 0.28 - 0.48 against 0.15 - 0.26; at 16 bits 0.063 - 0.074 against 0.090 - 0.124.
+    //  And 16-byte pieces only: with 4- or 2-byte pieces (rows that are not multiples of 16 bytes) a tile is 32 / 16 KB and the look-back is the kernel:
+    //  3 / 5 / 7 / 10 / 12 uint16 columns 0.199 / 0.284 / 0.220 / 0.147 / 0.133 against 0.160 / 0.158 / 0.154 / 0.125 / 0.121 ms.)
+    if constexpr (sizeof(U) == 2 && sizeof(T) == 16)
     if (dv <= (uint32_t)kChainMaxDv) {
         const uint64_t tile_e = (uint64_t)kChainWaves * kChainLoads * (uint64_t)((64 / dv) * dv) * kRowsPerLane;
         const uint64_t ntiles = (len_e + tile_e - 1) / tile_e;

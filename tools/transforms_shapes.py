@@ -31,7 +31,9 @@ def timed(fn, reps=10):
 g = torch.Generator(device="cuda")
 g.manual_seed(1)
 nbytes = 128 << 20
-for esz, D in ((1, 1), (1, 2), (1, 4), (1, 8), (1, 16), (1, 80), (1, 128), (2, 1), (2, 2), (2, 4), (2, 8), (2, 24), (2, 64)):
+SHAPES = os.environ.get("SHAPES")      # "2x3,2x5": element bytes x columns
+shapes = [tuple(int(v) for v in t.split("x")) for t in SHAPES.split(",")] if SHAPES else ((1, 1), (1, 2), (1, 4), (1, 8), (1, 16), (1, 80), (1, 128), (2, 1), (2, 2), (2, 4), (2, 8), (2, 24), (2, 64))
+for esz, D in shapes:
     n = nbytes // esz // D * D
     x = torch.randint(0, 1 << (8 * esz), (n,), generator=g, device="cuda", dtype=torch.int32).to(torch.uint8 if esz == 1 else torch.uint16)
     for kind in ("delta", "doubledelta"):
