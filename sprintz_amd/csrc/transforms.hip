@@ -297,7 +297,7 @@ template <typename P, int RB> struct Sub : V4<P> {
 template <typename E, int KIND, bool STORE>
 __global__ void __launch_bounds__(kTB) wave_scan_kernel(const typename E::T* y, uint64_t len_e, uint32_t dv, uint64_t nruns,
                                                         const typename E::T* xin, const typename E::T* din, typename E::T* s1_out,
-                                                        typename E::T* s2_out, typename E::T* dest)
+                                                        typename E::T* s2_out, typename E::T* dest, int run_loads)
 {
     typedef typename E::T T;
     const uint64_t run = ((uint64_t)blockIdx.x * kTB + threadIdx.x) >> 6;
@@ -321,19 +321,19 @@ __global__ void __launch_bounds__(kTB) wave_scan_kernel(const typename E::T* y, 
     __shared__ T xbuf[kTB / 64][64 * K];
     T* const xb = xbuf[threadIdx.x >> 6];
     const bool via_lds = dv < 3;                          // (1 or 2: powers of two, 64 pieces per row-step, which the hand-over is laid out for)
-    const uint64_t e0 = run * (uint64_t)kRunLoads * PL * K;
+    const uint64_t e0 = run * (uint64_t)run_loads * PL * K;
     // load j's pieces as this lane requests them: piece m * 64 + lane of the load (LDS hand-over) or the lane's own K rows
     auto fetch = [&](int j, T (&v)[K]) {
         const uint64_t eb = e0 + (uint64_t)j * PL * K;
 #pragma unroll
         for (int k = 0; k < K; k++) {
             const uint64_t e = via_lds ? eb + (uint64_t)k * 64 + lane : eb + (uint64_t)r * K * dv + (uint64_t)c + (uint64_t)k * dv;
-            v[k] = ((via_lds || act) && j < kRunLoads && e < len_e) ? y[e] : E::zero();
+            v[k] = ((via_lds || act) && j < run_loads && e < len_e) ? y[e] : E::zero();
         }
     };
     T nx[K];
     if (TR_PREFETCH) fetch(0, nx);
-    for (int j = 0; j < kRunLoads; j++) {
+    for (int j = 0; j < run_loads; j++) {
         const uint64_t eb = e0 + (uint64_t)j * PL * K;  // first piece of this load
         if (eb >= len_e) break;                         // wave-uniform
         const uint64_t el = eb + (uint64_t)r * K * dv + (uint64_t)c;   // this lane's first piece; its rows are dv pieces apart
@@ -934,7 +934,16 @@ int decode_wave(const U* y, uint64_t len, uint32_t D_real, U* dest, uint8_t* tmp
     const uint32_t dv = E::M > 1 ? 1u : (uint32_t)((uint64_t)D * sizeof(U) / sizeof(T));
     const uint64_t len_e = len * sizeof(U) / sizeof(T);
     const uint64_t rows0 = (len + D_real - 1) / D_real;                  // real rows
-    const uint64_t run_rows = (uint64_t)kRunLoads * kRowsPerLane * (64 / dv) * E::M;
+    // loads a run: 16 where there are runs enough to fill the chip; short streams take 4 or 1 -- a run's loads are a serial chain, and a stream of
+    // eight 16-load runs was two passes of 16 dependent round trips on eight waves: 52 us for 0.5 MB (tools/chain_sizes.py) -- as long as the
+    // runs' states still come from the one workgroup of scan_runs_kernel (<= 4 096 runs)
+    int run_loads = kRunLoads;
+    {
+        const uint64_t rows16 = (uint64_t)kRunLoads * kRowsPerLane * (64 / dv) * E::M, n16 = (rows0 + rows16 - 1) / rows16;
+        if (n16 * 16 <= 4096) run_loads = 1;
+        else if (n16 * 4 <= 4096) run_loads = 4;
+    }
+    const uint64_t run_rows = (uint64_t)run_loads * kRowsPerLane * (64 / dv) * E::M;
     const uint64_t nruns = (rows0 + run_rows - 1) / run_rows;
     const unsigned grid = (unsigned)((nruns * 64 + kTB - 1) / kTB);
     // ---- streams of at least TR_CHAIN_MIN_TILES tiles, rows of at most kChainMaxDv pieces: one pass (chain_scan_kernel)
@@ -964,7 +973,7 @@ int decode_wave(const U* y, uint64_t len, uint32_t D_real, U* dest, uint8_t* tmp
     }
     if (nruns == 1) {
         hipLaunchKernelGGL((wave_scan_kernel<E, KIND, true>), dim3(grid), dim3(kTB), 0, st, (const T*)y, len_e, dv, nruns,
-                           (const T*)nullptr, (const T*)nullptr, (T*)nullptr, (T*)nullptr, (T*)dest);
+                           (const T*)nullptr, (const T*)nullptr, (T*)nullptr, (T*)nullptr, (T*)dest, run_loads);
         return hipGetLastError() == hipSuccess ? 0 : fail(SPRINTZ_E_HIP, "transform decode launch");
     }
     // level 1 = one summary per run, laid out like rows of the stream
@@ -975,7 +984,7 @@ int decode_wave(const U* y, uint64_t len, uint32_t D_real, U* dest, uint8_t* tmp
     U* xi = take(nruns);
     U* di = KIND ? take(nruns) : nullptr;
     hipLaunchKernelGGL((wave_scan_kernel<E, KIND, false>), dim3(grid), dim3(kTB), 0, st, (const T*)y, len_e, dv, nruns, (const T*)nullptr,
-                       (const T*)nullptr, (T*)s1, (T*)s2, (T*)nullptr);
+                       (const T*)nullptr, (T*)s1, (T*)s2, (T*)nullptr, run_loads);
     const Level<U> base{s1, s2, xi, di, nruns, run_rows};
     if (D <= 64 && nruns <= 4096) {                      // (wide rows, or streams long enough that six ~4.6 us launches do not matter: the generic levels --
                                                          //  with 16 384 runs the one workgroup measured slower than they are: 0.72 against 0.66 ms at 512 Mi samples)
@@ -986,7 +995,7 @@ int decode_wave(const U* y, uint64_t len, uint32_t D_real, U* dest, uint8_t* tmp
         if (rc) return rc;
     }
     hipLaunchKernelGGL((wave_scan_kernel<E, KIND, true>), dim3(grid), dim3(kTB), 0, st, (const T*)y, len_e, dv, nruns, (const T*)xi,
-                       (const T*)di, (T*)nullptr, (T*)nullptr, (T*)dest);
+                       (const T*)di, (T*)nullptr, (T*)nullptr, (T*)dest, run_loads);
     return hipGetLastError() == hipSuccess ? 0 : fail(SPRINTZ_E_HIP, "transform decode launch");
 }
 
